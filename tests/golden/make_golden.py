@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference and amdflang); the
+fixtures it writes are committed, this script is committed, nothing of the
+reference is.  Two sources of truth are exercised:
+
+  * the reference's Fortran (lineshape.f, curgods.f, fparts_mod.f) compiled as
+    they lie under /root/reference into oracle/_ref/ (make -C oracle ref) and
+    called through ctypes (oracle/ref_fortran.py);
+  * the reference's Python, spect_classes.py, imported under Python 3 with the
+    f2py modules replaced by those ctypes wrappers and with a stub for the
+    module the reference tree does not contain (spect_base_module: only
+    isclose / extract_quanta_HITRAN / find_molec_metadata are touched here).
+
+Outputs (all numpy .npz, inputs + expected outputs side by side):
+  humliv_windows.npz   A1  humliv_bb on 13010-point windows, many (lw, dw, x0)
+  tips2003.npz         A7  bd_tips_2003 tables + CalcPartitionSum samples
+  curgods.npz          A10 curgod_fort_1..4 on three profiles
+  spcl_scalars.npz     A3/A4 widths, G-coefficients, Planck, LTE line strength
+  e2e_ch4_levels.npz   A2-A8 end to end, non-LTE levels, 3 (P,T), clipped windows
+  e2e_co_all.npz       A2-A8 end to end, 'all' level set (BASELINE configs[0] shape)
+"""
+import math
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+REF = "/root/reference"
+
+
+def import_reference_spcl():
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL)
+    from oracle import ref_fortran as RF
+    import matplotlib
+    matplotlib.use("Agg")
+
+    m_ls = types.ModuleType("lineshape")
+    m_ls.humliv_bb = lambda x, i1, i2, x0, lw, dw: RF.humliv_bb(x, i1, i2, x0, lw, dw)
+    m_fp = types.ModuleType("fparts_mod")
+    m_fp.bd_tips_2003 = lambda mol, iso: RF.bd_tips_2003(mol, iso)
+    m_sbm = types.ModuleType("spect_base_module")
+    m_sbm.isclose = lambda a, b, rtol=1e-9, atol=0.0: bool(np.isclose(a, b, rtol=rtol, atol=atol))
+    # the level label of a synthetic line IS its minimal string
+    m_sbm.extract_quanta_HITRAN = lambda mol, iso, s: (s.strip(), None, None)
+    m_sbm.find_molec_metadata = lambda mol, iso: {"iso_MM": float("nan"), "iso_ratio": float("nan")}
+    sys.modules.update({"lineshape": m_ls, "fparts_mod": m_fp, "spect_base_module": m_sbm,
+                        "cPickle": pickle})
+    sys.path.insert(0, REF)
+    import spect_classes as spcl  # the reference, unmodified
+    return spcl, RF
+
+
+class Level(object):
+    def __init__(self, name, energy):
+        self.name, self.energy = name, energy
+
+    def minimal_level_string(self):
+        return self.name
+
+
+class IsoMolec(object):
+    def __init__(self, mol, iso, MM, level_energies):
+        self.mol, self.iso, self.MM = mol, iso, MM
+        self.levels = []
+        for i, e in enumerate(level_energies):
+            nm = "lev_%02d" % i
+            self.levels.append(nm)
+            setattr(self, nm, Level("L%02d" % i, float(e)))
+
+
+def ref_lines(spcl, mol, iso, L, labels=True):
+    out = []
+    for i in range(len(L["freq"])):
+        up = ("L%02d" % L["lev_up"][i]) if (labels and L["lev_up"][i] >= 0) else "??"
+        lo = ("L%02d" % L["lev_lo"][i]) if (labels and L["lev_lo"][i] >= 0) else "??"
+        vals = [mol, iso, float(L["freq"][i]), 0.0, float(L["a_coeff"][i]), float(L["air_broad"][i]), 0.0,
+                float(L["e_lower"][i]), float(L["t_dep_broad"][i]), 0.0, up, lo, "", "", "",
+                float(L["g_up"][i]), float(L["g_lo"][i])]
+        out.append(spcl.SpectLine(vals, nomi=spcl.cose_hit))
+    return out
+
+
+def ref_abscoeff(spcl, grid, lines, isomolec, temps, press, tvib):
+    """The reference's useLUTs=False path with its own objects: PrepareCalcShapes
+    (spcl:1440) after the LinkToMolec filter of calc_shapes_lines (spcl:1384-1388),
+    one SpectralGcoeff per level and ctype filled as BuildCoeff selects lines
+    (spcl:1304-1321) -- accumulated with the reference's NumPy accumulate
+    add_to_spectrum (spcl:929) because add_lines_to_spectrum needs Python-2
+    integer division and a 4 GB matrix -- then the population-weighted combine of
+    make_abscoeff_isomolec (smm:2036-2080) with the reference's operators."""
+    sg = spcl.SpectralGrid(grid, units="cm_1")
+    ctypes_ = ["sp_emission", "ind_emission", "absorption"]
+    abs_out, emi_out, integ = [], [], []
+    for k, (P, T) in enumerate(zip(press, temps)):
+        lin = lines
+        if len(isomolec.levels) > 0:
+            oks = [l.LinkToMolec(isomolec) for l in lin]
+            lin = [l for l, ok in zip(lin, oks) if ok]
+        lin = spcl.PrepareCalcShapes(sg, lin, T, P, isomolec)
+        integ.append([l.shape.integrate() for l in lin[:5]])
+        zero = lambda: spcl.SpectralObject(np.zeros(len(grid)), sg)
+        abs_c, emi_c = zero(), zero()
+        Q = spcl.CalcPartitionSum(isomolec.mol, isomolec.iso, temp=T)
+        if len(isomolec.levels) == 0:
+            G = {}
+            for ct in ctypes_:
+                g = spcl.SpectralGcoeff(ct, sg, isomolec.mol, isomolec.iso, isomolec.MM, "",
+                                        unidentified_lines=True)
+                for l in lin:
+                    g.add_to_spectrum(l.shape, Strength=l.G_coeffs[ct])
+                G[ct] = g
+            pop = 1 / Q
+            abs_c += G["absorption"] * pop
+            abs_c -= G["ind_emission"] * pop
+            emi_c += G["sp_emission"] * pop
+        else:
+            for li, lev in enumerate(isomolec.levels):
+                levello = getattr(isomolec, lev)
+                G = {}
+                for ct in ctypes_:
+                    g = spcl.SpectralGcoeff(ct, sg, isomolec.mol, isomolec.iso, isomolec.MM,
+                                            levello.minimal_level_string())
+                    if ct in ("sp_emission", "ind_emission"):
+                        sel = [l for l in lin if g.lev_string == l.minimal_level_string_up()]
+                    else:
+                        sel = [l for l in lin if g.lev_string == l.minimal_level_string_lo()]
+                    for l in sel:
+                        g.add_to_spectrum(l.shape, Strength=l.G_coeffs[ct])
+                    G[ct] = g
+                vibt = T if tvib is None else tvib[li][k]
+                pop = spcl.Boltz_ratio_nodeg(levello.energy, vibt) / Q
+                abs_c += G["absorption"] * pop
+                abs_c -= G["ind_emission"] * pop
+                emi_c += G["sp_emission"] * pop
+        abs_out.append(abs_c.spectrum.copy())
+        emi_out.append(emi_c.spectrum.copy())
+    return np.array(abs_out), np.array(emi_out), np.array(integ)
+
+
+def main():
+    spcl, RF = import_reference_spcl()
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(20260001)
+    ln2 = math.log(2.0)
+
+    consts = dict(h_cgs=spcl.h_cgs, c_cgs=spcl.c_cgs, k_cgs=spcl.k_cgs, c2=spcl.c2,
+                  hpa_to_atm=spcl.hpa_to_atm, T_ref=spcl.T_ref)
+    print("constants", consts)
+
+    # ---------------- A1: humliv windows (compiled Fortran) ----------------
+    grid = syn.make_grid(2975.0, 5e-4, 100000)
+    sg = spcl.SpectralGrid(grid, units="cm_1")
+    lin_grid = np.arange(-spcl.imxsig * sg.step() / 2, spcl.imxsig * sg.step() / 2, sg.step(), dtype=float)
+    assert len(lin_grid) == 13010
+    cases = []
+    # (T, P_hPa, n_air, gamma, MM) -> ry from ~1e-8 (Doppler) to ~80 (Lorentz)
+    for P in (2e-7, 1e-4, 1e-2, 0.5, 3.0, 10.0, 150.0, 1013.25, 8000.0):
+        for frac in (0.0, 0.37):
+            T = float(rng.uniform(90, 200))
+            nu0 = float(grid[40000] + frac * sg.step() + rng.integers(0, 2000) * sg.step())
+            cases.append((T, P, float(rng.uniform(.55, .85)), float(rng.uniform(.04, .08)), 16.0313, nu0))
+    cases.append((70.0, 1.0, 0.7, 0.06, 27.994915, float(grid[50000] - 0.49 * sg.step())))  # CO-like
+    X, Y, par = [], [], []
+    for (T, P, n_air, gam, MM, nu0) in cases:
+        ic, fr = spcl.closest_grid(sg, nu0)
+        x = lin_grid + fr
+        lw = spcl.Lorenz_width(T, spcl.convert_to_atm(P), n_air, gam)
+        dw = spcl.Doppler_width(T, MM, nu0)
+        y = RF.humliv_bb(x, 1, 13010, nu0, lw, dw / math.sqrt(ln2))
+        X.append(x)
+        Y.append(y)
+        par.append([nu0, lw, dw / math.sqrt(ln2), T, P, n_air, gam, MM, ic])
+    # outer branches of humliv_bb (x0 outside the window) and the scalar humli_bb
+    xo = lin_grid + grid[50000]
+    outer = []
+    for x0, lw, dwp in ((xo[0] - 0.013, 2e-3, 4e-3), (xo[0], 1e-4, 4e-3), (xo[-1] + 0.02, 3e-3, 3.5e-3),
+                        (xo[-1], 5e-2, 4e-3), (xo[0] - 5.0, 1e-3, 4e-3), (xo[-1] + 4.0, 1e-3, 4e-3)):
+        outer.append((x0, lw, dwp, RF.humliv_bb(xo, 1, 13010, x0, lw, dwp)))
+    rxs = rng.uniform(0, 20, 64)
+    rys = 10.0 ** rng.uniform(-6, 1.3, 64)
+    hum = np.array([RF.humli_bb(float(a), float(b)) for a, b in zip(rxs, rys)])
+    np.savez_compressed(os.path.join(HERE, "humliv_windows.npz"), x=np.array(X), y=np.array(Y),
+                        par=np.array(par), par_names="nu0 lw dw_over_sqrtln2 T P n_air gamma MM ic",
+                        outer_x=xo, outer_par=np.array([o[:3] for o in outer]),
+                        outer_y=np.array([o[3] for o in outer]), humli_rx=rxs, humli_ry=rys, humli_y=hum)
+    print("humliv_windows: %d cases, ry range %.2e..%.2e" % (len(cases), min(p[1] / p[2] for p in par),
+                                                            max(p[1] / p[2] for p in par)))
+
+    # ---------------- A7: TIPS tables + CalcPartitionSum ----------------
+    tips = {}
+    molparam_isos = {1: 6, 2: 9, 3: 5, 4: 5, 5: 6, 6: 3, 7: 3, 8: 3, 9: 2, 10: 1, 11: 2, 12: 1, 13: 3,
+                     14: 1, 15: 2, 16: 2, 17: 1, 18: 2, 19: 5, 20: 3, 21: 2, 22: 1, 23: 3, 24: 2,
+                     25: 1, 26: 2, 27: 1, 28: 1, 29: 1, 31: 3, 32: 1, 33: 1, 34: 1, 35: 2, 36: 1,
+                     37: 2, 38: 2}
+    keys, gis, tabs = [], [], []
+    tgrid = None
+    for mol, niso in molparam_isos.items():
+        for iso in range(1, niso + 1):
+            gi, t, q = RF.bd_tips_2003(mol, iso)
+            if not np.all(np.isfinite(q)) or q[0] <= 0:
+                continue
+            tgrid = t
+            keys.append((mol, iso))
+            gis.append(gi)
+            tabs.append(q)
+    smp = []
+    for (mol, iso) in ((6, 1), (5, 1), (23, 1), (26, 1), (27, 1), (38, 1), (6, 2)):
+        for T in (60.0, 70.0, 84.99, 85.0, 110.0, 149.3, 175.0, 212.654, 296.0, 300.0, 1000.0):
+            smp.append([mol, iso, T, float(spcl.CalcPartitionSum(mol, iso, temp=T))])
+    np.savez_compressed(os.path.join(HERE, "tips2003.npz"), keys=np.array(keys), gi=np.array(gis),
+                        t_grid=tgrid, q_tab=np.array(tabs), samples=np.array(smp))
+    print("tips2003: %d (mol,iso) tables; Q(CH4,150)=%r" % (len(keys), spcl.CalcPartitionSum(6, 1, 150.0)))
+
+    # ---------------- A10: curgods ----------------
+    cg = []
+    for n_p, H in ((6, 45.0), (40, 60.0), (300, 33.0)):
+        xk = np.sort(rng.uniform(0, 400, n_p)) * 1e5  # cm
+        z = np.linspace(100, 500, n_p)
+        nd = 1e16 * np.exp(-(z - 100) / H) * (1 + 0.05 * rng.standard_normal(n_p))
+        vmr = 1e-2 * (1 + 0.3 * np.sin(z / 50.0))
+        f = 0.5 + 0.4 * np.cos(z / 70.0)
+        r = [RF.curgod(1, nd, xk), RF.curgod(2, nd, xk, vmr), RF.curgod(3, nd, xk, vmr, f),
+             RF.curgod(4, nd, xk, vmr, f)]
+        cg.append(dict(nd=nd, x=xk, vmr=vmr, f=f, res=np.array(r)))
+    np.savez_compressed(os.path.join(HERE, "curgods.npz"),
+                        **{"%s_%d" % (k, i): v for i, c in enumerate(cg) for k, v in c.items()})
+
+    # ---------------- A3/A4: scalar functions of spect_classes.py ----------------
+    n = 64
+    T = rng.uniform(60, 320, n)
+    P = 10.0 ** rng.uniform(-7, 3, n)
+    n_air = rng.uniform(.4, .9, n)
+    gam = rng.uniform(.02, .1, n)
+    MM = rng.choice([16.0313, 27.994915, 27.010899, 26.01565], n)
+    nu = rng.uniform(600, 4500, n)
+    A = 10.0 ** rng.uniform(-3, 2, n)
+    El = rng.uniform(0, 3000, n)
+    gu = rng.integers(1, 200, n).astype(float)
+    gl = rng.integers(1, 200, n).astype(float)
+    Evu = rng.uniform(0, 3000, n)
+    Evl = rng.uniform(0, 1500, n)
+    lw = np.array([spcl.Lorenz_width(T[i], spcl.convert_to_atm(P[i]), n_air[i], gam[i]) for i in range(n)])
+    dw = np.array([spcl.Doppler_width(T[i], MM[i], nu[i]) for i in range(n)])
+    G = np.zeros((n, 3))
+    S = np.zeros(n)
+    for i in range(n):
+        l = spcl.SpectLine([6, 1, nu[i], 0.0, A[i], gam[i], 0.0, El[i], n_air[i], 0.0, "a", "b", "", "", "",
+                            gu[i], gl[i]], nomi=spcl.cose_hit)
+        G[i] = [spcl.Einstein_A_to_Gcoeff_spem(l, T[i], Evu[i]), spcl.Einstein_A_to_Gcoeff_indem(l, T[i], Evu[i]),
+                spcl.Einstein_A_to_Gcoeff_abs(l, T[i], Evl[i])]
+        S[i] = spcl.Einstein_A_to_LineStrength_hitran(A[i], nu[i], T[i], 1.0, gu[i], El[i])
+    bb = np.array([spcl.Calc_BB_single(nu[i], T[i]) for i in range(n)])
+    br = np.array([spcl.Boltz_ratio_nodeg(El[i], T[i]) for i in range(n)])
+    cgi = np.array([spcl.closest_grid(sg, float(v))[0] for v in
+                    list(grid[1000] + sg.step() * np.array([0.0, 0.5, 0.4999, 0.5001, -0.5, 1e-9])) +
+                    [grid[0] - 1.0, grid[-1] + 1.0]])
+    cgv = np.array(list(grid[1000] + sg.step() * np.array([0.0, 0.5, 0.4999, 0.5001, -0.5, 1e-9])) +
+                   [grid[0] - 1.0, grid[-1] + 1.0])
+    np.savez_compressed(os.path.join(HERE, "spcl_scalars.npz"), T=T, P=P, n_air=n_air, gam=gam, MM=MM, nu=nu,
+                        A=A, El=El, gu=gu, gl=gl, Evu=Evu, Evl=Evl, lw=lw, dw=dw, G=G, S_hitran_Q1=S, bb=bb,
+                        boltz=br, closest_in=cgv, closest_idx=cgi, grid_w0=grid[0], grid_step=sg.step(),
+                        grid_n=len(grid), **{"const_" + k: v for k, v in consts.items()})
+
+    # ---------------- end to end, CH4-like non-LTE levels ----------------
+    n_grid = 16000  # 8 cm^-1: windows (6.5 cm^-1) are clipped at one or both ends for most lines
+    g2 = syn.make_grid(2990.0, 5e-4, n_grid)
+    L = syn.make_lines(200, g2, config_id=101, n_levels=4)
+    # pin the quirks: unidentified levels and lev_up == lev_lo lines are dropped
+    L["lev_up"][5] = -1
+    L["lev_lo"][9] = -1
+    L["lev_lo"][12] = L["lev_up"][12]
+    L["lev_lo"][40] = L["lev_up"][40]
+    L["a_coeff"][17] = 0.0            # 'linea non defined' -> zero G (spcl:326-337)
+    L["freq"][0] = g2[0] + 1e-7       # window clipped left
+    L["freq"][-1] = g2[-1] - 1e-7     # window clipped right
+    L["freq"] = np.sort(L["freq"])
+    e_lev = np.array([0.0, 1311.0, 1533.0, 3019.0])
+    iso = IsoMolec(6, 1, syn.CH4_MM, e_lev)
+    temps = np.array([172.3, 148.9, 131.0])
+    press = np.array([8.0, 0.31, 2.2e-5])
+    tvib = np.array([temps, temps + 11.0, temps + 23.5, temps + 35.25])
+    lines = ref_lines(spcl, 6, 1, L)
+    ab, em, integ = ref_abscoeff(spcl, g2, lines, iso, temps, press, tvib)
+    ab_lte, em_lte, _ = ref_abscoeff(spcl, g2, ref_lines(spcl, 6, 1, L), iso, temps[:1], press[:1], None)
+    qpart = np.array([float(spcl.CalcPartitionSum(6, 1, temp=t)) for t in temps])
+    np.savez_compressed(os.path.join(HERE, "e2e_ch4_levels.npz"), grid_w0=g2[0], grid_step=g2[1] - g2[0],
+                        grid_n=n_grid, mm=syn.CH4_MM, mol=6, iso=1, e_lev=e_lev, temps=temps, press=press,
+                        tvib=tvib, q_part=qpart, abs=ab, emi=em, abs_lte0=ab_lte, emi_lte0=em_lte,
+                        shape_integrals=integ, **{"line_" + k: v for k, v in L.items()})
+    print("e2e_ch4_levels: abs max %.3e, shape integrals %s" % (ab.max(), integ[0][:3]))
+
+    # ---------------- end to end, CO-like 'all' set (BASELINE configs[0] shape) ----------------
+    g3 = syn.make_grid(2100.0, 5e-4, 10000)
+    Lc = syn.make_lines(500, g3, config_id=1, n_levels=0, co_like=True)
+    iso_co = IsoMolec(5, 1, syn.CO_MM, [])
+    atm = syn.make_atmosphere(40, 0)
+    sel = np.array([0, 7, 15, 23, 31, 39])
+    abc, emc, _ = ref_abscoeff(spcl, g3, ref_lines(spcl, 5, 1, Lc, labels=False), iso_co, atm["temps"][sel],
+                               atm["press"][sel], None)
+    qco = np.array([float(spcl.CalcPartitionSum(5, 1, temp=t)) for t in atm["temps"]])
+    np.savez_compressed(os.path.join(HERE, "e2e_co_all.npz"), grid_w0=g3[0], grid_step=g3[1] - g3[0], grid_n=10000,
+                        mm=syn.CO_MM, mol=5, iso=1, temps=atm["temps"], press=atm["press"], q_part=qco,
+                        layer_sel=sel, abs=abc, emi=emc, **{"line_" + k: v for k, v in Lc.items()})
+    print("e2e_co_all: abs max %.3e" % abc.max())
+
+
+if __name__ == "__main__":
+    main()
