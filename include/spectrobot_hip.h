@@ -1,0 +1,185 @@
+/*
+ * spectrobot_hip.h -- C ABI of libspectrobot_hip.so, the MI355X (gfx950) engine
+ * for SpectRobot's spectral hot path: per-line Voigt evaluation and per-layer
+ * absorption / emission coefficient accumulation, plus the Curtis-Godson column
+ * integrals and the limb radiance recursion that consume them.
+ *
+ * This is the drop-in boundary.  The reference reaches this path through three
+ * f2py extension modules (`import lineshape`, `import fparts_mod`, `import
+ * curgods`; spect_classes.py:18, 1685 and the absent spect_base_module) and
+ * through the Python entry points spect_classes.calc_shapes_lines
+ * (spect_classes.py:1378) + LutSet.add_PT (spect_main_module.py:1122) called
+ * from make_abscoeff_isomolec(..., useLUTs=False) (spect_main_module.py:1880).
+ * Each entry point below names the reference interface it replaces.  Plain
+ * pointers and sizes only; no exceptions cross the boundary; every function
+ * returns SR_OK (0) or a negative sr_status (the Fortran `stop`s of
+ * lineshape.f:253-264 become SR_ERR_ARG).  All buffers are caller-owned.
+ *
+ * Pointer spaces: functions suffixed `_dev` take DEVICE pointers for the bulk
+ * in/out arrays (HBM-resident data path); the others take HOST pointers and
+ * stage through the device themselves (compat shims).  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).
+ */
+#ifndef SPECTROBOT_HIP_H
+#define SPECTROBOT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  SR_OK = 0,
+  SR_ERR_ARG = -1,      /* bad argument (also: where humliv_bb would `stop`) */
+  SR_ERR_LIMIT = -2,    /* a documented size limit exceeded */
+  SR_ERR_HIP = -3,      /* HIP runtime error, see sr_last_error() */
+  SR_ERR_NODEVICE = -4, /* no gfx950 device visible */
+  SR_ERR_UNSUPPORTED = -5,
+  SR_ERR_TABLE = -6     /* (mol, iso) not in the TIPS-2003 tables */
+} sr_status;
+
+#define SR_IMXSIG 13010 /* parameters.inc:65 -- points per line window */
+#define SR_MAX_LEVELS 64
+
+const char *sr_strerror(int status);
+const char *sr_last_error(void); /* text of the last HIP failure on this thread */
+int sr_abi_version(void);
+
+/* Device selection / query (one process per GPU: call once per rank). */
+int sr_set_device(int device);
+int sr_device_info(char *name, int name_len, int *cu_count, double *hbm_gib);
+
+/* ------------------------------------------------------------------------ *
+ * Fine-grained shims: the f2py call shapes, one reference routine each.     *
+ * Host pointers.  All evaluated on the GPU.                                  *
+ * ------------------------------------------------------------------------ */
+
+/* lineshape.humliv_bb(x, i1, i2, x0, lw, dw) -> y      (lineshape.f:226-569)
+ * x[n], y[n]; i1,i2 1-based inclusive.  The reference only ever calls it with
+ * x(i1) < x0 < x(i2); x0 outside the window returns
+ * SR_ERR_UNSUPPORTED. */
+int sr_humliv_bb(const double *x, int n, int i1, int i2, double x0, double lw,
+                 double dw, double *y);
+
+/* lineshape.sum_all_lines(spe_ini, matrix, init, fin, n_lines, n_spe)
+ * (lineshape.f:2-25).  spe[n_spe] is updated in place; rows is row-major
+ * [n_lines][row_len] (the Fortran's matrix(ilin, i)); init/fin 1-based. */
+int sr_sum_all_lines(double *spe, int64_t n_spe, const double *rows,
+                     const int32_t *init, const int32_t *fin, int n_lines,
+                     int row_len);
+
+/* fparts_mod.bd_tips_2003(MOL, ISO) -> gi, t_grid[119], QT_grid[119]
+ * (fparts_mod.f:33-295). */
+int sr_bd_tips_2003(int mol, int iso, double *gi, double *t_grid119,
+                    double *qt_grid119);
+
+/* spect_classes.CalcPartitionSum(mol, iso, temp) (spect_classes.py:1692-1710),
+ * vectorised over temps[n]. */
+int sr_calc_partition_sum(int mol, int iso, const double *temps, int n,
+                          double *q_out);
+
+/* curgods.curgod_fort_{1..4}(nd, [vmr, [f,]] x, n_p) -> res (curgods.f:2-98),
+ * batched: segment s covers samples off[s] .. off[s+1]-1 of the concatenated
+ * arrays; res[n_seg].  vmr / f may be NULL for the variants that do not use
+ * them. */
+int sr_curgod(int which, const double *nd, const double *vmr, const double *f,
+              const double *x, const int32_t *off, int n_seg, double *res);
+
+/* ------------------------------------------------------------------------ *
+ * Coarse-grained op: the real hot path.                                      *
+ * ------------------------------------------------------------------------ */
+
+/* Line list of one iso-molecule, structure of arrays, host pointers
+ * (SpectLine fields, spect_classes.py:50-51). lev_up/lev_lo: index into the
+ * level table or -1 (unidentified); ignored when n_levels == 0. */
+typedef struct {
+  int64_t n_lines;
+  const double *freq;        /* Freq        cm^-1 */
+  const double *a_coeff;     /* A_coeff     s^-1  */
+  const double *e_lower;     /* E_lower     cm^-1 */
+  const double *g_up, *g_lo; /* statistical weights */
+  const double *air_broad;   /* Air_broad   cm^-1/atm */
+  const double *t_dep_broad; /* T_dep_broad */
+  const int32_t *lev_up, *lev_lo;
+} sr_lines_desc;
+
+/* The iso-molecule the lines belong to (sbm IsoMolec as the path uses it:
+ * .mol .iso .MM .levels[].energy). n_levels == 0 is the reference's
+ * "unidentified_lines" / 'all' set (spect_main_module.py:1937-1953). */
+typedef struct {
+  int mol, iso;
+  double mm;
+  int n_levels;
+  const double *level_energy; /* [n_levels] cm^-1 */
+} sr_isomolec_desc;
+
+/* Spectral grid as prepare_spe_grid builds it (spect_main_module.py:1262-1272):
+ * grid[j] = w0 + j*step (numpy arange), j < n_grid <= 2e6 (imxsig_long). */
+typedef struct {
+  double w0, step;
+  int64_t n_grid;
+} sr_grid_desc;
+
+typedef struct sr_lineset sr_lineset; /* opaque, device resident */
+
+/* Upload a line list.  Replaces the per-call Python list of SpectLine objects
+ * handed to calc_shapes_lines (spect_classes.py:1378).  Applies the reference's
+ * line filter (spect_classes.py:1384-1388 with LinkToMolec 122-150), finds each
+ * line's window centre (closest_grid, spect_classes.py:1937-1943) and sorts by
+ * centre.  n_kept (may be NULL) receives the number of lines retained. */
+int sr_lineset_create(const sr_lines_desc *lines, const sr_isomolec_desc *iso,
+                      const sr_grid_desc *grid, sr_lineset **out,
+                      int64_t *n_kept);
+int sr_lineset_destroy(sr_lineset *ls);
+
+/* Layer stack (the Temps / Press lists of make_abscoeff_isomolec,
+ * spect_main_module.py:1880, plus level.local_vibtemp, :2065). Host pointers.
+ * tvib: [n_levels][n_layers] or NULL for LTE (:2062-2063).  q_part: [n_layers]
+ * or NULL to have the library evaluate CalcPartitionSum(mol, iso, T). */
+typedef struct {
+  int n_layers;
+  const double *temps; /* K   */
+  const double *press; /* hPa */
+  const double *tvib;
+  const double *q_part;
+} sr_layers_desc;
+
+/* abs/emi coefficient spectra for every layer over the grid shard
+ * [g_lo, g_hi): what make_abscoeff_isomolec(..., useLUTs=False) returns as
+ * AbsSetLOS lists (spect_main_module.py:2128-2131), i.e. calc_shapes_lines +
+ * add_PT + the population-weighted combine (:1974-1990, :2036-2080).
+ * abs_out / emi_out: DEVICE pointers, [n_layers][g_hi-g_lo] doubles. */
+int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm,
+                           int64_t g_lo, int64_t g_hi, double *abs_out,
+                           double *emi_out, void *stream);
+/* Same with HOST output buffers (copies back; PCIe-inclusive). */
+int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo,
+                       int64_t g_hi, double *abs_out, double *emi_out);
+
+/* Limb radiance recursion for a batch of rays over the shard (the build's own
+ * definition standing in for the absent sbm LineOfSight.radtran_fast, call
+ * sites spect_main_module.py:2838, 3214; parity unpinned):
+ * ray r crosses segments seg_off[r] .. seg_off[r+1]-1 in photon order; segment
+ * s applies layer seg_layer[s] with absorber column seg_col[s] (cm^-2):
+ *   tau = abs*col;  I <- I*exp(-tau) + emi*col*(1-exp(-tau))/tau.
+ * abs_c/emi_c: DEVICE [n_layers][n_pts]; rad: DEVICE [n_rays][n_pts], read as
+ * the initial intensity when init_from_rad != 0, else started from 0.
+ * seg_* are HOST arrays. */
+int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers,
+                         int64_t n_pts, int n_rays, const int32_t *seg_off,
+                         const int32_t *seg_layer, const double *seg_col,
+                         int init_from_rad, double *rad, void *stream);
+
+/* Tuning knob of sr_abscoeff_kernel: grid points per lane (1, 2 or 4; default 4). */
+int sr_set_points_per_lane(int p);
+
+/* Timing hook for bench.py: HIP-event time (ms) of the dominant kernel
+ * (sr_abscoeff_kernel) in the most recent sr_abscoeff_layers* call on this
+ * lineset, measured on the stream it was launched on.  Synchronises. */
+int sr_last_kernel_ms(sr_lineset *ls, float *prep_ms, float *main_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,38 @@
+"""Build libspectrobot_hip.so for gfx950 with hipcc (in-tree, no JIT cache)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "lib", "libspectrobot_hip.so")
+SOURCES = ["sr_api.hip", "sr_kernels.hip"]
+DEPS = SOURCES + ["sr_device.hpp", "sr_kernels.hpp", "tips2003_tables.inc", "../../include/spectrobot_hip.h"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def up_to_date():
+    if not os.path.exists(OUT):
+        return False
+    t = os.path.getmtime(OUT)
+    return all(os.path.getmtime(os.path.join(CSRC, d)) <= t for d in DEPS) and \
+        os.path.getmtime(os.path.abspath(__file__)) <= t
+
+
+def build(force=False, verbose=False, extra=()):
+    if not force and up_to_date():
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [HIPCC] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True,
+          extra=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])
+    print(OUT)

@@ -1,0 +1,607 @@
+// sr_api.hip -- host side of libspectrobot_hip.so: the C ABI of
+// include/spectrobot_hip.h on top of the kernels in sr_kernels.hip.
+//
+// Host work is limited to what the reference also does once per call in plain
+// Python: line filtering / window centres (spect_classes.py:1384-1388, 1937-1943),
+// per-layer scalars and level populations (spect_main_module.py:2049-2073),
+// TIPS-2003 lookup + 4-point Lagrange (spect_classes.py:1680-1710).  Every
+// per-(line, layer) and per-grid-point quantity is computed on the GPU; there is
+// no CPU fallback for any of it.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/spectrobot_hip.h"
+#include "sr_kernels.hpp"
+#include "tips2003_tables.inc"
+
+using namespace sr;
+
+namespace {
+
+thread_local std::string g_err;
+
+int hip_fail(hipError_t e, const char *what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return SR_ERR_HIP;
+}
+#define HIPCHK(expr)                                  \
+  do {                                                \
+    hipError_t e__ = (expr);                          \
+    if (e__ != hipSuccess) return hip_fail(e__, #expr); \
+  } while (0)
+#define LAUNCHCHK(expr)                                              \
+  do {                                                               \
+    int e__ = (expr);                                                \
+    if (e__ != 0) return hip_fail((hipError_t)e__, "kernel launch"); \
+  } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return SR_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(hipMalloc(&p, want));
+    cap = want;
+    return SR_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// Pinned host staging buffer with a device mirror: fill host(), then push() on
+// the caller's stream; the next prepare() waits for the previous copy only.
+struct Stager {
+  void *h = nullptr;
+  size_t hcap = 0;
+  DevBuf d;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+  int prepare(size_t bytes) {
+    if (pending) {
+      HIPCHK(hipEventSynchronize(done));
+      pending = false;
+    }
+    if (!done) HIPCHK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    if (bytes > hcap) {
+      if (h) (void)hipHostFree(h);
+      h = nullptr;
+      hcap = 0;
+      const size_t want = bytes + bytes / 8 + 256;
+      HIPCHK(hipHostMalloc(&h, want, hipHostMallocDefault));
+      hcap = want;
+    }
+    return d.ensure(std::max<size_t>(bytes, 16));
+  }
+  int push(size_t bytes, hipStream_t st) {
+    if (bytes) HIPCHK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(done, st));
+    pending = true;
+    return SR_OK;
+  }
+  void release() {
+    if (pending && done) (void)hipEventSynchronize(done);
+    pending = false;
+    if (h) (void)hipHostFree(h);
+    h = nullptr;
+    hcap = 0;
+    d.release();
+    if (done) (void)hipEventDestroy(done);
+    done = nullptr;
+  }
+  template <class T> T *host() const { return static_cast<T *>(h); }
+};
+
+// ---- TIPS-2003 (fparts_mod.f:33-295) + CalcPartitionSum (spect_classes.py:1692-1710) ----
+int tips_row(int mol, int iso) {
+  for (int i = 0; i < kTipsNTab; ++i)
+    if (kTipsKey[i][0] == mol && kTipsKey[i][1] == iso) return i;
+  return -1;
+}
+
+// scipy.interpolate.lagrange through the two table points <= T and the two > T:
+// polynomial assembled in coefficient form by successive products with
+// (x - x_k)/(x_j - x_k), summed, then evaluated by Horner -- the order of
+// operations of scipy's poly1d arithmetic, which the result depends on at 1e-13.
+double lagrange4(const double *tg, const double *qg, int n, double temp) {
+  double xs[4], qs[4];
+  int m = 0, n_le = 0;
+  while (n_le < n && tg[n_le] <= temp) ++n_le;
+  for (int i = std::max(0, n_le - 2); i < n_le; ++i, ++m) { xs[m] = tg[i]; qs[m] = qg[i]; }
+  for (int i = n_le; i < std::min(n, n_le + 2); ++i, ++m) { xs[m] = tg[i]; qs[m] = qg[i]; }
+  std::vector<double> poly(1, 0.0);
+  for (int j = 0; j < m; ++j) {
+    std::vector<double> pt(1, qs[j]);
+    for (int k = 0; k < m; ++k) {
+      if (k == j) continue;
+      const double fac = xs[j] - xs[k];
+      const double f0 = 1.0 / fac, f1 = -xs[k] / fac;
+      std::vector<double> nx(pt.size() + 1, 0.0);
+      for (size_t i = 0; i < nx.size(); ++i) {
+        double s = 0.0;
+        if (i < pt.size()) s += pt[i] * f0;
+        if (i >= 1) s += pt[i - 1] * f1;
+        nx[i] = s;
+      }
+      pt.swap(nx);
+    }
+    if (pt.size() > poly.size()) poly.insert(poly.begin(), pt.size() - poly.size(), 0.0);
+    const size_t off = poly.size() - pt.size();
+    for (size_t i = 0; i < pt.size(); ++i) poly[off + i] += pt[i];
+  }
+  double y = 0.0;
+  for (double c : poly) y = y * temp + c;
+  return y;
+}
+
+int g_variant = 4; // points per lane in sr_abscoeff_kernel
+
+} // namespace
+
+struct sr_lineset {
+  int64_t n_lines = 0; // kept
+  GridParams gp{};
+  int mol = 0, iso = 0, n_levels = 0;
+  double mm = 0.0;
+  std::vector<double> e_lev;
+  std::vector<int> ic; // host copy, sorted
+  DevBuf d_lines;      // one allocation, carved below
+  LinesDev L{};
+  Stager s_layers;
+  DevBuf d_fast, d_cold;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  bool timed = false;
+};
+
+extern "C" {
+
+const char *sr_strerror(int s) {
+  switch (s) {
+    case SR_OK: return "ok";
+    case SR_ERR_ARG: return "bad argument";
+    case SR_ERR_LIMIT: return "size limit exceeded";
+    case SR_ERR_HIP: return "HIP runtime error";
+    case SR_ERR_NODEVICE: return "no gfx950 device";
+    case SR_ERR_UNSUPPORTED: return "unsupported input";
+    case SR_ERR_TABLE: return "(mol, iso) not in TIPS-2003 tables";
+    default: return "unknown status";
+  }
+}
+const char *sr_last_error(void) { return g_err.c_str(); }
+int sr_abi_version(void) { return 1; }
+
+int sr_set_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_err = "no HIP device visible";
+    return SR_ERR_NODEVICE;
+  }
+  if (device < 0 || device >= n) return SR_ERR_ARG;
+  HIPCHK(hipSetDevice(device));
+  return SR_OK;
+}
+
+int sr_device_info(char *name, int name_len, int *cu_count, double *hbm_gib) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return SR_ERR_NODEVICE;
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, dev));
+  if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (hbm_gib) *hbm_gib = (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0);
+  return SR_OK;
+}
+
+int sr_set_points_per_lane(int p) {
+  if (p != 1 && p != 2 && p != 4) return SR_ERR_ARG;
+  g_variant = p;
+  return SR_OK;
+}
+
+// ------------------------------------------------------------------------
+int sr_bd_tips_2003(int mol, int iso, double *gi, double *t_grid119, double *qt_grid119) {
+  const int r = tips_row(mol, iso);
+  if (r < 0) return SR_ERR_TABLE;
+  if (gi) *gi = kTipsGi[r];
+  if (t_grid119) std::memcpy(t_grid119, kTipsT, sizeof(double) * kTipsNT);
+  if (qt_grid119) std::memcpy(qt_grid119, kTipsQ[r], sizeof(double) * kTipsNT);
+  return SR_OK;
+}
+
+int sr_calc_partition_sum(int mol, int iso, const double *temps, int n, double *q_out) {
+  if (!temps || !q_out || n < 0) return SR_ERR_ARG;
+  const int r = tips_row(mol, iso);
+  if (r < 0) return SR_ERR_TABLE;
+  for (int i = 0; i < n; ++i) q_out[i] = lagrange4(kTipsT, kTipsQ[r], kTipsNT, temps[i]);
+  return SR_OK;
+}
+
+// ------------------------------------------------------------------------
+int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, const sr_grid_desc *gd,
+                      sr_lineset **out, int64_t *n_kept) {
+  if (!ld || !iso || !gd || !out) return SR_ERR_ARG;
+  *out = nullptr;
+  if (ld->n_lines < 0 || iso->n_levels < 0 || !(gd->step > 0.0) || !(iso->mm > 0.0)) return SR_ERR_ARG;
+  if (gd->n_grid < 2) return SR_ERR_ARG;
+  if (gd->n_grid > 2000000) return SR_ERR_LIMIT;             // imxsig_long, spect_classes.py:29,362
+  if (iso->n_levels > SR_MAX_LEVELS) return SR_ERR_LIMIT;
+  if (ld->n_lines > 0 && (!ld->freq || !ld->a_coeff || !ld->e_lower || !ld->g_up || !ld->g_lo ||
+                          !ld->air_broad || !ld->t_dep_broad))
+    return SR_ERR_ARG;
+  if (iso->n_levels > 0 && (!iso->level_energy || (ld->n_lines > 0 && (!ld->lev_up || !ld->lev_lo))))
+    return SR_ERR_ARG;
+
+  GridParams gp;
+  gp.w0 = gd->w0;
+  gp.gstep = gd->step;
+  gp.n_grid = (int)gd->n_grid;
+  // spect_classes.py:1446: np.arange(-imxsig*s/2, imxsig*s/2, s) = start + m*delta
+  gp.lin_start = -(double)kImxsig * gp.gstep / 2;
+  {
+    const double lin_stop = (double)kImxsig * gp.gstep / 2;
+    const double len = std::ceil((lin_stop - gp.lin_start) / gp.gstep);
+    if (len != (double)kImxsig) {
+      g_err = "np.arange window would not have 13010 points for this step (f2py would reject it)";
+      return SR_ERR_UNSUPPORTED;
+    }
+    const double nxt = gp.lin_start + gp.gstep;
+    gp.lin_delta = nxt - gp.lin_start;
+  }
+
+  const int nlev = iso->n_levels;
+  const int64_t n = ld->n_lines;
+  std::vector<int64_t> keep;
+  keep.reserve(n);
+  for (int64_t i = 0; i < n; ++i) {
+    if (nlev > 0) {
+      const int lu = ld->lev_up[i], ll = ld->lev_lo[i];
+      // LinkToMolec must find both levels; its if/elif never finds the lower
+      // level when it equals the upper one (spect_classes.py:135-150)
+      if (lu < 0 || ll < 0 || lu >= nlev || ll >= nlev || lu == ll) continue;
+    }
+    keep.push_back(i);
+  }
+  const int64_t m = (int64_t)keep.size();
+  std::vector<int> ic(m);
+  const int ng = gp.n_grid;
+  for (int64_t q = 0; q < m; ++q) {
+    const double f = ld->freq[keep[q]];
+    if (!(f == f)) return SR_ERR_ARG;
+    // closest_grid: first arg-min of |grid - f| (spect_classes.py:1941)
+    double t = std::floor((f - gp.w0) / gp.gstep);
+    long j0 = t < -4 ? -4 : (t > ng + 4 ? ng + 4 : (long)t);
+    long a = std::max<long>(0, j0 - 2), b = std::min<long>(ng - 1, j0 + 3);
+    if (a > b) { a = b = (j0 < 0 ? 0 : ng - 1); }
+    long best = a;
+    double bv = std::fabs(grid_at(gp, (int)a) - f);
+    for (long j = a + 1; j <= b; ++j) {
+      const double v = std::fabs(grid_at(gp, (int)j) - f);
+      if (v < bv) { bv = v; best = j; }
+    }
+    ic[q] = (int)best;
+    WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, (int)best)};
+    if (!(xf(1) < f && f < xf(kImxsig))) {
+      g_err = "line centre outside its 13010-point window (line farther than 3.25 cm-1 from the grid): "
+              "the reference reaches humliv_bb's outer branches here, not supported";
+      return SR_ERR_UNSUPPORTED;
+    }
+  }
+  std::vector<int64_t> ord(m);
+  std::iota(ord.begin(), ord.end(), 0);
+  std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return ic[x] < ic[y]; });
+
+  sr_lineset *ls = new sr_lineset();
+  ls->n_lines = m;
+  ls->gp = gp;
+  ls->mol = iso->mol;
+  ls->iso = iso->iso;
+  ls->mm = iso->mm;
+  ls->n_levels = nlev;
+  ls->e_lev.assign(iso->level_energy, iso->level_energy + nlev);
+  ls->ic.resize(m);
+
+  const size_t md = (size_t)std::max<int64_t>(m, 1);
+  std::vector<double> hd(12 * md, 0.0);
+  std::vector<int> hi(3 * md, 0);
+  const double h = kHcgs, c = kCcgs;
+  for (int64_t q = 0; q < m; ++q) {
+    const int64_t s = keep[ord[q]];
+    const double f = ld->freq[s];
+    const double fact_2 = 2 * h * (c * c) * std::pow(f, 3.0); // spect_classes.py:1743
+    const double b21 = ld->a_coeff[s] / fact_2;               // :1750
+    const double b12 = ld->g_lo[s] != 0.0 ? b21 * ld->g_up[s] / ld->g_lo[s] : 0.0; // :1783
+    const int lu = nlev > 0 ? ld->lev_up[s] : 0, ll = nlev > 0 ? ld->lev_lo[s] : 0;
+    double *d = hd.data();
+    d[0 * md + q] = f;
+    d[1 * md + q] = h * c * f;
+    d[2 * md + q] = ld->a_coeff[s];
+    d[3 * md + q] = b21;
+    d[4 * md + q] = b12;
+    d[5 * md + q] = ld->e_lower[s];
+    d[6 * md + q] = ld->g_up[s];
+    d[7 * md + q] = ld->g_lo[s];
+    d[8 * md + q] = ld->air_broad[s];
+    d[9 * md + q] = ld->t_dep_broad[s];
+    d[10 * md + q] = nlev > 0 ? iso->level_energy[lu] : 0.0; // spect_classes.py:318-324
+    d[11 * md + q] = nlev > 0 ? iso->level_energy[ll] : 0.0;
+    hi[0 * md + q] = ic[ord[q]];
+    hi[1 * md + q] = lu;
+    hi[2 * md + q] = ll;
+    ls->ic[q] = ic[ord[q]];
+  }
+  const size_t bytes_d = hd.size() * sizeof(double), bytes_i = hi.size() * sizeof(int);
+  int rc = ls->d_lines.ensure(bytes_d + bytes_i);
+  if (rc) { delete ls; return rc; }
+  char *base = ls->d_lines.as<char>();
+  hipError_t e = hipMemcpy(base, hd.data(), bytes_d, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(base + bytes_d, hi.data(), bytes_i, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { ls->d_lines.release(); delete ls; return hip_fail(e, "upload lines"); }
+  const double *dd = reinterpret_cast<const double *>(base);
+  const int *di = reinterpret_cast<const int *>(base + bytes_d);
+  LinesDev &L = ls->L;
+  L.freq = dd + 0 * md; L.hcf = dd + 1 * md; L.a_coeff = dd + 2 * md; L.b21 = dd + 3 * md;
+  L.b12 = dd + 4 * md; L.e_lower = dd + 5 * md; L.g_up = dd + 6 * md; L.g_lo = dd + 7 * md;
+  L.air_broad = dd + 8 * md; L.t_dep = dd + 9 * md; L.evib_up = dd + 10 * md; L.evib_lo = dd + 11 * md;
+  L.ic = di + 0 * md; L.lev_up = di + 1 * md; L.lev_lo = di + 2 * md;
+  L.n_lines = (int)m;
+  for (auto &ev : ls->ev) {
+    e = hipEventCreate(&ev);
+    if (e != hipSuccess) { sr_lineset_destroy(ls); return hip_fail(e, "hipEventCreate"); }
+  }
+  if (n_kept) *n_kept = m;
+  *out = ls;
+  return SR_OK;
+}
+
+int sr_lineset_destroy(sr_lineset *ls) {
+  if (!ls) return SR_OK;
+  ls->d_lines.release();
+  ls->s_layers.release();
+  ls->d_fast.release();
+  ls->d_cold.release();
+  for (auto &ev : ls->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  delete ls;
+  return SR_OK;
+}
+
+int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi,
+                           double *abs_out, double *emi_out, void *stream) {
+  if (!ls || !atm || !abs_out || !emi_out) return SR_ERR_ARG;
+  if (atm->n_layers <= 0 || !atm->temps || !atm->press) return SR_ERR_ARG;
+  if (g_lo < 0 || g_hi > ls->gp.n_grid || g_lo >= g_hi) return SR_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nl = atm->n_layers, nlev = ls->n_levels, npop = nlev > 0 ? nlev : 1;
+  for (int k = 0; k < nl; ++k)
+    if (!(atm->temps[k] > 0.0) || !(atm->press[k] >= 0.0)) return SR_ERR_ARG;
+
+  // per-layer scalars (host, fp64)
+  const size_t hl_bytes = sizeof(double) * (size_t)nl * (4 + npop);
+  int rc = ls->s_layers.prepare(hl_bytes);
+  if (rc) return rc;
+  double *T = ls->s_layers.host<double>(), *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *pop = sq + nl;
+  std::vector<double> q(nl);
+  if (atm->q_part) {
+    std::copy(atm->q_part, atm->q_part + nl, q.begin());
+  } else {
+    rc = sr_calc_partition_sum(ls->mol, ls->iso, atm->temps, nl, q.data());
+    if (rc) return rc;
+  }
+  for (int k = 0; k < nl; ++k) {
+    T[k] = atm->temps[k];
+    pa[k] = atm->press[k] * kHpaToAtm;                                        // spect_classes.py:2034
+    tr[k] = kTref / T[k];                                                     // :1972
+    sq[k] = std::sqrt(2 * kAvogadro * kKcgs * T[k] * kLn2 / ls->mm);          // :1984
+    if (nlev > 0) {
+      for (int lv = 0; lv < nlev; ++lv) {
+        const double vibt = atm->tvib ? atm->tvib[(size_t)lv * nl + k] : T[k]; // smm:2062-2065
+        pop[(size_t)k * npop + lv] = std::exp(-kC2 * ls->e_lev[lv] / vibt) / q[k]; // smm:2073
+      }
+    } else {
+      pop[k] = 1 / q[k]; // smm:2054
+    }
+  }
+  rc = ls->s_layers.push(hl_bytes, st);
+  if (rc) return rc;
+  LayersDev A;
+  const double *dl = ls->s_layers.d.as<double>();
+  A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.pop = dl + 4 * nl;
+  A.n_layers = nl; A.n_pop = npop;
+  A.sqrt_ln2 = std::sqrt(kLn2);            // spect_classes.py:1999
+  A.sqrt_pi_ln2 = std::sqrt(kPi / kLn2);   // :1997
+
+  // lines whose window [ic-6505, ic+6504] meets the shard
+  const auto lo_it = std::lower_bound(ls->ic.begin(), ls->ic.end(), (int)g_lo - (kHalf - 1));
+  const auto hi_it = std::upper_bound(ls->ic.begin(), ls->ic.end(), (int)g_hi - 1 + kHalf);
+  const int line_lo = (int)(lo_it - ls->ic.begin());
+  const int n_sub = (int)(hi_it - lo_it);
+  const size_t n_pts = (size_t)(g_hi - g_lo);
+
+  ls->timed = false;
+  if (n_sub <= 0) {
+    HIPCHK(hipMemsetAsync(abs_out, 0, sizeof(double) * n_pts * nl, st));
+    HIPCHK(hipMemsetAsync(emi_out, 0, sizeof(double) * n_pts * nl, st));
+    return SR_OK;
+  }
+  rc = ls->d_fast.ensure(sizeof(FastRec) * (size_t)n_sub * nl);
+  if (rc) return rc;
+  rc = ls->d_cold.ensure(sizeof(ColdRec) * (size_t)n_sub * nl);
+  if (rc) return rc;
+
+  HIPCHK(hipEventRecord(ls->ev[0], st));
+  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, line_lo, n_sub, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), st));
+  HIPCHK(hipEventRecord(ls->ev[1], st));
+  LAUNCHCHK(launch_abscoeff(g_variant, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), ls->L.ic + line_lo,
+                            n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, abs_out, emi_out, st));
+  HIPCHK(hipEventRecord(ls->ev[2], st));
+  ls->timed = true;
+  return SR_OK;
+}
+
+int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi,
+                       double *abs_out, double *emi_out) {
+  if (!ls || !atm || !abs_out || !emi_out || g_lo >= g_hi || atm->n_layers <= 0) return SR_ERR_ARG;
+  const size_t bytes = sizeof(double) * (size_t)(g_hi - g_lo) * atm->n_layers;
+  DevBuf a, e;
+  int rc = a.ensure(bytes);
+  if (!rc) rc = e.ensure(bytes);
+  if (!rc) rc = sr_abscoeff_layers_dev(ls, atm, g_lo, g_hi, a.as<double>(), e.as<double>(), nullptr);
+  if (!rc) {
+    hipError_t er = hipMemcpy(abs_out, a.p, bytes, hipMemcpyDeviceToHost);
+    if (er == hipSuccess) er = hipMemcpy(emi_out, e.p, bytes, hipMemcpyDeviceToHost);
+    if (er != hipSuccess) rc = hip_fail(er, "copy back");
+  }
+  a.release();
+  e.release();
+  return rc;
+}
+
+int sr_last_kernel_ms(sr_lineset *ls, float *prep_ms, float *main_ms) {
+  if (!ls || !ls->timed) return SR_ERR_ARG;
+  HIPCHK(hipEventSynchronize(ls->ev[2]));
+  float a = 0, b = 0;
+  HIPCHK(hipEventElapsedTime(&a, ls->ev[0], ls->ev[1]));
+  HIPCHK(hipEventElapsedTime(&b, ls->ev[1], ls->ev[2]));
+  if (prep_ms) *prep_ms = a;
+  if (main_ms) *main_ms = b;
+  return SR_OK;
+}
+
+// ------------------------------------------------------------------------
+int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, int n_rays,
+                         const int32_t *seg_off, const int32_t *seg_layer, const double *seg_col,
+                         int init_from_rad, double *rad, void *stream) {
+  if (!abs_c || !emi_c || !rad || !seg_off || n_layers <= 0 || n_pts <= 0 || n_rays <= 0) return SR_ERR_ARG;
+  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  const int n_seg = seg_off[n_rays];
+  if (seg_off[0] != 0 || n_seg < 0) return SR_ERR_ARG;
+  if (n_seg > 0 && (!seg_layer || !seg_col)) return SR_ERR_ARG;
+  for (int r = 0; r < n_rays; ++r)
+    if (seg_off[r + 1] < seg_off[r]) return SR_ERR_ARG;
+  for (int s = 0; s < n_seg; ++s)
+    if (seg_layer[s] < 0 || seg_layer[s] >= n_layers) return SR_ERR_ARG; // would read out of bounds
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static thread_local Stager s_seg;
+  const size_t b_off = sizeof(int) * (size_t)(n_rays + 1), b_lay = sizeof(int) * (size_t)std::max(n_seg, 1);
+  const size_t o_lay = (b_off + 15) / 16 * 16, o_col = (o_lay + b_lay + 15) / 16 * 16;
+  const size_t total = o_col + sizeof(double) * (size_t)std::max(n_seg, 1);
+  int rc = s_seg.prepare(total);
+  if (rc) return rc;
+  std::memcpy(s_seg.host<char>(), seg_off, b_off);
+  if (n_seg > 0) {
+    std::memcpy(s_seg.host<char>() + o_lay, seg_layer, sizeof(int) * (size_t)n_seg);
+    std::memcpy(s_seg.host<char>() + o_col, seg_col, sizeof(double) * (size_t)n_seg);
+  }
+  rc = s_seg.push(total, st);
+  if (rc) return rc;
+  char *base = s_seg.d.as<char>();
+  LAUNCHCHK(launch_radiance(abs_c, emi_c, (int)n_pts, n_rays, reinterpret_cast<const int *>(base),
+                            reinterpret_cast<const int *>(base + o_lay),
+                            reinterpret_cast<const double *>(base + o_col), init_from_rad, rad, st));
+  return SR_OK;
+}
+
+// ------------------------------------------------------------------------
+// f2py-shaped shims (host pointers)
+// ------------------------------------------------------------------------
+int sr_humliv_bb(const double *x, int n, int i1, int i2, double x0, double lw, double dw, double *y) {
+  if (!x || !y || n < 2) return SR_ERR_ARG;
+  if (i1 > i2 || i1 < 1 || i2 > n) return SR_ERR_ARG; // lineshape.f:253-256
+  if (!(dw > 0.0)) return SR_ERR_ARG;                  // lineshape.f:260-264
+  if (i2 - i1 + 1 > 32767) return SR_ERR_LIMIT;        // window indices are 16-bit (imxsig = 13010)
+  if (i2 - i1 < 1) return SR_ERR_ARG;
+  if (!(x[i1 - 1] < x0 && x0 < x[i2 - 1])) return SR_ERR_UNSUPPORTED; // outer branches, :272-442
+  DevBuf dx, dy;
+  int rc = dx.ensure(sizeof(double) * n);
+  if (!rc) rc = dy.ensure(sizeof(double) * n);
+  if (rc) { dx.release(); dy.release(); return rc; }
+  hipError_t e = hipMemcpy(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(dy.p, 0, sizeof(double) * n);
+  if (e == hipSuccess) e = (hipError_t)launch_humliv(dx.as<double>(), i1, i2, x0, lw, dw, dy.as<double>(), nullptr);
+  if (e == hipSuccess) e = hipMemcpy(y, dy.p, sizeof(double) * n, hipMemcpyDeviceToHost);
+  dx.release();
+  dy.release();
+  return e == hipSuccess ? SR_OK : hip_fail(e, "sr_humliv_bb");
+}
+
+int sr_sum_all_lines(double *spe, int64_t n_spe, const double *rows, const int32_t *init, const int32_t *fin,
+                     int n_lines, int row_len) {
+  if (!spe || n_spe <= 0 || n_lines < 0 || row_len <= 0) return SR_ERR_ARG;
+  if (n_lines > 0 && (!rows || !init || !fin)) return SR_ERR_ARG;
+  if (n_spe > 2000000) return SR_ERR_LIMIT; // imxsig_long
+  for (int l = 0; l < n_lines; ++l)           // the Fortran would write out of bounds
+    if (init[l] < 1 || fin[l] > n_spe || fin[l] - init[l] + 1 > row_len) return SR_ERR_ARG;
+  if (n_lines == 0) return SR_OK;
+  DevBuf ds, dr, di;
+  const size_t b_rows = sizeof(double) * (size_t)n_lines * row_len;
+  int rc = ds.ensure(sizeof(double) * n_spe);
+  if (!rc) rc = dr.ensure(b_rows);
+  if (!rc) rc = di.ensure(sizeof(int) * 2 * (size_t)n_lines);
+  hipError_t e = hipSuccess;
+  if (!rc) {
+    e = hipMemcpy(ds.p, spe, sizeof(double) * n_spe, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dr.p, rows, b_rows, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(di.p, init, sizeof(int) * n_lines, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(di.as<int>() + n_lines, fin, sizeof(int) * n_lines, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+      e = (hipError_t)launch_sum_lines(ds.as<double>(), (long)n_spe, dr.as<double>(), di.as<int>(),
+                                       di.as<int>() + n_lines, n_lines, row_len, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(spe, ds.p, sizeof(double) * n_spe, hipMemcpyDeviceToHost);
+  }
+  ds.release(); dr.release(); di.release();
+  if (rc) return rc;
+  return e == hipSuccess ? SR_OK : hip_fail(e, "sr_sum_all_lines");
+}
+
+int sr_curgod(int which, const double *nd, const double *vmr, const double *f, const double *x,
+              const int32_t *off, int n_seg, double *res) {
+  if (which < 1 || which > 4 || !nd || !x || !off || !res || n_seg < 0) return SR_ERR_ARG;
+  if (which >= 2 && !vmr) return SR_ERR_ARG;
+  if (which >= 3 && !f) return SR_ERR_ARG;
+  if (n_seg == 0) return SR_OK;
+  if (off[0] != 0) return SR_ERR_ARG;
+  for (int s = 0; s < n_seg; ++s) {
+    if (off[s + 1] < off[s]) return SR_ERR_ARG;
+    if (off[s + 1] - off[s] > 8000) return SR_ERR_LIMIT; // imxstp, parameters.inc:64
+  }
+  const size_t n = (size_t)off[n_seg];
+  const int narr = which == 1 ? 2 : (which == 2 ? 3 : 4);
+  DevBuf d, dofs, dres;
+  int rc = d.ensure(sizeof(double) * std::max<size_t>(n, 1) * narr);
+  if (!rc) rc = dofs.ensure(sizeof(int) * (size_t)(n_seg + 1));
+  if (!rc) rc = dres.ensure(sizeof(double) * (size_t)n_seg);
+  hipError_t e = hipSuccess;
+  if (!rc) {
+    double *b = d.as<double>();
+    const double *srcs[4] = {nd, x, vmr, f};
+    for (int a = 0; a < narr && e == hipSuccess; ++a)
+      if (n) e = hipMemcpy(b + a * n, srcs[a], sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dofs.p, off, sizeof(int) * (size_t)(n_seg + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+      e = (hipError_t)launch_curgod(which, b, narr > 2 ? b + 2 * n : nullptr, narr > 3 ? b + 3 * n : nullptr,
+                                    b + n, dofs.as<int>(), n_seg, dres.as<double>(), nullptr);
+    if (e == hipSuccess) e = hipMemcpy(res, dres.p, sizeof(double) * (size_t)n_seg, hipMemcpyDeviceToHost);
+  }
+  d.release(); dofs.release(); dres.release();
+  if (rc) return rc;
+  return e == hipSuccess ? SR_OK : hip_fail(e, "sr_curgod");
+}
+
+} // extern "C"

@@ -1,0 +1,41 @@
+// sr_kernels.hpp -- launch interface between the host API and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sr_device.hpp"
+
+namespace sr {
+
+// Device-resident line list (filtered, sorted by window centre).
+struct LinesDev {
+  const double *freq, *hcf, *a_coeff, *b21, *b12, *e_lower, *g_up, *g_lo, *air_broad, *t_dep;
+  const double *evib_up, *evib_lo;
+  const int *ic, *lev_up, *lev_lo;
+  int n_lines;
+};
+
+// Device-resident layer stack; per-layer scalars are evaluated on the host in
+// fp64 with correctly rounded sqrt (80 values) and uploaded.
+struct LayersDev {
+  const double *temps, *p_atm, *trat, *sqk; // T, P[atm], 296/T, sqrt(2 N_A k T ln2 / MM)
+  const double *pop;                        // [n_layers][n_pop] level populations / Q
+  int n_layers, n_pop;
+  double sqrt_ln2, sqrt_pi_ln2;
+};
+
+int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub,
+                FastRec *fast, ColdRec *cold, hipStream_t st);
+int abscoeff_tile_points(int variant);
+int launch_abscoeff(int variant, const FastRec *fast, const ColdRec *cold, const int *ic_sub, int n_sub,
+                    int n_layers, int g_lo, int g_hi, const GridParams &gp, double *abs_out,
+                    double *emi_out, hipStream_t st);
+int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
+                    const int *seg_layer, const double *seg_col, int init_from_rad, double *rad,
+                    hipStream_t st);
+int launch_humliv(const double *x, int i1, int i2, double x0, double lw, double dwp, double *y,
+                  hipStream_t st);
+int launch_sum_lines(double *spe, long n_spe, const double *rows, const int *init, const int *fin,
+                     int n_lines, int row_len, hipStream_t st);
+int launch_curgod(int which, const double *nd, const double *vmr, const double *f, const double *x,
+                  const int *off, int n_seg, double *res, hipStream_t st);
+
+} // namespace sr

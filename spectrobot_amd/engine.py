@@ -1,0 +1,173 @@
+"""Host-side engine objects over the C ABI: device-resident line sets, per-layer
+coefficient spectra, limb radiances.  torch is used for device memory, streams
+and (in distributed.py) the RCCL all-gather only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, dp, ip
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(dp)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(ip)
+
+
+def grid_params(grid):
+    """(w0, step, n) of an equally spaced numpy-arange grid (spect_main_module.py:1267);
+    raises if the grid is not exactly w0 + j*step."""
+    grid = np.asarray(grid, dtype=np.float64)
+    if grid.ndim != 1 or grid.size < 2:
+        raise ValueError("spectral grid must be 1-D with at least 2 points")
+    w0, step = float(grid[0]), float(grid[1] - grid[0])
+    if not np.array_equal(grid, w0 + np.arange(grid.size) * step):
+        raise ValueError("spectral grid is not an np.arange grid (w0 + j*step); the reference assumes "
+                         "equal spacing (SpectralGrid.step, spect_classes.py:366)")
+    return w0, step, grid.size
+
+
+def set_device(index):
+    check(lib.sr_set_device(int(index)), "sr_set_device")
+    torch.cuda.set_device(int(index))
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cu = C.c_int(0)
+    mem = C.c_double(0)
+    check(lib.sr_device_info(name, 256, C.byref(cu), C.byref(mem)), "sr_device_info")
+    return dict(name=name.value.decode(), cu_count=cu.value, hbm_gib=mem.value)
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class LineSet(object):
+    """Device-resident line list of one iso-molecule bound to a spectral grid.
+
+    lines: dict of arrays freq, a_coeff, e_lower, g_up, g_lo, air_broad, t_dep_broad
+           [, lev_up, lev_lo] (SpectLine fields, spect_classes.py:50-51)
+    level_energies: [] for the reference's 'all' set, else E_vib per level (cm^-1)
+    """
+
+    def __init__(self, lines, grid, mol, iso, mm, level_energies=()):
+        self.w0, self.step, self.n_grid = grid_params(grid)
+        self.mol, self.iso, self.mm = int(mol), int(iso), float(mm)
+        self.level_energies = np.ascontiguousarray(level_energies, dtype=np.float64)
+        keep = {}
+        ld = _lib.LinesDesc()
+        ld.n_lines = len(lines["freq"])
+        for n in ("freq", "a_coeff", "e_lower", "g_up", "g_lo", "air_broad", "t_dep_broad"):
+            keep[n], p = _d(lines[n])
+            if keep[n].size != ld.n_lines:
+                raise ValueError("line array %s has the wrong length" % n)
+            setattr(ld, n, p)
+        if self.level_energies.size:
+            for n in ("lev_up", "lev_lo"):
+                keep[n], p = _i(lines[n])
+                setattr(ld, n, p)
+        iso_d = _lib.IsoMolecDesc(self.mol, self.iso, self.mm, self.level_energies.size,
+                                  self.level_energies.ctypes.data_as(dp))
+        gd = _lib.GridDesc(self.w0, self.step, self.n_grid)
+        h = C.c_void_p()
+        kept = C.c_int64(0)
+        check(lib.sr_lineset_create(C.byref(ld), C.byref(iso_d), C.byref(gd), C.byref(h), C.byref(kept)),
+              "sr_lineset_create")
+        self._h = h
+        self.n_kept = kept.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sr_lineset_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _layers(self, temps, press, tvib, q_part):
+        temps, tp = _d(temps)
+        press, pp = _d(press)
+        n = temps.size
+        if press.size != n:
+            raise ValueError("temps and press differ in length")
+        keep = [temps, press]
+        tvp = qp = None
+        if tvib is not None:
+            tvib, tvp = _d(tvib)
+            if tvib.shape != (self.level_energies.size, n):
+                raise ValueError("tvib must be [n_levels, n_layers]")
+            keep.append(tvib)
+        if q_part is not None:
+            q_part, qp = _d(q_part)
+            if q_part.size != n:
+                raise ValueError("q_part must be [n_layers]")
+            keep.append(q_part)
+        return _lib.LayersDesc(n, tp, pp, tvp, qp), keep, n
+
+    def abscoeff_layers(self, temps, press, tvib=None, q_part=None, g_lo=0, g_hi=None, out=None):
+        """Per-layer abs/emi coefficient spectra on the GPU over grid shard [g_lo, g_hi).
+        Returns two torch float64 CUDA tensors [n_layers, g_hi-g_lo] (HBM resident)."""
+        g_hi = self.n_grid if g_hi is None else int(g_hi)
+        desc, keep, n = self._layers(temps, press, tvib, q_part)
+        npts = g_hi - int(g_lo)
+        if npts <= 0:
+            raise ValueError("empty shard")
+        if out is None:
+            ab = torch.empty((n, npts), dtype=torch.float64, device="cuda")
+            em = torch.empty((n, npts), dtype=torch.float64, device="cuda")
+        else:
+            ab, em = out
+            assert ab.shape == (n, npts) and em.shape == (n, npts) and ab.is_contiguous() and em.is_contiguous()
+        check(lib.sr_abscoeff_layers_dev(self._h, C.byref(desc), int(g_lo), g_hi, C.c_void_p(ab.data_ptr()),
+                                         C.c_void_p(em.data_ptr()), _stream_ptr()), "sr_abscoeff_layers_dev")
+        return ab, em
+
+    def abscoeff_layers_host(self, temps, press, tvib=None, q_part=None, g_lo=0, g_hi=None):
+        """Same through the host-buffer entry point (numpy in, numpy out)."""
+        g_hi = self.n_grid if g_hi is None else int(g_hi)
+        desc, keep, n = self._layers(temps, press, tvib, q_part)
+        ab = np.empty((n, g_hi - int(g_lo)))
+        em = np.empty_like(ab)
+        check(lib.sr_abscoeff_layers(self._h, C.byref(desc), int(g_lo), g_hi, ab.ctypes.data_as(dp),
+                                     em.ctypes.data_as(dp)), "sr_abscoeff_layers")
+        return ab, em
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        check(lib.sr_last_kernel_ms(self._h, C.byref(a), C.byref(b)), "sr_last_kernel_ms")
+        return a.value, b.value
+
+
+def radiance_rays(abs_c, emi_c, seg_off, seg_layer, seg_col, rad0=None):
+    """Limb radiance recursion for a batch of rays (include/spectrobot_hip.h).
+    abs_c/emi_c: CUDA float64 [n_layers, n_pts]; returns CUDA float64 [n_rays, n_pts]."""
+    assert abs_c.is_cuda and abs_c.dtype == torch.float64 and abs_c.is_contiguous()
+    assert emi_c.shape == abs_c.shape and emi_c.is_contiguous()
+    n_layers, n_pts = abs_c.shape
+    seg_off, op = _i(seg_off)
+    seg_layer, lp = _i(seg_layer)
+    seg_col, cp = _d(seg_col)
+    n_rays = seg_off.size - 1
+    if rad0 is None:
+        rad = torch.empty((n_rays, n_pts), dtype=torch.float64, device="cuda")
+        init = 0
+    else:
+        rad = rad0
+        assert rad.shape == (n_rays, n_pts) and rad.is_contiguous()
+        init = 1
+    check(lib.sr_radiance_rays_dev(C.c_void_p(abs_c.data_ptr()), C.c_void_p(emi_c.data_ptr()), n_layers, n_pts,
+                                   n_rays, op, lp, cp, init, C.c_void_p(rad.data_ptr()), _stream_ptr()),
+          "sr_radiance_rays_dev")
+    return rad
+
+
+def set_points_per_lane(p):
+    check(lib.sr_set_points_per_lane(int(p)), "sr_set_points_per_lane")
