@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- limb spectra/s of the SpectRobot spectral hot path on MI355X.
+
+A "step" is one pass of the hot path over one synthetic limb case: per-layer
+abs/emi coefficient spectra (prep + gather kernels), the radiance recursion of
+the ray batch and, for N > 1, the all-gather of the spectral shards.  Default
+workload = BASELINE.json configs[1]: CH4 Titan limb, 1e5 lines x 1e5 nu-grid x 80
+layers, 1 ray, fp64.  Inputs are uploaded before the timed region (HBM resident).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
+(dominant kernel, HIP-event timed inside the timed region) and `cpu_baseline`
+(the oracle, i.e. the CPU restatement of the reference, on the host cores;
+N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (= fp64 matrix) dense peak, SURVEY 8-d / AMD datasheet
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+FLOP_PER_EVAL = 16             # SURVEY 8-d flop model per (line, layer, grid point)
+
+
+def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total):
+    """Oracle (kind 'port', mode 1 = direct accumulate) on all host cores over a bounded
+    sample of the SAME workload: all lines, full grid, the first `ns` layers."""
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # ~50 us per (line, layer) per core
+    per_layer_core_s = 55e-6 * len(L["freq"])
+    ns = int(max(1, min(n_layers_total, round(seconds_hint * cores / max(per_layer_core_s, 1e-9)))))
+    ns = max(min(ns, n_layers_total), min(cores, n_layers_total))
+    sel = np.linspace(0, n_layers_total - 1, ns).round().astype(int)
+    tv = None if atm["tvib"] is None else atm["tvib"][:, sel]
+    t0 = time.time()
+    O.abscoeff_layers(L, mm, e_lev, atm["temps"][sel], atm["press"][sel], q_part[sel], tv, grid, mode=1,
+                      n_threads=cores)
+    dt = time.time() - t0
+    out = {"value": (ns / n_layers_total) / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
+           "sample": "%d of %d layers (evenly spaced), all %d lines, full %d-point grid, coefficients only, "
+                     "%.1f s wall; extrapolated x%d/%d" % (ns, n_layers_total, len(L["freq"]), len(grid), dt,
+                                                          n_layers_total, ns)}
+    # reference's own Fortran kernel (oracle/_ref, compiled from the reference sources), 1 core
+    try:
+        from oracle import ref_fortran as RF
+        if RF.available():
+            st = grid[1] - grid[0]
+            lin = np.arange(-13010 * st / 2, 13010 * st / 2, st)
+            x = lin + grid[len(grid) // 2]
+            n = 300
+            t0 = time.time()
+            for i in range(n):
+                RF.humliv_bb(x, 1, 13010, float(x[6505] + 1e-4), 1e-4 * (1 + i % 7), 4e-3)
+            out["reference_humliv_bb_us_per_call"] = (time.time() - t0) / n * 1e6
+    except Exception as e:  # the reference build is optional on the box
+        out["reference_humliv_bb_us_per_call"] = None
+        out["reference_note"] = str(e)[:100]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--lines", type=int, default=100000)
+    ap.add_argument("--grid", type=int, default=100000)
+    ap.add_argument("--layers", type=int, default=80)
+    ap.add_argument("--rays", type=int, default=1)
+    ap.add_argument("--ppl", type=int, default=4, help="grid points per lane in the gather kernel")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    from spectrobot_amd import engine, synthetic as syn, distributed as sd
+    from spectrobot_amd._lib import lib, dp
+
+    rank, local, world = sd.init_from_env()
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    engine.set_device(local)
+    engine.set_points_per_lane(args.ppl)
+    info = engine.device_info()
+
+    # ---- synthetic workload, identical on every rank ----
+    n_lev = 12
+    grid = syn.make_grid(2975.0, 5e-4, args.grid)
+    L = syn.make_lines(args.lines, grid, config_id=2, n_levels=n_lev)
+    atm = syn.make_atmosphere(args.layers, n_lev)
+    e_lev = syn.CH4_LEVEL_ENERGIES
+    q_part = np.zeros(args.layers)
+    tt = np.ascontiguousarray(atm["temps"])
+    assert lib.sr_calc_partition_sum(6, 1, tt.ctypes.data_as(dp), args.layers, q_part.ctypes.data_as(dp)) == 0
+    # rays: tangent heights z_t = 100 + 12.5 r km; columns n*vmr*iso_ratio*ds
+    offs, lays, cols = [0], [], []
+    nd = syn.number_density(atm["press"], atm["temps"])
+    for r in range(args.rays):
+        sl, ln = syn.limb_path(atm["z"], 100.0 + 12.5 * r + 1e-3)
+        lays += list(sl)
+        cols += list(ln * 1e5 * nd[sl] * 0.0148 * syn.CH4_ISO_RATIO)
+        offs.append(len(lays))
+
+    ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)     # lines -> HBM (outside the timed region)
+    g_lo, g_hi = sd.shard_bounds(args.grid, world, rank)
+    npts = g_hi - g_lo
+    ab = torch.empty((args.layers, npts), dtype=torch.float64, device="cuda")
+    em = torch.empty_like(ab)
+    full = torch.empty((args.rays, args.grid), dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def step():
+        ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"], q_part=q_part, g_lo=g_lo, g_hi=g_hi,
+                           out=(ab, em))
+        rad = engine.radiance_rays(ab, em, offs, lays, cols)
+        return sd.all_gather_spectrum(rad, args.grid, world, rank, out=full)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    prep_ms = main_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        spec = step()
+        a, b = ls.last_kernel_ms()      # HIP events on the launch stream (syncs that step)
+        prep_ms += a
+        main_ms += b
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prep_ms /= args.steps
+    main_ms /= args.steps
+    checksum = float(spec.sum().item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = args.steps / elapsed  # one limb spectrum (x rays) per step, whole job
+        # dominant kernel: sr_abscoeff_kernel, one launch per step on this rank's shard
+        n_sub = args.lines if world == 1 else None
+        evals = float(args.lines) * 13010.0 * args.layers / world           # SURVEY 8-d, per launch
+        flops = FLOP_PER_EVAL * evals
+        alg_bytes = (8.0 * args.grid * args.layers * 2 + 80.0 * args.lines) / world
+        tf = flops / (main_ms * 1e-3) / 1e12
+        gbs = alg_bytes / (main_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+        if os.path.exists(pmc) and world == 1 and args.lines == 100000 and args.grid == 100000:
+            try:
+                traffic = json.load(open(pmc)).get("sr_abscoeff_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "limb spectra/sec (1e5 lines x 1e5 nu-grid, 80 layers)",
+            "value": value * args.rays, "unit": "spectra/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "CH4 Titan limb (BASELINE configs[1]): %d lines x %d-pt grid x %d layers, "
+                                   "%d ray(s), 12 non-LTE levels" % (args.lines, args.grid, args.layers, args.rays),
+                       "n_lines": args.lines, "n_grid": args.grid, "n_layers": args.layers, "n_rays": args.rays,
+                       "sharding": "spectral window / %d, one RCCL all-gather" % world if world > 1 else "none",
+                       "points_per_lane": args.ppl, "device": info["name"], "cu_count": info["cu_count"]},
+            "roofline": {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "sr_abscoeff_kernel", "kernel_ms": main_ms, "prep_kernel_ms": prep_ms,
+                         "flops_per_launch": flops,
+                         "note": "gather formulation is fp64-vector bound (arithmetic intensity ~1e4 flop/B, "
+                                 "no MFMA: not a contraction); 16 flop per (line, layer, point) x "
+                                 "n_lines*13010*n_layers evaluations (SURVEY 8-d); peak 78.6 TFLOP/s is both "
+                                 "the fp64 vector and the fp64 MFMA dense peak of MI355X"},
+            "roofline_hbm": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": alg_bytes,
+                             "note": "algorithmic bytes 8*n_grid*n_layers*2 + 80*n_lines (SURVEY 8-d); expected "
+                                     "<<1 because the kernel is compute bound"},
+            "checksum": checksum,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(L, atm, grid, syn.CH4_MM, e_lev, q_part, args.cpu_seconds,
+                                               args.layers)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

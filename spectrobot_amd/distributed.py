@@ -1,0 +1,58 @@
+"""Spectral-window sharding over the GPUs of one node (one process per GPU).
+
+The path shards naturally: every output grid point depends only on
+the lines within -6504..+6505 grid points and on its own layer stack -- the
+reference itself already splits the grid into n_split contiguous chunks
+(spect_main_module.py:1619-1630, 2814-2818).  Rank r of W owns the contiguous
+grid range shard_bounds(n_grid, W, r); the line list (8 MB) and the atmosphere
+are replicated; the only exchange step is ONE all-gather of the radiance shards
+(RCCL over xGMI with backend "nccl", gloo on CPU for tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_grid, world_size, rank):
+    """Contiguous, balanced: the first n_grid % W ranks own one extra point."""
+    q, r = divmod(int(n_grid), int(world_size))
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def init_from_env(backend=None):
+    """torch.distributed rendezvous from RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local, world
+
+
+def all_gather_spectrum(shard, n_grid, world_size, rank, out=None):
+    """Reassemble [n_rays, n_grid] from per-rank shards [n_rays, hi-lo] with a single
+    all-gather.  Shards may differ by one point, so each rank contributes a buffer
+    padded to the largest shard."""
+    if world_size == 1:
+        return shard
+    n_rays = shard.shape[0]
+    q = -(-int(n_grid) // int(world_size))
+    pad = torch.zeros((n_rays, q), dtype=shard.dtype, device=shard.device)
+    pad[:, :shard.shape[1]] = shard
+    gathered = torch.empty((world_size, n_rays, q), dtype=shard.dtype, device=shard.device)
+    dist.all_gather_into_tensor(gathered, pad)
+    if out is None:
+        out = torch.empty((n_rays, n_grid), dtype=shard.dtype, device=shard.device)
+    for r in range(world_size):
+        lo, hi = shard_bounds(n_grid, world_size, r)
+        out[:, lo:hi] = gathered[r, :, :hi - lo]
+    return out
