@@ -171,13 +171,14 @@ int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers,
                          const int32_t *seg_layer, const double *seg_col,
                          int init_from_rad, double *rad, void *stream);
 
-/* Tuning knob of sr_abscoeff_kernel: grid points per lane (1, 2 or 4; default 4). */
+/* Tuning knob of the coefficient kernels: grid points per lane (4 or 8; default 8). */
 int sr_set_points_per_lane(int p);
 
-/* Timing hook for bench.py: HIP-event time (ms) of the dominant kernel
- * (sr_abscoeff_kernel) in the most recent sr_abscoeff_layers* call on this
- * lineset, measured on the stream it was launched on.  Synchronises. */
-int sr_last_kernel_ms(sr_lineset *ls, float *prep_ms, float *main_ms);
+/* Timing hook for bench.py: HIP-event times (ms) of the three kernels of the
+ * most recent sr_abscoeff_layers* call on this lineset (sr_prep_kernel,
+ * sr_abscoeff_wings_kernel = the dominant one, sr_abscoeff_cores_kernel),
+ * measured on the stream they were launched on.  Synchronises. */
+int sr_last_kernel_ms(sr_lineset *ls, float *prep_ms, float *wings_ms, float *cores_ms);
 
 #ifdef __cplusplus
 }

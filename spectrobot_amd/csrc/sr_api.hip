@@ -149,7 +149,7 @@ double lagrange4(const double *tg, const double *qg, int n, double temp) {
   return y;
 }
 
-int g_variant = 4; // points per lane in sr_abscoeff_kernel
+int g_variant = 8; // points per lane in the coefficient kernels
 
 } // namespace
 
@@ -163,8 +163,8 @@ struct sr_lineset {
   DevBuf d_lines;      // one allocation, carved below
   LinesDev L{};
   Stager s_layers;
-  DevBuf d_fast, d_cold;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  DevBuf d_fast, d_cold, d_zmax;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool timed = false;
 };
 
@@ -210,7 +210,7 @@ int sr_device_info(char *name, int name_len, int *cu_count, double *hbm_gib) {
 }
 
 int sr_set_points_per_lane(int p) {
-  if (p != 1 && p != 2 && p != 4) return SR_ERR_ARG;
+  if (p != 4 && p != 8) return SR_ERR_ARG;
   g_variant = p;
   return SR_OK;
 }
@@ -376,6 +376,7 @@ int sr_lineset_destroy(sr_lineset *ls) {
   ls->s_layers.release();
   ls->d_fast.release();
   ls->d_cold.release();
+  ls->d_zmax.release();
   for (auto &ev : ls->ev)
     if (ev) (void)hipEventDestroy(ev);
   delete ls;
@@ -440,17 +441,25 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     HIPCHK(hipMemsetAsync(emi_out, 0, sizeof(double) * n_pts * nl, st));
     return SR_OK;
   }
-  rc = ls->d_fast.ensure(sizeof(FastRec) * (size_t)n_sub * nl);
+  rc = ls->d_fast.ensure(sizeof(FastRec) * ((size_t)n_sub * nl + 1)); // +1: the wings kernel prefetches one ahead
   if (rc) return rc;
   rc = ls->d_cold.ensure(sizeof(ColdRec) * (size_t)n_sub * nl);
   if (rc) return rc;
 
+  rc = ls->d_zmax.ensure(sizeof(int) * (size_t)nl);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(ls->d_zmax.p, 0, sizeof(int) * (size_t)nl, st));
+
   HIPCHK(hipEventRecord(ls->ev[0], st));
-  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, line_lo, n_sub, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), st));
+  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, line_lo, n_sub, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(),
+                        ls->d_zmax.as<int>(), st));
   HIPCHK(hipEventRecord(ls->ev[1], st));
-  LAUNCHCHK(launch_abscoeff(g_variant, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), ls->L.ic + line_lo,
-                            n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, abs_out, emi_out, st));
-  HIPCHK(hipEventRecord(ls->ev[2], st));
+  for (int which = 0; which < 2; ++which) {
+    LAUNCHCHK(launch_abscoeff(g_variant, which, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(),
+                              ls->L.ic + line_lo, ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
+                              abs_out, emi_out, st));
+    HIPCHK(hipEventRecord(ls->ev[2 + which], st));
+  }
   ls->timed = true;
   return SR_OK;
 }
@@ -473,14 +482,16 @@ int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, 
   return rc;
 }
 
-int sr_last_kernel_ms(sr_lineset *ls, float *prep_ms, float *main_ms) {
+int sr_last_kernel_ms(sr_lineset *ls, float *prep_ms, float *wings_ms, float *cores_ms) {
   if (!ls || !ls->timed) return SR_ERR_ARG;
-  HIPCHK(hipEventSynchronize(ls->ev[2]));
-  float a = 0, b = 0;
+  HIPCHK(hipEventSynchronize(ls->ev[3]));
+  float a = 0, b = 0, c = 0;
   HIPCHK(hipEventElapsedTime(&a, ls->ev[0], ls->ev[1]));
   HIPCHK(hipEventElapsedTime(&b, ls->ev[1], ls->ev[2]));
+  HIPCHK(hipEventElapsedTime(&c, ls->ev[2], ls->ev[3]));
   if (prep_ms) *prep_ms = a;
-  if (main_ms) *main_ms = b;
+  if (wings_ms) *wings_ms = b;
+  if (cores_ms) *cores_ms = c;
   return SR_OK;
 }
 

@@ -64,7 +64,10 @@ struct __attribute__((aligned(16))) FastRec {
   double a, b, c, d; // region-1 rational (lineshape.f:456-459), e = 4
   double wabs, wemi; // level-population weighted G coefficients / fac
   int32_t j1;        // grid index of window point k = 1 (ic - 6505; may be < 0)
-  int16_t il, ir;    // region-1 boundaries, 1-based window indices
+  uint32_t ilir;     // region-1 boundaries il | ir << 16 (1-based window indices);
+                     // one dword so that the whole record is scalar-loadable
+  __host__ __device__ inline int il() const { return (int)(ilir & 0xffffu); }
+  __host__ __device__ inline int ir() const { return (int)(ilir >> 16); }
 };
 static_assert(sizeof(FastRec) == 80, "FastRec must be 80 bytes");
 
@@ -197,7 +200,7 @@ __device__ inline Bounds humliv_bounds(const XF &xf, int n, double x0, double lw
 // follows the write order of lineshape.f:455-562 (last writer wins).
 template <class XF>
 __device__ inline double humliv_point(int k, const FastRec &r, const ColdRec &cr, const XF &xf) {
-  const int il = r.il, ir = r.ir, il2 = cr.il2, ir2 = cr.ir2;
+  const int il = r.il(), ir = r.ir(), il2 = cr.il2, ir2 = cr.ir2;
   const int il2a = (il2 == il) ? il - 1 : il2; // :524-525
   const int ir2a = (ir2 == ir) ? ir + 1 : ir2;
   if (k > il2a && k < ir2a) { // :526-562

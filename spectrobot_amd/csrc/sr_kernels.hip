@@ -3,14 +3,11 @@
 //   sr_prep_kernel      one thread per (line, layer): widths, G coefficients,
 //                       level-population weights, Humlicek region boundaries
 //                       -> FastRec / ColdRec tables in HBM.
-//   sr_abscoeff_kernel  the dominant kernel.  Gather formulation: a workgroup
-//                       owns a tile of grid points of one layer, walks the
-//                       nu-sorted lines whose 13010-point windows touch the
-//                       tile, stages their FastRecs through LDS, and every lane
-//                       accumulates abs/emi for its own P points in registers:
-//                       no atomics, no [n_lines x 13010] matrix, coalesced
-//                       fp64 stores.  fp64 VALU bound (no MFMA: not a
-//                       contraction, one divide per evaluation).
+//   sr_abscoeff_wings_kernel / sr_abscoeff_cores_kernel
+//                       the coefficient spectra, gather formulation (see below):
+//                       no atomics, no [n_lines x 13010] matrix, coalesced fp64
+//                       stores.  fp64 VALU bound (no MFMA: not a contraction,
+//                       a reciprocal per evaluation).
 //   sr_radiance_kernel  limb recursion per (point, ray).
 //   shims               humliv_bb / sum_all_lines / curgod_fort_N call shapes.
 #include "sr_device.hpp"
@@ -25,7 +22,8 @@ namespace sr {
 __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, GridParams gp,
                                                       int line_lo, int n_sub,
                                                       FastRec *__restrict__ fast,
-                                                      ColdRec *__restrict__ cold) {
+                                                      ColdRec *__restrict__ cold,
+                                                      int *__restrict__ zmax) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
   if (i >= n_sub) return;
@@ -70,8 +68,7 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
   r.wabs = wabs / fac; // shape = y/fac, spect_classes.py:2003
   r.wemi = wemi / fac;
   r.j1 = ic - kHalf;
-  r.il = (int16_t)B.il;
-  r.ir = (int16_t)B.ir;
+  r.ilir = (uint32_t)B.il | ((uint32_t)B.ir << 16);
   ColdRec c;
   c.ry = B.ry;
   c.dwp = dwp;
@@ -82,10 +79,31 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
   const size_t o = (size_t)k * n_sub + i;
   fast[o] = r;
   cold[o] = c;
+  // widest region-2/3/4 zone of the layer, in grid points from the window centre
+  // (k = 6506): tells sr_abscoeff_cores_kernel how far to look for candidates
+  int hw = max(kHalf + 1 - B.il, B.ir - (kHalf + 1));
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) hw = max(hw, __shfl_xor(hw, m));
+  if ((threadIdx.x & 63) == 0) atomicMax(&zmax[k], hw);
 }
 
 // ------------------------------------------------------------------------
-// main gather kernel
+// coefficient kernels (gather formulation)
+//
+// One wavefront owns WP = 64*P consecutive grid points of one layer ("wave
+// tile") and walks the nu-sorted lines whose 13010-point windows touch it.
+// Everything per line is wave-uniform and lives in SGPRs (records are read with
+// scalar loads); every lane accumulates abs/emi for its own P points (stride
+// 64, so each slot p is 64 consecutive points and stores are coalesced).
+//
+//   sr_abscoeff_wings_kernel  lines for which the WHOLE wave tile lies in one
+//       region-1 wing and inside the window (98 % of all evaluations):
+//       x = x_b + lane_p*xstep, (a + x^2 b)/(c + x^2 (d + 4 x^2)), one
+//       reciprocal shared by four points, no branches in the body.
+//   sr_abscoeff_cores_kernel  the remaining (line, wave tile) pairs -- tile meets
+//       the line's region-2/3/4 zone or a window end -- evaluated slot by slot
+//       with the general, region-by-index code; adds into the wings' output.
+// Both apply the same classify() so every (line, point) is counted exactly once.
 // ------------------------------------------------------------------------
 __device__ inline int lower_bound_ic(const int *__restrict__ ic, int n, int v) {
   int lo = 0, hi = n;
@@ -98,139 +116,220 @@ __device__ inline int lower_bound_ic(const int *__restrict__ ic, int n, int v) {
 
 // XCD-aware bijective remap (8 XCDs, blocks dealt round-robin): blocks that
 // share an XCD get consecutive work ids, so neighbouring tiles of one layer --
-// which read almost the same FastRecs -- hit the same L2.
+// which read almost the same records -- hit the same L2.
 __device__ inline int xcd_remap(int b, int nb) {
   const int q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <int P, int NR>
-__global__ __launch_bounds__(256) void sr_abscoeff_kernel(
-    const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold,
-    const int *__restrict__ ic_sub, // [n_sub] window centres of the prepped lines, sorted
-    int n_sub, int n_tiles, int g_lo, int g_hi, GridParams gp,
-    double *__restrict__ abs_out, double *__restrict__ emi_out) {
-  constexpr int WP = 64 * P;  // points per wave
-  constexpr int TP = 4 * WP;  // points per workgroup tile
-  constexpr int CH = 256;     // lines per LDS chunk
-  __shared__ FastRec s_rec[CH]; // 20 KiB
+// 1: every point of [lo, hi] is strictly left of il (region 1, running x from
+// k = 1) and inside the window; 2: strictly right of ir; 0: anything else.
+__device__ inline int classify(int j1, int il, int ir, int lo, int hi) {
+  if (lo >= j1 && hi < j1 + il - 1) return 1;
+  if (lo > j1 + ir - 1 && hi <= j1 + (kImxsig - 1)) return 2;
+  return 0;
+}
+// -x (left) or x (right) at grid index `at`: only x^2 is used.
+__device__ inline double wing_x_at(const FastRec &r, int cls, int j1, int at) {
+  return cls == 1 ? fma((double)(at - j1), r.xstep, -r.xl)
+                  : fma((double)(at - (j1 + r.ir() - 1)), r.xstep, r.xr);
+}
 
+// Region 1 at four points per lane (x = xb + fl[i]*xs) with ONE reciprocal:
+// 1/(d0 d1 d2 d3) by v_rcp_f64 (2^-24) + one Newton step (2e-15), unfolded by
+// multiplications.  den >= 4*15^4 and <= ~1e19 here, so the product of four
+// cannot leave the fp64 range.
+__device__ inline void wing_eval4(const double xb, const double xs, const double a, const double b,
+                                  const double c, const double d, const double wa, const double we,
+                                  const double *fl, double *acc_a, double *acc_e) {
+  double num[4], den[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double x = fma(fl[i], xs, xb);
+    const double x2 = x * x;
+    num[i] = fma(x2, b, a);
+    den[i] = fma(x2, fma(x2, 4.0, d), c);
+  }
+  const double d01 = den[0] * den[1], d23 = den[2] * den[3];
+  const double r = fast_rcp<1>(d01 * d23);
+  const double r01 = r * d23, r23 = r * d01;
+  const double q0 = (num[0] * den[1]) * r01, q1 = (num[1] * den[0]) * r01;
+  const double q2 = (num[2] * den[3]) * r23, q3 = (num[3] * den[2]) * r23;
+  acc_a[0] = fma(wa, q0, acc_a[0]); acc_e[0] = fma(we, q0, acc_e[0]);
+  acc_a[1] = fma(wa, q1, acc_a[1]); acc_e[1] = fma(we, q1, acc_e[1]);
+  acc_a[2] = fma(wa, q2, acc_a[2]); acc_e[2] = fma(we, q2, acc_e[2]);
+  acc_a[3] = fma(wa, q3, acc_a[3]); acc_e[3] = fma(we, q3, acc_e[3]);
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void sr_abscoeff_wings_kernel(
+    const FastRec *__restrict__ fast,
+    const int *__restrict__ ic_sub, // [n_sub] window centres of the prepped lines, sorted
+    int n_sub, int n_tiles, int g_lo, int g_hi, double *__restrict__ abs_out,
+    double *__restrict__ emi_out) {
+  static_assert(P % 4 == 0, "P must be a multiple of 4");
+  constexpr int WP = 64 * P;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
-  const int t0 = g_lo + tile * TP;
-  const int thi = min(t0 + TP, g_hi) - 1;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wlo = t0 + wave * WP;
+  const int wlo = g_lo + tile * WP;
   const int whi = min(wlo + WP, g_hi) - 1;
-  const bool wave_on = wlo <= whi;
+  const int lane = threadIdx.x;
 
-  // lines whose window [ic-6505, ic+6504] meets [t0, thi]
-  const int l0 = lower_bound_ic(ic_sub, n_sub, t0 - (kHalf - 1));
-  const int l1 = lower_bound_ic(ic_sub, n_sub, thi + kHalf + 1);
+  // lines whose window [ic-6505, ic+6504] meets [wlo, whi]
+  const int l0 = lower_bound_ic(ic_sub, n_sub, wlo - (kHalf - 1));
+  const int l1 = lower_bound_ic(ic_sub, n_sub, whi + kHalf + 1);
 
-  double acc_a[P], acc_e[P], flp[P];
+  double acc_a[P], acc_e[P], fl[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     acc_a[p] = 0.;
     acc_e[p] = 0.;
-    flp[p] = (double)(lane + 64 * p);
+    fl[p] = (double)(lane + 64 * p);
+  }
+  const FastRec *frow = fast + (size_t)layer * n_sub;
+  FastRec nxt = frow[l0 < l1 ? l0 : 0];
+  for (int l = l0; l < l1; ++l) {
+    // wave-uniform address: two scalar loads; the next record is fetched while this
+    // one is evaluated (the table has one record of slack behind its end)
+    const FastRec r = nxt;
+    nxt = frow[l + 1];
+    const int cls = classify(r.j1, r.il(), r.ir(), wlo, whi);
+    if (cls == 0) continue; // left to sr_abscoeff_cores_kernel
+    const double xb = wing_x_at(r, cls, r.j1, wlo);
+#pragma unroll
+    for (int g = 0; g < P; g += 4)
+      wing_eval4(xb, r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl + g, acc_a + g, acc_e + g);
+  }
+  const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int j = wlo + lane + 64 * p;
+    if (j <= whi) {
+      abs_out[row + (j - g_lo)] = acc_a[p];
+      emi_out[row + (j - g_lo)] = acc_e[p];
+    }
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
+    const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold,
+    const int *__restrict__ ic_sub, const int *__restrict__ zmax, // [n_layers] max zone half-width
+    int n_sub, int n_tiles, int g_lo, int g_hi, GridParams gp, double *__restrict__ abs_out,
+    double *__restrict__ emi_out) {
+  constexpr int WP = 64 * P;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
+  const int wlo = g_lo + tile * WP;
+  const int whi = min(wlo + WP, g_hi) - 1;
+  const int lane = threadIdx.x;
+  const int zm = min(zmax[layer], kHalf - 1);
+
+  // candidates (as ranges of the sorted centre list), C <= A <= B by start:
+  //  C: window END inside the tile      ic+6504 in [wlo, whi)
+  //  A: region-2/3/4 zone may meet it   ic in [wlo-zm, whi+zm]
+  //  B: window START inside the tile    ic-6505 in (wlo, whi]
+  const int c0 = lower_bound_ic(ic_sub, n_sub, wlo - (kHalf - 1));
+  const int c1 = lower_bound_ic(ic_sub, n_sub, whi - (kHalf - 1));
+  const int a0 = lower_bound_ic(ic_sub, n_sub, wlo - zm);
+  const int a1 = lower_bound_ic(ic_sub, n_sub, whi + zm + 1);
+  const int b0 = lower_bound_ic(ic_sub, n_sub, wlo + kHalf + 1);
+  const int b1 = lower_bound_ic(ic_sub, n_sub, whi + kHalf + 1);
+  int rs[3], re[3];
+  rs[0] = c0; re[0] = max(c1, c0);
+  rs[1] = max(a0, re[0]); re[1] = max(a1, rs[1]);
+  rs[2] = max(b0, re[1]); re[2] = max(b1, rs[2]);
+
+  double acc_a[P], acc_e[P], fl[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    acc_a[p] = 0.;
+    acc_e[p] = 0.;
+    fl[p] = (double)(lane + 64 * p);
   }
   const FastRec *frow = fast + (size_t)layer * n_sub;
   const ColdRec *crow = cold + (size_t)layer * n_sub;
-
-  for (int c = l0; c < l1; c += CH) {
-    const int cnt = min(CH, l1 - c);
-    __syncthreads();
-    {
-      const int4 *src = reinterpret_cast<const int4 *>(frow + c);
-      int4 *dst = reinterpret_cast<int4 *>(s_rec);
-      for (int i = threadIdx.x; i < cnt * 5; i += 256) dst[i] = src[i];
-    }
-    __syncthreads();
-    if (!wave_on) continue;
-    for (int l = 0; l < cnt; ++l) {
-      const FastRec &r = s_rec[l];
-      const int j1 = __builtin_amdgcn_readfirstlane(r.j1);
-      const int jN = j1 + (kImxsig - 1);
+  for (int rg = 0; rg < 3; ++rg) {
+    for (int l = rs[rg]; l < re[rg]; ++l) {
+      const FastRec r = frow[l];
+      const int j1 = r.j1, jN = j1 + (kImxsig - 1);
       if (jN < wlo || j1 > whi) continue;
-      const int il = __builtin_amdgcn_readfirstlane((int)r.il);
-      const int ir = __builtin_amdgcn_readfirstlane((int)r.ir);
-      const int jil = j1 + il - 1, jir = j1 + ir - 1;
-      double xb;
-      bool fastp = false;
-      if (wlo >= j1 && whi < jil) { // all points strictly left of il: region 1
-        xb = fma((double)(wlo - j1), r.xstep, -r.xl);
-        fastp = true;
-      } else if (wlo > jir && whi <= jN) { // strictly right of ir
-        xb = fma((double)(wlo - jir), r.xstep, r.xr);
-        fastp = true;
-      }
-      if (fastp) {
-        const double xs = r.xstep, a = r.a, b = r.b, cc = r.c, d = r.d;
-        const double wa = r.wabs, we = r.wemi;
+      if (classify(j1, r.il(), r.ir(), wlo, whi) != 0) continue; // done by the wings kernel
+      const ColdRec cr = crow[l];
+      const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const double x = fma(flp[p], xs, xb);
-          const double x2 = x * x;
-          const double num = fma(x2, b, a);
-          const double den = fma(x2, fma(x2, 4.0, d), cc);
-          const double q = num * fast_rcp<NR>(den);
-          acc_a[p] = fma(wa, q, acc_a[p]);
-          acc_e[p] = fma(we, q, acc_e[p]);
+      for (int g = 0; g < P; g += 4) {
+        const int glo = wlo + 64 * g, ghi = min(glo + 255, whi);
+        if (glo > whi || jN < glo || j1 > ghi) continue;
+        const int gcls = classify(j1, r.il(), r.ir(), glo, ghi);
+        if (gcls != 0) { // four whole slots in one wing
+          const double xb = wing_x_at(r, gcls, j1, wlo);
+          wing_eval4(xb, r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl + g, acc_a + g, acc_e + g);
+          continue;
         }
-      } else {
-        const ColdRec cr = crow[c + l];
-        WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
-        const FastRec rr = r;
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const int k = wlo + lane + 64 * p - j1 + 1; // 1-based window index
-          if (k >= 1 && k <= kImxsig) {
-            const double y = humliv_point(k, rr, cr, xf);
-            acc_a[p] = fma(rr.wabs, y, acc_a[p]);
-            acc_e[p] = fma(rr.wemi, y, acc_e[p]);
+        for (int p = g; p < g + 4; ++p) {
+          const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
+          if (slo > whi || jN < slo || j1 > shi) continue;
+          const int scls = classify(j1, r.il(), r.ir(), slo, shi);
+          double y;
+          if (scls != 0) {
+            const double x = fma(fl[p], r.xstep, wing_x_at(r, scls, j1, wlo));
+            const double x2 = x * x;
+            y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
+          } else {
+            const int k = slo + lane - j1 + 1; // 1-based window index
+            y = (k >= 1 && k <= kImxsig && slo + lane <= shi) ? humliv_point(k, r, cr, xf) : 0.0;
           }
+          acc_a[p] = fma(r.wabs, y, acc_a[p]);
+          acc_e[p] = fma(r.wemi, y, acc_e[p]);
         }
       }
     }
   }
-  if (wave_on) {
-    const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
+  const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int j = wlo + lane + 64 * p;
-      if (j <= whi) {
-        abs_out[row + (j - g_lo)] = acc_a[p];
-        emi_out[row + (j - g_lo)] = acc_e[p];
-      }
+  for (int p = 0; p < P; ++p) {
+    const int j = wlo + lane + 64 * p;
+    if (j <= whi) {
+      abs_out[row + (j - g_lo)] += acc_a[p];
+      emi_out[row + (j - g_lo)] += acc_e[p];
     }
   }
 }
 
 int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub,
-                FastRec *fast, ColdRec *cold, hipStream_t st) {
+                FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st) {
   if (n_sub <= 0 || A.n_layers <= 0) return 0;
   dim3 grid((n_sub + 255) / 256, A.n_layers);
-  hipLaunchKernelGGL(sr_prep_kernel, grid, dim3(256), 0, st, L, A, gp, line_lo, n_sub, fast, cold);
+  hipLaunchKernelGGL(sr_prep_kernel, grid, dim3(256), 0, st, L, A, gp, line_lo, n_sub, fast, cold, zmax);
   return (int)hipGetLastError();
 }
 
-int abscoeff_tile_points(int variant) { return 256 * (variant == 2 ? 2 : (variant == 1 ? 1 : 4)); }
+int abscoeff_tile_points(int variant) { return 64 * (variant == 4 ? 4 : 8); }
 
-int launch_abscoeff(int variant, const FastRec *fast, const ColdRec *cold, const int *ic_sub, int n_sub,
-                    int n_layers, int g_lo, int g_hi, const GridParams &gp, double *abs_out,
-                    double *emi_out, hipStream_t st) {
+int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *cold, const int *ic_sub,
+                    const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp,
+                    double *abs_out, double *emi_out, hipStream_t st) {
   const int tp = abscoeff_tile_points(variant);
   const int n_tiles = (g_hi - g_lo + tp - 1) / tp;
   if (n_tiles <= 0 || n_layers <= 0) return 0;
   dim3 grid((unsigned)(n_tiles * n_layers));
-#define SR_LAUNCH(P, NR)                                                                          \
-  hipLaunchKernelGGL((sr_abscoeff_kernel<P, NR>), grid, dim3(256), 0, st, fast, cold, ic_sub,     \
-                     n_sub, n_tiles, g_lo, g_hi, gp, abs_out, emi_out)
-  if (variant == 1) SR_LAUNCH(1, 2);
-  else if (variant == 2) SR_LAUNCH(2, 2);
-  else SR_LAUNCH(4, 2);
-#undef SR_LAUNCH
+  if (which == 0) {
+    if (variant == 4)
+      hipLaunchKernelGGL((sr_abscoeff_wings_kernel<4>), grid, dim3(64), 0, st, fast, ic_sub, n_sub, n_tiles,
+                         g_lo, g_hi, abs_out, emi_out);
+    else
+      hipLaunchKernelGGL((sr_abscoeff_wings_kernel<8>), grid, dim3(64), 0, st, fast, ic_sub, n_sub, n_tiles,
+                         g_lo, g_hi, abs_out, emi_out);
+  } else {
+    if (variant == 4)
+      hipLaunchKernelGGL((sr_abscoeff_cores_kernel<4>), grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub,
+                         n_tiles, g_lo, g_hi, gp, abs_out, emi_out);
+    else
+      hipLaunchKernelGGL((sr_abscoeff_cores_kernel<8>), grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub,
+                         n_tiles, g_lo, g_hi, gp, abs_out, emi_out);
+  }
   return (int)hipGetLastError();
 }
 
@@ -283,7 +382,7 @@ __global__ __launch_bounds__(256) void sr_humliv_kernel(const double *__restrict
   r.xl = B.xl; r.xr = B.xr; r.xstep = B.xstep;
   region1_coef(B.ry, r.a, r.b, r.c, r.d);
   r.wabs = r.wemi = 1.0; r.j1 = 0;
-  r.il = (int16_t)B.il; r.ir = (int16_t)B.ir;
+  r.ilir = (uint32_t)B.il | ((uint32_t)B.ir << 16);
   ColdRec c;
   c.ry = B.ry; c.dwp = dwp; c.x0 = x0; c.il2 = (int16_t)B.il2; c.ir2 = (int16_t)B.ir2; c.pad = 0;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x + 1; k <= n; k += gridDim.x * blockDim.x)

@@ -23,11 +23,12 @@ struct LayersDev {
 };
 
 int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub,
-                FastRec *fast, ColdRec *cold, hipStream_t st);
+                FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st);
 int abscoeff_tile_points(int variant);
-int launch_abscoeff(int variant, const FastRec *fast, const ColdRec *cold, const int *ic_sub, int n_sub,
-                    int n_layers, int g_lo, int g_hi, const GridParams &gp, double *abs_out,
-                    double *emi_out, hipStream_t st);
+// which = 0: wings kernel (writes abs/emi), 1: cores kernel (adds into them)
+int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *cold, const int *ic_sub,
+                    const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp,
+                    double *abs_out, double *emi_out, hipStream_t st);
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                     const int *seg_layer, const double *seg_col, int init_from_rad, double *rad,
                     hipStream_t st);

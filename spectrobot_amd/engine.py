@@ -141,9 +141,10 @@ class LineSet(object):
         return ab, em
 
     def last_kernel_ms(self):
-        a, b = C.c_float(0), C.c_float(0)
-        check(lib.sr_last_kernel_ms(self._h, C.byref(a), C.byref(b)), "sr_last_kernel_ms")
-        return a.value, b.value
+        """(prep, wings, cores) kernel times in ms of the last abscoeff_layers call."""
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+        check(lib.sr_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c)), "sr_last_kernel_ms")
+        return a.value, b.value, c.value
 
 
 def radiance_rays(abs_c, emi_c, seg_off, seg_layer, seg_col, rad0=None):
