@@ -48,8 +48,9 @@ def all_gather_spectrum(shard, n_grid, world_size, rank, out=None):
     q = -(-int(n_grid) // int(world_size))
     pad = torch.zeros((n_rays, q), dtype=shard.dtype, device=shard.device)
     pad[:, :shard.shape[1]] = shard
-    gathered = torch.empty((world_size, n_rays, q), dtype=shard.dtype, device=shard.device)
-    dist.all_gather_into_tensor(gathered, pad)
+    flat = torch.empty((world_size * n_rays, q), dtype=shard.dtype, device=shard.device)
+    dist.all_gather_into_tensor(flat, pad)  # concatenation along dim 0, rank-major
+    gathered = flat.view(world_size, n_rays, q)
     if out is None:
         out = torch.empty((n_rays, n_grid), dtype=shard.dtype, device=shard.device)
     for r in range(world_size):

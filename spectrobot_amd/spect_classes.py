@@ -1,0 +1,383 @@
+"""Host-side mirror of the reference's `spect_classes` interface for the hot path.
+
+Same names, argument meaning and error behaviour as the reference
+(spect_classes.py, cited per item) for what the spectral hot path touches:
+SpectLine, SpectralGrid, SpectralObject, the width / Einstein / partition-sum
+helpers, MakeShape and calc_shapes_lines.  The per-line physics that the
+reference evaluates in Python + f2py is evaluated on the GPU:
+
+  * MakeShape / MakeShapeLine        -> lineshape.humliv_bb shim (HIP kernel)
+  * calc_shapes_lines + BuildCoeff + make_abscoeff_isomolec
+                                     -> one coarse-grained call, see
+                                        spect_main_module.make_abscoeff_isomolec
+  * CalcPartitionSum                 -> library TIPS-2003 tables + Lagrange
+
+The scalar helpers (Lorenz_width, Doppler_width, Einstein_*, ...) are the
+reference's closed-form expressions; they exist for callers that inspect single
+lines (CheckWidths, Calc_Gcoeffs) and are not used by the GPU path, which
+computes the same quantities in sr_prep_kernel.
+"""
+import copy
+import math as mt
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, dp
+from .compat import lineshape
+
+n_threads = 4           # spect_classes.py:24 (kept for signature compatibility; unused)
+imxsig = 13010          # spect_classes.py:27
+imxlines = 40000        # spect_classes.py:28
+imxsig_long = 2000000   # spect_classes.py:29
+T_ref = 296.0           # spect_classes.py:39
+hpa_to_atm = 0.00098692326671601  # spect_classes.py:40
+
+# spect_classes.py:44-47 with scipy.constants (CODATA-2018) values written out
+h_cgs = 6.62607015e-34 * 1.e7
+c_cgs = 299792458.0 * 1.e2
+k_cgs = 1.380649e-23 * 1.e7
+c2 = h_cgs * c_cgs / k_cgs
+_AVOGADRO = 6.02214076e23
+
+cose = ('Mol', 'Iso', 'Freq', 'Strength', 'A_coeff', 'Air_broad', 'Self_broad', 'E_lower', 'T_dep_broad',
+        'P_shift', 'Up_lev_str', 'Lo_lev_str', 'Q_num_up', 'Q_num_lo')                    # spect_classes.py:50
+cose_hit = cose + ('others', 'g_up', 'g_lo')                                               # spect_classes.py:51
+cose_mas = ('Up_lev_id', 'Lo_lev_id', 'Up_lev', 'Lo_lev')                                 # spect_classes.py:53
+
+
+# ----------------------------------------------------------------------------
+# scalar helpers
+# ----------------------------------------------------------------------------
+def convert_to_atm(Pres, units='hPa'):
+    """spect_classes.py:2029-2036"""
+    if units == 'hPa':
+        return Pres * hpa_to_atm
+    raise ValueError('units {} not recognized'.format(units))
+
+
+def Lorenz_width(Temp, Pres_atm, T_dep_broad, Air_broad, Self_broad=0.0, Self_pres_atm=0.0):
+    """spect_classes.py:1967-1974"""
+    return (T_ref / Temp) ** T_dep_broad * (Air_broad * (Pres_atm - Self_pres_atm) + Self_broad * Self_pres_atm)
+
+
+def Doppler_width(Temp, MM, wn_0):
+    """spect_classes.py:1976-1986 (half width at half maximum; humliv_bb takes dw/sqrt(ln2))"""
+    return wn_0 / c_cgs * mt.sqrt(2 * _AVOGADRO * k_cgs * Temp * mt.log(2.0) / MM)
+
+
+def Boltz_ratio_nodeg(wavenumber, temp):
+    """spect_classes.py:1876-1878"""
+    return np.exp(-c2 * wavenumber / temp)
+
+
+def Calc_BB_single(nu, T):
+    """spect_classes.py:1895-1903, units erg s-1 cm-2 sr-1 (cm-1)-1"""
+    return 2 * h_cgs * c_cgs ** 2 * nu ** 3 / (np.exp(c2 * nu / T) - 1)
+
+
+def Einstein_A_to_B(A_coeff, wavenumber, units='cm3ergcm2'):
+    """spect_classes.py:1736-1754 (only the unit system the path uses)"""
+    if units != 'cm3ergcm2':
+        raise ValueError("only units='cm3ergcm2' is supported on this path")
+    return A_coeff / (2 * h_cgs * c_cgs ** 2 * wavenumber ** 3)
+
+
+def Einstein_B21_to_B12(B_21, g_1, g_2):
+    """spect_classes.py:1778-1785"""
+    return B_21 * g_2 / g_1
+
+
+def Einstein_A_to_Gcoeff_abs(line, Temp, E_vib):
+    """spect_classes.py:1806-1819"""
+    B_21 = line.Einstein_A_to_B()
+    B_12 = Einstein_B21_to_B12(B_21, line.g_lo, line.g_up)
+    rot_pop = line.g_lo * Boltz_ratio_nodeg(line.E_lower - E_vib, Temp)
+    return h_cgs * c_cgs * line.Freq * rot_pop * B_12 / (4 * np.pi)
+
+
+def Einstein_A_to_Gcoeff_indem(line, Temp, E_vib):
+    """spect_classes.py:1832-1842"""
+    B_21 = line.Einstein_A_to_B()
+    rot_pop = line.g_up * Boltz_ratio_nodeg(line.E_lower + line.Freq - E_vib, Temp)
+    return h_cgs * c_cgs * line.Freq * rot_pop * B_21 / (4 * np.pi)
+
+
+def Einstein_A_to_Gcoeff_spem(line, Temp, E_vib):
+    """spect_classes.py:1845-1853"""
+    rot_pop = line.g_up * Boltz_ratio_nodeg(line.E_lower + line.Freq - E_vib, Temp)
+    return h_cgs * c_cgs * line.Freq * rot_pop * line.A_coeff / (4 * np.pi)
+
+
+def Einstein_A_to_LineStrength_hitran(A_coeff, wavenumber, temp, Q_part, g_upper, E_lower, iso_ab=1.0):
+    """spect_classes.py:1856-1863"""
+    return iso_ab * A_coeff * g_upper * np.exp(-c2 * E_lower / temp) * (1 - np.exp(-c2 * wavenumber / temp)) / (
+        8 * np.pi * c_cgs * wavenumber ** 2 * Q_part)
+
+
+def ImportPartitionSumTable(mol, iso):
+    """spect_classes.py:1680-1689 -> gi, T_grid, Q_grid (library TIPS-2003 tables)"""
+    from .compat import fparts_mod
+    return fparts_mod.bd_tips_2003(mol, iso)
+
+
+def CalcPartitionSum(mol, iso, temp=296.0):
+    """spect_classes.py:1692-1710 (4-point Lagrange through the TIPS-2003 table)"""
+    t = np.ascontiguousarray(np.atleast_1d(temp), dtype=np.float64)
+    q = np.zeros_like(t)
+    check(lib.sr_calc_partition_sum(int(mol), int(iso), t.ctypes.data_as(dp), t.size, q.ctypes.data_as(dp)),
+          "CalcPartitionSum")
+    return q if np.ndim(temp) else float(q[0])
+
+
+def closest_grid(wn_arr, wn_0):
+    """spect_classes.py:1937-1943 -> (index, grid value) of the closest grid point"""
+    ind = np.argmin(np.abs(wn_arr.grid - wn_0))
+    return ind, wn_arr.grid[ind]
+
+
+# ----------------------------------------------------------------------------
+# containers
+# ----------------------------------------------------------------------------
+class SpectralGrid(object):
+    """spect_classes.py:354-432 (grid + units; conversions other than cm_1 are post-processing, not mirrored)"""
+
+    def __init__(self, spectral_grid, units='nm'):
+        self.grid = copy.deepcopy(np.asarray(spectral_grid, dtype=float))
+        self.units = units
+        if len(spectral_grid) > imxsig_long:
+            raise ValueError('Grid longer that the max value imxsig_long set to {}'.format(imxsig_long))
+
+    def step(self):
+        return self.grid[1] - self.grid[0]
+
+    def len_wn(self):
+        return len(self.grid)
+
+    def wn_range(self):
+        return [self.min_wn(), self.max_wn()]
+
+    def min_wn(self):
+        return min(self.grid)
+
+    def max_wn(self):
+        return max(self.grid)
+
+
+class SpectralObject(object):
+    """spect_classes.py:435-500, 670-691, 810-830, 929-953: spectrum on a grid with + - * and
+    add_to_spectrum / integrate."""
+
+    def __init__(self, spectrum, spectral_grid, direction=None, units='', link_grid=False):
+        self.spectrum = copy.deepcopy(spectrum)
+        self.direction = copy.deepcopy(direction)
+        self.spectral_grid = spectral_grid if link_grid else copy.deepcopy(spectral_grid)
+        self.units = units
+
+    def n_points(self):
+        return len(self.spectrum)
+
+    def __add__(self, obj2):
+        coso = copy.deepcopy(self)
+        if isinstance(obj2, SpectralObject):
+            if len(obj2.spectrum) == len(self.spectrum):
+                coso.spectrum += obj2.spectrum
+            else:
+                coso.add_to_spectrum(obj2)
+        else:
+            coso.spectrum += obj2
+        return coso
+
+    def __sub__(self, obj2):
+        coso = copy.deepcopy(self)
+        if isinstance(obj2, SpectralObject):
+            if len(obj2.spectrum) == len(self.spectrum):
+                coso.spectrum -= obj2.spectrum
+            else:
+                coso.add_to_spectrum(obj2, Strength=-1.0)
+        else:
+            coso.spectrum -= obj2
+        return coso
+
+    def __mul__(self, obj2):
+        coso = copy.deepcopy(self)
+        coso.spectrum *= obj2.spectrum if isinstance(obj2, SpectralObject) else obj2
+        return coso
+
+    def multiply(self, factor, save=True):
+        if save:
+            self.spectrum = self.spectrum * factor
+            return
+        coso = copy.deepcopy(self)
+        coso.spectrum = factor * self.spectrum
+        return coso
+
+    def integrate(self, w1=None, w2=None):
+        cond = ~np.isnan(self.spectrum)
+        if w1 is not None:
+            cond &= self.spectral_grid.grid >= w1
+        if w2 is not None:
+            cond &= self.spectral_grid.grid <= w2
+        return np.trapezoid(self.spectrum[cond], x=self.spectral_grid.grid[cond])
+
+    def add_to_spectrum(self, spectrum2, Strength=None, sumcheck=10.):
+        """spect_classes.py:929-953: spectrum2's grid is (partly) inside self's, same step."""
+        spino = self.spectral_grid.step() / 10.
+        g1, g2 = self.spectral_grid.grid, spectrum2.spectral_grid.grid
+        ok = (g1 > g2[0] - spino) & (g1 < g2[-1] + spino)
+        ok2 = (g2 > g1[0] - spino) & (g2 < g1[-1] + spino)
+        if Strength is not None:
+            self.spectrum[ok] += Strength * spectrum2.spectrum[ok2]
+        else:
+            self.spectrum[ok] += spectrum2.spectrum[ok2]
+
+    def erase_grid(self):
+        self.spectral_grid = None
+
+    def restore_grid(self, spectral_grid, link_grid=False):
+        self.spectral_grid = spectral_grid if link_grid else copy.deepcopy(spectral_grid)
+
+
+class SpectLine(object):
+    """One HITRAN line (spect_classes.py:56-351).  linea: dict, numpy record or sequence + nomi."""
+
+    def __init__(self, linea, nomi=None):
+        if nomi is None:
+            if isinstance(linea, dict):
+                nomi = tuple(linea.keys())
+            elif isinstance(linea, np.void):
+                nomi = linea.dtype.names
+            else:
+                raise ValueError('Missing names for line quantities')
+        else:
+            linea = dict(zip(nomi, linea))
+        for nome in nomi:
+            setattr(self, nome, linea[nome])
+        for nome in cose_mas:
+            setattr(self, nome, None)
+        for nome in cose_hit:
+            if not hasattr(self, nome):
+                setattr(self, nome, None)
+        self.E_vib_up = None
+        self.E_vib_lo = None
+
+    def minimal_level_string_up(self):
+        return self.Up_lev_str.strip() if self.Up_lev_str is not None else None
+
+    def minimal_level_string_lo(self):
+        return self.Lo_lev_str.strip() if self.Lo_lev_str is not None else None
+
+    def LinkToMolec(self, isomolec):
+        """spect_classes.py:122-150 (including its if/elif: a line whose two levels are the
+        same level never gets its lower level linked and is reported unlinked)."""
+        if isomolec is None:
+            return False
+        self.Up_lev_id = self.E_vib_up = self.Lo_lev_id = self.E_vib_lo = None
+        for lev in isomolec.levels:
+            Level = getattr(isomolec, lev)
+            if Level.minimal_level_string() == self.minimal_level_string_up():
+                self.Up_lev_id = lev
+                self.E_vib_up = Level.energy
+            elif Level.minimal_level_string() == self.minimal_level_string_lo():
+                self.Lo_lev_id = lev
+                self.E_vib_lo = Level.energy
+        return not (self.Up_lev_id is None or self.Lo_lev_id is None)
+
+    def Einstein_A_to_B(self):
+        return Einstein_A_to_B(self.A_coeff, self.Freq, units='cm3ergcm2')
+
+    def CheckWidths(self, Temp, Pres, MM):
+        """spect_classes.py:161-171 -> (dw, lw, p_shift)"""
+        Pres_atm = convert_to_atm(Pres, units='hPa')
+        return (Doppler_width(Temp, MM, self.Freq),
+                Lorenz_width(Temp, Pres_atm, self.T_dep_broad, self.Air_broad), self.P_shift * Pres_atm)
+
+    def MakeShapeLine(self, Temp, Pres, grid=None, MM=None, Strength=1.0, verbose=False, keep_memory=False):
+        """spect_classes.py:174-206.  The pressure shift is computed but, as in the
+        reference (line 197), not applied; self broadening is not used (line 190)."""
+        if MM is None:
+            raise ValueError('MM (molar mass) is required: spect_base_module.find_molec_metadata is not part '
+                             'of the reference tree')
+        if grid is None:
+            sp_step = 5.e-4
+            grid = np.arange(-imxsig * sp_step / 2, imxsig * sp_step / 2, sp_step, dtype=float)
+            grid = SpectralGrid(grid + self.Freq, units='cm_1')
+        Pres_atm = convert_to_atm(Pres, units='hPa')
+        lw = Lorenz_width(Temp, Pres_atm, self.T_dep_broad, self.Air_broad)
+        dw = Doppler_width(Temp, MM, self.Freq)
+        shape = MakeShape(grid, self.Freq, lw, dw, Strength=Strength)
+        if keep_memory:
+            self.shape = shape
+        return shape
+
+    def Calc_Gcoeffs(self, Temp, isomolec=None):
+        """spect_classes.py:312-343 -> {'sp_emission', 'ind_emission', 'absorption'}"""
+        ctypes_ = ['sp_emission', 'ind_emission', 'absorption']
+        ok = self.LinkToMolec(isomolec)
+        lev_energy_lo = self.E_vib_lo if ok else 0.0
+        lev_energy_up = self.E_vib_up if ok else 0.0
+        if self.A_coeff != 0.0 and self.g_lo != 0.0 and self.g_up != 0.0:
+            values = [Einstein_A_to_Gcoeff_spem(self, Temp, lev_energy_up),
+                      Einstein_A_to_Gcoeff_indem(self, Temp, lev_energy_up),
+                      Einstein_A_to_Gcoeff_abs(self, Temp, lev_energy_lo)]
+        else:
+            values = [0., 0., 0.]
+        self.G_coeffs = dict(zip(ctypes_, values))
+        return self.G_coeffs
+
+
+def MakeShape(wn_arr, wn_0, lw, dw, Strength=1.0):
+    """spect_classes.py:1990-2008: unit-area Voigt on the 13010-point window wn_arr
+    (humliv_bb evaluated on the GPU)."""
+    fac = float(dw * mt.sqrt(np.pi / mt.log(2.0)))
+    y = lineshape.humliv_bb(wn_arr.grid, 1, len(wn_arr.grid), wn_0, lw, dw / mt.sqrt(mt.log(2.0)))
+    y = Strength * y / fac
+    return SpectralObject(y, wn_arr)
+
+
+# ----------------------------------------------------------------------------
+# line list -> structure of arrays for the engine
+# ----------------------------------------------------------------------------
+def lines_to_soa(lines, isomolec=None):
+    """SpectLine objects -> the SoA dict the engine uploads.  Level indices are
+    resolved here once (the reference string-matches every level for every line
+    at every (P,T): LinkToMolec, spect_classes.py:122-150); -1 = not in the
+    level list."""
+    n = len(lines)
+    out = {k: np.zeros(n) for k in ("freq", "a_coeff", "e_lower", "g_up", "g_lo", "air_broad", "t_dep_broad")}
+    out["lev_up"] = np.full(n, -1, np.int32)
+    out["lev_lo"] = np.full(n, -1, np.int32)
+    names = []
+    if isomolec is not None:
+        names = [getattr(isomolec, lev).minimal_level_string() for lev in isomolec.levels]
+    for i, l in enumerate(lines):
+        out["freq"][i], out["a_coeff"][i], out["e_lower"][i] = l.Freq, l.A_coeff, l.E_lower
+        out["g_up"][i], out["g_lo"][i] = l.g_up, l.g_lo
+        out["air_broad"][i], out["t_dep_broad"][i] = l.Air_broad, l.T_dep_broad
+        if names:
+            up, lo = l.minimal_level_string_up(), l.minimal_level_string_lo()
+            # same loop as LinkToMolec: a level that matches the upper string is never
+            # also taken as the lower one (if/elif); a later duplicate overrides
+            for j, nm in enumerate(names):
+                if nm == up:
+                    out["lev_up"][i] = j
+                elif nm == lo:
+                    out["lev_lo"][i] = j
+    return out
+
+
+def calc_shapes_lines(wn_arr, lines, Temp, Pres, isomolec, n_threads=n_threads):
+    """spect_classes.py:1378-1415.  Kept for callers that want per-line shapes:
+    attaches .shape (13010-point SpectralObject) and .G_coeffs to every line that
+    links to the iso-molecule.  The production path does NOT go through per-line
+    shapes: use spect_main_module.make_abscoeff_isomolec."""
+    if len(isomolec.levels) > 0:
+        lines = [lin for lin in lines if lin.LinkToMolec(isomolec)]
+    sp_step = wn_arr.step()
+    lin_grid = np.arange(-imxsig * sp_step / 2, imxsig * sp_step / 2, sp_step, dtype=float)
+    for lin in lines:
+        ind_ok, fr_grid_ok = closest_grid(wn_arr, lin.Freq)
+        lin_grid_ok = SpectralGrid(lin_grid + fr_grid_ok, units='cm_1')
+        lin.MakeShapeLine(Temp, Pres, grid=lin_grid_ok, MM=isomolec.MM, keep_memory=True)
+        lin.Calc_Gcoeffs(Temp, isomolec=isomolec)
+    return lines

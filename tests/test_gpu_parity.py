@@ -146,3 +146,107 @@ def test_radiance_vs_oracle(eng, oracle):
     for r in range(3):
         want = oracle.radiance_ray(a, e, lays[offs[r]:offs[r + 1]], cols[offs[r]:offs[r + 1]])
         assert relerr(rad[r].cpu().numpy(), want) < 1e-13
+
+
+def test_compat_shims_vs_oracle(eng, oracle, golden):
+    """f2py-shaped drop-ins: lineshape.sum_all_lines, curgods.curgod_fort_1..4, fparts_mod."""
+    from spectrobot_amd.compat import lineshape, curgods, fparts_mod
+    rng = np.random.default_rng(5)
+    rows = rng.random((300, 200))
+    init = rng.integers(1, 2000, 300)
+    fin = init + 199
+    spe = rng.random(2300)
+    got = lineshape.sum_all_lines(spe, rows, init, fin, 300, spe.size)
+    want = oracle.sum_all_lines(spe, rows, init, fin)
+    assert np.array_equal(got, want)  # same summation order as the Fortran: bit-exact
+    g = golden("curgods")
+    for i in range(3):
+        nd, x, vmr, f = (g["%s_%d" % (k, i)] for k in ("nd", "x", "vmr", "f"))
+        r = [curgods.curgod_fort_1(nd, x, len(nd)), curgods.curgod_fort_2(nd, vmr, x, len(nd)),
+             curgods.curgod_fort_3(nd, vmr, f, x, len(nd)), curgods.curgod_fort_4(nd, vmr, f, x, len(nd))]
+        assert relerr(r, g["res_%d" % i]) < 1e-12
+    # batched: three segments in one launch
+    off = np.cumsum([0] + [len(g["nd_%d" % i]) for i in range(3)])
+    cat = lambda k: np.concatenate([g["%s_%d" % (k, i)] for i in range(3)])
+    rb = curgods.curgod_batch(2, cat("nd"), cat("x"), off, vmr=cat("vmr"))
+    assert relerr(rb, [g["res_%d" % i][1] for i in range(3)]) < 1e-12
+    gi, t, q = fparts_mod.bd_tips_2003(6, 1)
+    tg = golden("tips2003")
+    k = [tuple(v) for v in tg["keys"]].index((6, 1))
+    assert np.array_equal(q, tg["q_tab"][k]) and gi == tg["gi"][k]
+
+
+def test_make_abscoeff_isomolec_api(eng, golden):
+    """The reference's Python entry point (spect_main_module.py:1880) with SpectLine /
+    IsoMolec objects in and AbsSetLOS out, against the reference's own output."""
+    from spectrobot_amd import spect_classes as spcl, spect_base_module as sbm, spect_main_module as smm
+    g = golden("e2e_ch4_levels")
+    iso = sbm.IsoMolec(6, 1, float(g["mm"]))
+    for i, e in enumerate(g["e_lev"]):
+        iso.add_level("L%02d" % i, e, local_vibtemp=g["tvib"][i])
+    lines = []
+    for i in range(len(g["line_freq"])):
+        up = "L%02d" % g["line_lev_up"][i] if g["line_lev_up"][i] >= 0 else "??"
+        lo = "L%02d" % g["line_lev_lo"][i] if g["line_lev_lo"][i] >= 0 else "??"
+        lines.append(spcl.SpectLine([6, 1, g["line_freq"][i], 0.0, g["line_a_coeff"][i], g["line_air_broad"][i], 0.0,
+                                     g["line_e_lower"][i], g["line_t_dep_broad"][i], 0.0, up, lo, "", "", "",
+                                     g["line_g_up"][i], g["line_g_lo"][i]], nomi=spcl.cose_hit))
+    grid = _grid(g)
+    ab, em = smm.make_abscoeff_isomolec([grid[0], grid[-1]], iso, g["temps"], g["press"], LTE=False, lines=lines)
+    assert ab.counter == 3 and len(ab.set) == 3
+    assert np.array_equal(ab.spectral_grid.grid, grid)
+    assert relerr(np.array([s.spectrum for s in ab.set]), g["abs"]) < TOL
+    assert relerr(np.array([s.spectrum for s in em.set]), g["emi"]) < TOL
+    with pytest.raises(ValueError):
+        smm.make_abscoeff_isomolec([grid[0], grid[-1]], iso, g["temps"], g["press"])
+    # one line's shape through MakeShapeLine: unit area to the window truncation (spect_classes.py:1994)
+    sh = lines[3].MakeShapeLine(150.0, 0.5, MM=float(g["mm"]))
+    assert 0.9998 < sh.integrate() < 1.0
+
+
+def test_error_paths_on_device(eng):
+    from spectrobot_amd import synthetic as syn
+    from spectrobot_amd._lib import SpectRobotHipError, SR_ERR_UNSUPPORTED, SR_ERR_ARG
+    grid = syn.make_grid(2990.0, 5e-4, 5000)
+    L = syn.make_lines(10, grid, seed=3, n_levels=0)
+    L["freq"][0] = grid[0] - 5.0  # farther than half a window from the grid
+    with pytest.raises(SpectRobotHipError) as e:
+        eng.LineSet(L, grid, 6, 1, 16.0)
+    assert e.value.status == SR_ERR_UNSUPPORTED
+    L = syn.make_lines(10, grid, seed=3, n_levels=0)
+    ls = eng.LineSet(L, grid, 6, 1, 16.0)
+    with pytest.raises(SpectRobotHipError) as e:
+        ls.abscoeff_layers([150.0], [1.0], g_lo=10, g_hi=6000)
+    assert e.value.status == SR_ERR_ARG
+    with pytest.raises(SpectRobotHipError):
+        ls.abscoeff_layers([-1.0], [1.0])
+    # empty line list: zeros, no launch
+    empty = {k: v[:0] for k, v in L.items()}
+    ls0 = eng.LineSet(empty, grid, 6, 1, 16.0)
+    ab, em = ls0.abscoeff_layers([150.0, 160.0], [1.0, 0.1])
+    assert float(ab.abs().sum()) == 0.0 and float(em.abs().sum()) == 0.0
+
+
+def test_full_size_linearity_property(eng):
+    """BASELINE configs[1] size (1e5 lines x 1e5 grid), 2 layers: the spectrum of the whole line
+    list equals the sum of the spectra of its two halves (size-independent property)."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2975.0, 5e-4, 100000)
+    L = syn.make_lines(100000, grid, config_id=2, n_levels=12)
+    atm = syn.make_atmosphere(80, 12)
+    sel = [3, 60]
+    T, P, tv = atm["temps"][sel], atm["press"][sel], atm["tvib"][:, sel]
+    full = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    ab, em = full.abscoeff_layers(T, P, tvib=tv)
+    acc_a = torch.zeros_like(ab)
+    acc_e = torch.zeros_like(em)
+    for part in (slice(0, None, 2), slice(1, None, 2)):
+        sub = {k: v[part] for k, v in L.items()}
+        ls = eng.LineSet(sub, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+        a, e = ls.abscoeff_layers(T, P, tvib=tv)
+        acc_a += a
+        acc_e += e
+    assert float(((acc_a - ab).abs() / ab.abs()).max()) < 1e-11
+    assert float(((acc_e - em).abs() / em.abs()).max()) < 1e-11
+    assert bool((ab > 0).all()) and bool((em > 0).all())

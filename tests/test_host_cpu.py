@@ -1,0 +1,177 @@
+"""Host-side logic and the C-ABI surface, no GPU needed (no kernel is launched)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from spectrobot_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(L):
+    hdr = open(os.path.join(ROOT, "include", "spectrobot_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sr_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 15
+    raw = C.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), "library does not export %s" % name
+    assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
+    assert L.lib.sr_abi_version() == 1
+    assert L.lib.sr_strerror(0) == b"ok" and L.lib.sr_strerror(-1) == b"bad argument"
+
+
+def test_tips_tables_and_partition_sum(L, golden):
+    """sr_bd_tips_2003 / sr_calc_partition_sum (host code) against the reference's Fortran tables
+    and its Python CalcPartitionSum."""
+    g = golden("tips2003")
+    dp = L.dp
+    for key, gi, tab in zip(g["keys"], g["gi"], g["q_tab"]):
+        out_gi = C.c_double(0)
+        t = np.zeros(119)
+        q = np.zeros(119)
+        assert L.lib.sr_bd_tips_2003(int(key[0]), int(key[1]), C.byref(out_gi), t.ctypes.data_as(dp),
+                                     q.ctypes.data_as(dp)) == 0
+        assert out_gi.value == gi and np.array_equal(t, g["t_grid"]) and np.array_equal(q, tab)
+    assert L.lib.sr_bd_tips_2003(99, 1, None, None, None) == L.SR_ERR_TABLE
+    for mol, iso, T, qref in g["samples"]:
+        tt = np.array([T])
+        q = np.zeros(1)
+        assert L.lib.sr_calc_partition_sum(int(mol), int(iso), tt.ctypes.data_as(dp), 1, q.ctypes.data_as(dp)) == 0
+        assert abs(q[0] - qref) <= 1e-13 * abs(qref)
+
+
+def test_argument_checks_return_before_any_launch(L):
+    dp, ip = L.dp, L.ip
+    x = np.linspace(0.0, 1.0, 13010)
+    y = np.zeros_like(x)
+    xp, yp = x.ctypes.data_as(dp), y.ctypes.data_as(dp)
+    assert L.lib.sr_humliv_bb(xp, 13010, 5, 4, 0.5, 1e-3, 1e-3, yp) == L.SR_ERR_ARG      # i1 > i2 (Fortran stop)
+    assert L.lib.sr_humliv_bb(xp, 13010, 1, 13010, 0.5, 1e-3, 0.0, yp) == L.SR_ERR_ARG   # dw <= 0 (Fortran stop)
+    assert L.lib.sr_humliv_bb(xp, 13010, 1, 13010, 2.0, 1e-3, 1e-3, yp) == L.SR_ERR_UNSUPPORTED
+    assert L.lib.sr_curgod(5, xp, None, None, xp, None, 0, yp) == L.SR_ERR_ARG
+    assert L.lib.sr_sum_all_lines(yp, 0, None, None, None, 0, 1) == L.SR_ERR_ARG
+    init = np.array([0], np.int32)
+    fin = np.array([3], np.int32)
+    assert L.lib.sr_sum_all_lines(yp, 100, xp, init.ctypes.data_as(ip), fin.ctypes.data_as(ip), 1, 10) == L.SR_ERR_ARG
+    # lineset: bad grid / too many grid points are refused before anything is uploaded
+    ld = L.LinesDesc()
+    ld.n_lines = 0
+    iso = L.IsoMolecDesc(6, 1, 16.0, 0, None)
+    h = C.c_void_p()
+    assert L.lib.sr_lineset_create(C.byref(ld), C.byref(iso), C.byref(L.GridDesc(3000.0, -1.0, 100)),
+                                   C.byref(h), None) == L.SR_ERR_ARG
+    assert L.lib.sr_lineset_create(C.byref(ld), C.byref(iso), C.byref(L.GridDesc(3000.0, 5e-4, 2000001)),
+                                   C.byref(h), None) == L.SR_ERR_LIMIT
+    with pytest.raises(L.SpectRobotHipError):
+        L.check(L.SR_ERR_ARG, "x")
+
+
+def test_shard_bounds_cover_the_grid():
+    from spectrobot_amd.distributed import shard_bounds
+    for n in (100000, 99999, 8, 13):
+        for w in (1, 2, 3, 4, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_all_gather_spectrum_gloo_world2(tmp_path):
+    """The N > 1 reassembly path with the gloo backend, two CPU ranks."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from spectrobot_amd import distributed as sd\n"
+        "rank, local, world = sd.init_from_env(backend='gloo')\n"
+        "n, rays = 1001, 3\n"
+        "full = torch.arange(rays * n, dtype=torch.float64).reshape(rays, n)\n"
+        "lo, hi = sd.shard_bounds(n, world, rank)\n"
+        "out = sd.all_gather_spectrum(full[:, lo:hi].contiguous(), n, world, rank)\n"
+        "assert torch.equal(out, full), rank\n"
+        "torch.distributed.barrier()\n"
+        "print('rank', rank, 'ok')\n" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
+
+
+def test_lines_to_soa_matches_linktomolec(golden):
+    """Level resolution incl. the reference's quirks (unidentified and same-level lines)."""
+    from spectrobot_amd import spect_classes as spcl, spect_base_module as sbm
+    g = golden("e2e_ch4_levels")
+    iso = sbm.IsoMolec(6, 1, float(g["mm"]))
+    for i, e in enumerate(g["e_lev"]):
+        iso.add_level("L%02d" % i, e)
+    lines = []
+    for i in range(len(g["line_freq"])):
+        up = "L%02d" % g["line_lev_up"][i] if g["line_lev_up"][i] >= 0 else "??"
+        lo = "L%02d" % g["line_lev_lo"][i] if g["line_lev_lo"][i] >= 0 else "??"
+        lines.append(spcl.SpectLine([6, 1, g["line_freq"][i], 0.0, g["line_a_coeff"][i], g["line_air_broad"][i], 0.0,
+                                     g["line_e_lower"][i], g["line_t_dep_broad"][i], 0.0, up, lo, "", "", "",
+                                     g["line_g_up"][i], g["line_g_lo"][i]], nomi=spcl.cose_hit))
+    soa = spcl.lines_to_soa(lines, iso)
+    linked = np.array([l.LinkToMolec(iso) for l in lines])
+    kept = (soa["lev_up"] >= 0) & (soa["lev_lo"] >= 0) & (soa["lev_up"] != soa["lev_lo"])
+    assert np.array_equal(linked, kept)
+    assert (~linked).sum() >= 4          # the fixture pins at least 4 dropped lines
+    assert np.array_equal(soa["freq"], g["line_freq"])
+
+
+def test_scalar_mirror_against_reference_values(golden):
+    from spectrobot_amd import spect_classes as spcl
+    g = golden("spcl_scalars")
+    for k in ("h_cgs", "c_cgs", "k_cgs", "c2", "hpa_to_atm", "T_ref"):
+        assert getattr(spcl, k) == float(g["const_" + k])
+    for i in range(len(g["T"])):
+        lw = spcl.Lorenz_width(g["T"][i], spcl.convert_to_atm(g["P"][i]), g["n_air"][i], g["gam"][i])
+        assert abs(lw - g["lw"][i]) <= 1e-15 * g["lw"][i]
+        assert abs(spcl.Doppler_width(g["T"][i], g["MM"][i], g["nu"][i]) - g["dw"][i]) <= 1e-15 * g["dw"][i]
+        l = spcl.SpectLine([6, 1, g["nu"][i], 0.0, g["A"][i], g["gam"][i], 0.0, g["El"][i], g["n_air"][i], 0.0,
+                            "a", "b", "", "", "", g["gu"][i], g["gl"][i]], nomi=spcl.cose_hit)
+        G = [spcl.Einstein_A_to_Gcoeff_spem(l, g["T"][i], g["Evu"][i]),
+             spcl.Einstein_A_to_Gcoeff_indem(l, g["T"][i], g["Evu"][i]),
+             spcl.Einstein_A_to_Gcoeff_abs(l, g["T"][i], g["Evl"][i])]
+        assert np.allclose(G, g["G"][i], rtol=1e-14, atol=0)
+        assert abs(spcl.Calc_BB_single(g["nu"][i], g["T"][i]) - g["bb"][i]) <= 1e-14 * g["bb"][i]
+
+
+def test_grid_params_and_synthetic():
+    from spectrobot_amd import engine, synthetic as syn
+    grid = syn.make_grid(2975.0, 5e-4, 100000)
+    w0, step, n = engine.grid_params(grid)
+    assert (w0, n) == (2975.0, 100000) and step == grid[1] - grid[0]
+    with pytest.raises(ValueError):
+        engine.grid_params(np.array([1.0, 2.0, 4.0]))
+    a = syn.make_lines(100, grid, config_id=2)
+    b = syn.make_lines(100, grid, config_id=2)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert np.all(np.diff(a["freq"]) >= 0)
+    atm = syn.make_atmosphere(80, 12)
+    assert atm["temps"].shape == (80,) and atm["tvib"].shape == (12, 80)
+    sl, ln = syn.limb_path(atm["z"], 100.001)
+    assert len(sl) == 160 and np.all(ln > 0) and sl[0] == 79 and sl[79] == 0 and sl[80] == 0
+
+
+def test_no_product_import_of_the_oracle():
+    """The product must not import, link or execute anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "spectrobot_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".inc")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for bad in ("import oracle", "from oracle", "sr_oracle", "liboracle", "oracle/_ref", "ref_fortran"):
+                    assert bad not in txt, (f, bad)
