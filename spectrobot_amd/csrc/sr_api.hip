@@ -443,7 +443,7 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   }
   rc = ls->d_fast.ensure(sizeof(FastRec) * ((size_t)n_sub * nl + 1)); // +1: the wings kernel prefetches one ahead
   if (rc) return rc;
-  rc = ls->d_cold.ensure(sizeof(ColdRec) * (size_t)n_sub * nl);
+  rc = ls->d_cold.ensure(sizeof(ColdRec) * ((size_t)n_sub * nl + 1));
   if (rc) return rc;
 
   rc = ls->d_zmax.ensure(sizeof(int) * (size_t)nl);

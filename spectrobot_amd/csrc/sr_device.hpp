@@ -105,66 +105,97 @@ __device__ inline void region1_coef(double ry, double &a, double &b, double &c, 
 }
 
 // ---- region 2: lineshape.f:492-521 ----
-__device__ inline double region2_val(double ry, double x) {
-  double ry2 = ry * ry;
-  double a = ry * (1.0578555 + ry2 * (4.6545642 + ry2 * (3.1030428 + 0.5641896 * ry2)));
-  double b = ry * (2.9619954 + ry2 * (0.5641896 + 1.6925688 * ry2));
-  double c = ry * (-2.5388532 + ry2 * 1.6925688);
-  double d = ry * 0.5641896;
-  double e = 0.5625 + ry2 * (4.5 + ry2 * (10.5 + ry2 * (6. + ry2)));
-  double f = -4.5 + ry2 * (9. + ry2 * (6. + 4. * ry2));
-  double g = 10.5 + ry2 * (-6. + 6. * ry2);
-  double h = 4. * ry2 - 6.;
-  double x2 = x * x;
-  return (a + x2 * (b + x2 * (c + d * x2))) / (e + x2 * (f + x2 * (g + x2 * (h + x2))));
+struct R2Coef {
+  double a, b, c, d, e, f, g, h;
+};
+__device__ inline R2Coef region2_coef(double ry) {
+  const double ry2 = ry * ry;
+  R2Coef q;
+  q.a = ry * (1.0578555 + ry2 * (4.6545642 + ry2 * (3.1030428 + 0.5641896 * ry2)));
+  q.b = ry * (2.9619954 + ry2 * (0.5641896 + 1.6925688 * ry2));
+  q.c = ry * (-2.5388532 + ry2 * 1.6925688);
+  q.d = ry * 0.5641896;
+  q.e = 0.5625 + ry2 * (4.5 + ry2 * (10.5 + ry2 * (6. + ry2)));
+  q.f = -4.5 + ry2 * (9. + ry2 * (6. + 4. * ry2));
+  q.g = 10.5 + ry2 * (-6. + 6. * ry2);
+  q.h = 4. * ry2 - 6.;
+  return q;
+}
+__device__ inline double region2_val(const R2Coef &q, double x) {
+  const double x2 = x * x;
+  const double num = fma(x2, fma(x2, fma(q.d, x2, q.c), q.b), q.a);
+  const double den = fma(x2, fma(x2, fma(x2, x2 + q.h, q.g), q.f), q.e);
+  return num * fast_rcp<2>(den);
 }
 
 // ---- regions 3 / 4: lineshape.f:526-561 ----
-struct cplx {
-  double re, im;
-};
-__device__ inline cplx cmul(cplx a, cplx b) {
-  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
-}
-__device__ inline cplx radd(double r, cplx a) { return {r + a.re, a.im}; }  // r + a
-__device__ inline cplx rsub(double r, cplx a) { return {r - a.re, -a.im}; } // r - a
-__device__ inline cplx rmul(cplx a, double r) { return {a.re * r, a.im * r}; }
-__device__ inline double cdiv_re(cplx n, cplx d) {
-  return (n.re * d.re + n.im * d.im) / (d.re * d.re + d.im * d.im);
-}
-#define SR_F32(lit) ((double)(lit##f)) // un-suffixed Fortran literal
+#define SR_F32(lit) ((double)(lit##f)) // un-suffixed Fortran literal: rounded to single
 
-__device__ inline double core_point(double rx, double ry) {
-  double r2 = (0.195 * rx) - 0.176;
-  cplx c2 = {(double)(float)ry, (double)(float)(-rx)}; // default-kind cmplx()
-  if (ry < r2) { // region 4
-    cplx c1 = cmul(c2, c2);
-    cplx n = rsub(SR_F32(1.320522), rmul(c1, SR_F32(.56419)));
-    n = rsub(SR_F32(35.76683), cmul(c1, n));
-    n = rsub(SR_F32(219.0313), cmul(c1, n));
-    n = rsub(SR_F32(1540.787), cmul(c1, n));
-    n = rsub(SR_F32(3321.9905), cmul(c1, n));
-    n = rsub(SR_F32(36183.31), cmul(c1, n));
-    n = cmul(c2, n);
-    cplx d = rsub(SR_F32(1.841439), c1);
-    d = rsub(SR_F32(61.57037), cmul(c1, d));
-    d = rsub(SR_F32(364.2191), cmul(c1, d));
-    d = rsub(SR_F32(2186.181), cmul(c1, d));
-    d = rsub(SR_F32(9022.228), cmul(c1, d));
-    d = rsub(SR_F32(24322.84), cmul(c1, d));
-    d = rsub(SR_F32(32066.6), cmul(c1, d));
-    return exp(c1.re) * cos(c1.im) - cdiv_re(n, d);
-  } else { // region 3
-    cplx n = radd(SR_F32(3.778987), rmul(c2, SR_F32(.5642236)));
-    n = radd(SR_F32(11.96482), cmul(c2, n));
-    n = radd(SR_F32(20.20933), cmul(c2, n));
-    n = radd(SR_F32(16.4955), cmul(c2, n));
-    cplx d = radd(SR_F32(6.699398), c2);
-    d = radd(SR_F32(21.69274), cmul(c2, d));
-    d = radd(SR_F32(39.27121), cmul(c2, d));
-    d = radd(SR_F32(38.82363), cmul(c2, d));
-    d = radd(SR_F32(16.4955), cmul(c2, d));
-    return cdiv_re(n, d);
+// Real-coefficient polynomial at the complex point (zr, zi), coefficients c[0..N]
+// in ascending powers: the quadratic-factor recurrence (2 fma per coefficient
+// instead of a complex multiply-add; agrees with the reference's complex Horner
+// to 4e-15 in region 3 and 7e-14 in region 4, checked on the host in fp80).
+template <int N>
+__device__ inline void real_poly_at(const double (&c)[N + 1], double zr, double zi, double &pr, double &pi) {
+  const double r = zr + zr, s = fma(zr, zr, zi * zi);
+  double a = c[N], b = c[N - 1];
+#pragma unroll
+  for (int j = 2; j <= N; ++j) {
+    const double t = fma(r, a, b);
+    b = fma(-s, a, c[N - j]);
+    a = t;
+  }
+  pr = fma(zr, a, b);
+  pi = zi * a;
+}
+
+// cos(t) for |t| <= ~1e3 (here |Im c1| = 2 ry rx < 10): two-constant Cody-Waite
+// reduction by pi/2 and the fdlibm kernel polynomials, ~1 ulp.
+__device__ inline double cos_bounded(double t) {
+  const double n = rint(t * 6.36619772367581382433e-01);      // 2/pi
+  double r = fma(-n, 1.57079632673412561417e+00, t);           // pi/2 hi (33 bits)
+  r = fma(-n, 6.07710050650619224932e-11, r);                  // pi/2 mid
+  r = fma(-n, 2.02226624879595063154e-21, r);                  // pi/2 lo
+  const double z = r * r;
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                          -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                      2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                        8.33333333332248946124e-03);
+  const double sr = fma(r * z, fma(z, ps, -1.66666666666666324348e-01), r);
+  const int q = (int)n & 3;
+  const double v = (q & 1) ? sr : cr;          // cos(r + q pi/2): c, -s, -c, s
+  return (q == 1 || q == 2) ? -v : v;
+}
+
+// One core point; ryf = (double)(float)ry is hoisted by the caller (cmplx() is
+// default kind: both parts are rounded to single, lineshape.f:529).
+__device__ inline double core_point(double rx, double ry, double ryf) {
+  const double r2 = (0.195 * rx) - 0.176;
+  const double a = ryf, b = (double)(float)(-rx);
+  if (ry < r2) { // region 4, :530-546
+    const double P4[7] = {SR_F32(36183.31), -SR_F32(3321.9905), SR_F32(1540.787), -SR_F32(219.0313),
+                          SR_F32(35.76683), -SR_F32(1.320522), SR_F32(.56419)};
+    const double Q4[8] = {SR_F32(32066.6), -SR_F32(24322.84), SR_F32(9022.228), -SR_F32(2186.181),
+                          SR_F32(364.2191), -SR_F32(61.57037), SR_F32(1.841439), -1.0};
+    const double ur = fma(a, a, -(b * b)), ui = (a + a) * b; // c1 = c2*c2
+    double pr, pi, qr, qi;
+    real_poly_at<6>(P4, ur, ui, pr, pi);
+    real_poly_at<7>(Q4, ur, ui, qr, qi);
+    const double nr = fma(a, pr, -(b * pi)), ni = fma(a, pi, b * pr); // c2 * P
+    const double ratio = fma(nr, qr, ni * qi) * fast_rcp<2>(fma(qr, qr, qi * qi));
+    return exp(ur) * cos_bounded(ui) - ratio;
+  } else { // region 3, :554-560
+    const double N3[5] = {SR_F32(16.4955), SR_F32(20.20933), SR_F32(11.96482), SR_F32(3.778987),
+                          SR_F32(.5642236)};
+    const double D3[6] = {SR_F32(16.4955), SR_F32(38.82363), SR_F32(39.27121), SR_F32(21.69274),
+                          SR_F32(6.699398), 1.0};
+    double pr, pi, qr, qi;
+    real_poly_at<4>(N3, a, b, pr, pi);
+    real_poly_at<5>(D3, a, b, qr, qi);
+    return fma(pr, qr, pi * qi) * fast_rcp<2>(fma(qr, qr, qi * qi));
   }
 }
 
@@ -196,29 +227,49 @@ __device__ inline Bounds humliv_bounds(const XF &xf, int n, double x0, double lw
   return B;
 }
 
+// Everything of one (line, layer) that regions 2-4 need, computed once per
+// (line, wave tile) pair (wave-uniform).
+struct ZoneCtx {
+  R2Coef q2;
+  double ry, ryf, dwp, inv_dwp, x0, xs2l, xs2r;
+  int il, ir, il2, ir2, il2a, ir2a;
+};
+template <class XF>
+__device__ inline ZoneCtx zone_ctx(const FastRec &r, const ColdRec &cr, const XF &xf) {
+  ZoneCtx z;
+  z.ry = cr.ry;
+  z.ryf = (double)(float)cr.ry;
+  z.dwp = cr.dwp;
+  z.inv_dwp = fast_rcp<2>(cr.dwp);
+  z.x0 = cr.x0;
+  z.il = r.il(); z.ir = r.ir(); z.il2 = cr.il2; z.ir2 = cr.ir2;
+  z.il2a = (z.il2 == z.il) ? z.il - 1 : z.il2; // lineshape.f:524-525
+  z.ir2a = (z.ir2 == z.ir) ? z.ir + 1 : z.ir2;
+  z.q2 = region2_coef(cr.ry);
+  z.xs2l = (cr.x0 - xf(z.il)) / cr.dwp;  // :504
+  z.xs2r = (xf(z.ir2) - cr.x0) / cr.dwp; // :514
+  return z;
+}
+
 // Value of humliv_bb at 1-based index k (1..n) for one (line, layer), any region;
 // follows the write order of lineshape.f:455-562 (last writer wins).
 template <class XF>
-__device__ inline double humliv_point(int k, const FastRec &r, const ColdRec &cr, const XF &xf) {
-  const int il = r.il(), ir = r.ir(), il2 = cr.il2, ir2 = cr.ir2;
-  const int il2a = (il2 == il) ? il - 1 : il2; // :524-525
-  const int ir2a = (ir2 == ir) ? ir + 1 : ir2;
-  if (k > il2a && k < ir2a) { // :526-562
-    double rx = fabs(xf(k) - cr.x0) / cr.dwp;
-    return core_point(rx, cr.ry);
+__device__ inline double humliv_point(int k, const FastRec &r, const ZoneCtx &z, const XF &xf) {
+  if (k > z.il2a && k < z.ir2a) { // :526-562
+    // rx = |x(k)-x0|/dw, correctly rounded: q0 = a*(1/dw), one residual correction
+    const double a = fabs(xf(k) - z.x0);
+    double rx = a * z.inv_dwp;
+    rx = fma(fma(-z.dwp, rx, a), z.inv_dwp, rx);
+    return core_point(rx, z.ry, z.ryf);
   }
-  if (il < il2 && k >= il && k <= il2) { // :503-512
-    double xs = (cr.x0 - xf(il)) / cr.dwp;
-    return region2_val(cr.ry, fma(-(double)(k - il), r.xstep, xs));
-  }
-  if (ir2 < ir && k >= ir2 && k <= ir) { // :513-522
-    double xs = (xf(ir2) - cr.x0) / cr.dwp;
-    return region2_val(cr.ry, fma((double)(k - ir2), r.xstep, xs));
-  }
-  double x = (k <= il) ? fma(-(double)(k - 1), r.xstep, r.xl)  // :461-468
-                       : fma((double)(k - ir), r.xstep, r.xr); // :470-477
-  double x2 = x * x;
-  return (r.a + x2 * r.b) / (r.c + x2 * (r.d + 4. * x2));
+  if (z.il < z.il2 && k >= z.il && k <= z.il2) // :503-512
+    return region2_val(z.q2, fma(-(double)(k - z.il), r.xstep, z.xs2l));
+  if (z.ir2 < z.ir && k >= z.ir2 && k <= z.ir) // :513-522
+    return region2_val(z.q2, fma((double)(k - z.ir2), r.xstep, z.xs2r));
+  const double x = (k <= z.il) ? fma(-(double)(k - 1), r.xstep, r.xl)    // :461-468
+                               : fma((double)(k - z.ir), r.xstep, r.xr); // :470-477
+  const double x2 = x * x;
+  return fma(x2, r.b, r.a) * fast_rcp<2>(fma(x2, fma(x2, 4.0, r.d), r.c));
 }
 
 } // namespace sr

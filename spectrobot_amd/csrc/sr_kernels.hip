@@ -96,14 +96,15 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
 // scalar loads); every lane accumulates abs/emi for its own P points (stride
 // 64, so each slot p is 64 consecutive points and stores are coalesced).
 //
-//   sr_abscoeff_wings_kernel  lines for which the WHOLE wave tile lies in one
-//       region-1 wing and inside the window (98 % of all evaluations):
-//       x = x_b + lane_p*xstep, (a + x^2 b)/(c + x^2 (d + 4 x^2)), one
-//       reciprocal shared by four points, no branches in the body.
-//   sr_abscoeff_cores_kernel  the remaining (line, wave tile) pairs -- tile meets
+//   sr_abscoeff_wings_kernel  (line, group of 256 points) pairs for which the
+//       WHOLE group lies in one region-1 wing and inside the window (98 % of all
+//       evaluations): x = x_b + lane_p*xstep, (a + x^2 b)/(c + x^2 (d + 4 x^2)),
+//       one reciprocal shared by the group's four slots, no branches in the body.
+//   sr_abscoeff_cores_kernel  the remaining (line, group) pairs -- group meets
 //       the line's region-2/3/4 zone or a window end -- evaluated slot by slot
 //       with the general, region-by-index code; adds into the wings' output.
-// Both apply the same classify() so every (line, point) is counted exactly once.
+// Both apply the same classify() to the same groups, so every (line, point) is
+// counted exactly once.
 // ------------------------------------------------------------------------
 __device__ inline int lower_bound_ic(const int *__restrict__ ic, int n, int v) {
   int lo = 0, hi = n;
@@ -161,6 +162,8 @@ __device__ inline void wing_eval4(const double xb, const double xs, const double
   acc_a[3] = fma(wa, q3, acc_a[3]); acc_e[3] = fma(we, q3, acc_e[3]);
 }
 
+constexpr int kGroup = 256; // points per ownership group: 4 slots of 64 (one shared reciprocal)
+
 template <int P>
 __global__ __launch_bounds__(64) void sr_abscoeff_wings_kernel(
     const FastRec *__restrict__ fast,
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_wings_kernel(
     int n_sub, int n_tiles, int g_lo, int g_hi, double *__restrict__ abs_out,
     double *__restrict__ emi_out) {
   static_assert(P % 4 == 0, "P must be a multiple of 4");
-  constexpr int WP = 64 * P;
+  constexpr int WP = 64 * P, NG = P / 4;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
   const int wlo = g_lo + tile * WP;
@@ -179,13 +182,11 @@ __global__ __launch_bounds__(64) void sr_abscoeff_wings_kernel(
   const int l0 = lower_bound_ic(ic_sub, n_sub, wlo - (kHalf - 1));
   const int l1 = lower_bound_ic(ic_sub, n_sub, whi + kHalf + 1);
 
-  double acc_a[P], acc_e[P], fl[P];
+  double acc_a[P], acc_e[P], fl[4];
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    acc_a[p] = 0.;
-    acc_e[p] = 0.;
-    fl[p] = (double)(lane + 64 * p);
-  }
+  for (int p = 0; p < P; ++p) acc_a[p] = acc_e[p] = 0.;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fl[i] = (double)(lane + 64 * i);
   const FastRec *frow = fast + (size_t)layer * n_sub;
   FastRec nxt = frow[l0 < l1 ? l0 : 0];
   for (int l = l0; l < l1; ++l) {
@@ -193,12 +194,14 @@ __global__ __launch_bounds__(64) void sr_abscoeff_wings_kernel(
     // one is evaluated (the table has one record of slack behind its end)
     const FastRec r = nxt;
     nxt = frow[l + 1];
-    const int cls = classify(r.j1, r.il(), r.ir(), wlo, whi);
-    if (cls == 0) continue; // left to sr_abscoeff_cores_kernel
-    const double xb = wing_x_at(r, cls, r.j1, wlo);
 #pragma unroll
-    for (int g = 0; g < P; g += 4)
-      wing_eval4(xb, r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl + g, acc_a + g, acc_e + g);
+    for (int g = 0; g < NG; ++g) {
+      const int glo = wlo + kGroup * g, ghi = min(glo + kGroup - 1, whi);
+      const int cls = glo <= whi ? classify(r.j1, r.il(), r.ir(), glo, ghi) : 0;
+      if (cls == 0) continue; // left to sr_abscoeff_cores_kernel (or outside the window)
+      const double xb = wing_x_at(r, cls, r.j1, glo);
+      wing_eval4(xb, r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl, acc_a + 4 * g, acc_e + 4 * g);
+    }
   }
   const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
 #pragma unroll
@@ -211,24 +214,23 @@ __global__ __launch_bounds__(64) void sr_abscoeff_wings_kernel(
   }
 }
 
-template <int P>
+// One wave per group of 256 points: the (line, group) pairs the wings kernel skips.
 __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold,
     const int *__restrict__ ic_sub, const int *__restrict__ zmax, // [n_layers] max zone half-width
-    int n_sub, int n_tiles, int g_lo, int g_hi, GridParams gp, double *__restrict__ abs_out,
+    int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp, double *__restrict__ abs_out,
     double *__restrict__ emi_out) {
-  constexpr int WP = 64 * P;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
-  const int wlo = g_lo + tile * WP;
-  const int whi = min(wlo + WP, g_hi) - 1;
+  const int layer = wg / n_groups, grp = wg - layer * n_groups;
+  const int wlo = g_lo + grp * kGroup;
+  const int whi = min(wlo + kGroup, g_hi) - 1;
   const int lane = threadIdx.x;
   const int zm = min(zmax[layer], kHalf - 1);
 
   // candidates (as ranges of the sorted centre list), C <= A <= B by start:
-  //  C: window END inside the tile      ic+6504 in [wlo, whi)
-  //  A: region-2/3/4 zone may meet it   ic in [wlo-zm, whi+zm]
-  //  B: window START inside the tile    ic-6505 in (wlo, whi]
+  //  C: window END inside the group      ic+6504 in [wlo, whi)
+  //  A: region-2/3/4 zone may meet it    ic in [wlo-zm, whi+zm]
+  //  B: window START inside the group    ic-6505 in (wlo, whi]
   const int c0 = lower_bound_ic(ic_sub, n_sub, wlo - (kHalf - 1));
   const int c1 = lower_bound_ic(ic_sub, n_sub, whi - (kHalf - 1));
   const int a0 = lower_bound_ic(ic_sub, n_sub, wlo - zm);
@@ -240,9 +242,9 @@ __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
   rs[1] = max(a0, re[0]); re[1] = max(a1, rs[1]);
   rs[2] = max(b0, re[1]); re[2] = max(b1, rs[2]);
 
-  double acc_a[P], acc_e[P], fl[P];
+  double acc_a[4], acc_e[4], fl[4];
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
+  for (int p = 0; p < 4; ++p) {
     acc_a[p] = 0.;
     acc_e[p] = 0.;
     fl[p] = (double)(lane + 64 * p);
@@ -250,46 +252,41 @@ __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
   const FastRec *frow = fast + (size_t)layer * n_sub;
   const ColdRec *crow = cold + (size_t)layer * n_sub;
   for (int rg = 0; rg < 3; ++rg) {
+    if (rs[rg] >= re[rg]) continue;
+    FastRec nxt = frow[rs[rg]];
+    ColdRec cnxt = crow[rs[rg]];
     for (int l = rs[rg]; l < re[rg]; ++l) {
-      const FastRec r = frow[l];
+      const FastRec r = nxt;
+      const ColdRec cr = cnxt;
+      nxt = frow[l + 1]; // one record of slack behind both tables
+      cnxt = crow[l + 1];
       const int j1 = r.j1, jN = j1 + (kImxsig - 1);
       if (jN < wlo || j1 > whi) continue;
       if (classify(j1, r.il(), r.ir(), wlo, whi) != 0) continue; // done by the wings kernel
-      const ColdRec cr = crow[l];
       const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
+      const ZoneCtx zc = zone_ctx(r, cr, xf);
 #pragma unroll
-      for (int g = 0; g < P; g += 4) {
-        const int glo = wlo + 64 * g, ghi = min(glo + 255, whi);
-        if (glo > whi || jN < glo || j1 > ghi) continue;
-        const int gcls = classify(j1, r.il(), r.ir(), glo, ghi);
-        if (gcls != 0) { // four whole slots in one wing
-          const double xb = wing_x_at(r, gcls, j1, wlo);
-          wing_eval4(xb, r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl + g, acc_a + g, acc_e + g);
-          continue;
+      for (int p = 0; p < 4; ++p) {
+        const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
+        if (slo > whi || jN < slo || j1 > shi) continue;
+        const int scls = classify(j1, r.il(), r.ir(), slo, shi);
+        double y;
+        if (scls != 0) { // the whole slot in one wing
+          const double x = fma(fl[p], r.xstep, wing_x_at(r, scls, j1, wlo));
+          const double x2 = x * x;
+          y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
+        } else {
+          const int k = slo + lane - j1 + 1; // 1-based window index
+          y = (k >= 1 && k <= kImxsig && slo + lane <= shi) ? humliv_point(k, r, zc, xf) : 0.0;
         }
-#pragma unroll
-        for (int p = g; p < g + 4; ++p) {
-          const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
-          if (slo > whi || jN < slo || j1 > shi) continue;
-          const int scls = classify(j1, r.il(), r.ir(), slo, shi);
-          double y;
-          if (scls != 0) {
-            const double x = fma(fl[p], r.xstep, wing_x_at(r, scls, j1, wlo));
-            const double x2 = x * x;
-            y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
-          } else {
-            const int k = slo + lane - j1 + 1; // 1-based window index
-            y = (k >= 1 && k <= kImxsig && slo + lane <= shi) ? humliv_point(k, r, cr, xf) : 0.0;
-          }
-          acc_a[p] = fma(r.wabs, y, acc_a[p]);
-          acc_e[p] = fma(r.wemi, y, acc_e[p]);
-        }
+        acc_a[p] = fma(r.wabs, y, acc_a[p]);
+        acc_e[p] = fma(r.wemi, y, acc_e[p]);
       }
     }
   }
   const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
+  for (int p = 0; p < 4; ++p) {
     const int j = wlo + lane + 64 * p;
     if (j <= whi) {
       abs_out[row + (j - g_lo)] += acc_a[p];
@@ -311,11 +308,11 @@ int abscoeff_tile_points(int variant) { return 64 * (variant == 4 ? 4 : 8); }
 int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *cold, const int *ic_sub,
                     const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp,
                     double *abs_out, double *emi_out, hipStream_t st) {
-  const int tp = abscoeff_tile_points(variant);
-  const int n_tiles = (g_hi - g_lo + tp - 1) / tp;
-  if (n_tiles <= 0 || n_layers <= 0) return 0;
-  dim3 grid((unsigned)(n_tiles * n_layers));
+  if (g_hi <= g_lo || n_layers <= 0) return 0;
   if (which == 0) {
+    const int tp = abscoeff_tile_points(variant);
+    const int n_tiles = (g_hi - g_lo + tp - 1) / tp;
+    dim3 grid((unsigned)(n_tiles * n_layers));
     if (variant == 4)
       hipLaunchKernelGGL((sr_abscoeff_wings_kernel<4>), grid, dim3(64), 0, st, fast, ic_sub, n_sub, n_tiles,
                          g_lo, g_hi, abs_out, emi_out);
@@ -323,12 +320,10 @@ int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *
       hipLaunchKernelGGL((sr_abscoeff_wings_kernel<8>), grid, dim3(64), 0, st, fast, ic_sub, n_sub, n_tiles,
                          g_lo, g_hi, abs_out, emi_out);
   } else {
-    if (variant == 4)
-      hipLaunchKernelGGL((sr_abscoeff_cores_kernel<4>), grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub,
-                         n_tiles, g_lo, g_hi, gp, abs_out, emi_out);
-    else
-      hipLaunchKernelGGL((sr_abscoeff_cores_kernel<8>), grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub,
-                         n_tiles, g_lo, g_hi, gp, abs_out, emi_out);
+    const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
+    dim3 grid((unsigned)(n_groups * n_layers));
+    hipLaunchKernelGGL(sr_abscoeff_cores_kernel, grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub, n_groups,
+                       g_lo, g_hi, gp, abs_out, emi_out);
   }
   return (int)hipGetLastError();
 }
@@ -385,8 +380,9 @@ __global__ __launch_bounds__(256) void sr_humliv_kernel(const double *__restrict
   r.ilir = (uint32_t)B.il | ((uint32_t)B.ir << 16);
   ColdRec c;
   c.ry = B.ry; c.dwp = dwp; c.x0 = x0; c.il2 = (int16_t)B.il2; c.ir2 = (int16_t)B.ir2; c.pad = 0;
+  const ZoneCtx zc = zone_ctx(r, c, xf);
   for (int k = blockIdx.x * blockDim.x + threadIdx.x + 1; k <= n; k += gridDim.x * blockDim.x)
-    y[i1 - 1 + k - 1] = humliv_point(k, r, c, xf);
+    y[i1 - 1 + k - 1] = humliv_point(k, r, zc, xf);
 }
 
 int launch_humliv(const double *x, int i1, int i2, double x0, double lw, double dwp, double *y,
