@@ -171,13 +171,19 @@ int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers,
                          const int32_t *seg_layer, const double *seg_col,
                          int init_from_rad, double *rad, void *stream);
 
-/* Tuning knob of the coefficient kernels: grid points per lane (4 or 8; default 8). */
+/* Evaluation mode of the coefficient op.  1 (default): far region-1 wings by
+ * local Taylor expansions per box of grid points (truncation <= 5e-13 of a
+ * line's own contribution), near field exact.  0: every (line, point) evaluated
+ * exactly (sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel). */
+int sr_set_far_field(int on);
+/* Tuning knob of the exact wings kernel: grid points per lane (4 or 8; default 8). */
 int sr_set_points_per_lane(int p);
 
 /* Timing hook for bench.py: HIP-event times (ms) of the three kernels of the
- * most recent sr_abscoeff_layers* call on this lineset (sr_prep_kernel,
- * sr_abscoeff_wings_kernel = the dominant one, sr_abscoeff_cores_kernel),
- * measured on the stream they were launched on.  Synchronises. */
+ * most recent sr_abscoeff_layers* call on this lineset: sr_prep_kernel, then
+ * sr_farfield_kernel + sr_abscoeff_near_kernel (far-field mode) or
+ * sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel (exact mode), measured on
+ * the stream they were launched on.  Synchronises. */
 int sr_last_kernel_ms(sr_lineset *ls, float *prep_ms, float *wings_ms, float *cores_ms);
 
 #ifdef __cplusplus

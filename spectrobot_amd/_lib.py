@@ -71,6 +71,7 @@ SYMBOLS = {
     "sr_radiance_rays_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, ip, ip, dp, C.c_int,
                                        C.c_void_p, C.c_void_p]),
     "sr_set_points_per_lane": (C.c_int, [C.c_int]),
+    "sr_set_far_field": (C.c_int, [C.c_int]),
     "sr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                     C.POINTER(C.c_float)]),
 }

@@ -149,7 +149,8 @@ double lagrange4(const double *tg, const double *qg, int n, double temp) {
   return y;
 }
 
-int g_variant = 8; // points per lane in the coefficient kernels
+int g_variant = 8; // points per lane in the exact wings kernel
+int g_far_field = 1; // 1: far wings by local expansions (default), 0: every evaluation exact
 
 } // namespace
 
@@ -160,10 +161,11 @@ struct sr_lineset {
   double mm = 0.0;
   std::vector<double> e_lev;
   std::vector<int> ic; // host copy, sorted
+  double freq_max = 0.0;
   DevBuf d_lines;      // one allocation, carved below
   LinesDev L{};
   Stager s_layers;
-  DevBuf d_fast, d_cold, d_zmax;
+  DevBuf d_fast, d_cold, d_zmax, d_coef;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool timed = false;
 };
@@ -206,6 +208,11 @@ int sr_device_info(char *name, int name_len, int *cu_count, double *hbm_gib) {
   if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
   if (cu_count) *cu_count = p.multiProcessorCount;
   if (hbm_gib) *hbm_gib = (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0);
+  return SR_OK;
+}
+
+int sr_set_far_field(int on) {
+  g_far_field = on ? 1 : 0;
   return SR_OK;
 }
 
@@ -345,6 +352,7 @@ int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, cons
     hi[1 * md + q] = lu;
     hi[2 * md + q] = ll;
     ls->ic[q] = ic[ord[q]];
+    ls->freq_max = std::max(ls->freq_max, f);
   }
   const size_t bytes_d = hd.size() * sizeof(double), bytes_i = hi.size() * sizeof(int);
   int rc = ls->d_lines.ensure(bytes_d + bytes_i);
@@ -377,6 +385,7 @@ int sr_lineset_destroy(sr_lineset *ls) {
   ls->d_fast.release();
   ls->d_cold.release();
   ls->d_zmax.release();
+  ls->d_coef.release();
   for (auto &ev : ls->ev)
     if (ev) (void)hipEventDestroy(ev);
   delete ls;
@@ -394,7 +403,8 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     if (!(atm->temps[k] > 0.0) || !(atm->press[k] >= 0.0)) return SR_ERR_ARG;
 
   // per-layer scalars (host, fp64)
-  const size_t hl_bytes = sizeof(double) * (size_t)nl * (4 + npop);
+  const size_t hl_doubles = (size_t)nl * (4 + npop);
+  const size_t hl_bytes = sizeof(double) * hl_doubles + sizeof(int) * (size_t)nl;
   int rc = ls->s_layers.prepare(hl_bytes);
   if (rc) return rc;
   double *T = ls->s_layers.host<double>(), *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *pop = sq + nl;
@@ -410,6 +420,13 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     pa[k] = atm->press[k] * kHpaToAtm;                                        // spect_classes.py:2034
     tr[k] = kTref / T[k];                                                     // :1972
     sq[k] = std::sqrt(2 * kAvogadro * kKcgs * T[k] * kLn2 / ls->mm);          // :1984
+    {
+      // pole margin of the far-field expansions: the region-1 rational has its poles at
+      // |x| = sqrt(1/2 + ry^2), i.e. within 0.71 dw' of the line centre on the real axis
+      const double dwp_max = ls->freq_max / kCcgs * sq[k] / std::sqrt(kLn2);
+      int *pmh = reinterpret_cast<int *>(T + hl_doubles);
+      pmh[k] = (int)std::ceil(0.71 * dwp_max / ls->gp.gstep) + 1;
+    }
     if (nlev > 0) {
       for (int lv = 0; lv < nlev; ++lv) {
         const double vibt = atm->tvib ? atm->tvib[(size_t)lv * nl + k] : T[k]; // smm:2062-2065
@@ -425,6 +442,7 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   const double *dl = ls->s_layers.d.as<double>();
   A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.pop = dl + 4 * nl;
   A.n_layers = nl; A.n_pop = npop;
+  const int *d_pm = reinterpret_cast<const int *>(dl + hl_doubles);
   A.sqrt_ln2 = std::sqrt(kLn2);            // spect_classes.py:1999
   A.sqrt_pi_ln2 = std::sqrt(kPi / kLn2);   // :1997
 
@@ -454,11 +472,34 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   LAUNCHCHK(launch_prep(ls->L, A, ls->gp, line_lo, n_sub, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(),
                         ls->d_zmax.as<int>(), st));
   HIPCHK(hipEventRecord(ls->ev[1], st));
-  for (int which = 0; which < 2; ++which) {
-    LAUNCHCHK(launch_abscoeff(g_variant, which, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(),
-                              ls->L.ic + line_lo, ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
-                              abs_out, emi_out, st));
-    HIPCHK(hipEventRecord(ls->ev[2 + which], st));
+  if (g_far_field) {
+    FarParams fp;
+    fp.n_levels = kMaxFarLevels;
+    fp.n_layers = nl;
+    fp.n_boxes_total = 0;
+    for (int lv = 0; lv < kMaxFarLevels; ++lv) {
+      const int W = 64 << lv;
+      fp.box_count[lv] = (int)((n_pts + W - 1) / W);
+      fp.box_off[lv] = fp.n_boxes_total;
+      fp.n_boxes_total += fp.box_count[lv];
+    }
+    rc = ls->d_coef.ensure(sizeof(double) * (size_t)nl * fp.n_boxes_total * 2 * kFC);
+    if (rc) return rc;
+    fp.pm = d_pm;
+    fp.coef = ls->d_coef.as<double>();
+    LAUNCHCHK(launch_farfield(ls->d_fast.as<FastRec>(), ls->L.ic + line_lo, ls->d_zmax.as<int>(), n_sub, nl,
+                              (int)g_lo, (int)g_hi, fp, st));
+    HIPCHK(hipEventRecord(ls->ev[2], st));
+    LAUNCHCHK(launch_near(ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), ls->L.ic + line_lo,
+                          ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, st));
+    HIPCHK(hipEventRecord(ls->ev[3], st));
+  } else {
+    for (int which = 0; which < 2; ++which) {
+      LAUNCHCHK(launch_abscoeff(g_variant, which, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(),
+                                ls->L.ic + line_lo, ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
+                                abs_out, emi_out, st));
+      HIPCHK(hipEventRecord(ls->ev[2 + which], st));
+    }
   }
   ls->timed = true;
   return SR_OK;

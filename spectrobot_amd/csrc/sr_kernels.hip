@@ -295,6 +295,286 @@ __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
   }
 }
 
+// ------------------------------------------------------------------------
+// far field by local (Taylor) expansions
+//
+// Where a whole box of target points lies in one region-1 wing of a line, inside
+// its window and at least kTheta box half-widths from its centre, the line's
+// contribution w*(a + x^2 b)/(c + x^2(d + 4x^2)), x affine in the grid index, is
+// analytic over the box with convergence ratio <= 1/kTheta: its Taylor
+// coefficients in t = (j - centre)/half_width come from a 4-term linear
+// recurrence (power-series division of a quadratic by a quartic), the
+// coefficients of all such lines are summed per box (lanes = lines), and each
+// point evaluates ONE polynomial per level instead of one rational per line.
+// Truncation at degree kFD = 14 is <= 5e-13 of the line's own contribution
+// (worst case, nearest admissible line, box edge).  Boxes are nested (width
+// 64 << level); a (line, slot) pair is owned by the highest admissible level
+// (admissibility is monotone down the hierarchy) or, if none, by the exact
+// near-field kernel.  All ownership tests are integer and shared by the kernels.
+// ------------------------------------------------------------------------
+__device__ inline bool ff_admissible(int j1, int il, int ir, int blo, int bhi, int thr2) {
+  if (classify(j1, il, ir, blo, bhi) == 0) return false;
+  const int d2 = blo + bhi - 2 * (j1 + kHalf); // twice (box centre - line centre)
+  return (d2 < 0 ? -d2 : d2) >= thr2;
+}
+__device__ inline int ff_thr2(int level, int pm) { return kTheta * (64 << level) + 2 * pm; }
+
+__global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restrict__ fast,
+                                                         const int *__restrict__ ic_sub,
+                                                         const int *__restrict__ zmax, int n_sub, int g_lo,
+                                                         int g_hi, FarParams fp) {
+  // block -> (layer, level, box); the widest (longest-running) boxes first
+  const int per_layer = fp.n_boxes_total;
+  const int layer = blockIdx.x % fp.n_layers; // interleave layers: equal-cost blocks are neighbours
+  int idx = blockIdx.x / fp.n_layers;
+  int level = fp.n_levels - 1;
+  while (level > 0 && idx >= fp.box_count[level]) {
+    idx -= fp.box_count[level];
+    --level;
+  }
+  (void)per_layer;
+  const int b = idx;
+  const int lane = threadIdx.x;
+  const int W = 64 << level, h = W >> 1;
+  const int blo = g_lo + b * W, bhi = blo + W - 1;
+  const int pm = fp.pm[layer];
+  const int zm = min(zmax[layer], kHalf - 1);
+  const int thr2 = ff_thr2(level, pm);
+  const bool top = level == fp.n_levels - 1;
+  const int W2 = 2 * W, plo = g_lo + (b >> 1) * W2, phi = plo + W2 - 1, thr2p = ff_thr2(level + 1, pm);
+
+  // candidate centre intervals [lo, hi] (inclusive), see DESIGN.md
+  int clo[4], chi[4], nr;
+  const int mid = blo + h, near_in = kTheta * h + pm;
+  if (top) {
+    clo[0] = blo - kHalf - 1; chi[0] = mid - near_in + 1;
+    clo[1] = mid + near_in - 2; chi[1] = bhi + kHalf + 1;
+    nr = 2;
+  } else {
+    const int bn = max(2 * kTheta * h + h + pm, zm + 3 * h) + 2;
+    clo[0] = plo - kHalf; chi[0] = phi - (kHalf - 1) + 1;       // window end inside the parent
+    clo[1] = mid - bn - 1; chi[1] = mid - near_in + 1;           // left near band
+    clo[2] = mid + near_in - 2; chi[2] = mid + bn + 1;           // right near band
+    clo[3] = plo + kHalf - 1; chi[3] = phi + kHalf + 1;          // window start inside the parent
+    nr = 4;
+  }
+  int rs[4], re[4];
+  for (int i = 0; i < nr; ++i) {
+    rs[i] = lower_bound_ic(ic_sub, n_sub, clo[i]);
+    re[i] = lower_bound_ic(ic_sub, n_sub, chi[i] + 1);
+  }
+  for (int i = 1; i < nr; ++i) // sort by start (4 elements)
+    for (int k = i; k > 0 && rs[k] < rs[k - 1]; --k) {
+      int t0 = rs[k]; rs[k] = rs[k - 1]; rs[k - 1] = t0;
+      t0 = re[k]; re[k] = re[k - 1]; re[k - 1] = t0;
+    }
+  int done = 0; // make disjoint
+  for (int i = 0; i < nr; ++i) {
+    rs[i] = max(rs[i], done);
+    re[i] = max(re[i], rs[i]);
+    done = re[i];
+  }
+
+  double sa[kFC], se[kFC];
+#pragma unroll
+  for (int n = 0; n < kFC; ++n) sa[n] = se[n] = 0.;
+  const FastRec *frow = fast + (size_t)layer * n_sub;
+  const double hw = (double)h;
+  for (int i = 0; i < nr; ++i) {
+    for (int base = rs[i]; base < re[i]; base += 64) {
+      const int l = base + lane;
+      if (l >= re[i]) continue;
+      const FastRec r = frow[l];
+      const int j1 = r.j1, il = r.il(), ir = r.ir();
+      if (!ff_admissible(j1, il, ir, blo, bhi, thr2)) continue;
+      if (!top && ff_admissible(j1, il, ir, plo, phi, thr2p)) continue; // owned by a wider box
+      const int cls = classify(j1, il, ir, blo, bhi);
+      // x (or -x) at the box centre blo + h - 1/2, and the half-width in x units
+      const double xc = cls == 1 ? fma(0.5 * (double)(2 * (blo - j1) + W - 1), r.xstep, -r.xl)
+                                 : fma(0.5 * (double)(2 * (blo - (j1 + ir - 1)) + W - 1), r.xstep, r.xr);
+      const double e = hw * r.xstep;
+      const double u0 = xc * xc, u1 = 2. * xc * e, u2 = e * e;
+      const double n0 = fma(r.b, u0, r.a), n1 = r.b * u1, n2 = r.b * u2;
+      const double d0 = fma(u0, fma(4., u0, r.d), r.c);
+      const double d1 = u1 * fma(8., u0, r.d);
+      const double d2 = fma(u2, r.d, 4. * fma(u1, u1, 2. * u0 * u2));
+      const double d3 = 8. * u1 * u2, d4 = 4. * u2 * u2;
+      const double r0 = fast_rcp<2>(d0);
+      const double D1 = d1 * r0, D2 = d2 * r0, D3 = d3 * r0, D4 = d4 * r0;
+      double f[kFC];
+      f[0] = n0 * r0;
+      f[1] = fma(-D1, f[0], n1 * r0);
+      f[2] = fma(-D1, f[1], fma(-D2, f[0], n2 * r0));
+      f[3] = -fma(D1, f[2], fma(D2, f[1], D3 * f[0]));
+#pragma unroll
+      for (int n = 4; n < kFC; ++n)
+        f[n] = -fma(D1, f[n - 1], fma(D2, f[n - 2], fma(D3, f[n - 3], D4 * f[n - 4])));
+#pragma unroll
+      for (int n = 0; n < kFC; ++n) {
+        sa[n] = fma(r.wabs, f[n], sa[n]);
+        se[n] = fma(r.wemi, f[n], se[n]);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < kFC; ++n) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      sa[n] += __shfl_xor(sa[n], m);
+      se[n] += __shfl_xor(se[n], m);
+    }
+  }
+  if (lane == 0) {
+    double *o = fp.coef + ((size_t)layer * fp.n_boxes_total + fp.box_off[level] + b) * (2 * kFC);
+#pragma unroll
+    for (int n = 0; n < kFC; ++n) {
+      o[n] = sa[n];
+      o[kFC + n] = se[n];
+    }
+  }
+}
+
+// Exact near field + evaluation of the far-field polynomials: one wave per group
+// of 256 points; writes abs/emi.
+__global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
+    const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold,
+    const int *__restrict__ ic_sub, const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo,
+    int g_hi, GridParams gp, FarParams fp, double *__restrict__ abs_out, double *__restrict__ emi_out) {
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int layer = wg / n_groups, grp = wg - layer * n_groups;
+  const int wlo = g_lo + grp * kGroup;
+  const int whi = min(wlo + kGroup, g_hi) - 1;
+  const int lane = threadIdx.x;
+  const int pm = fp.pm[layer];
+  const int thr0 = ff_thr2(0, pm);
+  // lines with a slot of this group that no far-field level owns: closer than
+  // kTheta*32 + pm to a slot centre, zone meeting the slot, or a window end inside
+  const int zm = min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1);
+  // the far-field kernel tests NOMINAL boxes (they may reach past g_hi), so a line whose
+  // window ends between g_hi and the nominal end of the last slot is ours too
+  const int whn = wlo + kGroup - 1;
+  const int c0 = lower_bound_ic(ic_sub, n_sub, wlo - (kHalf - 1));
+  const int c1 = lower_bound_ic(ic_sub, n_sub, whn - (kHalf - 1) + 1);
+  const int a0 = lower_bound_ic(ic_sub, n_sub, wlo - zm);
+  const int a1 = lower_bound_ic(ic_sub, n_sub, whn + zm + 1);
+  const int b0 = lower_bound_ic(ic_sub, n_sub, wlo + kHalf + 1);
+  const int b1 = lower_bound_ic(ic_sub, n_sub, whn + kHalf + 1);
+  int rs[3], re[3];
+  rs[0] = c0; re[0] = max(c1, c0);
+  rs[1] = max(a0, re[0]); re[1] = max(a1, rs[1]);
+  rs[2] = max(b0, re[1]); re[2] = max(b1, rs[2]);
+
+  double acc_a[4], acc_e[4], fl[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    acc_a[p] = 0.;
+    acc_e[p] = 0.;
+    fl[p] = (double)(lane + 64 * p);
+  }
+  const FastRec *frow = fast + (size_t)layer * n_sub;
+  const ColdRec *crow = cold + (size_t)layer * n_sub;
+  for (int rg = 0; rg < 3; ++rg) {
+    if (rs[rg] >= re[rg]) continue;
+    FastRec nxt = frow[rs[rg]];
+    ColdRec cnxt = crow[rs[rg]];
+    for (int l = rs[rg]; l < re[rg]; ++l) {
+      const FastRec r = nxt;
+      const ColdRec cr = cnxt;
+      nxt = frow[l + 1]; // one record of slack behind both tables
+      cnxt = crow[l + 1];
+      const int j1 = r.j1, jN = j1 + (kImxsig - 1), il = r.il(), ir = r.ir();
+      if (jN < wlo || j1 > whi) continue;
+      // which slots are ours (nominal 64-point boxes, as the far-field kernel sees them)
+      bool mine[4], any = false, general = false;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int slo = wlo + 64 * p;
+        mine[p] = slo <= whi && jN >= slo && j1 <= min(slo + 63, whi) &&
+                  !ff_admissible(j1, il, ir, slo, slo + 63, thr0);
+        any = any || mine[p];
+        general = general || (mine[p] && classify(j1, il, ir, slo, min(slo + 63, whi)) == 0);
+      }
+      if (!any) continue;
+      if (!general && mine[0] && mine[1] && mine[2] && mine[3]) {
+        const int gcls = classify(j1, il, ir, wlo, whi);
+        if (gcls != 0) { // four whole slots in one wing: shared reciprocal
+          wing_eval4(wing_x_at(r, gcls, j1, wlo), r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl, acc_a, acc_e);
+          continue;
+        }
+      }
+      const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
+      ZoneCtx zc;
+      if (general) zc = zone_ctx(r, cr, xf);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (!mine[p]) continue;
+        const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
+        const int scls = classify(j1, il, ir, slo, shi);
+        double y;
+        if (scls != 0) { // the whole slot in one wing
+          const double x = fma(fl[p], r.xstep, wing_x_at(r, scls, j1, wlo));
+          const double x2 = x * x;
+          y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
+        } else {
+          const int k = slo + lane - j1 + 1; // 1-based window index
+          y = (k >= 1 && k <= kImxsig && slo + lane <= shi) ? humliv_point(k, r, zc, xf) : 0.0;
+        }
+        acc_a[p] = fma(r.wabs, y, acc_a[p]);
+        acc_e[p] = fma(r.wemi, y, acc_e[p]);
+      }
+    }
+  }
+  // far field: one polynomial per level and slot
+  const double *cl = fp.coef + (size_t)layer * fp.n_boxes_total * (2 * kFC);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int slo = wlo + 64 * p;
+    if (slo > whi) continue;
+    for (int lv = 0; lv < fp.n_levels; ++lv) {
+      const int W = 64 << lv;
+      const int b = (slo - g_lo) >> (6 + lv);
+      const int blo = g_lo + b * W;
+      const double t = (double)(2 * (slo + lane - blo) - (W - 1)) / (double)W;
+      const double *c = cl + (size_t)(fp.box_off[lv] + b) * (2 * kFC);
+      double pa = c[kFC - 1], pe = c[2 * kFC - 1];
+#pragma unroll
+      for (int n = kFC - 2; n >= 0; --n) {
+        pa = fma(pa, t, c[n]);
+        pe = fma(pe, t, c[kFC + n]);
+      }
+      acc_a[p] += pa;
+      acc_e[p] += pe;
+    }
+  }
+  const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int j = wlo + lane + 64 * p;
+    if (j <= whi) {
+      abs_out[row + (j - g_lo)] = acc_a[p];
+      emi_out[row + (j - g_lo)] = acc_e[p];
+    }
+  }
+}
+
+int launch_farfield(const FastRec *fast, const int *ic_sub, const int *zmax, int n_sub, int n_layers, int g_lo,
+                    int g_hi, const FarParams &fp, hipStream_t st) {
+  if (g_hi <= g_lo || n_layers <= 0) return 0;
+  hipLaunchKernelGGL(sr_farfield_kernel, dim3((unsigned)(fp.n_boxes_total * n_layers)), dim3(64), 0, st, fast,
+                     ic_sub, zmax, n_sub, g_lo, g_hi, fp);
+  return (int)hipGetLastError();
+}
+
+int launch_near(const FastRec *fast, const ColdRec *cold, const int *ic_sub, const int *zmax, int n_sub,
+                int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp, double *abs_out,
+                double *emi_out, hipStream_t st) {
+  if (g_hi <= g_lo || n_layers <= 0) return 0;
+  const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
+  hipLaunchKernelGGL(sr_abscoeff_near_kernel, dim3((unsigned)(n_groups * n_layers)), dim3(64), 0, st, fast, cold,
+                     ic_sub, zmax, n_sub, n_groups, g_lo, g_hi, gp, fp, abs_out, emi_out);
+  return (int)hipGetLastError();
+}
+
 int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub,
                 FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st) {
   if (n_sub <= 0 || A.n_layers <= 0) return 0;

@@ -22,6 +22,24 @@ struct LayersDev {
   double sqrt_ln2, sqrt_pi_ln2;
 };
 
+// Far-field (local expansion) hierarchy over one shard: level l has boxes of
+// 64 << l points starting at g_lo.
+constexpr int kTheta = 8;      // admissible distance, in box half-widths
+constexpr int kFD = 14;        // expansion degree
+constexpr int kFC = kFD + 1;   // coefficients per box and output
+constexpr int kMaxFarLevels = 5;
+struct FarParams {
+  int n_levels, n_layers, n_boxes_total;
+  int box_count[kMaxFarLevels], box_off[kMaxFarLevels];
+  const int *pm; // [n_layers] pole margin in grid points
+  double *coef;  // [n_layers][n_boxes_total][2][kFC]
+};
+int launch_farfield(const FastRec *fast, const int *ic_sub, const int *zmax, int n_sub, int n_layers, int g_lo,
+                    int g_hi, const FarParams &fp, hipStream_t st);
+int launch_near(const FastRec *fast, const ColdRec *cold, const int *ic_sub, const int *zmax, int n_sub,
+                int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp, double *abs_out,
+                double *emi_out, hipStream_t st);
+
 int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub,
                 FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st);
 int abscoeff_tile_points(int variant);

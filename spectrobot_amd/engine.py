@@ -86,7 +86,7 @@ class LineSet(object):
         self.n_kept = kept.value
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.sr_lineset_destroy(self._h)
             self._h = None
 
@@ -172,3 +172,8 @@ def radiance_rays(abs_c, emi_c, seg_off, seg_layer, seg_col, rad0=None):
 
 def set_points_per_lane(p):
     check(lib.sr_set_points_per_lane(int(p)), "sr_set_points_per_lane")
+
+
+def set_far_field(on):
+    """1 (default): far wings by local expansions; 0: every evaluation exact."""
+    check(lib.sr_set_far_field(int(bool(on))), "sr_set_far_field")

@@ -50,12 +50,14 @@ def test_humliv_shim_golden(eng, golden):
     assert worst < 2e-10, worst
 
 
-@pytest.mark.parametrize("ppl", [8, 4])
-def test_e2e_ch4_levels_golden(eng, golden, ppl):
+@pytest.mark.parametrize("ppl,far", [(8, 1), (8, 0), (4, 0)])
+def test_e2e_ch4_levels_golden(eng, golden, ppl, far):
     """A2-A8 against the reference Python run: non-LTE levels, clipped windows,
-    dropped (unidentified / same-level) lines, an A=0 line."""
+    dropped (unidentified / same-level) lines, an A=0 line.  far=1: far wings by
+    local expansions (default mode); far=0: every evaluation exact."""
     g = golden("e2e_ch4_levels")
     eng.set_points_per_lane(ppl)
+    eng.set_far_field(far)
     ls = eng.LineSet(_lines(g), _grid(g), int(g["mol"]), int(g["iso"]), float(g["mm"]), g["e_lev"])
     ab, em = ls.abscoeff_layers(g["temps"], g["press"], tvib=g["tvib"], q_part=g["q_part"])
     assert relerr(ab.cpu().numpy(), g["abs"]) < TOL
@@ -65,6 +67,7 @@ def test_e2e_ch4_levels_golden(eng, golden, ppl):
     assert relerr(ab0.cpu().numpy(), g["abs_lte0"]) < TOL
     assert relerr(em0.cpu().numpy(), g["emi_lte0"]) < TOL
     eng.set_points_per_lane(8)
+    eng.set_far_field(1)
 
 
 def test_e2e_co_all_golden(eng, golden):
@@ -250,3 +253,27 @@ def test_full_size_linearity_property(eng):
     assert float(((acc_a - ab).abs() / ab.abs()).max()) < 1e-11
     assert float(((acc_e - em).abs() / em.abs()).max()) < 1e-11
     assert bool((ab > 0).all()) and bool((em > 0).all())
+
+
+def test_far_field_vs_exact_mode(eng, oracle):
+    """The two evaluation modes of the coefficient op against each other and the oracle on a
+    case where every far-field level is populated (3e4-point grid, dense lines, 4 layers from
+    Doppler- to Lorentz-dominated, shard not aligned to the box hierarchy)."""
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2975.0, 5e-4, 30000)
+    L = syn.make_lines(6000, grid, config_id=11, n_levels=12)
+    T = np.array([180.0, 150.0, 120.0, 95.0])
+    P = np.array([900.0, 12.0, 0.2, 1e-5])
+    tv = np.array([T + 3.0 * i for i in range(12)])
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    lo, hi = 777, 29001
+    eng.set_far_field(0)
+    a0, e0 = ls.abscoeff_layers(T, P, tvib=tv, g_lo=lo, g_hi=hi)
+    eng.set_far_field(1)
+    a1, e1 = ls.abscoeff_layers(T, P, tvib=tv, g_lo=lo, g_hi=hi)
+    assert relerr(a1.cpu().numpy(), a0.cpu().numpy()) < 2e-11
+    assert relerr(e1.cpu().numpy(), e0.cpu().numpy()) < 2e-11
+    q = np.array([oracle.calc_partition_sum(*_tips(6, 1), t) for t in T])
+    abo, emo = oracle.abscoeff_layers(L, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES, T, P, q, tv, grid, mode=1, n_threads=4)
+    assert relerr(a1.cpu().numpy(), abo[:, lo:hi]) < TOL
+    assert relerr(e1.cpu().numpy(), emo[:, lo:hi]) < TOL
