@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--rays", type=int, default=1)
     ap.add_argument("--ppl", type=int, default=8, help="grid points per lane in the coefficient kernels")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--exact", action="store_true", help="evaluate every (line, point) exactly (no far-field expansions)")
     args = ap.parse_args()
 
     import torch
@@ -95,6 +96,7 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     engine.set_device(local)
     engine.set_points_per_lane(args.ppl)
+    engine.set_far_field(0 if args.exact else 1)
     info = engine.device_info()
 
     # ---- synthetic workload, identical on every rank ----
@@ -137,24 +139,20 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    prep_ms = wings_ms = cores_ms = 0.0
+    kms = np.zeros(4)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         spec = step()
-        a, b, c = ls.last_kernel_ms()   # HIP events on the launch stream (syncs that step)
-        prep_ms += a
-        wings_ms += b
-        cores_ms += c
+        kms += np.array(ls.last_kernel_ms())   # HIP events on the launch stream (syncs that step)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    prep_ms /= args.steps
-    wings_ms /= args.steps
-    cores_ms /= args.steps
-    main_ms = wings_ms + cores_ms
+    kms /= args.steps
+    prep_ms = float(kms[0])
+    main_ms = float(kms[1] + kms[2] + kms[3])
     checksum = float(spec.sum().item())
 
     if rank == 0:
@@ -183,19 +181,27 @@ def main():
                                    "%d ray(s), 12 non-LTE levels" % (args.lines, args.grid, args.layers, args.rays),
                        "n_lines": args.lines, "n_grid": args.grid, "n_layers": args.layers, "n_rays": args.rays,
                        "sharding": "spectral window / %d, one RCCL all-gather" % world if world > 1 else "none",
-                       "points_per_lane": args.ppl, "device": info["name"], "cu_count": info["cu_count"]},
+                       "mode": "exact" if args.exact else "far-field", "device": info["name"],
+                       "cu_count": info["cu_count"]},
             "roofline": {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "sr_abscoeff_wings_kernel (+ sr_abscoeff_cores_kernel, its complement: "
-                                   "the algorithmic flops are split between the two, so achieved = flops / "
-                                   "(wings_ms + cores_ms))",
-                         "kernel_ms": main_ms, "wings_kernel_ms": wings_ms, "cores_kernel_ms": cores_ms,
-                         "prep_kernel_ms": prep_ms,
+                         "kernel": ("sr_farfield_kernel + sr_abscoeff_near_kernel<1> + <2>" if not args.exact else
+                                    "sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel") +
+                                   " (the coefficient op; achieved = algorithmic flops / their summed time)",
+                         "kernel_ms": main_ms,
+                         "kernels_ms": dict(zip(["sr_prep_kernel"] + (
+                             ["sr_farfield_kernel", "sr_abscoeff_near_kernel<1>", "sr_abscoeff_near_kernel<2>"]
+                             if not args.exact else ["sr_abscoeff_wings_kernel", "sr_abscoeff_cores_kernel", "-"]),
+                             [float(v) for v in kms])),
+                         "mode": "exact" if args.exact else "far-field",
                          "flops_per_launch": flops,
-                         "note": "gather formulation is fp64-vector bound (arithmetic intensity ~1e4 flop/B, "
-                                 "no MFMA: not a contraction); 16 flop per (line, layer, point) x "
-                                 "n_lines*13010*n_layers evaluations (SURVEY 8-d); peak 78.6 TFLOP/s is both "
-                                 "the fp64 vector and the fp64 MFMA dense peak of MI355X"},
+                         "note": "fp64-vector bound (arithmetic intensity ~1e4 flop/B, no MFMA: not a "
+                                 "contraction); algorithmic flops = 16 per (line, layer, point) x "
+                                 "n_lines*13010*n_layers evaluations of the reference formulation (SURVEY 8-d); "
+                                 "peak 78.6 TFLOP/s = fp64 vector = fp64 MFMA dense peak of MI355X.  In far-field "
+                                 "mode ~90 % of those evaluations are replaced by per-box Taylor expansions, so "
+                                 "the algorithmic rate can exceed what brute force could reach; run with --exact "
+                                 "for the brute-force kernels (VALU-busy figures: DESIGN.md, profiles/)"},
             "roofline_hbm": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": alg_bytes,
                              "note": "algorithmic bytes 8*n_grid*n_layers*2 + 80*n_lines (SURVEY 8-d); expected "

@@ -72,8 +72,7 @@ SYMBOLS = {
                                        C.c_void_p, C.c_void_p]),
     "sr_set_points_per_lane": (C.c_int, [C.c_int]),
     "sr_set_far_field": (C.c_int, [C.c_int]),
-    "sr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
-                                    C.POINTER(C.c_float)]),
+    "sr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
 }
 
 if not os.path.exists(LIB_PATH):

@@ -166,7 +166,8 @@ struct sr_lineset {
   LinesDev L{};
   Stager s_layers;
   DevBuf d_fast, d_cold, d_zmax, d_coef;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int n_timed = 0; // kernels timed in the last call
   bool timed = false;
 };
 
@@ -490,10 +491,15 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     LAUNCHCHK(launch_farfield(ls->d_fast.as<FastRec>(), ls->L.ic + line_lo, ls->d_zmax.as<int>(), n_sub, nl,
                               (int)g_lo, (int)g_hi, fp, st));
     HIPCHK(hipEventRecord(ls->ev[2], st));
-    LAUNCHCHK(launch_near(ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), ls->L.ic + line_lo,
-                          ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, st));
-    HIPCHK(hipEventRecord(ls->ev[3], st));
+    for (int part = 1; part <= 2; ++part) {
+      LAUNCHCHK(launch_near(part, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), ls->L.ic + line_lo,
+                            ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out,
+                            st));
+      HIPCHK(hipEventRecord(ls->ev[2 + part], st));
+    }
+    ls->n_timed = 4;
   } else {
+    ls->n_timed = 3;
     for (int which = 0; which < 2; ++which) {
       LAUNCHCHK(launch_abscoeff(g_variant, which, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(),
                                 ls->L.ic + line_lo, ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
@@ -523,16 +529,13 @@ int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, 
   return rc;
 }
 
-int sr_last_kernel_ms(sr_lineset *ls, float *prep_ms, float *wings_ms, float *cores_ms) {
-  if (!ls || !ls->timed) return SR_ERR_ARG;
-  HIPCHK(hipEventSynchronize(ls->ev[3]));
-  float a = 0, b = 0, c = 0;
-  HIPCHK(hipEventElapsedTime(&a, ls->ev[0], ls->ev[1]));
-  HIPCHK(hipEventElapsedTime(&b, ls->ev[1], ls->ev[2]));
-  HIPCHK(hipEventElapsedTime(&c, ls->ev[2], ls->ev[3]));
-  if (prep_ms) *prep_ms = a;
-  if (wings_ms) *wings_ms = b;
-  if (cores_ms) *cores_ms = c;
+int sr_last_kernel_ms(sr_lineset *ls, float *ms4) {
+  if (!ls || !ls->timed || !ms4) return SR_ERR_ARG;
+  HIPCHK(hipEventSynchronize(ls->ev[ls->n_timed]));
+  for (int i = 0; i < 4; ++i) {
+    ms4[i] = 0.f;
+    if (i < ls->n_timed) HIPCHK(hipEventElapsedTime(&ms4[i], ls->ev[i], ls->ev[i + 1]));
+  }
   return SR_OK;
 }
 

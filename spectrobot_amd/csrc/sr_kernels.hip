@@ -435,7 +435,11 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
 }
 
 // Exact near field + evaluation of the far-field polynomials: one wave per group
-// of 256 points; writes abs/emi.
+// of 256 points.  PART 1: the (line, slot) pairs that lie wholly in a region-1
+// wing, plus the far-field polynomials; writes abs/emi (lean: high occupancy).
+// PART 2: the pairs that meet a region-2/3/4 zone or a window end (general,
+// index-driven evaluation); adds into abs/emi.
+template <int PART>
 __global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold,
     const int *__restrict__ ic_sub, const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo,
@@ -449,7 +453,8 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
   const int thr0 = ff_thr2(0, pm);
   // lines with a slot of this group that no far-field level owns: closer than
   // kTheta*32 + pm to a slot centre, zone meeting the slot, or a window end inside
-  const int zm = min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1);
+  const int zm = PART == 2 ? min(zmax[layer], kHalf - 1)
+                           : min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1);
   // the far-field kernel tests NOMINAL boxes (they may reach past g_hi), so a line whose
   // window ends between g_hi and the nominal end of the last slot is ours too
   const int whn = wlo + kGroup - 1;
@@ -473,56 +478,88 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
   }
   const FastRec *frow = fast + (size_t)layer * n_sub;
   const ColdRec *crow = cold + (size_t)layer * n_sub;
+  // The scalar unit is shared by the CU's four SIMDs, so the per-(line, slot)
+  // ownership tests run on the VALU, 64 candidate lines at a time (lane = line);
+  // only the lines with work are then walked one by one, their records fetched
+  // with scalar loads one line ahead.
   for (int rg = 0; rg < 3; ++rg) {
-    if (rs[rg] >= re[rg]) continue;
-    FastRec nxt = frow[rs[rg]];
-    ColdRec cnxt = crow[rs[rg]];
-    for (int l = rs[rg]; l < re[rg]; ++l) {
-      const FastRec r = nxt;
-      const ColdRec cr = cnxt;
-      nxt = frow[l + 1]; // one record of slack behind both tables
-      cnxt = crow[l + 1];
-      const int j1 = r.j1, jN = j1 + (kImxsig - 1), il = r.il(), ir = r.ir();
-      if (jN < wlo || j1 > whi) continue;
-      // which slots are ours (nominal 64-point boxes, as the far-field kernel sees them)
-      bool mine[4], any = false, general = false;
+    for (int base = rs[rg]; base < re[rg]; base += 64) {
+      const int lv = base + lane;
+      int flags = 0;
+      if (lv < re[rg]) {
+        const int j1 = frow[lv].j1;
+        const unsigned ilir = frow[lv].ilir;
+        const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int slo = wlo + 64 * p;
-        mine[p] = slo <= whi && jN >= slo && j1 <= min(slo + 63, whi) &&
-                  !ff_admissible(j1, il, ir, slo, slo + 63, thr0);
-        any = any || mine[p];
-        general = general || (mine[p] && classify(j1, il, ir, slo, min(slo + 63, whi)) == 0);
-      }
-      if (!any) continue;
-      if (!general && mine[0] && mine[1] && mine[2] && mine[3]) {
-        const int gcls = classify(j1, il, ir, wlo, whi);
-        if (gcls != 0) { // four whole slots in one wing: shared reciprocal
-          wing_eval4(wing_x_at(r, gcls, j1, wlo), r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl, acc_a, acc_e);
-          continue;
+        for (int p = 0; p < 4; ++p) {
+          const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
+          const bool m = slo <= whi && jN >= slo && j1 <= shi && !ff_admissible(j1, il, ir, slo, slo + 63, thr0);
+          const bool wing = classify(j1, il, ir, slo, shi) != 0;
+          if (m && (PART == 1 ? wing : !wing)) flags |= 1 << p;
         }
+        if (PART == 1 && flags == 15 && classify(j1, il, ir, wlo, whi) != 0) flags |= 16;
       }
-      const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
-      ZoneCtx zc;
-      if (general) zc = zone_ctx(r, cr, xf);
+      unsigned long long todo = __ballot(flags != 0);
+      if (todo == 0) continue;
+      int cur = __builtin_ctzll(todo);
+      FastRec nxt = frow[base + cur];
+      ColdRec cnxt = crow[PART == 2 ? base + cur : 0];
+      while (todo) {
+        const int i = cur;
+        const FastRec r = nxt;
+        const ColdRec cr = cnxt;
+        todo &= todo - 1;
+        if (todo) {
+          cur = __builtin_ctzll(todo);
+          nxt = frow[base + cur];
+          if (PART == 2) cnxt = crow[base + cur];
+        }
+        const int f = __builtin_amdgcn_readlane(flags, i);
+        const int j1 = r.j1, il = r.il(), ir = r.ir();
+        if (PART == 1) {
+          if (f & 16) { // four whole slots in one wing: shared reciprocal
+            wing_eval4(wing_x_at(r, classify(j1, il, ir, wlo, whi), j1, wlo), r.xstep, r.a, r.b, r.c, r.d, r.wabs,
+                       r.wemi, fl, acc_a, acc_e);
+            continue;
+          }
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        if (!mine[p]) continue;
-        const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
-        const int scls = classify(j1, il, ir, slo, shi);
-        double y;
-        if (scls != 0) { // the whole slot in one wing
-          const double x = fma(fl[p], r.xstep, wing_x_at(r, scls, j1, wlo));
-          const double x2 = x * x;
-          y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
+          for (int p = 0; p < 4; ++p) {
+            if (!(f & (1 << p))) continue;
+            const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
+            const int scls = classify(j1, il, ir, slo, shi);
+            const double x = fma(fl[p], r.xstep, wing_x_at(r, scls, j1, wlo));
+            const double x2 = x * x;
+            const double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
+            acc_a[p] = fma(r.wabs, y, acc_a[p]);
+            acc_e[p] = fma(r.wemi, y, acc_e[p]);
+          }
         } else {
-          const int k = slo + lane - j1 + 1; // 1-based window index
-          y = (k >= 1 && k <= kImxsig && slo + lane <= shi) ? humliv_point(k, r, zc, xf) : 0.0;
+          const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
+          const ZoneCtx zc = zone_ctx(r, cr, xf);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            if (!(f & (1 << p))) continue;
+            const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
+            const int k = slo + lane - j1 + 1; // 1-based window index
+            const double y = (k >= 1 && k <= kImxsig && slo + lane <= shi) ? humliv_point(k, r, zc, xf) : 0.0;
+            acc_a[p] = fma(r.wabs, y, acc_a[p]);
+            acc_e[p] = fma(r.wemi, y, acc_e[p]);
+          }
         }
-        acc_a[p] = fma(r.wabs, y, acc_a[p]);
-        acc_e[p] = fma(r.wemi, y, acc_e[p]);
       }
     }
+  }
+  const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
+  if (PART == 2) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int j = wlo + lane + 64 * p;
+      if (j <= whi) {
+        abs_out[row + (j - g_lo)] += acc_a[p];
+        emi_out[row + (j - g_lo)] += acc_e[p];
+      }
+    }
+    return;
   }
   // far field: one polynomial per level and slot
   const double *cl = fp.coef + (size_t)layer * fp.n_boxes_total * (2 * kFC);
@@ -546,7 +583,6 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
       acc_e[p] += pe;
     }
   }
-  const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int j = wlo + lane + 64 * p;
@@ -565,13 +601,18 @@ int launch_farfield(const FastRec *fast, const int *ic_sub, const int *zmax, int
   return (int)hipGetLastError();
 }
 
-int launch_near(const FastRec *fast, const ColdRec *cold, const int *ic_sub, const int *zmax, int n_sub,
+int launch_near(int part, const FastRec *fast, const ColdRec *cold, const int *ic_sub, const int *zmax, int n_sub,
                 int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp, double *abs_out,
                 double *emi_out, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
   const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
-  hipLaunchKernelGGL(sr_abscoeff_near_kernel, dim3((unsigned)(n_groups * n_layers)), dim3(64), 0, st, fast, cold,
-                     ic_sub, zmax, n_sub, n_groups, g_lo, g_hi, gp, fp, abs_out, emi_out);
+  const dim3 grid((unsigned)(n_groups * n_layers));
+  if (part == 1)
+    hipLaunchKernelGGL(sr_abscoeff_near_kernel<1>, grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub, n_groups,
+                       g_lo, g_hi, gp, fp, abs_out, emi_out);
+  else
+    hipLaunchKernelGGL(sr_abscoeff_near_kernel<2>, grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub, n_groups,
+                       g_lo, g_hi, gp, fp, abs_out, emi_out);
   return (int)hipGetLastError();
 }
 

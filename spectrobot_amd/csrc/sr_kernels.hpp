@@ -36,7 +36,8 @@ struct FarParams {
 };
 int launch_farfield(const FastRec *fast, const int *ic_sub, const int *zmax, int n_sub, int n_layers, int g_lo,
                     int g_hi, const FarParams &fp, hipStream_t st);
-int launch_near(const FastRec *fast, const ColdRec *cold, const int *ic_sub, const int *zmax, int n_sub,
+// part 1: wing-only pairs + far-field polynomials (writes); part 2: general pairs (adds)
+int launch_near(int part, const FastRec *fast, const ColdRec *cold, const int *ic_sub, const int *zmax, int n_sub,
                 int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp, double *abs_out,
                 double *emi_out, hipStream_t st);
 

@@ -141,10 +141,11 @@ class LineSet(object):
         return ab, em
 
     def last_kernel_ms(self):
-        """(prep, wings, cores) kernel times in ms of the last abscoeff_layers call."""
-        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
-        check(lib.sr_last_kernel_ms(self._h, C.byref(a), C.byref(b), C.byref(c)), "sr_last_kernel_ms")
-        return a.value, b.value, c.value
+        """Kernel times (ms) of the last abscoeff_layers call: (prep, farfield|wings,
+        near-wing|cores, near-general|0), see sr_last_kernel_ms."""
+        ms = (C.c_float * 4)()
+        check(lib.sr_last_kernel_ms(self._h, ms), "sr_last_kernel_ms")
+        return tuple(ms)
 
 
 def radiance_rays(abs_c, emi_c, seg_off, seg_layer, seg_col, rad0=None):
