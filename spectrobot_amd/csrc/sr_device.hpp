@@ -71,13 +71,20 @@ struct __attribute__((aligned(16))) FastRec {
 };
 static_assert(sizeof(FastRec) == 80, "FastRec must be 80 bytes");
 
-// Read only where a wave's points meet regions 2-4 or a window edge.
+// Everything regions 2-4 of one (line, layer) need, read (two scalar loads) only
+// where a wave's points meet the line's region-2/3/4 zone.  128 bytes.
 struct __attribute__((aligned(16))) ColdRec {
-  double ry, dwp, x0;
-  int16_t il2, ir2;
-  int32_t pad;
+  double ry, ryf;        // lw/dw' and (double)(float)ry: cmplx() is default kind (lineshape.f:529)
+  double dwp, inv_dwp;   // dw' = dw/sqrt(ln2) and ~1/dw'
+  double x0;             // line centre
+  double xs2l, xs2r;     // region-2 running-x starts (lineshape.f:504, 514)
+  double q2[8];          // region-2 coefficients a..h (lineshape.f:492-502)
+  uint32_t il2ir2;       // il2 | ir2 << 16
+  uint32_t pad;
+  __host__ __device__ inline int il2() const { return (int)(il2ir2 & 0xffffu); }
+  __host__ __device__ inline int ir2() const { return (int)(il2ir2 >> 16); }
 };
-static_assert(sizeof(ColdRec) == 32, "ColdRec must be 32 bytes");
+static_assert(sizeof(ColdRec) == 128, "ColdRec must be 128 bytes");
 
 // max(nint(v), 0) of lineshape.f:448,453,484,489 (nint rounds half away from zero)
 __device__ inline int nint_clamp0(double v) { return v <= 0.0 ? 0 : (int)round(v); }
@@ -105,26 +112,21 @@ __device__ inline void region1_coef(double ry, double &a, double &b, double &c, 
 }
 
 // ---- region 2: lineshape.f:492-521 ----
-struct R2Coef {
-  double a, b, c, d, e, f, g, h;
-};
-__device__ inline R2Coef region2_coef(double ry) {
+__device__ inline void region2_coef(double ry, double (&q)[8]) {
   const double ry2 = ry * ry;
-  R2Coef q;
-  q.a = ry * (1.0578555 + ry2 * (4.6545642 + ry2 * (3.1030428 + 0.5641896 * ry2)));
-  q.b = ry * (2.9619954 + ry2 * (0.5641896 + 1.6925688 * ry2));
-  q.c = ry * (-2.5388532 + ry2 * 1.6925688);
-  q.d = ry * 0.5641896;
-  q.e = 0.5625 + ry2 * (4.5 + ry2 * (10.5 + ry2 * (6. + ry2)));
-  q.f = -4.5 + ry2 * (9. + ry2 * (6. + 4. * ry2));
-  q.g = 10.5 + ry2 * (-6. + 6. * ry2);
-  q.h = 4. * ry2 - 6.;
-  return q;
+  q[0] = ry * (1.0578555 + ry2 * (4.6545642 + ry2 * (3.1030428 + 0.5641896 * ry2)));
+  q[1] = ry * (2.9619954 + ry2 * (0.5641896 + 1.6925688 * ry2));
+  q[2] = ry * (-2.5388532 + ry2 * 1.6925688);
+  q[3] = ry * 0.5641896;
+  q[4] = 0.5625 + ry2 * (4.5 + ry2 * (10.5 + ry2 * (6. + ry2)));
+  q[5] = -4.5 + ry2 * (9. + ry2 * (6. + 4. * ry2));
+  q[6] = 10.5 + ry2 * (-6. + 6. * ry2);
+  q[7] = 4. * ry2 - 6.;
 }
-__device__ inline double region2_val(const R2Coef &q, double x) {
+__device__ inline double region2_val(const double (&q)[8], double x) {
   const double x2 = x * x;
-  const double num = fma(x2, fma(x2, fma(q.d, x2, q.c), q.b), q.a);
-  const double den = fma(x2, fma(x2, fma(x2, x2 + q.h, q.g), q.f), q.e);
+  const double num = fma(x2, fma(x2, fma(q[3], x2, q[2]), q[1]), q[0]);
+  const double den = fma(x2, fma(x2, fma(x2, x2 + q[7], q[6]), q[5]), q[4]);
   return num * fast_rcp<2>(den);
 }
 
@@ -227,47 +229,43 @@ __device__ inline Bounds humliv_bounds(const XF &xf, int n, double x0, double lw
   return B;
 }
 
-// Everything of one (line, layer) that regions 2-4 need, computed once per
-// (line, wave tile) pair (wave-uniform).
-struct ZoneCtx {
-  R2Coef q2;
-  double ry, ryf, dwp, inv_dwp, x0, xs2l, xs2r;
-  int il, ir, il2, ir2, il2a, ir2a;
-};
+// Fill the ColdRec of one (line, layer) (prep kernel / humliv shim).
 template <class XF>
-__device__ inline ZoneCtx zone_ctx(const FastRec &r, const ColdRec &cr, const XF &xf) {
-  ZoneCtx z;
-  z.ry = cr.ry;
-  z.ryf = (double)(float)cr.ry;
-  z.dwp = cr.dwp;
-  z.inv_dwp = fast_rcp<2>(cr.dwp);
-  z.x0 = cr.x0;
-  z.il = r.il(); z.ir = r.ir(); z.il2 = cr.il2; z.ir2 = cr.ir2;
-  z.il2a = (z.il2 == z.il) ? z.il - 1 : z.il2; // lineshape.f:524-525
-  z.ir2a = (z.ir2 == z.ir) ? z.ir + 1 : z.ir2;
-  z.q2 = region2_coef(cr.ry);
-  z.xs2l = (cr.x0 - xf(z.il)) / cr.dwp;  // :504
-  z.xs2r = (xf(z.ir2) - cr.x0) / cr.dwp; // :514
-  return z;
+__device__ inline ColdRec make_cold(const Bounds &B, double dwp, double x0, const XF &xf) {
+  ColdRec c;
+  c.ry = B.ry;
+  c.ryf = (double)(float)B.ry;
+  c.dwp = dwp;
+  c.inv_dwp = fast_rcp<2>(dwp);
+  c.x0 = x0;
+  c.xs2l = (x0 - xf(B.il)) / dwp;  // lineshape.f:504
+  c.xs2r = (xf(B.ir2) - x0) / dwp; // :514
+  region2_coef(B.ry, c.q2);
+  c.il2ir2 = (uint32_t)B.il2 | ((uint32_t)B.ir2 << 16);
+  c.pad = 0;
+  return c;
 }
 
 // Value of humliv_bb at 1-based index k (1..n) for one (line, layer), any region;
 // follows the write order of lineshape.f:455-562 (last writer wins).
 template <class XF>
-__device__ inline double humliv_point(int k, const FastRec &r, const ZoneCtx &z, const XF &xf) {
-  if (k > z.il2a && k < z.ir2a) { // :526-562
+__device__ inline double humliv_point(int k, const FastRec &r, const ColdRec &z, const XF &xf) {
+  const int il = r.il(), ir = r.ir(), il2 = z.il2(), ir2 = z.ir2();
+  const int il2a = (il2 == il) ? il - 1 : il2; // lineshape.f:524-525
+  const int ir2a = (ir2 == ir) ? ir + 1 : ir2;
+  if (k > il2a && k < ir2a) { // :526-562
     // rx = |x(k)-x0|/dw, correctly rounded: q0 = a*(1/dw), one residual correction
     const double a = fabs(xf(k) - z.x0);
     double rx = a * z.inv_dwp;
     rx = fma(fma(-z.dwp, rx, a), z.inv_dwp, rx);
     return core_point(rx, z.ry, z.ryf);
   }
-  if (z.il < z.il2 && k >= z.il && k <= z.il2) // :503-512
-    return region2_val(z.q2, fma(-(double)(k - z.il), r.xstep, z.xs2l));
-  if (z.ir2 < z.ir && k >= z.ir2 && k <= z.ir) // :513-522
-    return region2_val(z.q2, fma((double)(k - z.ir2), r.xstep, z.xs2r));
-  const double x = (k <= z.il) ? fma(-(double)(k - 1), r.xstep, r.xl)    // :461-468
-                               : fma((double)(k - z.ir), r.xstep, r.xr); // :470-477
+  if (il < il2 && k >= il && k <= il2) // :503-512
+    return region2_val(z.q2, fma(-(double)(k - il), r.xstep, z.xs2l));
+  if (ir2 < ir && k >= ir2 && k <= ir) // :513-522
+    return region2_val(z.q2, fma((double)(k - ir2), r.xstep, z.xs2r));
+  const double x = (k <= il) ? fma(-(double)(k - 1), r.xstep, r.xl)  // :461-468
+                             : fma((double)(k - ir), r.xstep, r.xr); // :470-477
   const double x2 = x * x;
   return fma(x2, r.b, r.a) * fast_rcp<2>(fma(x2, fma(x2, 4.0, r.d), r.c));
 }

@@ -69,13 +69,7 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
   r.wemi = wemi / fac;
   r.j1 = ic - kHalf;
   r.ilir = (uint32_t)B.il | ((uint32_t)B.ir << 16);
-  ColdRec c;
-  c.ry = B.ry;
-  c.dwp = dwp;
-  c.x0 = x0;
-  c.il2 = (int16_t)B.il2;
-  c.ir2 = (int16_t)B.ir2;
-  c.pad = 0;
+  const ColdRec c = make_cold(B, dwp, x0, xf);
   const size_t o = (size_t)k * n_sub + i;
   fast[o] = r;
   cold[o] = c;
@@ -264,7 +258,6 @@ __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
       if (jN < wlo || j1 > whi) continue;
       if (classify(j1, r.il(), r.ir(), wlo, whi) != 0) continue; // done by the wings kernel
       const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
-      const ZoneCtx zc = zone_ctx(r, cr, xf);
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
@@ -277,7 +270,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
           y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
         } else {
           const int k = slo + lane - j1 + 1; // 1-based window index
-          y = (k >= 1 && k <= kImxsig && slo + lane <= shi) ? humliv_point(k, r, zc, xf) : 0.0;
+          y = (k >= 1 && k <= kImxsig && slo + lane <= shi) ? humliv_point(k, r, cr, xf) : 0.0;
         }
         acc_a[p] = fma(r.wabs, y, acc_a[p]);
         acc_e[p] = fma(r.wemi, y, acc_e[p]);
@@ -495,24 +488,36 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
           const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
           const bool m = slo <= whi && jN >= slo && j1 <= shi && !ff_admissible(j1, il, ir, slo, slo + 63, thr0);
           const bool wing = classify(j1, il, ir, slo, shi) != 0;
-          if (m && (PART == 1 ? wing : !wing)) flags |= 1 << p;
+          if (PART == 1) {
+            if (m && wing) flags |= 1 << p;
+          } else if (m && !wing) {
+            // bit p: the slot meets the region-2/3/4 zone; bit 4+p: it only straddles a window
+            // end (all of its in-window points are region 1)
+            const bool zone = shi >= j1 + il - 1 && slo <= j1 + ir - 1;
+            flags |= zone ? (1 << p) : (16 << p);
+          }
         }
         if (PART == 1 && flags == 15 && classify(j1, il, ir, wlo, whi) != 0) flags |= 16;
       }
       unsigned long long todo = __ballot(flags != 0);
       if (todo == 0) continue;
+      // PART 1 fetches the next record while the current one is evaluated; PART 2 holds a
+      // 128-byte ColdRec as well and has no SGPRs left for that (spills cost more than
+      // the exposed scalar-load latency, which its long per-line evaluation hides)
       int cur = __builtin_ctzll(todo);
-      FastRec nxt = frow[base + cur];
-      ColdRec cnxt = crow[PART == 2 ? base + cur : 0];
+      FastRec nxt = frow[PART == 1 ? base + cur : 0];
       while (todo) {
         const int i = cur;
-        const FastRec r = nxt;
-        const ColdRec cr = cnxt;
         todo &= todo - 1;
-        if (todo) {
-          cur = __builtin_ctzll(todo);
-          nxt = frow[base + cur];
-          if (PART == 2) cnxt = crow[base + cur];
+        if (todo) cur = __builtin_ctzll(todo);
+        FastRec r;
+        ColdRec cr;
+        if (PART == 1) {
+          r = nxt;
+          if (todo) nxt = frow[base + cur];
+        } else {
+          r = frow[base + i];
+          cr = crow[base + i];
         }
         const int f = __builtin_amdgcn_readlane(flags, i);
         const int j1 = r.j1, il = r.il(), ir = r.ir();
@@ -535,13 +540,21 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
           }
         } else {
           const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
-          const ZoneCtx zc = zone_ctx(r, cr, xf);
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
-            if (!(f & (1 << p))) continue;
+            if (!(f & (17 << p))) continue;
             const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
             const int k = slo + lane - j1 + 1; // 1-based window index
-            const double y = (k >= 1 && k <= kImxsig && slo + lane <= shi) ? humliv_point(k, r, zc, xf) : 0.0;
+            const bool in = k >= 1 && k <= kImxsig && slo + lane <= shi;
+            double y;
+            if (f & (1 << p)) {
+              y = in ? humliv_point(k, r, cr, xf) : 0.0;
+            } else { // window end inside the slot: region 1 on one side, masked
+              const int side = shi < j1 + il - 1 ? 1 : 2;
+              const double x = fma(fl[p], r.xstep, wing_x_at(r, side, j1, wlo));
+              const double x2 = x * x;
+              y = in ? fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c)) : 0.0;
+            }
             acc_a[p] = fma(r.wabs, y, acc_a[p]);
             acc_e[p] = fma(r.wemi, y, acc_e[p]);
           }
@@ -699,11 +712,9 @@ __global__ __launch_bounds__(256) void sr_humliv_kernel(const double *__restrict
   region1_coef(B.ry, r.a, r.b, r.c, r.d);
   r.wabs = r.wemi = 1.0; r.j1 = 0;
   r.ilir = (uint32_t)B.il | ((uint32_t)B.ir << 16);
-  ColdRec c;
-  c.ry = B.ry; c.dwp = dwp; c.x0 = x0; c.il2 = (int16_t)B.il2; c.ir2 = (int16_t)B.ir2; c.pad = 0;
-  const ZoneCtx zc = zone_ctx(r, c, xf);
+  const ColdRec c = make_cold(B, dwp, x0, xf);
   for (int k = blockIdx.x * blockDim.x + threadIdx.x + 1; k <= n; k += gridDim.x * blockDim.x)
-    y[i1 - 1 + k - 1] = humliv_point(k, r, zc, xf);
+    y[i1 - 1 + k - 1] = humliv_point(k, r, c, xf);
 }
 
 int launch_humliv(const double *x, int i1, int i2, double x0, double lw, double dwp, double *y,
