@@ -94,7 +94,7 @@ def main():
 
     rank, local, world = sd.init_from_env()
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
-    engine.set_device(local)
+    engine.set_device(local % max(torch.cuda.device_count(), 1))
     engine.set_points_per_lane(args.ppl)
     engine.set_far_field(0 if args.exact else 1)
     info = engine.device_info()
@@ -147,7 +147,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     kms /= args.steps

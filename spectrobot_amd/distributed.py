@@ -30,7 +30,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SR_DIST_BACKEND=gloo lets several ranks share ONE GPU (rehearsal on a 1-GPU box;
+            # RCCL needs one device per rank)
+            backend = os.environ.get("SR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local)
@@ -48,8 +50,13 @@ def all_gather_spectrum(shard, n_grid, world_size, rank, out=None):
     q = -(-int(n_grid) // int(world_size))
     pad = torch.zeros((n_rays, q), dtype=shard.dtype, device=shard.device)
     pad[:, :shard.shape[1]] = shard
-    flat = torch.empty((world_size * n_rays, q), dtype=shard.dtype, device=shard.device)
-    dist.all_gather_into_tensor(flat, pad)  # concatenation along dim 0, rank-major
+    if shard.is_cuda and dist.get_backend() == "gloo":  # rehearsal only: stage through the host
+        flat_h = torch.empty((world_size * n_rays, q), dtype=shard.dtype)
+        dist.all_gather_into_tensor(flat_h, pad.cpu())
+        flat = flat_h.to(shard.device)
+    else:
+        flat = torch.empty((world_size * n_rays, q), dtype=shard.dtype, device=shard.device)
+        dist.all_gather_into_tensor(flat, pad)  # concatenation along dim 0, rank-major
     gathered = flat.view(world_size, n_rays, q)
     if out is None:
         out = torch.empty((n_rays, n_grid), dtype=shard.dtype, device=shard.device)

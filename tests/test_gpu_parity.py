@@ -253,6 +253,12 @@ def test_full_size_linearity_property(eng):
     assert float(((acc_a - ab).abs() / ab.abs()).max()) < 1e-11
     assert float(((acc_e - em).abs() / em.abs()).max()) < 1e-11
     assert bool((ab > 0).all()) and bool((em > 0).all())
+    # the two evaluation modes at full size (far-field expansions vs every evaluation exact)
+    eng.set_far_field(0)
+    ab0, em0 = full.abscoeff_layers(T, P, tvib=tv)
+    eng.set_far_field(1)
+    assert float(((ab0 - ab).abs() / ab0.abs()).max()) < 2e-11
+    assert float(((em0 - em).abs() / em0.abs()).max()) < 2e-11
 
 
 def test_far_field_vs_exact_mode(eng, oracle):
