@@ -171,6 +171,21 @@ int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers,
                          const int32_t *seg_layer, const double *seg_col,
                          int init_from_rad, double *rad, void *stream);
 
+/* Instrument step that follows the path: what
+ * SpectralIntensity.hires_to_lowres(lowres_obs, spectral_widths) does
+ * (spect_classes.py:1180-1191) for a hi-res spectrum on the cm^-1 grid
+ * w0 + j*step in 'ergscm2': conversion of grid and spectrum to nm
+ * (spect_classes.py:404-407, 779-783), Gaussian ILS over +-n_sigma sigma by the
+ * trapezoid rule on the irregular nm grid (spect_classes.py:883-918, 1926-1934,
+ * 1162-1164), conversion to the observation's units (out_units 0 'Wm2',
+ * 1 'ergscm2', 2 'nWcm2'; spect_classes.py:1200-1235).
+ * rad: DEVICE [n_rays][n_pts] (the whole spectrum); centers_nm / widths_nm:
+ * HOST [n_bands] (band centres and Gaussian sigmas, nm); out_host: HOST
+ * [n_rays][n_bands].  Synchronises the stream. */
+int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double w0, double step,
+                           const double *centers_nm, const double *widths_nm, int n_bands, double n_sigma,
+                           int out_units, double *out_host, void *stream);
+
 /* Evaluation mode of the coefficient op.  1 (default): far region-1 wings by
  * local Taylor expansions per box of grid points (truncation <= 5e-13 of a
  * line's own contribution), near field exact.  0: every (line, point) evaluated

@@ -74,6 +74,8 @@ def lib():
         L.sro_abscoeff_layers.argtypes = [C.POINTER(_Lines), C.c_double, C.c_int, _dp, C.c_int,
                                           _dp, _dp, _dp, _dp, _dp, C.c_long, C.c_int, C.c_int,
                                           _dp, _dp]
+        L.sro_hires_to_lowres.restype = None
+        L.sro_hires_to_lowres.argtypes = [_dp, _dp, C.c_long, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp]
         L.sro_radiance_ray.restype = None
         L.sro_radiance_ray.argtypes = [_dp, _dp, C.c_long, C.c_int, _ip, _dp, _dp]
         _LIB = L
@@ -225,3 +227,14 @@ def radiance_ray(abs_c, emi_c, seg_layer, col, rad0=None):
     rad = np.zeros(n) if rad0 is None else np.array(rad0, dtype=np.float64)
     lib().sro_radiance_ray(ap, ep, n, seg_layer.size, sp, cp, rad.ctypes.data_as(_dp))
     return rad
+
+
+def hires_to_lowres(grid_cm, spec, centers_nm, widths_nm, out_units="Wm2", n_sigma=5.0):
+    grid_cm, gp = _d(grid_cm)
+    spec, sp = _d(spec)
+    centers_nm, cp = _d(centers_nm)
+    widths_nm, wp = _d(widths_nm)
+    out = np.zeros(centers_nm.size)
+    lib().sro_hires_to_lowres(gp, sp, grid_cm.size, cp, wp, centers_nm.size, n_sigma,
+                              {"Wm2": 0, "ergscm2": 1, "nWcm2": 2}[out_units], out.ctypes.data_as(_dp))
+    return out

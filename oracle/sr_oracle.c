@@ -726,3 +726,42 @@ void sro_radiance_ray(const double *abs_c, const double *emi_c, long n_grid,
     }
   }
 }
+
+/* ------------------------------------------------------------------ */
+/* N2: SpectralIntensity.hires_to_lowres (spect_classes.py:1180-1191)   */
+/* ------------------------------------------------------------------ */
+/* cm-1 -> nm conversion of grid and spectrum (spcl:404-407, 779-783), Gaussian
+ * ILS of convolve_to_grid_from_irregular (spcl:883-918) with gaussian()
+ * (spcl:1926-1934) and conv_single = np.trapz (spcl:1162-1164), then convertto
+ * (spcl:1200-1235) from 'ergscm2': out_units 0 = Wm2, 1 = ergscm2, 2 = nWcm2. */
+void sro_hires_to_lowres(const double *grid_cm, const double *spec, long n, const double *cen_nm,
+                         const double *wid_nm, int nb, double n_sigma, int out_units, double *out) {
+  double *xn = (double *)malloc(sizeof(double) * n), *yn = (double *)malloc(sizeof(double) * n);
+  for (long i = 0; i < n; i++) {
+    long j = n - 1 - i; /* [::-1] */
+    xn[i] = 1.e7 / grid_cm[j];
+    yn[i] = spec[j] * (grid_cm[j] * grid_cm[j]) * 1.e-7;
+  }
+  for (int b = 0; b < nb; b++) {
+    const double f = cen_nm[b], w = wid_nm[b];
+    const double lo = f - n_sigma * w, hi = f + n_sigma * w;
+    const double fac = 1 / (w * sqrt(2. * SRO_PI));
+    double acc = 0.0, xp = 0.0, yp = 0.0;
+    int have = 0;
+    for (long i = 0; i < n; i++) {
+      if (!(xn[i] >= lo && xn[i] <= hi)) continue;
+      const double t = (xn[i] - f) / w;
+      const double y = yn[i] * (fac * exp(-0.5 * (t * t)));
+      if (have) acc += (xn[i] - xp) * (y + yp) / 2.0;
+      xp = xn[i];
+      yp = y;
+      have = 1;
+    }
+    double v = acc * 1.e-3; /* ergscm2 -> Wm2 */
+    if (out_units == 1) v = v * 1.e3;
+    if (out_units == 2) v = v * 1.e5;
+    out[b] = v;
+  }
+  free(xn);
+  free(yn);
+}

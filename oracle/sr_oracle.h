@@ -131,6 +131,12 @@ void sro_radiance_ray(const double *abs_c, const double *emi_c, long n_grid,
                       int n_seg, const int *seg_layer, const double *col,
                       double *rad);
 
+/* N2, spect_classes.py:1180-1191 hires_to_lowres: cm-1 -> nm, Gaussian ILS (n_sigma
+ * sigmas, np.trapz on the irregular nm grid), unit conversion from 'ergscm2'
+ * (out_units 0 = Wm2, 1 = ergscm2, 2 = nWcm2).  out[nb]. */
+void sro_hires_to_lowres(const double *grid_cm, const double *spec, long n, const double *cen_nm,
+                         const double *wid_nm, int nb, double n_sigma, int out_units, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -574,6 +574,34 @@ int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers,
 }
 
 // ------------------------------------------------------------------------
+int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double w0, double step,
+                           const double *centers_nm, const double *widths_nm, int n_bands, double n_sigma,
+                           int out_units, double *out_host, void *stream) {
+  if (!rad || !centers_nm || !widths_nm || !out_host || n_rays <= 0 || n_pts < 2 || n_bands <= 0) return SR_ERR_ARG;
+  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  if (!(step > 0.0) || !(w0 > 0.0) || !(n_sigma > 0.0) || out_units < 0 || out_units > 2) return SR_ERR_ARG;
+  for (int b = 0; b < n_bands; ++b)
+    if (!(widths_nm[b] > 0.0)) return SR_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static thread_local Stager s_bands;
+  static thread_local DevBuf d_out;
+  const size_t nb = (size_t)n_bands;
+  int rc = s_bands.prepare(sizeof(double) * 2 * nb);
+  if (rc) return rc;
+  std::memcpy(s_bands.host<double>(), centers_nm, sizeof(double) * nb);
+  std::memcpy(s_bands.host<double>() + nb, widths_nm, sizeof(double) * nb);
+  rc = s_bands.push(sizeof(double) * 2 * nb, st);
+  if (rc) return rc;
+  rc = d_out.ensure(sizeof(double) * nb * n_rays);
+  if (rc) return rc;
+  LAUNCHCHK(launch_lowres(rad, (int)n_pts, n_rays, w0, step, s_bands.d.as<double>(), s_bands.d.as<double>() + nb,
+                          n_bands, n_sigma, out_units, d_out.as<double>(), st));
+  HIPCHK(hipMemcpyAsync(out_host, d_out.p, sizeof(double) * nb * n_rays, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return SR_OK;
+}
+
+// ------------------------------------------------------------------------
 // f2py-shaped shims (host pointers)
 // ------------------------------------------------------------------------
 int sr_humliv_bb(const double *x, int n, int i1, int i2, double x0, double lw, double dw, double *y) {

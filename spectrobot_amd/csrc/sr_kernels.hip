@@ -799,6 +799,66 @@ __global__ void sr_curgod_kernel(int which, const double *__restrict__ nd, const
   res[s] = acc;
 }
 
+// ------------------------------------------------------------------------
+// N2: SpectralIntensity.hires_to_lowres (spect_classes.py:1180-1191): cm-1 -> nm
+// (grid and spectrum, spcl:404-407, 779-783), Gaussian ILS over +-n_sigma sigma
+// by the trapezoid rule on the irregular nm grid (convolve_to_grid_from_irregular,
+// spcl:883-918; gaussian, spcl:1926-1934; conv_single = np.trapz, spcl:1162-1164).
+// One block per (band, ray); nm index i <-> cm-1 index n-1-i.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sr_lowres_kernel(const double *__restrict__ rad, int n_pts, double w0,
+                                                        double gstep, const double *__restrict__ cen,
+                                                        const double *__restrict__ wid, int n_bands,
+                                                        double n_sigma, int out_units,
+                                                        double *__restrict__ out) {
+  const int b = blockIdx.x, ray = blockIdx.y;
+  const double f = cen[b], w = wid[b];
+  const double lo = f - n_sigma * w, hi = f + n_sigma * w;
+  const double fac = 1 / (w * sqrt(2. * kPi));
+  const double *sp = rad + (size_t)ray * n_pts;
+  auto xnm = [&](int i) { return 1.e7 / (w0 + (double)(n_pts - 1 - i) * gstep); };
+  // first i with x >= lo, first i with x > hi (x ascending in i)
+  int i0, i1;
+  {
+    int a = 0, c = n_pts;
+    while (a < c) { int m = (a + c) >> 1; if (xnm(m) < lo) a = m + 1; else c = m; }
+    i0 = a;
+    a = 0; c = n_pts;
+    while (a < c) { int m = (a + c) >> 1; if (xnm(m) <= hi) a = m + 1; else c = m; }
+    i1 = a; // selected: i0 .. i1-1
+  }
+  double acc = 0.0;
+  for (int i = i0 + threadIdx.x; i + 1 < i1; i += blockDim.x) {
+    const int j0 = n_pts - 1 - i, j1 = j0 - 1;
+    const double g0 = w0 + (double)j0 * gstep, g1 = w0 + (double)j1 * gstep;
+    const double x0 = 1.e7 / g0, x1 = 1.e7 / g1;
+    const double t0 = (x0 - f) / w, t1 = (x1 - f) / w;
+    const double y0 = (sp[j0] * (g0 * g0) * 1.e-7) * (fac * exp(-0.5 * (t0 * t0)));
+    const double y1 = (sp[j1] * (g1 * g1) * 1.e-7) * (fac * exp(-0.5 * (t1 * t1)));
+    acc += (x1 - x0) * (y1 + y0) / 2.0;
+  }
+  __shared__ double red[4];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = (red[0] + red[1]) + (red[2] + red[3]);
+    v = v * 1.e-3;                  // 'ergscm2' -> 'Wm2', spcl:1215-1218
+    if (out_units == 1) v = v * 1.e3; // -> 'ergscm2', spcl:1224-1228
+    if (out_units == 2) v = v * 1.e5; // -> 'nWcm2',   spcl:1230-1234
+    out[(size_t)ray * n_bands + b] = v;
+  }
+}
+
+int launch_lowres(const double *rad, int n_pts, int n_rays, double w0, double gstep, const double *cen,
+                  const double *wid, int n_bands, double n_sigma, int out_units, double *out, hipStream_t st) {
+  if (n_bands <= 0 || n_rays <= 0) return 0;
+  hipLaunchKernelGGL(sr_lowres_kernel, dim3(n_bands, n_rays), dim3(256), 0, st, rad, n_pts, w0, gstep, cen, wid,
+                     n_bands, n_sigma, out_units, out);
+  return (int)hipGetLastError();
+}
+
 int launch_curgod(int which, const double *nd, const double *vmr, const double *f, const double *x,
                   const int *off, int n_seg, double *res, hipStream_t st) {
   if (n_seg <= 0) return 0;

@@ -55,6 +55,8 @@ int launch_humliv(const double *x, int i1, int i2, double x0, double lw, double 
                   hipStream_t st);
 int launch_sum_lines(double *spe, long n_spe, const double *rows, const int *init, const int *fin,
                      int n_lines, int row_len, hipStream_t st);
+int launch_lowres(const double *rad, int n_pts, int n_rays, double w0, double gstep, const double *cen,
+                  const double *wid, int n_bands, double n_sigma, int out_units, double *out, hipStream_t st);
 int launch_curgod(int which, const double *nd, const double *vmr, const double *f, const double *x,
                   const int *off, int n_seg, double *res, hipStream_t st);
 

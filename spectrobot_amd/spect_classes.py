@@ -238,6 +238,39 @@ class SpectralObject(object):
         self.spectral_grid = spectral_grid if link_grid else copy.deepcopy(spectral_grid)
 
 
+class SpectralIntensity(SpectralObject):
+    """spect_classes.py:1167-1243: spectral intensity ('ergscm2' | 'Wm2' | 'nWcm2').  hires_to_lowres
+    runs the Gaussian-ILS degradation on the GPU."""
+
+    def __init__(self, intensity, spectral_grid, direction=None, units='ergscm2'):
+        self.spectrum = copy.deepcopy(intensity)
+        self.direction = copy.deepcopy(direction)
+        self.spectral_grid = copy.deepcopy(spectral_grid)
+        self.units = units
+
+    def hires_to_lowres(self, lowres_obs, spectral_widths=None, keep_original_hires=True):
+        """spect_classes.py:1180-1191.  self: hi-res on a cm_1 np.arange grid in 'ergscm2';
+        lowres_obs: object with .spectral_grid (units 'nm') and .units; spectral_widths: Gaussian
+        sigma per band (nm); default = the low-res grid step, as in the reference (spcl:890-892)."""
+        import torch
+        from . import engine
+        if self.spectral_grid.units != 'cm_1' or self.units != 'ergscm2':
+            raise ValueError("hires_to_lowres on the GPU takes a cm_1 grid and 'ergscm2' intensities")
+        if lowres_obs.spectral_grid.units != 'nm':
+            raise ValueError("the low-resolution grid must be in nm")
+        new_len = len(lowres_obs.spectral_grid.grid)
+        if spectral_widths is None:
+            spectral_widths = [lowres_obs.spectral_grid.step()] * new_len
+        elif type(spectral_widths) is int or type(spectral_widths) is float:
+            spectral_widths = [spectral_widths] * new_len
+        if len(spectral_widths) != new_len:
+            raise ValueError('{} spectral widths for {} grid points'.format(len(spectral_widths), new_len))
+        dev = torch.as_tensor(np.ascontiguousarray(self.spectrum, dtype=np.float64), device="cuda")
+        low = engine.hires_to_lowres(dev, self.spectral_grid.grid, lowres_obs.spectral_grid.grid, spectral_widths,
+                                     out_units=lowres_obs.units)[0]
+        return SpectralIntensity(low, lowres_obs.spectral_grid, units=lowres_obs.units)
+
+
 class SpectLine(object):
     """One HITRAN line (spect_classes.py:56-351).  linea: dict, numpy record or sequence + nomi."""
 

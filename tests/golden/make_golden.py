@@ -314,5 +314,38 @@ def main():
     print("e2e_co_all: abs max %.3e" % abc.max())
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--lowres" not in sys.argv:
     main()
+
+
+def golden_lowres():
+    """N2: SpectralIntensity.hires_to_lowres (spect_classes.py:1180-1191) = unit/grid conversion
+    cm-1 -> nm, Gaussian ILS (5 sigma) by np.trapz on the irregular nm grid, conversion of the
+    result to the observation's units.  Run with the reference's own classes."""
+    spcl, RF = import_reference_spcl()
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(20260002)
+    grid = syn.make_grid(2990.0, 5e-4, 24000)  # 12 cm-1
+    spec = np.abs(rng.standard_normal(24000)) * 1e-3 + 1e-3 * np.exp(-((grid - 2996.0) / 0.05) ** 2)
+    centers = np.array([3328.5, 3331.0, 3333.3, 3336.0, 3338.2, 3340.9, 3343.0])  # nm
+    widths = np.array([0.8, 1.1, 0.9, 1.3, 1.0, 0.7, 1.2])                            # nm (gaussian sigma)
+
+    class Obs(object):
+        pass
+    out = {}
+    for units in ("Wm2", "nWcm2", "ergscm2"):
+        hi = spcl.SpectralIntensity(spec.copy(), spcl.SpectralGrid(grid, units="cm_1"), units="ergscm2")
+        obs = Obs()
+        obs.spectral_grid = spcl.SpectralGrid(centers, units="nm")
+        obs.units = units
+        low = hi.hires_to_lowres(obs, spectral_widths=list(widths))
+        out[units] = np.array(low.spectrum, dtype=float)
+        assert low.units == units
+    np.savez_compressed(os.path.join(HERE, "lowres_ils.npz"), grid_w0=grid[0], grid_step=grid[1] - grid[0],
+                        grid_n=len(grid), spectrum=spec, centers_nm=centers, widths_nm=widths,
+                        low_Wm2=out["Wm2"], low_nWcm2=out["nWcm2"], low_ergscm2=out["ergscm2"])
+    print("lowres_ils:", out["Wm2"])
+
+
+if __name__ == "__main__" and "--lowres" in sys.argv:
+    golden_lowres()

@@ -283,3 +283,27 @@ def test_far_field_vs_exact_mode(eng, oracle):
     abo, emo = oracle.abscoeff_layers(L, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES, T, P, q, tv, grid, mode=1, n_threads=4)
     assert relerr(a1.cpu().numpy(), abo[:, lo:hi]) < TOL
     assert relerr(e1.cpu().numpy(), emo[:, lo:hi]) < TOL
+
+
+def test_hires_to_lowres_golden(eng, golden):
+    """N2 on the GPU against the reference's own SpectralIntensity.hires_to_lowres."""
+    import torch
+    from spectrobot_amd import spect_classes as spcl
+    g = golden("lowres_ils")
+    grid = _grid(g)
+    dev = torch.tensor(np.stack([g["spectrum"], 2.0 * g["spectrum"]]), device="cuda")
+    for u in ("Wm2", "ergscm2", "nWcm2"):
+        low = eng.hires_to_lowres(dev, grid, g["centers_nm"], g["widths_nm"], out_units=u)
+        assert relerr(low[0], g["low_" + u]) < 1e-12
+        assert relerr(low[1], 2.0 * g["low_" + u]) < 1e-12
+
+    class Obs(object):
+        pass
+    obs = Obs()
+    obs.spectral_grid = spcl.SpectralGrid(g["centers_nm"], units="nm")
+    obs.units = "nWcm2"
+    hi = spcl.SpectralIntensity(g["spectrum"], spcl.SpectralGrid(grid, units="cm_1"), units="ergscm2")
+    low = hi.hires_to_lowres(obs, spectral_widths=list(g["widths_nm"]))
+    assert low.units == "nWcm2" and relerr(low.spectrum, g["low_nWcm2"]) < 1e-12
+    with pytest.raises(ValueError):
+        hi.hires_to_lowres(obs, spectral_widths=[1.0, 2.0])

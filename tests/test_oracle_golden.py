@@ -158,3 +158,12 @@ def test_radiance_slab(oracle):
     assert np.allclose(r, want, rtol=1e-13)
     r2 = oracle.radiance_ray(a, e, [0, 0], [u / 2, u / 2])
     assert np.allclose(r2, want, rtol=1e-13)
+
+
+def test_hires_to_lowres(oracle, golden):
+    """N2: SpectralIntensity.hires_to_lowres (spect_classes.py:1180-1191) against the reference run."""
+    g = golden("lowres_ils")
+    grid = float(g["grid_w0"]) + float(g["grid_step"]) * np.arange(int(g["grid_n"]))
+    for u in ("Wm2", "ergscm2", "nWcm2"):
+        o = oracle.hires_to_lowres(grid, g["spectrum"], g["centers_nm"], g["widths_nm"], u)
+        assert relerr(o, g["low_" + u]) < 1e-13
