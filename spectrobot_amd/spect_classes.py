@@ -369,6 +369,79 @@ def MakeShape(wn_arr, wn_0, lw, dw, Strength=1.0):
 
 
 # ----------------------------------------------------------------------------
+# line databases
+# ----------------------------------------------------------------------------
+_HITRAN_WIDTHS = (2, 1, 12, 10, 10, 5, 5, 10, 4, 8, 15, 15, 15, 15, 19, 7, 7)   # 160 columns, HITRAN 2004+
+_GBB_WIDTHS = (2, 1, 12, 10, 10, 6, 6, 10, 4, 8, 15, 15, 15, 15)
+
+
+def _num(txt, kind):
+    txt = txt.strip()
+    if not txt:
+        return -1 if kind is int else float('nan')     # what np.genfromtxt yields for an empty field
+    try:
+        return kind(txt)
+    except ValueError:
+        return -1 if kind is int else float('nan')
+
+
+def read_line_database(nome_sp, mol=None, iso=None, up_lev=None, down_lev=None, fraction_to_keep=None,
+                       db_format='HITRAN', freq_range=None, n_skip=0, link_to_isomolecs=None, verbose=False):
+    """spect_classes.py:1532-1601: fixed-width HITRAN ('HITRAN', 160 columns with g_up / g_lo) or
+    MAKE_MW ('gbb') line files -> list of SpectLine.  Same selection rules: mol / iso / level-string
+    filters, freq_range (the file is assumed sorted: reading stops past the upper bound), zero
+    broadening coefficients replaced by 0.05 (air) and 0.07 (self), fraction_to_keep by line strength."""
+    if db_format == 'gbb':
+        widths, names = _GBB_WIDTHS, cose
+    elif db_format == 'HITRAN':
+        widths, names = _HITRAN_WIDTHS, cose_hit
+    else:
+        raise ValueError('Allowed values for db_format: {}, {}'.format('gbb', 'HITRAN'))
+    if n_skip == -1:
+        raise NotImplementedError('n_skip=-1 (sbm.trova_spip header search) needs spect_base_module')
+    edges = np.concatenate([[0], np.cumsum(widths)])
+    kinds = [int, int] + [float] * 8 + [str] * (5 if db_format == 'HITRAN' else 4) + \
+        ([float, float] if db_format == 'HITRAN' else [])
+    linee_ok = []
+    with open(nome_sp, 'r') as infi:
+        for _ in range(n_skip):
+            infi.readline()
+        for raw in infi:
+            raw = raw.rstrip('\n').rstrip('\r')
+            if not raw.strip():
+                continue
+            vals = []
+            for a, b, kind in zip(edges[:-1], edges[1:], kinds):
+                cell = raw[a:b]
+                vals.append(cell if kind is str else _num(cell, kind))
+            linea = dict(zip(names, vals))
+            if freq_range is not None:
+                if linea['Freq'] < freq_range[0]:
+                    continue
+                if linea['Freq'] > freq_range[1]:
+                    break
+            if (linea['Mol'] == mol or mol is None) and (linea['Iso'] == iso or iso is None) and \
+                    (linea['Up_lev_str'] == up_lev or up_lev is None) and \
+                    (linea['Lo_lev_str'] == down_lev or down_lev is None):
+                line = SpectLine(linea)
+                if line.Air_broad == 0.0:
+                    line.Air_broad = 0.05      # spect_classes.py:1578-1579
+                if line.Self_broad == 0.0:
+                    line.Self_broad = 0.07     # spect_classes.py:1580-1581
+                if link_to_isomolecs is not None:
+                    cand = [m for m in link_to_isomolecs if (m.mol == line.Mol and m.iso == line.Iso)]
+                    if len(cand) > 1:
+                        raise ValueError('Multiple levels corresponding to line! WTF?')
+                    if cand:
+                        line.LinkToMolec(cand[0])
+                linee_ok.append(line)
+    if fraction_to_keep is not None and linee_ok:
+        essort = np.sort(np.array([lin.Strength for lin in linee_ok]))[int(fraction_to_keep * (len(linee_ok) - 1))]
+        return [lin for lin in linee_ok if lin.Strength >= essort]
+    return linee_ok
+
+
+# ----------------------------------------------------------------------------
 # line list -> structure of arrays for the engine
 # ----------------------------------------------------------------------------
 def lines_to_soa(lines, isomolec=None):

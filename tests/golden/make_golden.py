@@ -314,7 +314,7 @@ def main():
     print("e2e_co_all: abs max %.3e" % abc.max())
 
 
-if __name__ == "__main__" and "--lowres" not in sys.argv:
+if __name__ == "__main__" and "--lowres" not in sys.argv and "--hitran" not in sys.argv:
     main()
 
 
@@ -349,3 +349,40 @@ def golden_lowres():
 
 if __name__ == "__main__" and "--lowres" in sys.argv:
     golden_lowres()
+
+
+def golden_hitran():
+    """N3: read_line_database (spect_classes.py:1532-1601) on a HITRAN-2012 160-column file written by
+    the reference's own SpectLine.Print_hitran (spect_classes.py:100-109) from synthetic values."""
+    spcl, RF = import_reference_spcl()
+    rng = np.random.default_rng(20260003)
+    path = os.path.join(HERE, "hitran_sample.par")
+    n = 60
+    freqs = np.sort(rng.uniform(2900.0, 3100.0, n))
+    with open(path, "w") as f:
+        for i in range(n):
+            mol, iso = (6, 1) if i % 5 else (23, 2)
+            vals = [mol, iso, float(freqs[i]), float(10 ** rng.uniform(-28, -19)), float(10 ** rng.uniform(-3, 2)),
+                    float(rng.choice([0.0, rng.uniform(0.03, 0.09)])), float(rng.choice([0.0, rng.uniform(0.05, 0.1)])),
+                    float(rng.uniform(0, 3000)), float(rng.uniform(0.4, 0.9)), float(rng.uniform(-0.01, 0.0)),
+                    "    0 0 1 0 1F2", "    0 0 0 0 1A1", ("    %2d F2 %2d" % (i % 20, i % 7)).ljust(15)[:15],
+                    ("    %2d F1 %2d" % ((i + 1) % 20, i % 5)).ljust(15)[:15], " 465540 5 6 2 2 1 0", float(2 * (i % 20) + 1) * 3.0,
+                    float(2 * ((i + 1) % 20) + 1) * 5.0]
+            l = spcl.SpectLine(vals, nomi=spcl.cose_hit)
+            l.Print_hitran(ofile=f)
+    lines = spcl.read_line_database(path)
+    sel = spcl.read_line_database(path, mol=6, iso=1, freq_range=[2950.0, 3050.0])
+    frac = spcl.read_line_database(path, fraction_to_keep=0.5)
+    fields = ("Mol", "Iso", "Freq", "Strength", "A_coeff", "Air_broad", "Self_broad", "E_lower", "T_dep_broad",
+              "P_shift", "g_up", "g_lo")
+    out = {k: np.array([getattr(l, k) for l in lines], dtype=float) for k in fields}
+    out["Up_lev_str"] = np.array([l.Up_lev_str.decode() for l in lines])
+    out["Q_num_lo"] = np.array([l.Q_num_lo.decode() for l in lines])
+    out["sel_freq"] = np.array([l.Freq for l in sel])
+    out["frac_freq"] = np.array([l.Freq for l in frac])
+    np.savez_compressed(os.path.join(HERE, "hitran_sample.npz"), **out)
+    print("hitran_sample: %d lines, %d selected, %d kept at fraction 0.5" % (len(lines), len(sel), len(frac)))
+
+
+if __name__ == "__main__" and "--hitran" in sys.argv:
+    golden_hitran()

@@ -175,3 +175,26 @@ def test_no_product_import_of_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 for bad in ("import oracle", "from oracle", "sr_oracle", "liboracle", "oracle/_ref", "ref_fortran"):
                     assert bad not in txt, (f, bad)
+
+
+def test_read_line_database_hitran(golden):
+    """N3: the HITRAN 160-column reader against the reference's read_line_database
+    (spect_classes.py:1532-1601) on a file written by the reference's Print_hitran."""
+    from spectrobot_amd import spect_classes as spcl
+    g = golden("hitran_sample")
+    path = os.path.join(ROOT, "tests", "golden", "hitran_sample.par")
+    lines = spcl.read_line_database(path)
+    assert len(lines) == len(g["Freq"])
+    for k in ("Mol", "Iso", "Freq", "Strength", "A_coeff", "Air_broad", "Self_broad", "E_lower", "T_dep_broad",
+              "P_shift", "g_up", "g_lo"):
+        assert np.array_equal(np.array([getattr(l, k) for l in lines], dtype=float), g[k]), k
+    assert [l.Up_lev_str for l in lines] == list(g["Up_lev_str"])
+    assert [l.Q_num_lo for l in lines] == list(g["Q_num_lo"])
+    sel = spcl.read_line_database(path, mol=6, iso=1, freq_range=[2950.0, 3050.0])
+    assert np.array_equal([l.Freq for l in sel], g["sel_freq"])
+    frac = spcl.read_line_database(path, fraction_to_keep=0.5)
+    assert np.array_equal([l.Freq for l in frac], g["frac_freq"])
+    with pytest.raises(ValueError):
+        spcl.read_line_database(path, db_format="xyz")
+    soa = spcl.lines_to_soa(sel)
+    assert np.array_equal(soa["freq"], g["sel_freq"]) and soa["lev_up"].min() == -1
