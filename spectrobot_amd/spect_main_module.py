@@ -95,3 +95,47 @@ def make_abscoeff_isomolec(wn_range_tot, isomolec, Temps, Press, LTE=True, allLU
             abs_coeffs.add_set(spcl.SpectralObject(abh[i], spectral_grid, link_grid=True))
             emi_coeffs.add_set(spcl.SpectralObject(emh[i], spectral_grid, link_grid=True))
     return abs_coeffs, emi_coeffs
+
+
+# ----------------------------------------------------------------------------
+# optimal-estimation algebra (spect_main_module.py:3399-3469)
+# ----------------------------------------------------------------------------
+def genvec(obs, sims, noise, masks=None):
+    """Concatenate observation / simulation / noise spectra (optionally masked), spect_main_module.py:3399-3423."""
+    cat = lambda objs: np.concatenate([np.asarray(o.spectrum, dtype=float) for o in objs])
+    obs_vec, sim_vec, noi_vec = cat(obs), cat(sims), cat(noise)
+    if masks is not None:
+        masktot = np.concatenate([np.asarray(m, dtype=bool) for m in masks])
+        obs_vec, sim_vec, noi_vec = obs_vec[masktot], sim_vec[masktot], noi_vec[masktot]
+    return obs_vec, sim_vec, noi_vec
+
+
+def chicalc(obs, sims, noise, masks, n_ret):
+    """Reduced chi square, spect_main_module.py:3426-3431."""
+    obs_vec, sim_vec, noi_vec = genvec(obs, sims, noise, masks=masks)
+    return np.sum(((obs_vec - sim_vec) / noi_vec) ** 2) / (len(obs_vec) - n_ret)
+
+
+def inversion_algebra(obs, sims, noise, bayes_set, lambda_LM=0.1, L1_reg=False, masks=None):
+    """One Levenberg-Marquardt step of the Bayesian optimal estimation, spect_main_module.py:3433-3469:
+    dx = (K^T Sy^-1 K + Sa^-1 + lambda diag(.))^-1 (K^T Sy^-1 (y - F) + Sa^-1 (xa - x)); stores the
+    averaging kernel and the retrieval covariance in bayes_set.  Small dense algebra (n_par ~ 10-50),
+    host side as in the reference; S_y is diagonal, so it is applied as a row scaling instead of
+    inverting an n_obs x n_obs matrix."""
+    jac = np.asarray(bayes_set.build_jacobian(masks=masks), dtype=float)
+    xi = np.asarray(bayes_set.param_vector(), dtype=float)
+    obs_vec, sim_vec, noi_vec = genvec(obs, sims, noise, masks=masks)
+    S_ap = np.asarray(bayes_set.VCM_apriori(), dtype=float)
+    x_ap = np.asarray(bayes_set.apriori_vector(), dtype=float)
+    KtSy = jac.T / noi_vec ** 2.0
+    G_inv = KtSy @ jac
+    Sa_inv = np.linalg.inv(S_ap)
+    S_inv = G_inv + Sa_inv
+    LM = np.diag(np.diag(S_inv))
+    S_x = np.linalg.inv(S_inv)
+    AVK = S_x @ G_inv
+    rhs = KtSy @ (obs_vec - sim_vec) + Sa_inv @ (x_ap - xi)
+    deltax = np.linalg.solve(S_inv + lambda_LM * LM, rhs)
+    bayes_set.update_params(deltax)
+    bayes_set.store_avk(AVK)
+    bayes_set.store_VCM(S_x)

@@ -314,7 +314,7 @@ def main():
     print("e2e_co_all: abs max %.3e" % abc.max())
 
 
-if __name__ == "__main__" and "--lowres" not in sys.argv and "--hitran" not in sys.argv:
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--lowres", "--hitran", "--inversion")):
     main()
 
 
@@ -386,3 +386,53 @@ def golden_hitran():
 
 if __name__ == "__main__" and "--hitran" in sys.argv:
     golden_hitran()
+
+
+def golden_inversion():
+    """N4 (algebra only): inversion_algebra / chicalc (spect_main_module.py:3399-3469) run with the
+    reference's own code on a small synthetic problem; bayes_set is a stub exposing the five methods
+    the function calls."""
+    spcl, RF = import_reference_spcl()
+    m_mp = types.ModuleType("memory_profiler")
+    m_mp.profile = lambda f: f
+    sys.modules["memory_profiler"] = m_mp
+    import spect_main_module as smm
+    rng = np.random.default_rng(20260004)
+    n_obs, n_par = 40, 6
+    K = rng.standard_normal((n_obs, n_par)) * 1e-7
+    xi = rng.uniform(1, 2, n_par)
+    x_ap = xi * (1 + 0.1 * rng.standard_normal(n_par))
+    A = rng.standard_normal((n_par, n_par))
+    S_ap = A @ A.T * 0.01 + np.eye(n_par) * 0.04
+    noise = np.abs(rng.standard_normal(n_obs)) * 1e-8 + 2e-8
+    sim = np.abs(rng.standard_normal(n_obs)) * 1e-6
+    obs = sim + K @ (0.05 * rng.standard_normal(n_par)) + noise * rng.standard_normal(n_obs)
+
+    class BS(object):
+        def build_jacobian(self, masks=None): return K
+        def param_vector(self): return xi
+        def VCM_apriori(self): return S_ap
+        def apriori_vector(self): return x_ap
+        def update_params(self, dx): self.dx = np.array(dx)
+        def store_avk(self, a): self.avk = np.array(a)
+        def store_VCM(self, s): self.vcm = np.array(s)
+
+    class Sp(object):
+        def __init__(self, v): self.spectrum = v
+    half = n_obs // 2
+    o = [Sp(obs[:half]), Sp(obs[half:])]
+    s = [Sp(sim[:half]), Sp(sim[half:])]
+    nz = [Sp(noise[:half]), Sp(noise[half:])]
+    res = {}
+    for lam in (0.1, 1.0):
+        bs = BS()
+        smm.inversion_algebra(o, s, nz, bs, lambda_LM=lam)
+        res["dx_%g" % lam], res["avk_%g" % lam], res["vcm_%g" % lam] = bs.dx, bs.avk, bs.vcm
+    chi = smm.chicalc(o, s, nz, None, n_par)
+    np.savez_compressed(os.path.join(HERE, "inversion_algebra.npz"), K=K, xi=xi, x_ap=x_ap, S_ap=S_ap, noise=noise,
+                        sim=sim, obs=obs, chi=chi, **res)
+    print("inversion_algebra: chi", chi, "dx", res["dx_0.1"][:3])
+
+
+if __name__ == "__main__" and "--inversion" in sys.argv:
+    golden_inversion()

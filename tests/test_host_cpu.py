@@ -198,3 +198,30 @@ def test_read_line_database_hitran(golden):
         spcl.read_line_database(path, db_format="xyz")
     soa = spcl.lines_to_soa(sel)
     assert np.array_equal(soa["freq"], g["sel_freq"]) and soa["lev_up"].min() == -1
+
+
+def test_inversion_algebra_against_reference(golden):
+    """N4 algebra: one Levenberg-Marquardt step against the reference's inversion_algebra / chicalc."""
+    from spectrobot_amd import spect_main_module as smm
+    g = golden("inversion_algebra")
+
+    class BS(object):
+        def build_jacobian(self, masks=None): return g["K"]
+        def param_vector(self): return g["xi"]
+        def VCM_apriori(self): return g["S_ap"]
+        def apriori_vector(self): return g["x_ap"]
+        def update_params(self, dx): self.dx = dx
+        def store_avk(self, a): self.avk = a
+        def store_VCM(self, s): self.vcm = s
+
+    class Sp(object):
+        def __init__(self, v): self.spectrum = v
+    h = len(g["obs"]) // 2
+    o, s, nz = ([Sp(g[k][:h]), Sp(g[k][h:])] for k in ("obs", "sim", "noise"))
+    for lam in ("0.1", "1"):
+        bs = BS()
+        smm.inversion_algebra(o, s, nz, bs, lambda_LM=float(lam))
+        assert np.allclose(bs.dx, g["dx_" + lam], rtol=1e-9, atol=0)
+        assert np.allclose(bs.avk, g["avk_" + lam], rtol=1e-9, atol=1e-14)
+        assert np.allclose(bs.vcm, g["vcm_" + lam], rtol=1e-9, atol=0)
+    assert abs(smm.chicalc(o, s, nz, None, len(g["xi"])) - float(g["chi"])) < 1e-12 * float(g["chi"])
