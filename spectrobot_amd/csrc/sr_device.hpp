@@ -80,9 +80,11 @@ struct __attribute__((aligned(16))) ColdRec {
   double xs2l, xs2r;     // region-2 running-x starts (lineshape.f:504, 514)
   double q2[8];          // region-2 coefficients a..h (lineshape.f:492-502)
   uint32_t il2ir2;       // il2 | ir2 << 16
-  uint32_t pad;
+  uint32_t k3;           // region-3 interval of the core, k3lo | k3hi << 16 (k3lo > k3hi: empty)
   __host__ __device__ inline int il2() const { return (int)(il2ir2 & 0xffffu); }
   __host__ __device__ inline int ir2() const { return (int)(il2ir2 >> 16); }
+  __host__ __device__ inline int k3lo() const { return (int)(k3 & 0xffffu); }
+  __host__ __device__ inline int k3hi() const { return (int)(k3 >> 16); }
 };
 static_assert(sizeof(ColdRec) == 128, "ColdRec must be 128 bytes");
 
@@ -172,33 +174,36 @@ __device__ inline double cos_bounded(double t) {
   return (q == 1 || q == 2) ? -v : v;
 }
 
-// One core point; ryf = (double)(float)ry is hoisted by the caller (cmplx() is
-// default kind: both parts are rounded to single, lineshape.f:529).
+// Regions 3 and 4 at c2 = (a, b) = ((double)(float)ry, (double)(float)(-rx)): cmplx() is
+// default kind, both parts are rounded to single (lineshape.f:529).
+__device__ inline double core_region4(double a, double b) { // :530-546
+  const double P4[7] = {SR_F32(36183.31), -SR_F32(3321.9905), SR_F32(1540.787), -SR_F32(219.0313),
+                        SR_F32(35.76683), -SR_F32(1.320522), SR_F32(.56419)};
+  const double Q4[8] = {SR_F32(32066.6), -SR_F32(24322.84), SR_F32(9022.228), -SR_F32(2186.181),
+                        SR_F32(364.2191), -SR_F32(61.57037), SR_F32(1.841439), -1.0};
+  const double ur = fma(a, a, -(b * b)), ui = (a + a) * b; // c1 = c2*c2
+  double pr, pi, qr, qi;
+  real_poly_at<6>(P4, ur, ui, pr, pi);
+  real_poly_at<7>(Q4, ur, ui, qr, qi);
+  const double nr = fma(a, pr, -(b * pi)), ni = fma(a, pi, b * pr); // c2 * P
+  const double ratio = fma(nr, qr, ni * qi) * fast_rcp<2>(fma(qr, qr, qi * qi));
+  return exp(ur) * cos_bounded(ui) - ratio;
+}
+__device__ inline double core_region3(double a, double b) { // :554-560
+  const double N3[5] = {SR_F32(16.4955), SR_F32(20.20933), SR_F32(11.96482), SR_F32(3.778987),
+                        SR_F32(.5642236)};
+  const double D3[6] = {SR_F32(16.4955), SR_F32(38.82363), SR_F32(39.27121), SR_F32(21.69274),
+                        SR_F32(6.699398), 1.0};
+  double pr, pi, qr, qi;
+  real_poly_at<4>(N3, a, b, pr, pi);
+  real_poly_at<5>(D3, a, b, qr, qi);
+  return fma(pr, qr, pi * qi) * fast_rcp<2>(fma(qr, qr, qi * qi));
+}
+// the reference's region test, :528-530
+__device__ inline bool core_is_region4(double rx, double ry) { return ry < (0.195 * rx) - 0.176; }
 __device__ inline double core_point(double rx, double ry, double ryf) {
-  const double r2 = (0.195 * rx) - 0.176;
-  const double a = ryf, b = (double)(float)(-rx);
-  if (ry < r2) { // region 4, :530-546
-    const double P4[7] = {SR_F32(36183.31), -SR_F32(3321.9905), SR_F32(1540.787), -SR_F32(219.0313),
-                          SR_F32(35.76683), -SR_F32(1.320522), SR_F32(.56419)};
-    const double Q4[8] = {SR_F32(32066.6), -SR_F32(24322.84), SR_F32(9022.228), -SR_F32(2186.181),
-                          SR_F32(364.2191), -SR_F32(61.57037), SR_F32(1.841439), -1.0};
-    const double ur = fma(a, a, -(b * b)), ui = (a + a) * b; // c1 = c2*c2
-    double pr, pi, qr, qi;
-    real_poly_at<6>(P4, ur, ui, pr, pi);
-    real_poly_at<7>(Q4, ur, ui, qr, qi);
-    const double nr = fma(a, pr, -(b * pi)), ni = fma(a, pi, b * pr); // c2 * P
-    const double ratio = fma(nr, qr, ni * qi) * fast_rcp<2>(fma(qr, qr, qi * qi));
-    return exp(ur) * cos_bounded(ui) - ratio;
-  } else { // region 3, :554-560
-    const double N3[5] = {SR_F32(16.4955), SR_F32(20.20933), SR_F32(11.96482), SR_F32(3.778987),
-                          SR_F32(.5642236)};
-    const double D3[6] = {SR_F32(16.4955), SR_F32(38.82363), SR_F32(39.27121), SR_F32(21.69274),
-                          SR_F32(6.699398), 1.0};
-    double pr, pi, qr, qi;
-    real_poly_at<4>(N3, a, b, pr, pi);
-    real_poly_at<5>(D3, a, b, qr, qi);
-    return fma(pr, qr, pi * qi) * fast_rcp<2>(fma(qr, qr, qi * qi));
-  }
+  const double b = (double)(float)(-rx);
+  return core_is_region4(rx, ry) ? core_region4(ryf, b) : core_region3(ryf, b);
 }
 
 // Region boundaries and running-x starts of one humliv_bb call on x(1..n)
@@ -242,7 +247,41 @@ __device__ inline ColdRec make_cold(const Bounds &B, double dwp, double x0, cons
   c.xs2r = (xf(B.ir2) - x0) / dwp; // :514
   region2_coef(B.ry, c.q2);
   c.il2ir2 = (uint32_t)B.il2 | ((uint32_t)B.ir2 << 16);
-  c.pad = 0;
+  // Region-3 interval inside the core (il2a, ir2a): rx = |x(k)-x0|/dw grows away from the
+  // centre and the region test is monotone in rx, so region 3 is one interval around the
+  // centre; its ends are found with the reference's own per-point test (IEEE division).
+  {
+    const int n_ = B.ir; // (unused bound, keeps the signature small)
+    (void)n_;
+    const int clo = ((B.il2 == B.il) ? B.il - 1 : B.il2) + 1, chi = ((B.ir2 == B.ir) ? B.ir + 1 : B.ir2) - 1;
+    int k3lo = 1, k3hi = 0; // empty
+    if (clo <= chi) {
+      auto is3 = [&](int k) { return !core_is_region4(fabs(xf(k) - x0) / dwp, B.ry); };
+      // the point closest to the centre: |x(k) - x0| is V-shaped in k
+      int a = clo, b = chi;
+      while (a < b) {
+        const int m = (a + b) >> 1;
+        if (xf(m) < x0) a = m + 1; else b = m;
+      }
+      int kc = a; // first k with x(k) >= x0 (or chi)
+      if (kc > clo && fabs(xf(kc - 1) - x0) < fabs(xf(kc) - x0)) --kc;
+      if (is3(kc)) {
+        int lo = clo, hi = kc; // smallest k in [clo, kc] with is3 (true ... true towards kc)
+        while (lo < hi) {
+          const int m = (lo + hi) >> 1;
+          if (is3(m)) hi = m; else lo = m + 1;
+        }
+        k3lo = lo;
+        lo = kc; hi = chi;     // largest k in [kc, chi] with is3
+        while (lo < hi) {
+          const int m = (lo + hi + 1) >> 1;
+          if (is3(m)) lo = m; else hi = m - 1;
+        }
+        k3hi = lo;
+      }
+    }
+    c.k3 = (uint32_t)k3lo | ((uint32_t)k3hi << 16);
+  }
   return c;
 }
 

@@ -427,29 +427,28 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
   }
 }
 
-// Exact near field + evaluation of the far-field polynomials: one wave per group
-// of 256 points.  PART 1: the (line, slot) pairs that lie wholly in a region-1
-// wing, plus the far-field polynomials; writes abs/emi (lean: high occupancy).
-// PART 2: the pairs that meet a region-2/3/4 zone or a window end (general,
-// index-driven evaluation); adds into abs/emi.
-template <int PART>
-__global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
-    const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold,
-    const int *__restrict__ ic_sub, const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo,
-    int g_hi, GridParams gp, FarParams fp, double *__restrict__ abs_out, double *__restrict__ emi_out) {
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int layer = wg / n_groups, grp = wg - layer * n_groups;
-  const int wlo = g_lo + grp * kGroup;
-  const int whi = min(wlo + kGroup, g_hi) - 1;
-  const int lane = threadIdx.x;
-  const int pm = fp.pm[layer];
-  const int thr0 = ff_thr2(0, pm);
-  // lines with a slot of this group that no far-field level owns: closer than
-  // kTheta*32 + pm to a slot centre, zone meeting the slot, or a window end inside
-  const int zm = PART == 2 ? min(zmax[layer], kHalf - 1)
-                           : min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1);
-  // the far-field kernel tests NOMINAL boxes (they may reach past g_hi), so a line whose
-  // window ends between g_hi and the nominal end of the last slot is ours too
+// Exact near field + evaluation of the far-field polynomials: one wave per group of
+// 256 points.  The scalar unit is shared by the CU's four SIMDs, so ownership tests
+// run on the VALU, 64 candidate lines at a time (lane = line); a ballot marks the
+// lines with work and only those are walked, their records fetched by scalar loads.
+//
+// sr_abscoeff_near_wings_kernel: every REGION-1 point of the lines that no
+//   far-field level owns for a slot (whole slots with one reciprocal per four
+//   points where possible; slots that also hold zone points or a window end with
+//   a per-lane mask), plus one far-field polynomial per level; writes abs/emi.
+// sr_abscoeff_near_zones_kernel: the region-2/3/4 points.  Lanes are packed by
+//   REGION, not by position: the region-2 points of a line (two intervals), its
+//   region-4 points (two intervals) and its region-3 points each form one run of
+//   consecutive lanes executing uniform code; the sums go through a 256-point LDS
+//   image of the group (one wave per block: read-modify-write is race-free).
+// ------------------------------------------------------------------------
+__device__ inline void near_ranges(const int *__restrict__ ic_sub, int n_sub, int wlo, int zm, int rs[3],
+                                   int re[3]) {
+  // candidates as ranges of the sorted centre list, C <= A <= B by start; NOMINAL group end
+  // (the far-field kernel tests nominal boxes, which may reach past g_hi):
+  //  C: window END inside the group      ic+6504 in [wlo, whn]
+  //  A: within zm of the group           ic in [wlo-zm, whn+zm]
+  //  B: window START inside the group    ic-6505 in (wlo, whn]
   const int whn = wlo + kGroup - 1;
   const int c0 = lower_bound_ic(ic_sub, n_sub, wlo - (kHalf - 1));
   const int c1 = lower_bound_ic(ic_sub, n_sub, whn - (kHalf - 1) + 1);
@@ -457,10 +456,23 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
   const int a1 = lower_bound_ic(ic_sub, n_sub, whn + zm + 1);
   const int b0 = lower_bound_ic(ic_sub, n_sub, wlo + kHalf + 1);
   const int b1 = lower_bound_ic(ic_sub, n_sub, whn + kHalf + 1);
-  int rs[3], re[3];
   rs[0] = c0; re[0] = max(c1, c0);
   rs[1] = max(a0, re[0]); re[1] = max(a1, rs[1]);
   rs[2] = max(b0, re[1]); re[2] = max(b1, rs[2]);
+}
+
+__global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
+    const FastRec *__restrict__ fast, const int *__restrict__ ic_sub, const int *__restrict__ zmax, int n_sub,
+    int n_groups, int g_lo, int g_hi, FarParams fp, double *__restrict__ abs_out, double *__restrict__ emi_out) {
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int layer = wg / n_groups, grp = wg - layer * n_groups;
+  const int wlo = g_lo + grp * kGroup;
+  const int whi = min(wlo + kGroup, g_hi) - 1;
+  const int lane = threadIdx.x;
+  const int pm = fp.pm[layer];
+  const int thr0 = ff_thr2(0, pm);
+  int rs[3], re[3];
+  near_ranges(ic_sub, n_sub, wlo, min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1), rs, re);
 
   double acc_a[4], acc_e[4], fl[4];
 #pragma unroll
@@ -470,14 +482,11 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
     fl[p] = (double)(lane + 64 * p);
   }
   const FastRec *frow = fast + (size_t)layer * n_sub;
-  const ColdRec *crow = cold + (size_t)layer * n_sub;
-  // The scalar unit is shared by the CU's four SIMDs, so the per-(line, slot)
-  // ownership tests run on the VALU, 64 candidate lines at a time (lane = line);
-  // only the lines with work are then walked one by one, their records fetched
-  // with scalar loads one line ahead.
   for (int rg = 0; rg < 3; ++rg) {
     for (int base = rs[rg]; base < re[rg]; base += 64) {
       const int lv = base + lane;
+      // bits 0-3: slot p lies wholly in one wing; bit 4: all four do, same wing;
+      // bits 5-8: slot p has region-1 points but also zone points or a window end
       int flags = 0;
       if (lv < re[rg]) {
         const int j1 = frow[lv].j1;
@@ -486,93 +495,49 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
-          const bool m = slo <= whi && jN >= slo && j1 <= shi && !ff_admissible(j1, il, ir, slo, slo + 63, thr0);
-          const bool wing = classify(j1, il, ir, slo, shi) != 0;
-          if (PART == 1) {
-            if (m && wing) flags |= 1 << p;
-          } else if (m && !wing) {
-            // bit p: the slot meets the region-2/3/4 zone; bit 4+p: it only straddles a window
-            // end (all of its in-window points are region 1)
-            const bool zone = shi >= j1 + il - 1 && slo <= j1 + ir - 1;
-            flags |= zone ? (1 << p) : (16 << p);
+          if (slo <= whi && jN >= slo && j1 <= shi && !ff_admissible(j1, il, ir, slo, slo + 63, thr0)) {
+            if (classify(j1, il, ir, slo, shi) != 0) flags |= 1 << p;
+            else if (slo < j1 + il - 1 || shi > j1 + ir - 1) flags |= 32 << p; // some point outside the zone
           }
         }
-        if (PART == 1 && flags == 15 && classify(j1, il, ir, wlo, whi) != 0) flags |= 16;
+        if (flags == 15 && classify(j1, il, ir, wlo, whi) != 0) flags |= 16;
       }
       unsigned long long todo = __ballot(flags != 0);
       if (todo == 0) continue;
-      // PART 1 fetches the next record while the current one is evaluated; PART 2 holds a
-      // 128-byte ColdRec as well and has no SGPRs left for that (spills cost more than
-      // the exposed scalar-load latency, which its long per-line evaluation hides)
       int cur = __builtin_ctzll(todo);
-      FastRec nxt = frow[PART == 1 ? base + cur : 0];
+      FastRec nxt = frow[base + cur];
       while (todo) {
         const int i = cur;
+        const FastRec r = nxt;
         todo &= todo - 1;
-        if (todo) cur = __builtin_ctzll(todo);
-        FastRec r;
-        ColdRec cr;
-        if (PART == 1) {
-          r = nxt;
-          if (todo) nxt = frow[base + cur];
-        } else {
-          r = frow[base + i];
-          cr = crow[base + i];
+        if (todo) { // fetch the next record while this one is evaluated
+          cur = __builtin_ctzll(todo);
+          nxt = frow[base + cur];
         }
         const int f = __builtin_amdgcn_readlane(flags, i);
         const int j1 = r.j1, il = r.il(), ir = r.ir();
-        if (PART == 1) {
-          if (f & 16) { // four whole slots in one wing: shared reciprocal
-            wing_eval4(wing_x_at(r, classify(j1, il, ir, wlo, whi), j1, wlo), r.xstep, r.a, r.b, r.c, r.d, r.wabs,
-                       r.wemi, fl, acc_a, acc_e);
-            continue;
-          }
+        if (f & 16) { // four whole slots in one wing: shared reciprocal
+          wing_eval4(wing_x_at(r, classify(j1, il, ir, wlo, whi), j1, wlo), r.xstep, r.a, r.b, r.c, r.d, r.wabs,
+                     r.wemi, fl, acc_a, acc_e);
+          continue;
+        }
+        const double xbl = wing_x_at(r, 1, j1, wlo), xbr = wing_x_at(r, 2, j1, wlo);
 #pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            if (!(f & (1 << p))) continue;
-            const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
-            const int scls = classify(j1, il, ir, slo, shi);
-            const double x = fma(fl[p], r.xstep, wing_x_at(r, scls, j1, wlo));
-            const double x2 = x * x;
-            const double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
-            acc_a[p] = fma(r.wabs, y, acc_a[p]);
-            acc_e[p] = fma(r.wemi, y, acc_e[p]);
-          }
-        } else {
-          const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            if (!(f & (17 << p))) continue;
-            const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
-            const int k = slo + lane - j1 + 1; // 1-based window index
-            const bool in = k >= 1 && k <= kImxsig && slo + lane <= shi;
-            double y;
-            if (f & (1 << p)) {
-              y = in ? humliv_point(k, r, cr, xf) : 0.0;
-            } else { // window end inside the slot: region 1 on one side, masked
-              const int side = shi < j1 + il - 1 ? 1 : 2;
-              const double x = fma(fl[p], r.xstep, wing_x_at(r, side, j1, wlo));
-              const double x2 = x * x;
-              y = in ? fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c)) : 0.0;
-            }
-            acc_a[p] = fma(r.wabs, y, acc_a[p]);
-            acc_e[p] = fma(r.wemi, y, acc_e[p]);
-          }
+        for (int p = 0; p < 4; ++p) {
+          if (!(f & (33 << p))) continue;
+          const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
+          const int k = slo + lane - j1 + 1; // 1-based window index
+          const bool left = k < il; // region 1: k < il or k > ir (lineshape.f:461-477, last writer wins)
+          const double x = fma(fl[p], r.xstep, left ? xbl : xbr);
+          const double x2 = x * x;
+          double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
+          if (f & (32 << p)) // mask the zone, the window ends and the grid end
+            y = ((left || k > ir) && k >= 1 && k <= kImxsig && slo + lane <= shi) ? y : 0.0;
+          acc_a[p] = fma(r.wabs, y, acc_a[p]);
+          acc_e[p] = fma(r.wemi, y, acc_e[p]);
         }
       }
     }
-  }
-  const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
-  if (PART == 2) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int j = wlo + lane + 64 * p;
-      if (j <= whi) {
-        abs_out[row + (j - g_lo)] += acc_a[p];
-        emi_out[row + (j - g_lo)] += acc_e[p];
-      }
-    }
-    return;
   }
   // far field: one polynomial per level and slot
   const double *cl = fp.coef + (size_t)layer * fp.n_boxes_total * (2 * kFC);
@@ -596,12 +561,116 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_kernel(
       acc_e[p] += pe;
     }
   }
+  const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int j = wlo + lane + 64 * p;
     if (j <= whi) {
       abs_out[row + (j - g_lo)] = acc_a[p];
       emi_out[row + (j - g_lo)] = acc_e[p];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
+    const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, const int *__restrict__ ic_sub,
+    const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp,
+    double *__restrict__ abs_out, double *__restrict__ emi_out) {
+  __shared__ double s_a[kGroup], s_e[kGroup];
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int layer = wg / n_groups, grp = wg - layer * n_groups;
+  const int wlo = g_lo + grp * kGroup;
+  const int whi = min(wlo + kGroup, g_hi) - 1;
+  const int lane = threadIdx.x;
+  const int zm = min(zmax[layer], kHalf - 1);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) s_a[lane + 64 * p] = s_e[lane + 64 * p] = 0.;
+  // lines whose zone [ic - zm, ic + zm] can meet the group
+  const int l0 = lower_bound_ic(ic_sub, n_sub, wlo - zm), l1 = lower_bound_ic(ic_sub, n_sub, whi + zm + 1);
+  const FastRec *frow = fast + (size_t)layer * n_sub;
+  const ColdRec *crow = cold + (size_t)layer * n_sub;
+  for (int base = l0; base < l1; base += 64) {
+    const int lv = base + lane;
+    bool act = false;
+    if (lv < l1) {
+      const int j1 = frow[lv].j1;
+      const unsigned ilir = frow[lv].ilir;
+      const int zl = max(j1 + (int)(ilir & 0xffffu) - 1, j1), zh = min(j1 + (int)(ilir >> 16) - 1, j1 + (kImxsig - 1));
+      act = zl <= whi && zh >= wlo; // zone (inside the window) meets the group
+    }
+    unsigned long long todo = __ballot(act);
+    while (todo) {
+      const int i = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const FastRec r = frow[base + i];
+      const ColdRec z = crow[base + i];
+      const int j1 = r.j1, il = r.il(), ir = r.ir(), il2 = z.il2(), ir2 = z.ir2();
+      const int k_lo = max(wlo - j1 + 1, 1), k_hi = min(whi - j1 + 1, kImxsig); // group & window, as k
+      const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
+      const double wa = r.wabs, we = r.wemi;
+      // ---- region 2: [il, il2] (if il < il2) then [ir2, ir] (if ir2 < ir), lineshape.f:503-522
+      {
+        const int a0 = max(il, k_lo), a1 = il < il2 ? min(il2, k_hi) : a0 - 1;
+        const int b0 = max(ir2, k_lo), b1 = ir2 < ir ? min(ir, k_hi) : b0 - 1;
+        const int na = max(a1 - a0 + 1, 0), nb = max(b1 - b0 + 1, 0);
+        for (int t0 = 0; t0 < na + nb; t0 += 64) {
+          const int t = t0 + lane;
+          if (t < na + nb) {
+            const bool lf = t < na;
+            const int k = lf ? a0 + t : b0 + (t - na);
+            const double x = lf ? fma(-(double)(k - il), r.xstep, z.xs2l) : fma((double)(k - ir2), r.xstep, z.xs2r);
+            const double y = region2_val(z.q2, x);
+            const int idx = k + j1 - 1 - wlo;
+            s_a[idx] = fma(wa, y, s_a[idx]);
+            s_e[idx] = fma(we, y, s_e[idx]);
+          }
+        }
+      }
+      // ---- core (il2a, ir2a), lineshape.f:524-562: region 3 = [k3lo, k3hi], region 4 on both sides
+      {
+        const int c_lo = max(((il2 == il) ? il - 1 : il2) + 1, k_lo), c_hi = min(((ir2 == ir) ? ir + 1 : ir2) - 1, k_hi);
+        const int k3lo = z.k3lo(), k3hi = z.k3hi();
+        const bool has3 = k3lo <= k3hi;
+        // region 4: [c_lo, k3lo-1] and [k3hi+1, c_hi] (the whole core if region 3 is empty)
+        const int a0 = c_lo, a1 = has3 ? min(k3lo - 1, c_hi) : c_hi;
+        const int b0 = has3 ? max(k3hi + 1, c_lo) : c_hi + 1, b1 = c_hi;
+        const int na = max(a1 - a0 + 1, 0), nb = max(b1 - b0 + 1, 0);
+        for (int t0 = 0; t0 < na + nb; t0 += 64) {
+          const int t = t0 + lane;
+          if (t < na + nb) {
+            const int k = t < na ? a0 + t : b0 + (t - na);
+            const double d = fabs(xf(k) - z.x0);
+            double rx = d * z.inv_dwp; // |x(k)-x0|/dw correctly rounded: one residual correction
+            rx = fma(fma(-z.dwp, rx, d), z.inv_dwp, rx);
+            const double y = core_region4(z.ryf, (double)(float)(-rx));
+            const int idx = k + j1 - 1 - wlo;
+            s_a[idx] = fma(wa, y, s_a[idx]);
+            s_e[idx] = fma(we, y, s_e[idx]);
+          }
+        }
+        const int e0 = max(k3lo, c_lo), e1 = min(k3hi, c_hi);
+        for (int t0 = 0; has3 && t0 <= e1 - e0; t0 += 64) {
+          const int k = e0 + t0 + lane;
+          if (k <= e1) {
+            const double d = fabs(xf(k) - z.x0);
+            double rx = d * z.inv_dwp;
+            rx = fma(fma(-z.dwp, rx, d), z.inv_dwp, rx);
+            const double y = core_region3(z.ryf, (double)(float)(-rx));
+            const int idx = k + j1 - 1 - wlo;
+            s_a[idx] = fma(wa, y, s_a[idx]);
+            s_e[idx] = fma(we, y, s_e[idx]);
+          }
+        }
+      }
+    }
+  }
+  const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int j = wlo + lane + 64 * p;
+    if (j <= whi) {
+      abs_out[row + (j - g_lo)] += s_a[lane + 64 * p];
+      emi_out[row + (j - g_lo)] += s_e[lane + 64 * p];
     }
   }
 }
@@ -621,11 +690,11 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const int *i
   const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
   const dim3 grid((unsigned)(n_groups * n_layers));
   if (part == 1)
-    hipLaunchKernelGGL(sr_abscoeff_near_kernel<1>, grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub, n_groups,
-                       g_lo, g_hi, gp, fp, abs_out, emi_out);
+    hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel, grid, dim3(64), 0, st, fast, ic_sub, zmax, n_sub, n_groups,
+                       g_lo, g_hi, fp, abs_out, emi_out);
   else
-    hipLaunchKernelGGL(sr_abscoeff_near_kernel<2>, grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub, n_groups,
-                       g_lo, g_hi, gp, fp, abs_out, emi_out);
+    hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel, grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub,
+                       n_groups, g_lo, g_hi, gp, abs_out, emi_out);
   return (int)hipGetLastError();
 }
 
