@@ -307,3 +307,50 @@ def test_hires_to_lowres_golden(eng, golden):
     assert low.units == "nWcm2" and relerr(low.spectrum, g["low_nWcm2"]) < 1e-12
     with pytest.raises(ValueError):
         hi.hires_to_lowres(obs, spectral_widths=[1.0, 2.0])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_randomized_configs_far_vs_exact_vs_oracle(eng, oracle, seed):
+    """Random grids (step, length not a multiple of 64, shard offsets), molar masses, pressures from
+    Doppler- to Lorentz-dominated (zones wider than the far-field near band), line densities: the
+    far-field mode, the exact mode and the oracle must agree."""
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(1000 + seed)
+    step = float(rng.choice([2.5e-4, 5e-4, 1e-3, 2e-3]))
+    n_grid = int(rng.integers(700, 9000))
+    w0 = float(rng.choice([650.0, 2100.0, 2990.0, 4300.0]))
+    grid = syn.make_grid(w0, step, n_grid)
+    n_lines = int(rng.integers(1, 900))
+    nlev = int(rng.choice([0, 3, 12]))
+    L = syn.make_lines(n_lines, grid, seed=2000 + seed, n_levels=nlev)
+    # a few lines outside the grid but within their window of it
+    if n_lines > 4:
+        L["freq"][0] = grid[0] - 1500 * step
+        L["freq"][-1] = grid[-1] + 2000 * step
+    mm = float(rng.choice([16.0313, 27.994915, 2.0159, 44.0]))
+    nl = 3
+    T = rng.uniform(70, 300, nl)
+    P = 10.0 ** rng.uniform(-7, 3.3, nl)
+    e_lev = syn.CH4_LEVEL_ENERGIES[:nlev]
+    tv = None if nlev == 0 else np.array([T + 2.0 * i for i in range(nlev)])
+    q = rng.uniform(50, 500, nl)
+    ls = eng.LineSet(L, grid, 6, 1, mm, e_lev)
+    lo = int(rng.integers(0, n_grid // 3))
+    hi = int(rng.integers(2 * n_grid // 3, n_grid + 1))
+    eng.set_far_field(0)
+    a0, e0 = ls.abscoeff_layers(T, P, tvib=tv, q_part=q, g_lo=lo, g_hi=hi)
+    eng.set_far_field(1)
+    a1, e1 = ls.abscoeff_layers(T, P, tvib=tv, q_part=q, g_lo=lo, g_hi=hi)
+    abo, emo = oracle.abscoeff_layers(L, mm, e_lev, T, P, q, tv, grid, mode=1, n_threads=3)
+    a0, e0, a1, e1 = (x.cpu().numpy() for x in (a0, e0, a1, e1))
+    ref_a, ref_e = abo[:, lo:hi], emo[:, lo:hi]
+    nz = ref_a != 0
+    assert np.array_equal(a1 != 0, nz) and np.array_equal(a0 != 0, nz)
+    # The reference advances x by 6500 repeated additions of xstep; with a constant addend the
+    # rounding errors do not average out but drift by up to n*ulp(x)/2 (here x ~ 1e4, xstep ~ 1.7:
+    # 6e-9 in x, 2e-10 in y next to a line).  The kernels evaluate x = x_start + m*xstep with one
+    # fma, so on coarse grids they differ from the reference by that drift (measured 1.9e-10);
+    # on the BASELINE grids it is <= 2e-11.  The two GPU modes agree to 1e-11 regardless.
+    assert relerr(a0[nz], ref_a[nz]) < 1e-9 and relerr(e0[nz], ref_e[nz]) < 1e-9
+    assert relerr(a1[nz], ref_a[nz]) < 1e-9 and relerr(e1[nz], ref_e[nz]) < 1e-9
+    assert relerr(a1[nz], a0[nz]) < 2e-11 and relerr(e1[nz], e0[nz]) < 2e-11
