@@ -442,14 +442,14 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
 //   consecutive lanes executing uniform code; the sums go through a 256-point LDS
 //   image of the group (one wave per block: read-modify-write is race-free).
 // ------------------------------------------------------------------------
-__device__ inline void near_ranges(const int *__restrict__ ic_sub, int n_sub, int wlo, int zm, int rs[3],
-                                   int re[3]) {
-  // candidates as ranges of the sorted centre list, C <= A <= B by start; NOMINAL group end
+__device__ inline void near_ranges(const int *__restrict__ ic_sub, int n_sub, int wlo, int width, int zm,
+                                   int rs[3], int re[3]) {
+  // candidates as ranges of the sorted centre list, C <= A <= B by start; NOMINAL tile end
   // (the far-field kernel tests nominal boxes, which may reach past g_hi):
-  //  C: window END inside the group      ic+6504 in [wlo, whn]
-  //  A: within zm of the group           ic in [wlo-zm, whn+zm]
-  //  B: window START inside the group    ic-6505 in (wlo, whn]
-  const int whn = wlo + kGroup - 1;
+  //  C: window END inside the tile      ic+6504 in [wlo, whn]
+  //  A: within zm of the tile           ic in [wlo-zm, whn+zm]
+  //  B: window START inside the tile    ic-6505 in (wlo, whn]
+  const int whn = wlo + width - 1;
   const int c0 = lower_bound_ic(ic_sub, n_sub, wlo - (kHalf - 1));
   const int c1 = lower_bound_ic(ic_sub, n_sub, whn - (kHalf - 1) + 1);
   const int a0 = lower_bound_ic(ic_sub, n_sub, wlo - zm);
@@ -461,46 +461,53 @@ __device__ inline void near_ranges(const int *__restrict__ ic_sub, int n_sub, in
   rs[2] = max(b0, re[1]); re[2] = max(b1, rs[2]);
 }
 
+// NG groups of 256 points per wave (NG = 2 halves the scalar work per point but costs occupancy
+// and SGPR spills: measured slower, NG = 1 is launched).
+template <int NG>
 __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
     const FastRec *__restrict__ fast, const int *__restrict__ ic_sub, const int *__restrict__ zmax, int n_sub,
-    int n_groups, int g_lo, int g_hi, FarParams fp, double *__restrict__ abs_out, double *__restrict__ emi_out) {
+    int n_tiles, int g_lo, int g_hi, FarParams fp, double *__restrict__ abs_out, double *__restrict__ emi_out) {
+  constexpr int NS = 4 * NG, WT = kGroup * NG;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int layer = wg / n_groups, grp = wg - layer * n_groups;
-  const int wlo = g_lo + grp * kGroup;
-  const int whi = min(wlo + kGroup, g_hi) - 1;
+  const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
+  const int wlo = g_lo + tile * WT;
+  const int whi = min(wlo + WT, g_hi) - 1;
   const int lane = threadIdx.x;
   const int pm = fp.pm[layer];
   const int thr0 = ff_thr2(0, pm);
   int rs[3], re[3];
-  near_ranges(ic_sub, n_sub, wlo, min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1), rs, re);
+  near_ranges(ic_sub, n_sub, wlo, WT, min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1), rs, re);
 
-  double acc_a[4], acc_e[4], fl[4];
+  double acc_a[NS], acc_e[NS], fl[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    acc_a[p] = 0.;
-    acc_e[p] = 0.;
-    fl[p] = (double)(lane + 64 * p);
-  }
+  for (int p = 0; p < NS; ++p) acc_a[p] = acc_e[p] = 0.;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) fl[p] = (double)(lane + 64 * p);
   const FastRec *frow = fast + (size_t)layer * n_sub;
   for (int rg = 0; rg < 3; ++rg) {
     for (int base = rs[rg]; base < re[rg]; base += 64) {
       const int lv = base + lane;
-      // bits 0-3: slot p lies wholly in one wing; bit 4: all four do, same wing;
-      // bits 5-8: slot p has region-1 points but also zone points or a window end
+      // per group g, at bit 9g: bits 0-3 slot lies wholly in one wing; bit 4 all four do, same
+      // wing; bits 5-8 slot has region-1 points but also zone points or a window end
       int flags = 0;
       if (lv < re[rg]) {
         const int j1 = frow[lv].j1;
         const unsigned ilir = frow[lv].ilir;
         const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
-          if (slo <= whi && jN >= slo && j1 <= shi && !ff_admissible(j1, il, ir, slo, slo + 63, thr0)) {
-            if (classify(j1, il, ir, slo, shi) != 0) flags |= 1 << p;
-            else if (slo < j1 + il - 1 || shi > j1 + ir - 1) flags |= 32 << p; // some point outside the zone
+        for (int g = 0; g < NG; ++g) {
+          int fg = 0;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int slo = wlo + kGroup * g + 64 * p, shi = min(slo + 63, whi);
+            if (slo <= whi && jN >= slo && j1 <= shi && !ff_admissible(j1, il, ir, slo, slo + 63, thr0)) {
+              if (classify(j1, il, ir, slo, shi) != 0) fg |= 1 << p;
+              else if (slo < j1 + il - 1 || shi > j1 + ir - 1) fg |= 32 << p; // some point outside the zone
+            }
           }
+          if (fg == 15 && classify(j1, il, ir, wlo + kGroup * g, min(wlo + kGroup * (g + 1), g_hi) - 1) != 0) fg |= 16;
+          flags |= fg << (9 * g);
         }
-        if (flags == 15 && classify(j1, il, ir, wlo, whi) != 0) flags |= 16;
       }
       unsigned long long todo = __ballot(flags != 0);
       if (todo == 0) continue;
@@ -516,25 +523,32 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
         }
         const int f = __builtin_amdgcn_readlane(flags, i);
         const int j1 = r.j1, il = r.il(), ir = r.ir();
-        if (f & 16) { // four whole slots in one wing: shared reciprocal
-          wing_eval4(wing_x_at(r, classify(j1, il, ir, wlo, whi), j1, wlo), r.xstep, r.a, r.b, r.c, r.d, r.wabs,
-                     r.wemi, fl, acc_a, acc_e);
-          continue;
-        }
-        const double xbl = wing_x_at(r, 1, j1, wlo), xbr = wing_x_at(r, 2, j1, wlo);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          if (!(f & (33 << p))) continue;
-          const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
-          const int k = slo + lane - j1 + 1; // 1-based window index
-          const bool left = k < il; // region 1: k < il or k > ir (lineshape.f:461-477, last writer wins)
-          const double x = fma(fl[p], r.xstep, left ? xbl : xbr);
-          const double x2 = x * x;
-          double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
-          if (f & (32 << p)) // mask the zone, the window ends and the grid end
-            y = ((left || k > ir) && k >= 1 && k <= kImxsig && slo + lane <= shi) ? y : 0.0;
-          acc_a[p] = fma(r.wabs, y, acc_a[p]);
-          acc_e[p] = fma(r.wemi, y, acc_e[p]);
+        for (int g = 0; g < NG; ++g) {
+          const int fg = (f >> (9 * g)) & 511;
+          if (fg == 0) continue;
+          const int glo = wlo + kGroup * g;
+          if (fg & 16) { // four whole slots in one wing: shared reciprocal
+            const int cls = classify(j1, il, ir, glo, min(glo + kGroup, g_hi) - 1);
+            wing_eval4(wing_x_at(r, cls, j1, glo), r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl, acc_a + 4 * g,
+                       acc_e + 4 * g);
+            continue;
+          }
+          const double xbl = wing_x_at(r, 1, j1, glo), xbr = wing_x_at(r, 2, j1, glo);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            if (!(fg & (33 << p))) continue;
+            const int slo = glo + 64 * p, shi = min(slo + 63, whi);
+            const int k = slo + lane - j1 + 1; // 1-based window index
+            const bool left = k < il; // region 1: k < il or k > ir (lineshape.f:461-477, last writer wins)
+            const double x = fma(fl[p], r.xstep, left ? xbl : xbr);
+            const double x2 = x * x;
+            double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
+            if (fg & (32 << p)) // mask the zone, the window ends and the grid end
+              y = ((left || k > ir) && k >= 1 && k <= kImxsig && slo + lane <= shi) ? y : 0.0;
+            acc_a[4 * g + p] = fma(r.wabs, y, acc_a[4 * g + p]);
+            acc_e[4 * g + p] = fma(r.wemi, y, acc_e[4 * g + p]);
+          }
         }
       }
     }
@@ -542,7 +556,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   // far field: one polynomial per level and slot
   const double *cl = fp.coef + (size_t)layer * fp.n_boxes_total * (2 * kFC);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NS; ++p) {
     const int slo = wlo + 64 * p;
     if (slo > whi) continue;
     for (int lv = 0; lv < fp.n_levels; ++lv) {
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   }
   const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NS; ++p) {
     const int j = wlo + lane + 64 * p;
     if (j <= whi) {
       abs_out[row + (j - g_lo)] = acc_a[p];
@@ -689,10 +703,11 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const int *i
   if (g_hi <= g_lo || n_layers <= 0) return 0;
   const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
   const dim3 grid((unsigned)(n_groups * n_layers));
-  if (part == 1)
-    hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel, grid, dim3(64), 0, st, fast, ic_sub, zmax, n_sub, n_groups,
+  if (part == 1) {
+    // one group per wave: two (NG = 2) need 109 VGPRs + SGPR spills and measured 7.2 ms vs 5.6 ms
+    hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<1>, grid, dim3(64), 0, st, fast, ic_sub, zmax, n_sub, n_groups,
                        g_lo, g_hi, fp, abs_out, emi_out);
-  else
+  } else
     hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel, grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub,
                        n_groups, g_lo, g_hi, gp, abs_out, emi_out);
   return (int)hipGetLastError();
