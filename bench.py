@@ -116,6 +116,7 @@ def main():
         lays += list(sl)
         cols += list(ln * 1e5 * nd[sl] * 0.0148 * syn.CH4_ISO_RATIO)
         offs.append(len(lays))
+    offs, lays, cols = np.array(offs, np.int32), np.array(lays, np.int32), np.array(cols, np.float64)
 
     ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)     # lines -> HBM (outside the timed region)
     g_lo, g_hi = sd.shard_bounds(args.grid, world, rank)
@@ -143,9 +144,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         spec = step()
-        kms += np.array(ls.last_kernel_ms())   # HIP events on the launch stream (syncs that step)
+        if world == 1:
+            kms += np.array(ls.last_kernel_ms())   # HIP events on the launch stream (syncs that step)
     barrier()
     elapsed = time.perf_counter() - t0
+    if world > 1:  # per-kernel times of this rank's shard, outside the timed region
+        for _ in range(args.steps):
+            step()
+            kms += np.array(ls.last_kernel_ms())
+        barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
@@ -197,12 +204,12 @@ def main():
                        "cu_count": info["cu_count"]},
             "roofline": {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": ("sr_farfield_kernel + sr_abscoeff_near_kernel<1> + <2>" if not args.exact else
+                         "kernel": ("sr_farfield_kernel + sr_abscoeff_near_wings_kernel + sr_abscoeff_near_zones_kernel" if not args.exact else
                                     "sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel") +
                                    " (the coefficient op; achieved = algorithmic flops / their summed time)",
                          "kernel_ms": main_ms,
                          "kernels_ms": dict(zip(["sr_prep_kernel"] + (
-                             ["sr_farfield_kernel", "sr_abscoeff_near_kernel<1>", "sr_abscoeff_near_kernel<2>"]
+                             ["sr_farfield_kernel", "sr_abscoeff_near_wings_kernel", "sr_abscoeff_near_zones_kernel"]
                              if not args.exact else ["sr_abscoeff_wings_kernel", "sr_abscoeff_cores_kernel", "-"]),
                              [float(v) for v in kms])),
                          "mode": "exact" if args.exact else "far-field",

@@ -354,3 +354,30 @@ def test_randomized_configs_far_vs_exact_vs_oracle(eng, oracle, seed):
     assert relerr(a0[nz], ref_a[nz]) < 1e-9 and relerr(e0[nz], ref_e[nz]) < 1e-9
     assert relerr(a1[nz], ref_a[nz]) < 1e-9 and relerr(e1[nz], ref_e[nz]) < 1e-9
     assert relerr(a1[nz], a0[nz]) < 2e-11 and relerr(e1[nz], e0[nz]) < 2e-11
+
+
+def test_maximum_grid_size(eng):
+    """imxsig_long = 2e6 grid points (spect_classes.py:29, 362): the largest grid the reference accepts.
+    Properties at that size: the two evaluation modes agree on a shard in the middle and at both ends,
+    grid points farther than a window from every line stay exactly zero, one more point is refused."""
+    from spectrobot_amd import synthetic as syn
+    from spectrobot_amd._lib import SpectRobotHipError, SR_ERR_LIMIT
+    n = 2000000
+    grid = syn.make_grid(2000.0, 5e-4, n)
+    L = syn.make_lines(3000, grid[:600000], seed=77, n_levels=0)   # lines only in the first 30 %
+    L["freq"][-1] = grid[-1] - 0.2                                  # and one near the far end
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM)
+    T, P = [140.0], [0.7]
+    for lo, hi in ((0, 30000), (590000, 625000), (n - 20000, n)):
+        eng.set_far_field(0)
+        a0, e0 = ls.abscoeff_layers(T, P, g_lo=lo, g_hi=hi)
+        eng.set_far_field(1)
+        a1, e1 = ls.abscoeff_layers(T, P, g_lo=lo, g_hi=hi)
+        nz = (a0 != 0)
+        assert bool(((a1 != 0) == nz).all())
+        assert float(((a1 - a0).abs()[nz] / a0[nz]).max()) < 2e-11
+    a, _ = ls.abscoeff_layers(T, P, g_lo=1000000, g_hi=1050000)   # > 6505 points from every line
+    assert float(a.abs().max()) == 0.0
+    with pytest.raises(SpectRobotHipError) as e:
+        eng.LineSet(L, syn.make_grid(2000.0, 5e-4, n + 1), 6, 1, syn.CH4_MM)
+    assert e.value.status == SR_ERR_LIMIT
