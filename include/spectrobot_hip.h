@@ -171,6 +171,17 @@ int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers,
                          const int32_t *seg_layer, const double *seg_col,
                          int init_from_rad, double *rad, void *stream);
 
+/* Radiances and their Jacobian with respect to n_par retrieval parameters on which the absorber
+ * columns depend linearly, col_s = sum_p dcol_dpar[s][p] * x_p (VMR profile parameters of the
+ * reference's RetParam / LinearProfile classes, spect_main_module.py:319-375; the reference's own
+ * derivative code lives in the absent spect_base_module, call site spect_main_module.py:2874, so this
+ * is the build's definition, parity unpinned, checked against finite differences).  Same recursion
+ * and layouts as sr_radiance_rays_dev; dcol_dpar: HOST [n_seg][n_par]; rad: DEVICE [n_rays][n_pts];
+ * jac: DEVICE [n_rays][n_par][n_pts] = d rad / d x_p. */
+int sr_radiance_jac_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, int n_rays,
+                        const int32_t *seg_off, const int32_t *seg_layer, const double *seg_col,
+                        const double *dcol_dpar, int n_par, double *rad, double *jac, void *stream);
+
 /* Instrument step that follows the path: what
  * SpectralIntensity.hires_to_lowres(lowres_obs, spectral_widths) does
  * (spect_classes.py:1180-1191) for a hi-res spectrum on the cm^-1 grid

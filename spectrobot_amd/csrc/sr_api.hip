@@ -574,6 +574,43 @@ int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers,
 }
 
 // ------------------------------------------------------------------------
+int sr_radiance_jac_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, int n_rays,
+                        const int32_t *seg_off, const int32_t *seg_layer, const double *seg_col,
+                        const double *dcol_dpar, int n_par, double *rad, double *jac, void *stream) {
+  if (!abs_c || !emi_c || !rad || !jac || !seg_off || !dcol_dpar || n_layers <= 0 || n_pts <= 0 || n_rays <= 0 ||
+      n_par <= 0)
+    return SR_ERR_ARG;
+  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  const int n_seg = seg_off[n_rays];
+  if (seg_off[0] != 0 || n_seg <= 0 || !seg_layer || !seg_col) return SR_ERR_ARG;
+  for (int r = 0; r < n_rays; ++r)
+    if (seg_off[r + 1] < seg_off[r]) return SR_ERR_ARG;
+  for (int s = 0; s < n_seg; ++s)
+    if (seg_layer[s] < 0 || seg_layer[s] >= n_layers) return SR_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static thread_local Stager s_seg;
+  const size_t b_off = sizeof(int) * (size_t)(n_rays + 1), b_lay = sizeof(int) * (size_t)n_seg;
+  const size_t o_lay = (b_off + 15) / 16 * 16, o_col = (o_lay + b_lay + 15) / 16 * 16;
+  const size_t o_d = o_col + sizeof(double) * (size_t)n_seg;
+  const size_t total = o_d + sizeof(double) * (size_t)n_seg * n_par;
+  int rc = s_seg.prepare(total);
+  if (rc) return rc;
+  char *h = s_seg.host<char>();
+  std::memcpy(h, seg_off, b_off);
+  std::memcpy(h + o_lay, seg_layer, b_lay);
+  std::memcpy(h + o_col, seg_col, sizeof(double) * (size_t)n_seg);
+  std::memcpy(h + o_d, dcol_dpar, sizeof(double) * (size_t)n_seg * n_par);
+  rc = s_seg.push(total, st);
+  if (rc) return rc;
+  char *base = s_seg.d.as<char>();
+  LAUNCHCHK(launch_radiance_jac(abs_c, emi_c, (int)n_pts, n_rays, reinterpret_cast<const int *>(base),
+                                reinterpret_cast<const int *>(base + o_lay),
+                                reinterpret_cast<const double *>(base + o_col),
+                                reinterpret_cast<const double *>(base + o_d), n_par, rad, jac, st));
+  return SR_OK;
+}
+
+// ------------------------------------------------------------------------
 int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double w0, double step,
                            const double *centers_nm, const double *widths_nm, int n_bands, double n_sigma,
                            int out_units, double *out_host, void *stream) {

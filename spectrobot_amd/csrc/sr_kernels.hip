@@ -772,6 +772,59 @@ __global__ __launch_bounds__(256) void sr_radiance_kernel(const double *__restri
   rad[(size_t)ray * n_pts + j] = I;
 }
 
+// Radiance and its derivatives with respect to NP retrieval parameters the absorber columns
+// depend on linearly (VMR profile parameters, spect_main_module.py:319-375: col_s = sum_p
+// dcol[s][p] * x_p).  Forward sensitivity of the same recursion:
+//   d/dcol [I e^-tau + emi col (1 - e^-tau)/tau] = e^-tau (emi - abs I)
+//   J_p <- J_p e^-tau + e^-tau (emi - abs I_prev) dcol[s][p];   I <- I e^-tau + src
+// Thread = (point, ray, chunk of NP parameters).
+template <int NP>
+__global__ __launch_bounds__(256) void sr_radiance_jac_kernel(const double *__restrict__ abs_c,
+                                                              const double *__restrict__ emi_c, int n_pts,
+                                                              int n_rays, const int *__restrict__ seg_off,
+                                                              const int *__restrict__ seg_layer,
+                                                              const double *__restrict__ seg_col,
+                                                              const double *__restrict__ dcol, int n_par,
+                                                              double *__restrict__ rad, double *__restrict__ jac) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ray = blockIdx.y, p0 = blockIdx.z * NP;
+  if (j >= n_pts) return;
+  double I = 0.0, J[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) J[q] = 0.0;
+  const int s0 = seg_off[ray], s1 = seg_off[ray + 1];
+  for (int s = s0; s < s1; ++s) {
+    const size_t o = (size_t)seg_layer[s] * n_pts + j;
+    const double u = seg_col[s], a = abs_c[o], e = emi_c[o];
+    const double tau = a * u;
+    const double t = exp(-tau);
+    const double em1 = -expm1(-tau);
+    const double src = fabs(tau) > 1e-12 ? (e * u) * (em1 / tau) : e * u;
+    const double g = t * (e - a * I);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const double d = (p0 + q < n_par) ? dcol[(size_t)s * n_par + p0 + q] : 0.0;
+      J[q] = fma(J[q], t, g * d);
+    }
+    I = I * t + src;
+  }
+  if (blockIdx.z == 0) rad[(size_t)ray * n_pts + j] = I;
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+    if (p0 + q < n_par) jac[((size_t)ray * n_par + p0 + q) * n_pts + j] = J[q];
+}
+
+int launch_radiance_jac(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
+                        const int *seg_layer, const double *seg_col, const double *dcol, int n_par, double *rad,
+                        double *jac, hipStream_t st) {
+  if (n_pts <= 0 || n_rays <= 0 || n_par <= 0) return 0;
+  constexpr int NP = 4;
+  dim3 grid((n_pts + 255) / 256, n_rays, (n_par + NP - 1) / NP);
+  hipLaunchKernelGGL(sr_radiance_jac_kernel<NP>, grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_rays, seg_off,
+                     seg_layer, seg_col, dcol, n_par, rad, jac);
+  return (int)hipGetLastError();
+}
+
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                     const int *seg_layer, const double *seg_col, int init_from_rad, double *rad,
                     hipStream_t st) {

@@ -51,6 +51,9 @@ int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                     const int *seg_layer, const double *seg_col, int init_from_rad, double *rad,
                     hipStream_t st);
+int launch_radiance_jac(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
+                        const int *seg_layer, const double *seg_col, const double *dcol, int n_par, double *rad,
+                        double *jac, hipStream_t st);
 int launch_humliv(const double *x, int i1, int i2, double x0, double lw, double dwp, double *y,
                   hipStream_t st);
 int launch_sum_lines(double *spe, long n_spe, const double *rows, const int *init, const int *fin,

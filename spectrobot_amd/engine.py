@@ -171,6 +171,27 @@ def radiance_rays(abs_c, emi_c, seg_off, seg_layer, seg_col, rad0=None):
     return rad
 
 
+def radiance_jacobian(abs_c, emi_c, seg_off, seg_layer, seg_col, dcol_dpar):
+    """Radiances [n_rays, n_pts] and d rad / d x_p [n_rays, n_par, n_pts] for parameters on which the
+    segment columns depend linearly: dcol_dpar[s, p] = d col_s / d x_p (sr_radiance_jac_dev)."""
+    assert abs_c.is_cuda and abs_c.dtype == torch.float64 and abs_c.is_contiguous()
+    assert emi_c.shape == abs_c.shape and emi_c.is_contiguous()
+    n_layers, n_pts = abs_c.shape
+    seg_off, op = _i(seg_off)
+    seg_layer, lp = _i(seg_layer)
+    seg_col, cp = _d(seg_col)
+    dcol, dpp = _d(dcol_dpar)
+    if dcol.ndim != 2 or dcol.shape[0] != seg_col.size:
+        raise ValueError("dcol_dpar must be [n_seg, n_par]")
+    n_rays, n_par = seg_off.size - 1, dcol.shape[1]
+    rad = torch.empty((n_rays, n_pts), dtype=torch.float64, device="cuda")
+    jac = torch.empty((n_rays, n_par, n_pts), dtype=torch.float64, device="cuda")
+    check(lib.sr_radiance_jac_dev(C.c_void_p(abs_c.data_ptr()), C.c_void_p(emi_c.data_ptr()), n_layers, n_pts,
+                                  n_rays, op, lp, cp, dpp, n_par, C.c_void_p(rad.data_ptr()),
+                                  C.c_void_p(jac.data_ptr()), _stream_ptr()), "sr_radiance_jac_dev")
+    return rad, jac
+
+
 def set_points_per_lane(p):
     check(lib.sr_set_points_per_lane(int(p)), "sr_set_points_per_lane")
 

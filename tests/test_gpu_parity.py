@@ -381,3 +381,41 @@ def test_maximum_grid_size(eng):
     with pytest.raises(SpectRobotHipError) as e:
         eng.LineSet(L, syn.make_grid(2000.0, 5e-4, n + 1), 6, 1, syn.CH4_MM)
     assert e.value.status == SR_ERR_LIMIT
+
+
+def test_radiance_jacobian_finite_differences(eng, oracle):
+    """Build's own definition (parity unpinned): the analytic Jacobian of the radiance recursion with
+    respect to parameters the columns depend on linearly, against central finite differences of the
+    oracle's recursion, and the radiance itself against sr_radiance_rays_dev."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(21)
+    n_lay, n_pts, n_par = 6, 300, 5
+    a = rng.uniform(0, 4e-18, (n_lay, n_pts))
+    e = rng.uniform(0, 1e-24, (n_lay, n_pts))
+    z = 100.0 + 10.0 * np.arange(n_lay)
+    offs, lays = [0], []
+    for zt in (100.0, 123.0):
+        sl, ln = syn.limb_path(z, zt)
+        lays += list(sl)
+        offs.append(len(lays))
+    n_seg = len(lays)
+    D = rng.uniform(0, 1, (n_seg, n_par)) * 2e16     # d col / d x
+    x = rng.uniform(0.5, 1.5, n_par)
+    col = D @ x
+    ad, ed = torch.tensor(a, device="cuda"), torch.tensor(e, device="cuda")
+    rad, jac = eng.radiance_jacobian(ad, ed, offs, lays, col, D)
+    rad0 = eng.radiance_rays(ad, ed, offs, lays, col)
+    assert relerr(rad.cpu().numpy(), rad0.cpu().numpy()) < 1e-14
+    jac = jac.cpu().numpy()
+    for r in range(2):
+        sel = slice(offs[r], offs[r + 1])
+        for p in range(n_par):
+            h = 1e-5 * x[p]
+            xp, xm = x.copy(), x.copy()
+            xp[p] += h
+            xm[p] -= h
+            fd = (oracle.radiance_ray(a, e, lays[sel], (D @ xp)[sel]) -
+                  oracle.radiance_ray(a, e, lays[sel], (D @ xm)[sel])) / (2 * h)
+            scale = np.max(np.abs(fd))
+            assert np.max(np.abs(jac[r, p] - fd)) < 2e-8 * scale
