@@ -586,19 +586,22 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   }
 }
 
+// WT points per wave (a multiple of 64): the wider the image, the fewer zones are cut in two by
+// its ends (a zone is ~280 points), i.e. the fewer partially filled lane runs.
+template <int WT>
 __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, const int *__restrict__ ic_sub,
     const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp,
     double *__restrict__ abs_out, double *__restrict__ emi_out) {
-  __shared__ double s_a[kGroup], s_e[kGroup];
+  __shared__ double s_a[WT], s_e[WT];
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_groups, grp = wg - layer * n_groups;
-  const int wlo = g_lo + grp * kGroup;
-  const int whi = min(wlo + kGroup, g_hi) - 1;
+  const int wlo = g_lo + grp * WT;
+  const int whi = min(wlo + WT, g_hi) - 1;
   const int lane = threadIdx.x;
   const int zm = min(zmax[layer], kHalf - 1);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) s_a[lane + 64 * p] = s_e[lane + 64 * p] = 0.;
+  for (int p = 0; p < WT / 64; ++p) s_a[lane + 64 * p] = s_e[lane + 64 * p] = 0.;
   // lines whose zone [ic - zm, ic + zm] can meet the group
   const int l0 = lower_bound_ic(ic_sub, n_sub, wlo - zm), l1 = lower_bound_ic(ic_sub, n_sub, whi + zm + 1);
   const FastRec *frow = fast + (size_t)layer * n_sub;
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
   }
   const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < WT / 64; ++p) {
     const int j = wlo + lane + 64 * p;
     if (j <= whi) {
       abs_out[row + (j - g_lo)] += s_a[lane + 64 * p];
@@ -707,9 +710,12 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const int *i
     // one group per wave: two (NG = 2) need 109 VGPRs + SGPR spills and measured 7.2 ms vs 5.6 ms
     hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<1>, grid, dim3(64), 0, st, fast, ic_sub, zmax, n_sub, n_groups,
                        g_lo, g_hi, fp, abs_out, emi_out);
-  } else
-    hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel, grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub,
-                       n_groups, g_lo, g_hi, gp, abs_out, emi_out);
+  } else {
+    constexpr int WT = 256; // 512 and 1024 measured equal / slower (LDS image limits occupancy)
+    const int n_t = (g_hi - g_lo + WT - 1) / WT;
+    hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel<WT>, dim3((unsigned)(n_t * n_layers)), dim3(64), 0, st, fast,
+                       cold, ic_sub, zmax, n_sub, n_t, g_lo, g_hi, gp, abs_out, emi_out);
+  }
   return (int)hipGetLastError();
 }
 
