@@ -3,12 +3,14 @@
 //   sr_prep_kernel      one thread per (line, layer): widths, G coefficients,
 //                       level-population weights, Humlicek region boundaries
 //                       -> FastRec / ColdRec tables in HBM.
-//   sr_abscoeff_wings_kernel / sr_abscoeff_cores_kernel
-//                       the coefficient spectra, gather formulation (see below):
-//                       no atomics, no [n_lines x 13010] matrix, coalesced fp64
-//                       stores.  fp64 VALU bound (no MFMA: not a contraction,
-//                       a reciprocal per evaluation).
-//   sr_radiance_kernel  limb recursion per (point, ray).
+//   coefficient spectra, gather formulation (no atomics, no [n_lines x 13010]
+//   matrix, coalesced fp64 stores; fp64 VALU bound, no MFMA: not a contraction):
+//     default  sr_farfield_kernel            far region-1 wings as per-box Taylor sums
+//              sr_abscoeff_near_wings_kernel  exact region 1 of the near lines + polynomials
+//              sr_abscoeff_near_zones_kernel  regions 2/3/4, lanes packed by region
+//     exact    sr_abscoeff_wings_kernel / sr_abscoeff_cores_kernel: every evaluation
+//   sr_radiance_kernel / sr_radiance_jac_kernel   limb recursion (+ Jacobian) per (point, ray)
+//   sr_lowres_kernel    Gaussian ILS onto low-resolution bands (hires_to_lowres)
 //   shims               humliv_bb / sum_all_lines / curgod_fort_N call shapes.
 #include "sr_device.hpp"
 #include "sr_kernels.hpp"
