@@ -56,9 +56,9 @@ int sr_device_info(char *name, int name_len, int *cu_count, double *hbm_gib);
  * ------------------------------------------------------------------------ */
 
 /* lineshape.humliv_bb(x, i1, i2, x0, lw, dw) -> y      (lineshape.f:226-569)
- * x[n], y[n]; i1,i2 1-based inclusive.  The reference only ever calls it with
- * x(i1) < x0 < x(i2); x0 outside the window returns
- * SR_ERR_UNSUPPORTED. */
+ * x[n], y[n]; i1,i2 1-based inclusive.  All three branches: x(i1) < x0 < x(i2)
+ * (the only one the reference's Python reaches) in parallel, the two
+ * with x0 at or beyond an end as the Fortran's sequential loops. */
 int sr_humliv_bb(const double *x, int n, int i1, int i2, double x0, double lw,
                  double dw, double *y);
 

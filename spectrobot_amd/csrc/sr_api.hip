@@ -647,14 +647,15 @@ int sr_humliv_bb(const double *x, int n, int i1, int i2, double x0, double lw, d
   if (!(dw > 0.0)) return SR_ERR_ARG;                  // lineshape.f:260-264
   if (i2 - i1 + 1 > 32767) return SR_ERR_LIMIT;        // window indices are 16-bit (imxsig = 13010)
   if (i2 - i1 < 1) return SR_ERR_ARG;
-  if (!(x[i1 - 1] < x0 && x0 < x[i2 - 1])) return SR_ERR_UNSUPPORTED; // outer branches, :272-442
+  const int outer = !(x[i1 - 1] < x0 && x0 < x[i2 - 1]); // lineshape.f:272, 358
   DevBuf dx, dy;
   int rc = dx.ensure(sizeof(double) * n);
   if (!rc) rc = dy.ensure(sizeof(double) * n);
   if (rc) { dx.release(); dy.release(); return rc; }
   hipError_t e = hipMemcpy(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(dy.p, 0, sizeof(double) * n);
-  if (e == hipSuccess) e = (hipError_t)launch_humliv(dx.as<double>(), i1, i2, x0, lw, dw, dy.as<double>(), nullptr);
+  if (e == hipSuccess)
+    e = (hipError_t)launch_humliv(dx.as<double>(), i1, i2, x0, lw, dw, dy.as<double>(), outer, nullptr);
   if (e == hipSuccess) e = hipMemcpy(y, dy.p, sizeof(double) * n, hipMemcpyDeviceToHost);
   dx.release();
   dy.release();

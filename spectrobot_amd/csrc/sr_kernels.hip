@@ -862,10 +862,78 @@ __global__ __launch_bounds__(256) void sr_humliv_kernel(const double *__restrict
     y[i1 - 1 + k - 1] = humliv_point(k, r, c, xf);
 }
 
-int launch_humliv(const double *x, int i1, int i2, double x0, double lw, double dwp, double *y,
+// lineshape.f:272-442: x0 at or beyond an end of x(i1..i2).  These two branches advance rx and the
+// region starts by running sums from the near end, so they are inherently sequential; no caller on
+// the hot path reaches them, one thread walks the Fortran's loops as written.
+__global__ void sr_humliv_outer_kernel(const double *__restrict__ x, int i1, int i2, double x0, double lw,
+                                       double dw, double *__restrict__ y) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+#define SR_X(k) x[(k)-1]
+#define SR_Y(k) y[(k)-1]
+  const double ry = lw / dw, xstep = (SR_X(i1 + 1) - SR_X(i1)) / dw, ryf = (double)(float)ry;
+  double q2[8], a1, b1, c1, d1;
+  region2_coef(ry, q2);
+  region1_coef(ry, a1, b1, c1, d1);
+  auto r1 = [&](double xr) { const double x2 = xr * xr; return (a1 + x2 * b1) / (c1 + x2 * (d1 + 4. * x2)); };
+  auto r2 = [&](double xr) {
+    const double x2 = xr * xr;
+    return (q2[0] + x2 * (q2[1] + x2 * (q2[2] + q2[3] * x2))) / (q2[4] + x2 * (q2[5] + x2 * (q2[6] + x2 * (q2[7] + x2))));
+  };
+  if (x0 <= SR_X(i1)) { // :272-357
+    int j = i1;
+    double rx = (SR_X(j) - x0) / dw;
+    while ((rx + ry < 5.5) && (j <= i2)) {
+      SR_Y(j) = core_point(rx, ry, ryf);
+      j = j + 1;
+      rx = rx + xstep;
+    }
+    if (j <= i2) {
+      int l = max((int)round((15.0 - ry - rx) / xstep), 0) + j;
+      l = min(l, i2);
+      if (l > j) {
+        double xrun = (SR_X(j) - x0) / dw;
+        for (int k = j; k <= l; ++k) { SR_Y(k) = r2(xrun); xrun = xrun + xstep; }
+        l = l + 1;
+      }
+      if (l < j) l = j;
+      if (l < i2) {
+        double xrun = (SR_X(l) - x0) / dw;
+        for (int k = l; k <= i2; ++k) { SR_Y(k) = r1(xrun); xrun = xrun + xstep; }
+      }
+    }
+  } else { // x0 >= x(i2), :358-442
+    int j = i2;
+    double rx = (x0 - SR_X(j)) / dw;
+    while ((rx + ry < 5.5) && (j >= i1)) {
+      SR_Y(j) = core_point(rx, ry, ryf);
+      j = j - 1;
+      rx = rx + xstep;
+    }
+    if (j >= i1) {
+      int l = j - max((int)round((15.0 - ry - rx) / dw / xstep), 0); // sic, :404
+      l = max(l, i1);
+      if (l == i2) l = i2 + 1;
+      if (l < j) {
+        double xrun = (x0 - SR_X(l)) / dw;
+        for (int k = l; k <= j; ++k) { SR_Y(k) = r2(xrun); xrun = xrun - xstep; }
+      }
+      if (l >= i1) {
+        double xrun = (x0 - SR_X(i1)) / dw;
+        for (int k = i1; k <= l - 1; ++k) { SR_Y(k) = r1(xrun); xrun = xrun - xstep; }
+      }
+    }
+  }
+#undef SR_X
+#undef SR_Y
+}
+
+int launch_humliv(const double *x, int i1, int i2, double x0, double lw, double dwp, double *y, int outer,
                   hipStream_t st) {
   const int n = i2 - i1 + 1;
-  hipLaunchKernelGGL(sr_humliv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, i1, n, x0, lw, dwp, y);
+  if (outer)
+    hipLaunchKernelGGL(sr_humliv_outer_kernel, dim3(1), dim3(64), 0, st, x, i1, i2, x0, lw, dwp, y);
+  else
+    hipLaunchKernelGGL(sr_humliv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, i1, n, x0, lw, dwp, y);
   return (int)hipGetLastError();
 }
 

@@ -54,7 +54,8 @@ int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_r
 int launch_radiance_jac(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                         const int *seg_layer, const double *seg_col, const double *dcol, int n_par, double *rad,
                         double *jac, hipStream_t st);
-int launch_humliv(const double *x, int i1, int i2, double x0, double lw, double dwp, double *y,
+// outer != 0: x0 at or beyond an end of x(i1..i2) (the sequential branches of humliv_bb)
+int launch_humliv(const double *x, int i1, int i2, double x0, double lw, double dwp, double *y, int outer,
                   hipStream_t st);
 int launch_sum_lines(double *spe, long n_spe, const double *rows, const int *init, const int *fin,
                      int n_lines, int row_len, hipStream_t st);

@@ -48,6 +48,13 @@ def test_humliv_shim_golden(eng, golden):
     # the Fortran advances x by repeated addition of xstep (lineshape.f:467,476); the
     # kernel evaluates x = x_start + m*xstep with one fma: ~1e-11 apart over 6500 steps
     assert worst < 2e-10, worst
+    # x0 at or beyond an end of the window: the Fortran's sequential branches, restated loop by loop
+    for p, y in zip(g["outer_par"], g["outer_y"]):
+        x = np.ascontiguousarray(g["outer_x"])
+        out = np.zeros_like(x)
+        check(lib.sr_humliv_bb(x.ctypes.data_as(dp), x.size, 1, x.size, p[0], p[1], p[2],
+                               out.ctypes.data_as(dp)), "sr_humliv_bb outer")
+        assert relerr(out, y) < 1e-13
 
 
 @pytest.mark.parametrize("ppl,far", [(8, 1), (8, 0), (4, 0)])

@@ -57,7 +57,6 @@ def test_argument_checks_return_before_any_launch(L):
     xp, yp = x.ctypes.data_as(dp), y.ctypes.data_as(dp)
     assert L.lib.sr_humliv_bb(xp, 13010, 5, 4, 0.5, 1e-3, 1e-3, yp) == L.SR_ERR_ARG      # i1 > i2 (Fortran stop)
     assert L.lib.sr_humliv_bb(xp, 13010, 1, 13010, 0.5, 1e-3, 0.0, yp) == L.SR_ERR_ARG   # dw <= 0 (Fortran stop)
-    assert L.lib.sr_humliv_bb(xp, 13010, 1, 13010, 2.0, 1e-3, 1e-3, yp) == L.SR_ERR_UNSUPPORTED
     assert L.lib.sr_curgod(5, xp, None, None, xp, None, 0, yp) == L.SR_ERR_ARG
     assert L.lib.sr_sum_all_lines(yp, 0, None, None, None, 0, 1) == L.SR_ERR_ARG
     init = np.array([0], np.int32)
