@@ -202,6 +202,10 @@ int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double 
  * line's own contribution), near field exact.  0: every (line, point) evaluated
  * exactly (sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel). */
 int sr_set_far_field(int on);
+/* Memory knob: the per-(line, layer) record tables (208 B each) of one launch are kept
+ * under this many bytes (default 48 GiB of the 288 GB); a longer layer stack (the reference
+ * allows imxstp = 8000 LOS steps) is processed in batches of layers. */
+int sr_set_table_budget(int64_t bytes);
 /* Tuning knob of the exact wings kernel: grid points per lane (4 or 8; default 8). */
 int sr_set_points_per_lane(int p);
 

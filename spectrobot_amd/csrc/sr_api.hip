@@ -151,6 +151,7 @@ double lagrange4(const double *tg, const double *qg, int n, double temp) {
 
 int g_variant = 8; // points per lane in the exact wings kernel
 int g_far_field = 1; // 1: far wings by local expansions (default), 0: every evaluation exact
+size_t g_table_budget = (size_t)48 << 30; // bytes of FastRec + ColdRec tables per layer batch
 
 } // namespace
 
@@ -209,6 +210,12 @@ int sr_device_info(char *name, int name_len, int *cu_count, double *hbm_gib) {
   if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
   if (cu_count) *cu_count = p.multiProcessorCount;
   if (hbm_gib) *hbm_gib = (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0);
+  return SR_OK;
+}
+
+int sr_set_table_budget(int64_t bytes) {
+  if (bytes < (int64_t)(sizeof(FastRec) + sizeof(ColdRec))) return SR_ERR_ARG;
+  g_table_budget = (size_t)bytes;
   return SR_OK;
 }
 
@@ -402,6 +409,35 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   const int nl = atm->n_layers, nlev = ls->n_levels, npop = nlev > 0 ? nlev : 1;
   for (int k = 0; k < nl; ++k)
     if (!(atm->temps[k] > 0.0) || !(atm->press[k] >= 0.0)) return SR_ERR_ARG;
+
+  // The per-(line, layer) record tables cost 208 B each; a long LOS (the reference allows
+  // imxstp = 8000 steps) is processed in layer batches that keep them under g_table_budget.
+  {
+    const size_t per_layer = (size_t)std::max<int64_t>(ls->n_lines, 1) * (sizeof(FastRec) + sizeof(ColdRec));
+    const int nl_max = (int)std::max<size_t>(1, g_table_budget / per_layer);
+    if (nl > nl_max) {
+      const size_t n_pts_all = (size_t)(g_hi - g_lo);
+      for (int k0 = 0; k0 < nl; k0 += nl_max) {
+        sr_layers_desc sub = *atm;
+        sub.n_layers = std::min(nl_max, nl - k0);
+        sub.temps = atm->temps + k0;
+        sub.press = atm->press + k0;
+        sub.q_part = atm->q_part ? atm->q_part + k0 : nullptr;
+        std::vector<double> tv;
+        if (atm->tvib) { // [n_levels][n_layers] -> the batch's columns
+          tv.resize((size_t)nlev * sub.n_layers);
+          for (int lv = 0; lv < nlev; ++lv)
+            std::copy(atm->tvib + (size_t)lv * nl + k0, atm->tvib + (size_t)lv * nl + k0 + sub.n_layers,
+                      tv.begin() + (size_t)lv * sub.n_layers);
+          sub.tvib = tv.data();
+        }
+        const int rc = sr_abscoeff_layers_dev(ls, &sub, g_lo, g_hi, abs_out + (size_t)k0 * n_pts_all,
+                                              emi_out + (size_t)k0 * n_pts_all, stream);
+        if (rc) return rc;
+      }
+      return SR_OK;
+    }
+  }
 
   // per-layer scalars (host, fp64)
   const size_t hl_doubles = (size_t)nl * (4 + npop);

@@ -220,3 +220,8 @@ def hires_to_lowres(rad, grid, centers_nm, widths_nm, out_units="Wm2", n_sigma=5
                                      centers_nm.size, float(n_sigma), _UNITS[out_units], out.ctypes.data_as(dp),
                                      _stream_ptr()), "sr_hires_to_lowres_dev")
     return out
+
+
+def set_table_budget(n_bytes):
+    """Bytes of per-(line, layer) record tables per launch; longer layer stacks run in batches."""
+    check(lib.sr_set_table_budget(int(n_bytes)), "sr_set_table_budget")
