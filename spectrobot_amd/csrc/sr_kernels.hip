@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
 // recurrence (power-series division of a quadratic by a quartic), the
 // coefficients of all such lines are summed per box (lanes = lines), and each
 // point evaluates ONE polynomial per level instead of one rational per line.
-// Truncation at degree kFD = 14 is <= 5e-13 of the line's own contribution
+// Truncation at degree kFD = 19 is <= 2e-13 of the line's own contribution
 // (worst case, nearest admissible line, box edge).  Boxes are nested (width
 // 64 << level); a (line, slot) pair is owned by the highest admissible level
 // (admissibility is monotone down the hierarchy) or, if none, by the exact
@@ -314,10 +314,43 @@ __device__ inline bool ff_admissible(int j1, int il, int ir, int blo, int bhi, i
 }
 __device__ inline int ff_thr2(int level, int pm) { return kTheta * (64 << level) + 2 * pm; }
 
+// Sum N per-lane values over the 64 lanes: at step M the pairs (i, i + N/2) are split
+// between the lanes with bit M clear / set, an unpaired last value takes a plain butterfly.
+// Afterwards v[0] of each lane is the total of value lane_reduce_index(lane) (several lanes
+// can hold the same one: `primary` picks one of them).
+template <int N, int M>
+__device__ inline void lane_reduce(double *v, int lane) {
+  if constexpr (M >= 1) {
+    constexpr int half = N / 2;
+    const bool up = (lane & M) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const double keep = up ? v[i + half] : v[i];
+      const double send = up ? v[i] : v[i + half];
+      v[i] = keep + __shfl_xor(send, M);
+    }
+    if constexpr (N & 1) v[half] = v[2 * half] + __shfl_xor(v[2 * half], M);
+    lane_reduce<half + (N & 1), M / 2>(v, lane);
+  }
+}
+template <int N, int M>
+__device__ inline int lane_reduce_index(int lane, bool &primary) {
+  if constexpr (M == 0) {
+    return 0;
+  } else {
+    constexpr int half = N / 2;
+    const int s = lane_reduce_index<half + (N & 1), M / 2>(lane, primary); // slot after this step
+    const bool up = (lane & M) != 0;
+    if (s < half) return s + (up ? half : 0);
+    if (up) primary = false;
+    return 2 * half;
+  }
+}
+
 __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restrict__ fast,
                                                          const int *__restrict__ ic_sub,
                                                          const int *__restrict__ zmax, int n_sub, int g_lo,
-                                                         int g_hi, FarParams fp) {
+                                                         int /*g_hi*/, FarParams fp) {
   // block -> (layer, level, box); the widest (longest-running) boxes first
   const int per_layer = fp.n_boxes_total;
   const int layer = blockIdx.x % fp.n_layers; // interleave layers: equal-cost blocks are neighbours
@@ -411,22 +444,21 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
       }
     }
   }
+  // Sum the 2*kFC coefficient sets over the lanes.  A butterfly per value would cost
+  // 6 exchanges each (480 ds_bpermute per box); exchanging HALF of the values at every
+  // step instead (the lanes with bit m set keep the upper half) needs 2*kFC - 1 in all
+  // and leaves one finished sum per lane.
+  double v[2 * kFC];
 #pragma unroll
   for (int n = 0; n < kFC; ++n) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      sa[n] += __shfl_xor(sa[n], m);
-      se[n] += __shfl_xor(se[n], m);
-    }
+    v[n] = sa[n];
+    v[kFC + n] = se[n];
   }
-  if (lane == 0) {
-    double *o = fp.coef + ((size_t)layer * fp.n_boxes_total + fp.box_off[level] + b) * (2 * kFC);
-#pragma unroll
-    for (int n = 0; n < kFC; ++n) {
-      o[n] = sa[n];
-      o[kFC + n] = se[n];
-    }
-  }
+  lane_reduce<2 * kFC, 32>(v, lane);
+  bool primary = true;
+  const int n_out = lane_reduce_index<2 * kFC, 32>(lane, primary);
+  if (primary)
+    fp.coef[((size_t)layer * fp.n_boxes_total + fp.box_off[level] + b) * (2 * kFC) + n_out] = v[0];
 }
 
 // Exact near field + evaluation of the far-field polynomials: one wave per group of
@@ -588,6 +620,57 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   }
 }
 
+// Region-3/4 points waiting for evaluation, one per lane.  The core runs of consecutive lines are
+// packed into full 64-lane chunks (a line's own runs would leave the last chunk of each partly
+// empty: 57 % lane use before); a chunk can hold points of several lines at the same grid index,
+// hence the LDS atomics (same wave, program order: the sums stay deterministic).
+struct CorePend {
+  int k, base; // window index; idx in the image = k + base
+  double gc, x0, dwp, inv_dwp, ryf, wa, we;
+};
+template <int REGION>
+__device__ inline void core_eval(const CorePend &P, bool on, const GridParams &gp, double *s_a, double *s_e) {
+  if (on) {
+    const WinX xf{gp.lin_start, gp.lin_delta, P.gc};
+    const double d = fabs(xf(P.k) - P.x0);
+    double rx = d * P.inv_dwp; // |x(k)-x0|/dw correctly rounded: one residual correction
+    rx = fma(fma(-P.dwp, rx, d), P.inv_dwp, rx);
+    const double b = (double)(float)(-rx);
+    const double y = REGION == 4 ? core_region4(P.ryf, b) : core_region3(P.ryf, b);
+    const int idx = P.k + P.base;
+    atomicAdd(&s_a[idx], P.wa * y);
+    atomicAdd(&s_e[idx], P.we * y);
+  }
+}
+// append the points [a0, a0+na) and [b0, b0+nb) of one line; fill is wave-uniform
+template <int REGION>
+__device__ inline void core_push(CorePend &P, int &fill, int lane, int a0, int na, int b0, int nb, int base,
+                                 double gc, const ColdRec &z, double wa, double we, const GridParams &gp,
+                                 double *s_a, double *s_e) {
+  const int n = na + nb;
+  for (int done = 0; done < n;) {
+    const int m = min(64 - fill, n - done);
+    const int t = done + lane - fill;
+    if (lane >= fill && lane < fill + m) {
+      P.k = t < na ? a0 + t : b0 + (t - na);
+      P.base = base;
+      P.gc = gc;
+      P.x0 = z.x0;
+      P.dwp = z.dwp;
+      P.inv_dwp = z.inv_dwp;
+      P.ryf = z.ryf;
+      P.wa = wa;
+      P.we = we;
+    }
+    fill += m;
+    done += m;
+    if (fill == 64) {
+      core_eval<REGION>(P, true, gp, s_a, s_e);
+      fill = 0;
+    }
+  }
+}
+
 // WT points per wave (a multiple of 64): the wider the image, the fewer zones are cut in two by
 // its ends (a zone is ~280 points), i.e. the fewer partially filled lane runs.
 template <int WT>
@@ -604,6 +687,12 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
   const int zm = min(zmax[layer], kHalf - 1);
 #pragma unroll
   for (int p = 0; p < WT / 64; ++p) s_a[lane + 64 * p] = s_e[lane + 64 * p] = 0.;
+  CorePend p4, p3;
+  p4.k = p3.k = 1;
+  p4.base = p3.base = 0;
+  p4.gc = p4.x0 = p4.dwp = p4.inv_dwp = p4.ryf = p4.wa = p4.we = 0.;
+  p3 = p4;
+  int fill4 = 0, fill3 = 0;
   // lines whose zone [ic - zm, ic + zm] can meet the group
   const int l0 = lower_bound_ic(ic_sub, n_sub, wlo - zm), l1 = lower_bound_ic(ic_sub, n_sub, whi + zm + 1);
   const FastRec *frow = fast + (size_t)layer * n_sub;
@@ -645,7 +734,8 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
           }
         }
       }
-      // ---- core (il2a, ir2a), lineshape.f:524-562: region 3 = [k3lo, k3hi], region 4 on both sides
+      // ---- core (il2a, ir2a), lineshape.f:524-562: region 3 = [k3lo, k3hi], region 4 on both sides.
+      // These points join the pending chunks (evaluated whenever 64 are waiting).
       {
         const int c_lo = max(((il2 == il) ? il - 1 : il2) + 1, k_lo), c_hi = min(((ir2 == ir) ? ir + 1 : ir2) - 1, k_hi);
         const int k3lo = z.k3lo(), k3hi = z.k3hi();
@@ -653,36 +743,18 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
         // region 4: [c_lo, k3lo-1] and [k3hi+1, c_hi] (the whole core if region 3 is empty)
         const int a0 = c_lo, a1 = has3 ? min(k3lo - 1, c_hi) : c_hi;
         const int b0 = has3 ? max(k3hi + 1, c_lo) : c_hi + 1, b1 = c_hi;
-        const int na = max(a1 - a0 + 1, 0), nb = max(b1 - b0 + 1, 0);
-        for (int t0 = 0; t0 < na + nb; t0 += 64) {
-          const int t = t0 + lane;
-          if (t < na + nb) {
-            const int k = t < na ? a0 + t : b0 + (t - na);
-            const double d = fabs(xf(k) - z.x0);
-            double rx = d * z.inv_dwp; // |x(k)-x0|/dw correctly rounded: one residual correction
-            rx = fma(fma(-z.dwp, rx, d), z.inv_dwp, rx);
-            const double y = core_region4(z.ryf, (double)(float)(-rx));
-            const int idx = k + j1 - 1 - wlo;
-            s_a[idx] = fma(wa, y, s_a[idx]);
-            s_e[idx] = fma(we, y, s_e[idx]);
-          }
-        }
-        const int e0 = max(k3lo, c_lo), e1 = min(k3hi, c_hi);
-        for (int t0 = 0; has3 && t0 <= e1 - e0; t0 += 64) {
-          const int k = e0 + t0 + lane;
-          if (k <= e1) {
-            const double d = fabs(xf(k) - z.x0);
-            double rx = d * z.inv_dwp;
-            rx = fma(fma(-z.dwp, rx, d), z.inv_dwp, rx);
-            const double y = core_region3(z.ryf, (double)(float)(-rx));
-            const int idx = k + j1 - 1 - wlo;
-            s_a[idx] = fma(wa, y, s_a[idx]);
-            s_e[idx] = fma(we, y, s_e[idx]);
-          }
+        const int base_idx = j1 - 1 - wlo;
+        core_push<4>(p4, fill4, lane, a0, max(a1 - a0 + 1, 0), b0, max(b1 - b0 + 1, 0), base_idx, xf.gc, z, wa, we, gp,
+                     s_a, s_e);
+        if (has3) {
+          const int e0 = max(k3lo, c_lo), e1 = min(k3hi, c_hi);
+          core_push<3>(p3, fill3, lane, e0, max(e1 - e0 + 1, 0), 0, 0, base_idx, xf.gc, z, wa, we, gp, s_a, s_e);
         }
       }
     }
   }
+  core_eval<4>(p4, lane < fill4, gp, s_a, s_e); // what is still waiting
+  core_eval<3>(p3, lane < fill3, gp, s_a, s_e);
   const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
 #pragma unroll
   for (int p = 0; p < WT / 64; ++p) {
@@ -759,7 +831,7 @@ int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sr_radiance_kernel(const double *__restrict__ abs_c,
                                                           const double *__restrict__ emi_c,
-                                                          int n_pts, int n_rays,
+                                                          int n_pts, int /*n_rays: gridDim.y*/,
                                                           const int *__restrict__ seg_off,
                                                           const int *__restrict__ seg_layer,
                                                           const double *__restrict__ seg_col,
@@ -789,7 +861,7 @@ __global__ __launch_bounds__(256) void sr_radiance_kernel(const double *__restri
 template <int NP>
 __global__ __launch_bounds__(256) void sr_radiance_jac_kernel(const double *__restrict__ abs_c,
                                                               const double *__restrict__ emi_c, int n_pts,
-                                                              int n_rays, const int *__restrict__ seg_off,
+                                                              int /*n_rays: gridDim.y*/, const int *__restrict__ seg_off,
                                                               const int *__restrict__ seg_layer,
                                                               const double *__restrict__ seg_col,
                                                               const double *__restrict__ dcol, int n_par,

@@ -24,8 +24,11 @@ struct LayersDev {
 
 // Far-field (local expansion) hierarchy over one shard: level l has boxes of
 // 64 << l points starting at g_lo.
-constexpr int kTheta = 8;      // admissible distance, in box half-widths
-constexpr int kFD = 14;        // expansion degree
+// (kTheta, kFD) = (5, 19) keeps the truncation bound (18 * 5^-20 = 2e-13 of a line's own
+// contribution) while shrinking the exactly evaluated near field: measured on config 2
+// (tools/sweep_farfield.sh) 18.2 ms with (8, 14), 17.5 (6, 17), 17.2 (5, 19), 17.6 (4, 22).
+constexpr int kTheta = 5;      // admissible distance, in box half-widths
+constexpr int kFD = 19;        // expansion degree
 constexpr int kFC = kFD + 1;   // coefficients per box and output
 constexpr int kMaxFarLevels = 5;
 struct FarParams {
