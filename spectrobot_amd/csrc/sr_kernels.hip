@@ -495,13 +495,14 @@ __device__ inline void near_ranges(const int *__restrict__ ic_sub, int n_sub, in
   rs[2] = max(b0, re[1]); re[2] = max(b1, rs[2]);
 }
 
-// NG groups of 256 points per wave (NG = 2 halves the scalar work per point but costs occupancy
-// and SGPR spills: measured slower, NG = 1 is launched).
-template <int NG>
+// One group of 256 points (4 slots) per wave (two groups per wave measured slower: occupancy, SGPR
+// spills).  The walk is per SLOT: a ballot per slot and kind, and a loop body without flag tests --
+// the shared scalar unit is what bounds this kernel (walking the lines once with per-slot flag
+// tests and a record prefetch cost 117 scalar instructions per line against 100 vector ones).
 __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
     const FastRec *__restrict__ fast, const int *__restrict__ ic_sub, const int *__restrict__ zmax, int n_sub,
     int n_tiles, int g_lo, int g_hi, FarParams fp, double *__restrict__ abs_out, double *__restrict__ emi_out) {
-  constexpr int NS = 4 * NG, WT = kGroup * NG;
+  constexpr int NS = 4, WT = kGroup;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
   const int wlo = g_lo + tile * WT;
@@ -521,68 +522,57 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   for (int rg = 0; rg < 3; ++rg) {
     for (int base = rs[rg]; base < re[rg]; base += 64) {
       const int lv = base + lane;
-      // per group g, at bit 9g: bits 0-3 slot lies wholly in one wing; bit 4 all four do, same
-      // wing; bits 5-8 slot has region-1 points but also zone points or a window end
+      // bits 0-3: slot lies wholly in one wing; bit 4: all four do, same wing; bits 5-8: slot has
+      // region-1 points but also zone points or a window end
       int flags = 0;
       if (lv < re[rg]) {
         const int j1 = frow[lv].j1;
         const unsigned ilir = frow[lv].ilir;
         const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          int fg = 0;
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            const int slo = wlo + kGroup * g + 64 * p, shi = min(slo + 63, whi);
-            if (slo <= whi && jN >= slo && j1 <= shi && !ff_admissible(j1, il, ir, slo, slo + 63, thr0)) {
-              if (classify(j1, il, ir, slo, shi) != 0) fg |= 1 << p;
-              else if (slo < j1 + il - 1 || shi > j1 + ir - 1) fg |= 32 << p; // some point outside the zone
-            }
+        for (int p = 0; p < 4; ++p) {
+          const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
+          if (slo <= whi && jN >= slo && j1 <= shi && !ff_admissible(j1, il, ir, slo, slo + 63, thr0)) {
+            if (classify(j1, il, ir, slo, shi) != 0) flags |= 1 << p;
+            else if (slo < j1 + il - 1 || shi > j1 + ir - 1) flags |= 32 << p; // some point outside the zone
           }
-          if (fg == 15 && classify(j1, il, ir, wlo + kGroup * g, min(wlo + kGroup * (g + 1), g_hi) - 1) != 0) fg |= 16;
-          flags |= fg << (9 * g);
         }
+        if (flags == 15 && classify(j1, il, ir, wlo, whi) != 0) flags = 16;
       }
-      unsigned long long todo = __ballot(flags != 0);
-      if (todo == 0) continue;
-      int cur = __builtin_ctzll(todo);
-      FastRec nxt = frow[base + cur];
-      while (todo) {
-        const int i = cur;
-        const FastRec r = nxt;
-        todo &= todo - 1;
-        if (todo) { // fetch the next record while this one is evaluated
-          cur = __builtin_ctzll(todo);
-          nxt = frow[base + cur];
+      if (__ballot(flags != 0) == 0) continue;
+      // four whole slots in one wing: shared reciprocal
+      for (unsigned long long todo = __ballot(flags == 16); todo; todo &= todo - 1) {
+        const FastRec r = frow[base + __builtin_ctzll(todo)];
+        const int cls = wlo < r.j1 + kHalf ? 1 : 2; // the group lies before / after the line centre
+        wing_eval4(wing_x_at(r, cls, r.j1, wlo), r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl, acc_a, acc_e);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int slo = wlo + 64 * p;
+        // whole slot in one wing
+        for (unsigned long long todo = __ballot((flags & (1 << p)) != 0); todo; todo &= todo - 1) {
+          const FastRec r = frow[base + __builtin_ctzll(todo)];
+          const double xb = wing_x_at(r, slo < r.j1 + kHalf ? 1 : 2, r.j1, slo);
+          const double x = fma(fl[0], r.xstep, xb);
+          const double x2 = x * x;
+          const double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
+          acc_a[p] = fma(r.wabs, y, acc_a[p]);
+          acc_e[p] = fma(r.wemi, y, acc_e[p]);
         }
-        const int f = __builtin_amdgcn_readlane(flags, i);
-        const int j1 = r.j1, il = r.il(), ir = r.ir();
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          const int fg = (f >> (9 * g)) & 511;
-          if (fg == 0) continue;
-          const int glo = wlo + kGroup * g;
-          if (fg & 16) { // four whole slots in one wing: shared reciprocal
-            const int cls = classify(j1, il, ir, glo, min(glo + kGroup, g_hi) - 1);
-            wing_eval4(wing_x_at(r, cls, j1, glo), r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl, acc_a + 4 * g,
-                       acc_e + 4 * g);
-            continue;
-          }
-          const double xbl = wing_x_at(r, 1, j1, glo), xbr = wing_x_at(r, 2, j1, glo);
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            if (!(fg & (33 << p))) continue;
-            const int slo = glo + 64 * p, shi = min(slo + 63, whi);
-            const int k = slo + lane - j1 + 1; // 1-based window index
-            const bool left = k < il; // region 1: k < il or k > ir (lineshape.f:461-477, last writer wins)
-            const double x = fma(fl[p], r.xstep, left ? xbl : xbr);
-            const double x2 = x * x;
-            double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
-            if (fg & (32 << p)) // mask the zone, the window ends and the grid end
-              y = ((left || k > ir) && k >= 1 && k <= kImxsig && slo + lane <= shi) ? y : 0.0;
-            acc_a[4 * g + p] = fma(r.wabs, y, acc_a[4 * g + p]);
-            acc_e[4 * g + p] = fma(r.wemi, y, acc_e[4 * g + p]);
-          }
+        // slot with zone points, a window end or the grid end: per-lane mask
+        for (unsigned long long todo = __ballot((flags & (32 << p)) != 0); todo; todo &= todo - 1) {
+          const FastRec r = frow[base + __builtin_ctzll(todo)];
+          const int j1 = r.j1, il = r.il(), ir = r.ir();
+          const int klo = max(1, wlo - j1 + 1), khi = min(kImxsig, whi - j1 + 1); // window and group, as k
+          const int k = slo + lane - j1 + 1;                                      // 1-based window index
+          const bool left = k < il; // region 1: k < il or k > ir (lineshape.f:461-477, last writer wins)
+          const double x = fma(fl[0], r.xstep, left ? wing_x_at(r, 1, j1, slo) : wing_x_at(r, 2, j1, slo));
+          const double x2 = x * x;
+          double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
+          const bool on = ((unsigned)(k - klo) <= (unsigned)(khi - klo)) & ((unsigned)(k - il) > (unsigned)(ir - il));
+          y = on ? y : 0.0;
+          acc_a[p] = fma(r.wabs, y, acc_a[p]);
+          acc_e[p] = fma(r.wemi, y, acc_e[p]);
         }
       }
     }
@@ -781,8 +771,7 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const int *i
   const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
   const dim3 grid((unsigned)(n_groups * n_layers));
   if (part == 1) {
-    // one group per wave: two (NG = 2) need 109 VGPRs + SGPR spills and measured 7.2 ms vs 5.6 ms
-    hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<1>, grid, dim3(64), 0, st, fast, ic_sub, zmax, n_sub, n_groups,
+    hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel, grid, dim3(64), 0, st, fast, ic_sub, zmax, n_sub, n_groups,
                        g_lo, g_hi, fp, abs_out, emi_out);
   } else {
     constexpr int WT = 256; // 512 and 1024 measured equal / slower (LDS image limits occupancy)
