@@ -166,7 +166,8 @@ struct sr_lineset {
   DevBuf d_lines;      // one allocation, carved below
   LinesDev L{};
   Stager s_layers;
-  DevBuf d_fast, d_cold, d_zmax, d_coef;
+  DevBuf d_fast, d_cold, d_zmax, d_coef, d_first;
+  int first_x0 = 0, first_n = 0; // IcIndex table domain
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int n_timed = 0; // kernels timed in the last call
   bool timed = false;
@@ -377,6 +378,21 @@ int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, cons
   L.air_broad = dd + 8 * md; L.t_dep = dd + 9 * md; L.evib_up = dd + 10 * md; L.evib_lo = dd + 11 * md;
   L.ic = di + 0 * md; L.lev_up = di + 1 * md; L.lev_lo = di + 2 * md;
   L.n_lines = (int)m;
+  { // direct index into the sorted centres (IcIndex)
+    const int x0 = m > 0 ? ls->ic.front() : 0, n_tab = m > 0 ? ls->ic.back() - x0 + 2 : 1;
+    std::vector<int> first((size_t)n_tab);
+    size_t q = 0;
+    for (int t = 0; t < n_tab; ++t) {
+      while (q < (size_t)m && ls->ic[q] < x0 + t) ++q;
+      first[(size_t)t] = (int)q;
+    }
+    rc = ls->d_first.ensure(sizeof(int) * (size_t)n_tab);
+    if (rc) { sr_lineset_destroy(ls); return rc; }
+    e = hipMemcpy(ls->d_first.p, first.data(), sizeof(int) * (size_t)n_tab, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { sr_lineset_destroy(ls); return hip_fail(e, "upload index"); }
+    ls->first_x0 = x0;
+    ls->first_n = n_tab;
+  }
   for (auto &ev : ls->ev) {
     e = hipEventCreate(&ev);
     if (e != hipSuccess) { sr_lineset_destroy(ls); return hip_fail(e, "hipEventCreate"); }
@@ -394,6 +410,7 @@ int sr_lineset_destroy(sr_lineset *ls) {
   ls->d_cold.release();
   ls->d_zmax.release();
   ls->d_coef.release();
+  ls->d_first.release();
   for (auto &ev : ls->ev)
     if (ev) (void)hipEventDestroy(ev);
   delete ls;
@@ -490,6 +507,8 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   const int n_sub = (int)(hi_it - lo_it);
   const size_t n_pts = (size_t)(g_hi - g_lo);
 
+  const IcIndex ix{ls->d_first.as<int>(), ls->first_x0, ls->first_n, line_lo, n_sub};
+
   ls->timed = false;
   if (n_sub <= 0) {
     HIPCHK(hipMemsetAsync(abs_out, 0, sizeof(double) * n_pts * nl, st));
@@ -524,11 +543,11 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     if (rc) return rc;
     fp.pm = d_pm;
     fp.coef = ls->d_coef.as<double>();
-    LAUNCHCHK(launch_farfield(ls->d_fast.as<FastRec>(), ls->L.ic + line_lo, ls->d_zmax.as<int>(), n_sub, nl,
+    LAUNCHCHK(launch_farfield(ls->d_fast.as<FastRec>(), ix, ls->d_zmax.as<int>(), n_sub, nl,
                               (int)g_lo, (int)g_hi, fp, st));
     HIPCHK(hipEventRecord(ls->ev[2], st));
     for (int part = 1; part <= 2; ++part) {
-      LAUNCHCHK(launch_near(part, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), ls->L.ic + line_lo,
+      LAUNCHCHK(launch_near(part, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), ix,
                             ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out,
                             st));
       HIPCHK(hipEventRecord(ls->ev[2 + part], st));
@@ -538,7 +557,7 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     ls->n_timed = 3;
     for (int which = 0; which < 2; ++which) {
       LAUNCHCHK(launch_abscoeff(g_variant, which, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(),
-                                ls->L.ic + line_lo, ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
+                                ix, ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
                                 abs_out, emi_out, st));
       HIPCHK(hipEventRecord(ls->ev[2 + which], st));
     }

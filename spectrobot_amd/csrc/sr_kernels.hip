@@ -102,13 +102,10 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
 // Both apply the same classify() to the same groups, so every (line, point) is
 // counted exactly once.
 // ------------------------------------------------------------------------
-__device__ inline int lower_bound_ic(const int *__restrict__ ic, int n, int v) {
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (ic[mid] < v) lo = mid + 1; else hi = mid;
-  }
-  return lo;
+// first line (index into the shard's record table) whose window centre is >= v
+__device__ inline int lower_bound_ic(const IcIndex &ix, int v) {
+  const int g = ix.first[min(max(v - ix.x0, 0), ix.n_tab - 1)];
+  return min(max(g - ix.line_lo, 0), ix.n_sub);
 }
 
 // XCD-aware bijective remap (8 XCDs, blocks dealt round-robin): blocks that
@@ -163,7 +160,7 @@ constexpr int kGroup = 256; // points per ownership group: 4 slots of 64 (one sh
 template <int P>
 __global__ __launch_bounds__(64) void sr_abscoeff_wings_kernel(
     const FastRec *__restrict__ fast,
-    const int *__restrict__ ic_sub, // [n_sub] window centres of the prepped lines, sorted
+    IcIndex ix, // index into the sorted window centres of the prepped lines
     int n_sub, int n_tiles, int g_lo, int g_hi, double *__restrict__ abs_out,
     double *__restrict__ emi_out) {
   static_assert(P % 4 == 0, "P must be a multiple of 4");
@@ -175,8 +172,8 @@ __global__ __launch_bounds__(64) void sr_abscoeff_wings_kernel(
   const int lane = threadIdx.x;
 
   // lines whose window [ic-6505, ic+6504] meets [wlo, whi]
-  const int l0 = lower_bound_ic(ic_sub, n_sub, wlo - (kHalf - 1));
-  const int l1 = lower_bound_ic(ic_sub, n_sub, whi + kHalf + 1);
+  const int l0 = lower_bound_ic(ix, wlo - (kHalf - 1));
+  const int l1 = lower_bound_ic(ix, whi + kHalf + 1);
 
   double acc_a[P], acc_e[P], fl[4];
 #pragma unroll
@@ -213,7 +210,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_wings_kernel(
 // One wave per group of 256 points: the (line, group) pairs the wings kernel skips.
 __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold,
-    const int *__restrict__ ic_sub, const int *__restrict__ zmax, // [n_layers] max zone half-width
+    IcIndex ix, const int *__restrict__ zmax, // [n_layers] max zone half-width
     int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp, double *__restrict__ abs_out,
     double *__restrict__ emi_out) {
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -227,12 +224,12 @@ __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
   //  C: window END inside the group      ic+6504 in [wlo, whi)
   //  A: region-2/3/4 zone may meet it    ic in [wlo-zm, whi+zm]
   //  B: window START inside the group    ic-6505 in (wlo, whi]
-  const int c0 = lower_bound_ic(ic_sub, n_sub, wlo - (kHalf - 1));
-  const int c1 = lower_bound_ic(ic_sub, n_sub, whi - (kHalf - 1));
-  const int a0 = lower_bound_ic(ic_sub, n_sub, wlo - zm);
-  const int a1 = lower_bound_ic(ic_sub, n_sub, whi + zm + 1);
-  const int b0 = lower_bound_ic(ic_sub, n_sub, wlo + kHalf + 1);
-  const int b1 = lower_bound_ic(ic_sub, n_sub, whi + kHalf + 1);
+  const int c0 = lower_bound_ic(ix, wlo - (kHalf - 1));
+  const int c1 = lower_bound_ic(ix, whi - (kHalf - 1));
+  const int a0 = lower_bound_ic(ix, wlo - zm);
+  const int a1 = lower_bound_ic(ix, whi + zm + 1);
+  const int b0 = lower_bound_ic(ix, wlo + kHalf + 1);
+  const int b1 = lower_bound_ic(ix, whi + kHalf + 1);
   int rs[3], re[3];
   rs[0] = c0; re[0] = max(c1, c0);
   rs[1] = max(a0, re[0]); re[1] = max(a1, rs[1]);
@@ -348,7 +345,7 @@ __device__ inline int lane_reduce_index(int lane, bool &primary) {
 }
 
 __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restrict__ fast,
-                                                         const int *__restrict__ ic_sub,
+                                                         IcIndex ix,
                                                          const int *__restrict__ zmax, int n_sub, int g_lo,
                                                          int /*g_hi*/, FarParams fp) {
   // block -> (layer, level, box); the widest (longest-running) boxes first
@@ -388,8 +385,8 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
   }
   int rs[4], re[4];
   for (int i = 0; i < nr; ++i) {
-    rs[i] = lower_bound_ic(ic_sub, n_sub, clo[i]);
-    re[i] = lower_bound_ic(ic_sub, n_sub, chi[i] + 1);
+    rs[i] = lower_bound_ic(ix, clo[i]);
+    re[i] = lower_bound_ic(ix, chi[i] + 1);
   }
   for (int i = 1; i < nr; ++i) // sort by start (4 elements)
     for (int k = i; k > 0 && rs[k] < rs[k - 1]; --k) {
@@ -476,7 +473,7 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
 //   consecutive lanes executing uniform code; the sums go through a 256-point LDS
 //   image of the group (one wave per block: read-modify-write is race-free).
 // ------------------------------------------------------------------------
-__device__ inline void near_ranges(const int *__restrict__ ic_sub, int n_sub, int wlo, int width, int zm,
+__device__ inline void near_ranges(const IcIndex &ix, int wlo, int width, int zm,
                                    int rs[3], int re[3]) {
   // candidates as ranges of the sorted centre list, C <= A <= B by start; NOMINAL tile end
   // (the far-field kernel tests nominal boxes, which may reach past g_hi):
@@ -484,12 +481,12 @@ __device__ inline void near_ranges(const int *__restrict__ ic_sub, int n_sub, in
   //  A: within zm of the tile           ic in [wlo-zm, whn+zm]
   //  B: window START inside the tile    ic-6505 in (wlo, whn]
   const int whn = wlo + width - 1;
-  const int c0 = lower_bound_ic(ic_sub, n_sub, wlo - (kHalf - 1));
-  const int c1 = lower_bound_ic(ic_sub, n_sub, whn - (kHalf - 1) + 1);
-  const int a0 = lower_bound_ic(ic_sub, n_sub, wlo - zm);
-  const int a1 = lower_bound_ic(ic_sub, n_sub, whn + zm + 1);
-  const int b0 = lower_bound_ic(ic_sub, n_sub, wlo + kHalf + 1);
-  const int b1 = lower_bound_ic(ic_sub, n_sub, whn + kHalf + 1);
+  const int c0 = lower_bound_ic(ix, wlo - (kHalf - 1));
+  const int c1 = lower_bound_ic(ix, whn - (kHalf - 1) + 1);
+  const int a0 = lower_bound_ic(ix, wlo - zm);
+  const int a1 = lower_bound_ic(ix, whn + zm + 1);
+  const int b0 = lower_bound_ic(ix, wlo + kHalf + 1);
+  const int b1 = lower_bound_ic(ix, whn + kHalf + 1);
   rs[0] = c0; re[0] = max(c1, c0);
   rs[1] = max(a0, re[0]); re[1] = max(a1, rs[1]);
   rs[2] = max(b0, re[1]); re[2] = max(b1, rs[2]);
@@ -500,7 +497,7 @@ __device__ inline void near_ranges(const int *__restrict__ ic_sub, int n_sub, in
 // the shared scalar unit is what bounds this kernel (walking the lines once with per-slot flag
 // tests and a record prefetch cost 117 scalar instructions per line against 100 vector ones).
 __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
-    const FastRec *__restrict__ fast, const int *__restrict__ ic_sub, const int *__restrict__ zmax, int n_sub,
+    const FastRec *__restrict__ fast, IcIndex ix, const int *__restrict__ zmax, int n_sub,
     int n_tiles, int g_lo, int g_hi, FarParams fp, double *__restrict__ abs_out, double *__restrict__ emi_out) {
   constexpr int NS = 4, WT = kGroup;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -511,7 +508,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   const int pm = fp.pm[layer];
   const int thr0 = ff_thr2(0, pm);
   int rs[3], re[3];
-  near_ranges(ic_sub, n_sub, wlo, WT, min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1), rs, re);
+  near_ranges(ix, wlo, WT, min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1), rs, re);
 
   double acc_a[NS], acc_e[NS], fl[4];
 #pragma unroll
@@ -665,7 +662,7 @@ __device__ inline void core_push(CorePend &P, int &fill, int lane, int a0, int n
 // its ends (a zone is ~280 points), i.e. the fewer partially filled lane runs.
 template <int WT>
 __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
-    const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, const int *__restrict__ ic_sub,
+    const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, IcIndex ix,
     const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp,
     double *__restrict__ abs_out, double *__restrict__ emi_out) {
   __shared__ double s_a[WT], s_e[WT];
@@ -684,7 +681,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
   p3 = p4;
   int fill4 = 0, fill3 = 0;
   // lines whose zone [ic - zm, ic + zm] can meet the group
-  const int l0 = lower_bound_ic(ic_sub, n_sub, wlo - zm), l1 = lower_bound_ic(ic_sub, n_sub, whi + zm + 1);
+  const int l0 = lower_bound_ic(ix, wlo - zm), l1 = lower_bound_ic(ix, whi + zm + 1);
   const FastRec *frow = fast + (size_t)layer * n_sub;
   const ColdRec *crow = cold + (size_t)layer * n_sub;
   for (int base = l0; base < l1; base += 64) {
@@ -756,28 +753,28 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
   }
 }
 
-int launch_farfield(const FastRec *fast, const int *ic_sub, const int *zmax, int n_sub, int n_layers, int g_lo,
+int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo,
                     int g_hi, const FarParams &fp, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
   hipLaunchKernelGGL(sr_farfield_kernel, dim3((unsigned)(fp.n_boxes_total * n_layers)), dim3(64), 0, st, fast,
-                     ic_sub, zmax, n_sub, g_lo, g_hi, fp);
+                     ix, zmax, n_sub, g_lo, g_hi, fp);
   return (int)hipGetLastError();
 }
 
-int launch_near(int part, const FastRec *fast, const ColdRec *cold, const int *ic_sub, const int *zmax, int n_sub,
+int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax, int n_sub,
                 int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp, double *abs_out,
                 double *emi_out, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
   const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
   const dim3 grid((unsigned)(n_groups * n_layers));
   if (part == 1) {
-    hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel, grid, dim3(64), 0, st, fast, ic_sub, zmax, n_sub, n_groups,
+    hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel, grid, dim3(64), 0, st, fast, ix, zmax, n_sub, n_groups,
                        g_lo, g_hi, fp, abs_out, emi_out);
   } else {
     constexpr int WT = 256; // 512 and 1024 measured equal / slower (LDS image limits occupancy)
     const int n_t = (g_hi - g_lo + WT - 1) / WT;
     hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel<WT>, dim3((unsigned)(n_t * n_layers)), dim3(64), 0, st, fast,
-                       cold, ic_sub, zmax, n_sub, n_t, g_lo, g_hi, gp, abs_out, emi_out);
+                       cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, abs_out, emi_out);
   }
   return (int)hipGetLastError();
 }
@@ -792,7 +789,7 @@ int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int
 
 int abscoeff_tile_points(int variant) { return 64 * (variant == 4 ? 4 : 8); }
 
-int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *cold, const int *ic_sub,
+int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *cold, const IcIndex &ix,
                     const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp,
                     double *abs_out, double *emi_out, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
@@ -801,15 +798,15 @@ int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *
     const int n_tiles = (g_hi - g_lo + tp - 1) / tp;
     dim3 grid((unsigned)(n_tiles * n_layers));
     if (variant == 4)
-      hipLaunchKernelGGL((sr_abscoeff_wings_kernel<4>), grid, dim3(64), 0, st, fast, ic_sub, n_sub, n_tiles,
+      hipLaunchKernelGGL((sr_abscoeff_wings_kernel<4>), grid, dim3(64), 0, st, fast, ix, n_sub, n_tiles,
                          g_lo, g_hi, abs_out, emi_out);
     else
-      hipLaunchKernelGGL((sr_abscoeff_wings_kernel<8>), grid, dim3(64), 0, st, fast, ic_sub, n_sub, n_tiles,
+      hipLaunchKernelGGL((sr_abscoeff_wings_kernel<8>), grid, dim3(64), 0, st, fast, ix, n_sub, n_tiles,
                          g_lo, g_hi, abs_out, emi_out);
   } else {
     const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
     dim3 grid((unsigned)(n_groups * n_layers));
-    hipLaunchKernelGGL(sr_abscoeff_cores_kernel, grid, dim3(64), 0, st, fast, cold, ic_sub, zmax, n_sub, n_groups,
+    hipLaunchKernelGGL(sr_abscoeff_cores_kernel, grid, dim3(64), 0, st, fast, cold, ix, zmax, n_sub, n_groups,
                        g_lo, g_hi, gp, abs_out, emi_out);
   }
   return (int)hipGetLastError();

@@ -22,6 +22,16 @@ struct LayersDev {
   double sqrt_ln2, sqrt_pi_ln2;
 };
 
+// Direct index into the sorted window-centre list: first[x - x0] = number of lines with
+// centre < x, for x in [x0, x0 + n_tab) (x0 = smallest centre, last entry = n_lines), so a
+// kernel finds a candidate range with ONE load instead of a 17-step dependent binary search
+// (which was most of a far-field box's lifetime).  line_lo / n_sub select the lines whose
+// window meets the shard: the kernels' record tables are indexed relative to line_lo.
+struct IcIndex {
+  const int *first;
+  int x0, n_tab, line_lo, n_sub;
+};
+
 // Far-field (local expansion) hierarchy over one shard: level l has boxes of
 // 64 << l points starting at g_lo.
 // (kTheta, kFD) = (5, 19) keeps the truncation bound (18 * 5^-20 = 2e-13 of a line's own
@@ -37,10 +47,10 @@ struct FarParams {
   const int *pm; // [n_layers] pole margin in grid points
   double *coef;  // [n_layers][n_boxes_total][2][kFC]
 };
-int launch_farfield(const FastRec *fast, const int *ic_sub, const int *zmax, int n_sub, int n_layers, int g_lo,
+int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo,
                     int g_hi, const FarParams &fp, hipStream_t st);
 // part 1: wing-only pairs + far-field polynomials (writes); part 2: general pairs (adds)
-int launch_near(int part, const FastRec *fast, const ColdRec *cold, const int *ic_sub, const int *zmax, int n_sub,
+int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax, int n_sub,
                 int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp, double *abs_out,
                 double *emi_out, hipStream_t st);
 
@@ -48,7 +58,7 @@ int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int
                 FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st);
 int abscoeff_tile_points(int variant);
 // which = 0: wings kernel (writes abs/emi), 1: cores kernel (adds into them)
-int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *cold, const int *ic_sub,
+int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *cold, const IcIndex &ix,
                     const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp,
                     double *abs_out, double *emi_out, hipStream_t st);
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
