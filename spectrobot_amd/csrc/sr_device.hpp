@@ -153,25 +153,68 @@ __device__ inline void real_poly_at(const double (&c)[N + 1], double zr, double 
   pi = zi * a;
 }
 
-// cos(t) for |t| <= ~1e3 (here |Im c1| = 2 ry rx < 10): two-constant Cody-Waite
+// a*b + c in the three-address form.  For a Horner chain whose coefficients live in
+// VGPRs across a loop the compiler emits the two-address v_fmac_f64 and a v_mov_b64 copy of
+// the coefficient per step (21 copies in the region-4 body); this keeps one instruction.
+__device__ inline double fma3(double a, double b, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// cos(t) for |t| <= ~1e3 (here |Im c1| = 2 ry rx < 10): three-constant Cody-Waite
 // reduction by pi/2 and the fdlibm kernel polynomials, ~1 ulp.
 __device__ inline double cos_bounded(double t) {
-  const double n = rint(t * 6.36619772367581382433e-01);      // 2/pi
-  double r = fma(-n, 1.57079632673412561417e+00, t);           // pi/2 hi (33 bits)
-  r = fma(-n, 6.07710050650619224932e-11, r);                  // pi/2 mid
-  r = fma(-n, 2.02226624879595063154e-21, r);                  // pi/2 lo
+  // |t| < 0.78 on every active lane (2 ry rx of a low-pressure layer): n = 0, r = t and the
+  // result is the cosine kernel -- bit for bit what the general path returns, without the
+  // reduction, the sine kernel and the quadrant selects.
+  const bool small = __all(fabs(t) < 0.78);
+  double n = 0., r = t;
+  if (!small) {
+    n = rint(t * 6.36619772367581382433e-01);            // 2/pi
+    r = fma(-n, 1.57079632673412561417e+00, t);           // pi/2 hi (33 bits)
+    r = fma(-n, 6.07710050650619224932e-11, r);           // pi/2 mid
+    r = fma(-n, 2.02226624879595063154e-21, r);           // pi/2 lo
+  }
   const double z = r * r;
-  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                                          -2.75573143513906633035e-07), 2.48015872894767294178e-05),
-                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  double pc = fma3(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma3(z, pc, -2.75573143513906633035e-07);
+  pc = fma3(z, pc, 2.48015872894767294178e-05);
+  pc = fma3(z, pc, -1.38888888888741095749e-03);
+  pc = fma3(z, pc, 4.16666666666666019037e-02);
   const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
-  const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                                      2.75573137070700676789e-06), -1.98412698298579493134e-04),
-                        8.33333333332248946124e-03);
-  const double sr = fma(r * z, fma(z, ps, -1.66666666666666324348e-01), r);
+  if (small) return cr;
+  double ps = fma3(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma3(z, ps, 2.75573137070700676789e-06);
+  ps = fma3(z, ps, -1.98412698298579493134e-04);
+  ps = fma3(z, ps, 8.33333333332248946124e-03);
+  ps = fma3(z, ps, -1.66666666666666324348e-01);
+  const double sr = fma(r * z, ps, r);
   const int q = (int)n & 3;
   const double v = (q & 1) ? sr : cr;          // cos(r + q pi/2): c, -s, -c, s
   return (q == 1 || q == 2) ? -v : v;
+}
+
+// exp(u) for -700 < u < 700 without the special-case handling of the library routine (here
+// u = Re c1 in [-30.3, 0.1]): u = n ln2 + r, degree-11 minimax polynomial (the coefficients
+// of ROCm device-libs' double-precision exp), 2^n by ldexp; <= 1 ulp (checked on the host
+// against exact rational arithmetic, max 1.5e-16).
+__device__ inline double exp_bounded(double u) {
+  const double n = rint(u * 0x1.71547652b82fep+0);  // log2(e)
+  double r = fma(-n, 0x1.62e42fefa39efp-1, u);      // ln2 hi
+  r = fma(-n, 0x1.abc9e3b39803fp-56, r);            // ln2 lo
+  double p = fma3(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+  p = fma3(r, p, 0x1.71dee623fde64p-19);
+  p = fma3(r, p, 0x1.a01997c89e6b0p-16);
+  p = fma3(r, p, 0x1.a01a014761f6ep-13);
+  p = fma3(r, p, 0x1.6c16c1852b7b0p-10);
+  p = fma3(r, p, 0x1.1111111122322p-7);
+  p = fma3(r, p, 0x1.55555555502a1p-5);
+  p = fma3(r, p, 0x1.5555555555511p-3);
+  p = fma3(r, p, 0x1.000000000000bp-1);
+  p = fma(r, p, 1.0);
+  p = fma(r, p, 1.0);
+  return ldexp(p, (int)n);
 }
 
 // Regions 3 and 4 at c2 = (a, b) = ((double)(float)ry, (double)(float)(-rx)): cmplx() is
@@ -186,8 +229,8 @@ __device__ inline double core_region4(double a, double b) { // :530-546
   real_poly_at<6>(P4, ur, ui, pr, pi);
   real_poly_at<7>(Q4, ur, ui, qr, qi);
   const double nr = fma(a, pr, -(b * pi)), ni = fma(a, pi, b * pr); // c2 * P
-  const double ratio = fma(nr, qr, ni * qi) * fast_rcp<2>(fma(qr, qr, qi * qi));
-  return exp(ur) * cos_bounded(ui) - ratio;
+  const double ratio = fma(nr, qr, ni * qi) * fast_rcp<1>(fma(qr, qr, qi * qi));
+  return exp_bounded(ur) * cos_bounded(ui) - ratio;
 }
 __device__ inline double core_region3(double a, double b) { // :554-560
   const double N3[5] = {SR_F32(16.4955), SR_F32(20.20933), SR_F32(11.96482), SR_F32(3.778987),
@@ -197,7 +240,7 @@ __device__ inline double core_region3(double a, double b) { // :554-560
   double pr, pi, qr, qi;
   real_poly_at<4>(N3, a, b, pr, pi);
   real_poly_at<5>(D3, a, b, qr, qi);
-  return fma(pr, qr, pi * qi) * fast_rcp<2>(fma(qr, qr, qi * qi));
+  return fma(pr, qr, pi * qi) * fast_rcp<1>(fma(qr, qr, qi * qi));
 }
 // the reference's region test, :528-530
 __device__ inline bool core_is_region4(double rx, double ry) { return ry < (0.195 * rx) - 0.176; }
