@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--rays", type=int, default=1)
     ap.add_argument("--ppl", type=int, default=8, help="grid points per lane in the coefficient kernels")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--shard", default="", help="R/W: time only the spectral shard of rank R of W on this GPU "
+                    "(tuning aid for the multi-GPU shard size; not a bench line of the metric)")
     ap.add_argument("--exact", action="store_true", help="evaluate every (line, point) exactly (no far-field expansions)")
     args = ap.parse_args()
 
@@ -120,6 +122,9 @@ def main():
 
     ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)     # lines -> HBM (outside the timed region)
     g_lo, g_hi = sd.shard_bounds(args.grid, world, rank)
+    if args.shard:
+        assert world == 1
+        g_lo, g_hi = sd.shard_bounds(args.grid, int(args.shard.split("/")[1]), int(args.shard.split("/")[0]))
     npts = g_hi - g_lo
     ab = torch.empty((args.layers, npts), dtype=torch.float64, device="cuda")
     em = torch.empty_like(ab)
@@ -129,6 +134,8 @@ def main():
         ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"], q_part=q_part, g_lo=g_lo, g_hi=g_hi,
                            out=(ab, em))
         rad = engine.radiance_rays(ab, em, offs, lays, cols)
+        if args.shard:
+            return rad
         return sd.all_gather_spectrum(rad, args.grid, world, rank, out=full)
 
     def barrier():
@@ -199,7 +206,8 @@ def main():
             "config": {"workload": "CH4 Titan limb (BASELINE configs[1]): %d lines x %d-pt grid x %d layers, "
                                    "%d ray(s), 12 non-LTE levels" % (args.lines, args.grid, args.layers, args.rays),
                        "n_lines": args.lines, "n_grid": args.grid, "n_layers": args.layers, "n_rays": args.rays,
-                       "sharding": "spectral window / %d, one RCCL all-gather" % world if world > 1 else "none",
+                       "sharding": ("spectral window / %d, one RCCL all-gather" % world if world > 1 else
+                                    ("ONLY shard %s timed (tuning aid)" % args.shard if args.shard else "none")),
                        "mode": "exact" if args.exact else "far-field", "device": info["name"],
                        "cu_count": info["cu_count"]},
             "roofline": {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

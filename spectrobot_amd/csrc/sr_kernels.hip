@@ -348,16 +348,17 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
                                                          IcIndex ix,
                                                          const int *__restrict__ zmax, int n_sub, int g_lo,
                                                          int /*g_hi*/, FarParams fp) {
-  // block -> (layer, level, box); the widest (longest-running) boxes first
-  const int per_layer = fp.n_boxes_total;
-  const int layer = blockIdx.x % fp.n_layers; // interleave layers: equal-cost blocks are neighbours
-  int idx = blockIdx.x / fp.n_layers;
+  // block -> (layer, level, box).  Layer-major, each XCD working through its own run of
+  // layers (xcd_remap): the blocks resident on an XCD then share one stretch of one layer's
+  // record row, which its L2 holds; within a layer the widest (longest-running) boxes first.
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int layer = wid / fp.n_boxes_total;
+  int idx = wid - layer * fp.n_boxes_total;
   int level = fp.n_levels - 1;
   while (level > 0 && idx >= fp.box_count[level]) {
     idx -= fp.box_count[level];
     --level;
   }
-  (void)per_layer;
   const int b = idx;
   const int lane = threadIdx.x;
   const int W = 64 << level, h = W >> 1;
@@ -400,9 +401,9 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
     done = re[i];
   }
 
-  double sa[kFC], se[kFC];
+  double v[2 * kFC]; // [0, kFC): abs coefficients, [kFC, 2 kFC): emi
 #pragma unroll
-  for (int n = 0; n < kFC; ++n) sa[n] = se[n] = 0.;
+  for (int n = 0; n < 2 * kFC; ++n) v[n] = 0.;
   const FastRec *frow = fast + (size_t)layer * n_sub;
   const double hw = (double)h;
   for (int i = 0; i < nr; ++i) {
@@ -426,18 +427,21 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
       const double d3 = 8. * u1 * u2, d4 = 4. * u2 * u2;
       const double r0 = fast_rcp<2>(d0);
       const double D1 = d1 * r0, D2 = d2 * r0, D3 = d3 * r0, D4 = d4 * r0;
-      double f[kFC];
-      f[0] = n0 * r0;
-      f[1] = fma(-D1, f[0], n1 * r0);
-      f[2] = fma(-D1, f[1], fma(-D2, f[0], n2 * r0));
-      f[3] = -fma(D1, f[2], fma(D2, f[1], D3 * f[0]));
+      // series coefficients f_n, accumulated as they are produced (a window of four is live)
+      double f0 = n0 * r0;
+      double f1 = fma(-D1, f0, n1 * r0);
+      double f2 = fma(-D1, f1, fma(-D2, f0, n2 * r0));
+      double f3 = -fma(D1, f2, fma(D2, f1, D3 * f0));
+      v[0] = fma(r.wabs, f0, v[0]); v[kFC + 0] = fma(r.wemi, f0, v[kFC + 0]);
+      v[1] = fma(r.wabs, f1, v[1]); v[kFC + 1] = fma(r.wemi, f1, v[kFC + 1]);
+      v[2] = fma(r.wabs, f2, v[2]); v[kFC + 2] = fma(r.wemi, f2, v[kFC + 2]);
+      v[3] = fma(r.wabs, f3, v[3]); v[kFC + 3] = fma(r.wemi, f3, v[kFC + 3]);
 #pragma unroll
-      for (int n = 4; n < kFC; ++n)
-        f[n] = -fma(D1, f[n - 1], fma(D2, f[n - 2], fma(D3, f[n - 3], D4 * f[n - 4])));
-#pragma unroll
-      for (int n = 0; n < kFC; ++n) {
-        sa[n] = fma(r.wabs, f[n], sa[n]);
-        se[n] = fma(r.wemi, f[n], se[n]);
+      for (int n = 4; n < kFC; ++n) {
+        const double fn = -fma(D1, f3, fma(D2, f2, fma(D3, f1, D4 * f0)));
+        v[n] = fma(r.wabs, fn, v[n]);
+        v[kFC + n] = fma(r.wemi, fn, v[kFC + n]);
+        f0 = f1; f1 = f2; f2 = f3; f3 = fn;
       }
     }
   }
@@ -445,12 +449,6 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
   // 6 exchanges each (480 ds_bpermute per box); exchanging HALF of the values at every
   // step instead (the lanes with bit m set keep the upper half) needs 2*kFC - 1 in all
   // and leaves one finished sum per lane.
-  double v[2 * kFC];
-#pragma unroll
-  for (int n = 0; n < kFC; ++n) {
-    v[n] = sa[n];
-    v[kFC + n] = se[n];
-  }
   lane_reduce<2 * kFC, 32>(v, lane);
   bool primary = true;
   const int n_out = lane_reduce_index<2 * kFC, 32>(lane, primary);
@@ -771,10 +769,19 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcInde
     hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel, grid, dim3(64), 0, st, fast, ix, zmax, n_sub, n_groups,
                        g_lo, g_hi, fp, abs_out, emi_out);
   } else {
-    constexpr int WT = 256; // 512 and 1024 measured equal / slower (LDS image limits occupancy)
-    const int n_t = (g_hi - g_lo + WT - 1) / WT;
-    hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel<WT>, dim3((unsigned)(n_t * n_layers)), dim3(64), 0, st, fast,
-                       cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, abs_out, emi_out);
+    // Image width: wider images cut fewer zones in two (fewer (line, group) pairs: 7.1 -> 6.7 ms on
+    // 1e5 points x 80 layers with 512 instead of 256) as long as the waves still fill the chip
+    // several times over (1024: 9.3 ms, too few waves and 16 KB LDS each).
+    const long waves512 = (long)((g_hi - g_lo + 511) / 512) * n_layers;
+    if (waves512 >= 3 * 4096) {
+      const int n_t = (g_hi - g_lo + 511) / 512;
+      hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel<512>, dim3((unsigned)(n_t * n_layers)), dim3(64), 0, st, fast,
+                         cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, abs_out, emi_out);
+    } else {
+      const int n_t = (g_hi - g_lo + 255) / 256;
+      hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel<256>, dim3((unsigned)(n_t * n_layers)), dim3(64), 0, st, fast,
+                         cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, abs_out, emi_out);
+    }
   }
   return (int)hipGetLastError();
 }
