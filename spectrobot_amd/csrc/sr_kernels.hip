@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
 // recurrence (power-series division of a quadratic by a quartic), the
 // coefficients of all such lines are summed per box (lanes = lines), and each
 // point evaluates ONE polynomial per level instead of one rational per line.
-// Truncation at degree kFD = 19 is <= 2e-13 of the line's own contribution
+// Truncation at degree kFD = 22 (kTheta = 4) is <= 2.6e-13 of the line's own contribution
 // (worst case, nearest admissible line, box edge).  Boxes are nested (width
 // 64 << level); a (line, slot) pair is owned by the highest admissible level
 // (admissibility is monotone down the hierarchy) or, if none, by the exact

@@ -34,11 +34,14 @@ struct IcIndex {
 
 // Far-field (local expansion) hierarchy over one shard: level l has boxes of
 // 64 << l points starting at g_lo.
-// (kTheta, kFD) = (5, 19) keeps the truncation bound (18 * 5^-20 = 2e-13 of a line's own
-// contribution) while shrinking the exactly evaluated near field: measured on config 2
-// (tools/sweep_farfield.sh) 18.2 ms with (8, 14), 17.5 (6, 17), 17.2 (5, 19), 17.6 (4, 22).
-constexpr int kTheta = 5;      // admissible distance, in box half-widths
-constexpr int kFD = 19;        // expansion degree
+// (kTheta, kFD): the truncation bound is 18 * kTheta^-(kFD+1) of a line's own contribution;
+// a smaller kTheta shrinks the exactly evaluated near field, a larger kFD costs far-field
+// time and registers.  Config 2, sum of the coefficient kernels (tools/sweep_farfield.sh):
+// (8,14) 18.2 ms and (5,19) 17.2 ms with the first far-field kernel; with the streamed
+// recurrence (6,17) 13.8, (5,19) 13.4, (4,22) 12.8, (4,24) 13.2, (3,28) 13.2.
+// (4, 22): bound 2.6e-13.
+constexpr int kTheta = 4;      // admissible distance, in box half-widths
+constexpr int kFD = 22;        // expansion degree
 constexpr int kFC = kFD + 1;   // coefficients per box and output
 constexpr int kMaxFarLevels = 5;
 struct FarParams {
