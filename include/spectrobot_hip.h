@@ -198,7 +198,7 @@ int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double 
                            int out_units, double *out_host, void *stream);
 
 /* Evaluation mode of the coefficient op.  1 (default): far region-1 wings by
- * local Taylor expansions per box of grid points (truncation <= 5e-13 of a
+ * local Taylor expansions per box of grid points (truncation <= 2.6e-13 of a
  * line's own contribution), near field exact.  0: every (line, point) evaluated
  * exactly (sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel). */
 int sr_set_far_field(int on);
