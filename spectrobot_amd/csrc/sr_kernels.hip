@@ -26,9 +26,17 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
                                                       FastRec *__restrict__ fast,
                                                       ColdRec *__restrict__ cold,
                                                       int *__restrict__ zmax) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // records leave through LDS: a lane's 80 / 128 B record is written in 16-byte pieces at a
+  // 80 / 128 B stride across the lanes, which the memory side handles badly (1.8 TB/s); the
+  // wave's 64 records are contiguous in the table, so they are transposed and stored 1 KB per
+  // instruction instead.
+  __shared__ uint4 s_rec[4][64 * sizeof(ColdRec) / 16];
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
-  if (i >= n_sub) return;
+  const int wave_first = i0 - (threadIdx.x & 63);
+  if (wave_first >= n_sub) return; // whole wave out of range
+  const bool valid = i0 < n_sub;
+  const int i = valid ? i0 : n_sub - 1;
   const int ln = line_lo + i;
   const double T = A.temps[k];
   const double x0 = L.freq[ln];
@@ -72,12 +80,34 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
   r.j1 = ic - kHalf;
   r.ilir = (uint32_t)B.il | ((uint32_t)B.ir << 16);
   const ColdRec c = make_cold(B, dwp, x0, xf);
-  const size_t o = (size_t)k * n_sub + i;
-  fast[o] = r;
-  cold[o] = c;
+  {
+    const int lane = threadIdx.x & 63, n_valid = min(64, n_sub - wave_first);
+    uint4 *buf = s_rec[threadIdx.x >> 6];
+    const size_t o = (size_t)k * n_sub + wave_first;
+    constexpr int NF = sizeof(FastRec) / 16, NC = sizeof(ColdRec) / 16;
+    const uint4 *rp = reinterpret_cast<const uint4 *>(&r);
+#pragma unroll
+    for (int q = 0; q < NF; ++q) buf[lane * NF + q] = rp[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint4 *gf = reinterpret_cast<uint4 *>(fast + o);
+#pragma unroll
+    for (int q = 0; q < NF; ++q)
+      if (q * 64 + lane < n_valid * NF) gf[q * 64 + lane] = buf[q * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    const uint4 *cp = reinterpret_cast<const uint4 *>(&c);
+#pragma unroll
+    for (int q = 0; q < NC; ++q) buf[lane * NC + q] = cp[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint4 *gc = reinterpret_cast<uint4 *>(cold + o);
+#pragma unroll
+    for (int q = 0; q < NC; ++q)
+      if (q * 64 + lane < n_valid * NC) gc[q * 64 + lane] = buf[q * 64 + lane];
+  }
   // widest region-2/3/4 zone of the layer, in grid points from the window centre
   // (k = 6506): tells sr_abscoeff_cores_kernel how far to look for candidates
-  int hw = max(kHalf + 1 - B.il, B.ir - (kHalf + 1));
+  int hw = valid ? max(kHalf + 1 - B.il, B.ir - (kHalf + 1)) : 0;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) hw = max(hw, __shfl_xor(hw, m));
   if ((threadIdx.x & 63) == 0) atomicMax(&zmax[k], hw);
