@@ -162,6 +162,14 @@ __device__ inline double fma3(double a, double b, double c) {
   return r;
 }
 
+// The same with the addend in an SGPR pair (wave-uniform coefficient fetched by a scalar load):
+// otherwise two v_mov_b32 + v_fmac_f64 per Horner step.
+__device__ inline double fma3s(double a, double b, double c_uniform) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+  return r;
+}
+
 // cos(t) for |t| <= ~1e3 (here |Im c1| = 2 ry rx < 10): three-constant Cody-Waite
 // reduction by pi/2 and the fdlibm kernel polynomials, ~1 ulp.
 __device__ inline double cos_bounded(double t) {

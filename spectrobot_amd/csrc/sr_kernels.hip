@@ -543,6 +543,9 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   for (int p = 0; p < NS; ++p) acc_a[p] = acc_e[p] = 0.;
 #pragma unroll
   for (int p = 0; p < 4; ++p) fl[p] = (double)(lane + 64 * p);
+  int lp[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) lp[p] = lane + 64 * p;
   const FastRec *frow = fast + (size_t)layer * n_sub;
   for (int rg = 0; rg < 3; ++rg) {
     for (int base = rs[rg]; base < re[rg]; base += 64) {
@@ -584,16 +587,17 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
           acc_a[p] = fma(r.wabs, y, acc_a[p]);
           acc_e[p] = fma(r.wemi, y, acc_e[p]);
         }
-        // slot with zone points, a window end or the grid end: per-lane mask
+        // slot with zone points, a window end or the grid end: per-lane mask (branch-free body)
         for (unsigned long long todo = __ballot((flags & (32 << p)) != 0); todo; todo &= todo - 1) {
           const FastRec r = frow[base + __builtin_ctzll(todo)];
           const int j1 = r.j1, il = r.il(), ir = r.ir();
           const int klo = max(1, wlo - j1 + 1), khi = min(kImxsig, whi - j1 + 1); // window and group, as k
-          const int k = slo + lane - j1 + 1;                                      // 1-based window index
+          const int k = lp[p] + (wlo - j1 + 1);                                   // 1-based window index
           const bool left = k < il; // region 1: k < il or k > ir (lineshape.f:461-477, last writer wins)
-          const double x = fma(fl[0], r.xstep, left ? wing_x_at(r, 1, j1, slo) : wing_x_at(r, 2, j1, slo));
+          // x = (k - 1) xstep - xl (left, = -x) or (k - ir) xstep + xr (right): wing_x_at per lane
+          const double x = fma((double)(k - (left ? 1 : ir)), r.xstep, left ? -r.xl : r.xr);
           const double x2 = x * x;
-          double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
+          double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma3s(x2, fma3s(x2, 4.0, r.d), r.c));
           const bool on = ((unsigned)(k - klo) <= (unsigned)(khi - klo)) & ((unsigned)(k - il) > (unsigned)(ir - il));
           y = on ? y : 0.0;
           acc_a[p] = fma(r.wabs, y, acc_a[p]);
@@ -612,13 +616,13 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
       const int W = 64 << lv;
       const int b = (slo - g_lo) >> (6 + lv);
       const int blo = g_lo + b * W;
-      const double t = (double)(2 * (slo + lane - blo) - (W - 1)) / (double)W;
+      const double t = (double)(2 * (slo + lane - blo) - (W - 1)) * (1.0 / 64 / (double)(1 << lv)); // exact: W = 2^(6+lv)
       const double *c = cl + (size_t)(fp.box_off[lv] + b) * (2 * kFC);
       double pa = c[kFC - 1], pe = c[2 * kFC - 1];
 #pragma unroll
       for (int n = kFC - 2; n >= 0; --n) {
-        pa = fma(pa, t, c[n]);
-        pe = fma(pe, t, c[kFC + n]);
+        pa = fma3s(pa, t, c[n]);
+        pe = fma3s(pe, t, c[kFC + n]);
       }
       acc_a[p] += pa;
       acc_e[p] += pe;
