@@ -147,7 +147,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    kms = np.zeros(4)
+    kms = np.zeros(5)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         spec = step()
@@ -167,14 +167,14 @@ def main():
         elapsed = float(t.item())
     kms /= args.steps
     prep_ms = float(kms[0])
-    main_ms = float(kms[1] + kms[2] + kms[3])
+    main_ms = float(kms[1:].sum())
     checksum = float(spec.sum().item())
     # outside the timed region: the brute-force kernels (every evaluation exact) for reference
     exact_kms = None
     if not args.exact and world == 1:
         engine.set_far_field(0)
         step()
-        exact_kms = np.zeros(4)
+        exact_kms = np.zeros(5)
         for _ in range(2):
             spec_x = step()
             exact_kms += np.array(ls.last_kernel_ms()) / 2

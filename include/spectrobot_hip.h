@@ -211,11 +211,12 @@ int sr_set_points_per_lane(int p);
 
 /* Timing hook for bench.py: HIP-event times (ms) of the kernels of the most
  * recent sr_abscoeff_layers* call on this lineset, measured on the stream they
- * were launched on: ms4[0] sr_prep_kernel; far-field mode: ms4[1]
- * sr_farfield_kernel, ms4[2] sr_abscoeff_near_wings_kernel, ms4[3]
- * sr_abscoeff_near_zones_kernel; exact mode: ms4[1] sr_abscoeff_wings_kernel,
- * ms4[2] sr_abscoeff_cores_kernel, ms4[3] 0.  Synchronises. */
-int sr_last_kernel_ms(sr_lineset *ls, float *ms4);
+ * were launched on: ms5[0] sr_prep_kernel; far-field mode: ms5[1]
+ * sr_farfield_kernel, ms5[2] sr_abscoeff_near_wings_kernel, ms5[3]
+ * sr_abscoeff_near_zones_kernel; exact mode: ms5[1] sr_abscoeff_wings_kernel,
+ * ms5[2] sr_abscoeff_cores_kernel; unused entries 0 (ms5[4] is reserved).
+ * Synchronises. */
+int sr_last_kernel_ms(sr_lineset *ls, float *ms5);
 
 #ifdef __cplusplus
 }

@@ -168,7 +168,7 @@ struct sr_lineset {
   Stager s_layers;
   DevBuf d_fast, d_cold, d_zmax, d_coef, d_first;
   int first_x0 = 0, first_n = 0; // IcIndex table domain
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int n_timed = 0; // kernels timed in the last call
   bool timed = false;
 };
@@ -584,12 +584,12 @@ int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, 
   return rc;
 }
 
-int sr_last_kernel_ms(sr_lineset *ls, float *ms4) {
-  if (!ls || !ls->timed || !ms4) return SR_ERR_ARG;
+int sr_last_kernel_ms(sr_lineset *ls, float *ms5) {
+  if (!ls || !ls->timed || !ms5) return SR_ERR_ARG;
   HIPCHK(hipEventSynchronize(ls->ev[ls->n_timed]));
-  for (int i = 0; i < 4; ++i) {
-    ms4[i] = 0.f;
-    if (i < ls->n_timed) HIPCHK(hipEventElapsedTime(&ms4[i], ls->ev[i], ls->ev[i + 1]));
+  for (int i = 0; i < 5; ++i) {
+    ms5[i] = 0.f;
+    if (i < ls->n_timed) HIPCHK(hipEventElapsedTime(&ms5[i], ls->ev[i], ls->ev[i + 1]));
   }
   return SR_OK;
 }

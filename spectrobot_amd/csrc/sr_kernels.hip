@@ -706,24 +706,52 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
   const int zm = min(zmax[layer], kHalf - 1);
 #pragma unroll
   for (int p = 0; p < WT / 64; ++p) s_a[lane + 64 * p] = s_e[lane + 64 * p] = 0.;
-  CorePend p4, p3;
-  p4.k = p3.k = 1;
-  p4.base = p3.base = 0;
+  CorePend p4;
+  p4.k = 1;
+  p4.base = 0;
   p4.gc = p4.x0 = p4.dwp = p4.inv_dwp = p4.ryf = p4.wa = p4.we = 0.;
-  p3 = p4;
-  int fill4 = 0, fill3 = 0;
+  int fill4 = 0;
   // lines whose zone [ic - zm, ic + zm] can meet the group
   const int l0 = lower_bound_ic(ix, wlo - zm), l1 = lower_bound_ic(ix, whi + zm + 1);
   const FastRec *frow = fast + (size_t)layer * n_sub;
   const ColdRec *crow = cold + (size_t)layer * n_sub;
   for (int base = l0; base < l1; base += 64) {
-    const int lv = base + lane;
-    bool act = false;
-    if (lv < l1) {
-      const int j1 = frow[lv].j1;
-      const unsigned ilir = frow[lv].ilir;
-      const int zl = max(j1 + (int)(ilir & 0xffffu) - 1, j1), zh = min(j1 + (int)(ilir >> 16) - 1, j1 + (kImxsig - 1));
-      act = zl <= whi && zh >= wlo; // zone (inside the window) meets the group
+    const int lv = min(base + lane, l1 - 1);
+    bool act;
+    {
+      // ---- lane = line: which lines have work here, and their REGION 3 (lineshape.f:554-560), the
+      // ~15 points around the centre.  All lanes step through their own interval together (the
+      // intervals of neighbouring lines are equally long), the line's data sit in the lane's
+      // registers and die before the walk below; sums by ds_add_f64.  Walked line by line with
+      // lanes = points these few points cost a whole 64-lane chunk per line (1.1 of 6.6 ms).
+      const FastRec &r = frow[lv];
+      const int j1 = r.j1, il = r.il(), ir = r.ir();
+      const int zl = max(j1 + il - 1, j1), zh = min(j1 + ir - 1, j1 + (kImxsig - 1));
+      act = base + lane < l1 && zl <= whi && zh >= wlo; // zone (inside the window) meets the group
+      if (__ballot(act) == 0) continue;
+      const ColdRec &z = crow[lv];
+      const int k3lo = z.k3lo(), k3hi = z.k3hi();
+      const int il2 = z.il2(), ir2 = z.ir2();
+      const int k_lo = max(wlo - j1 + 1, 1), k_hi = min(whi - j1 + 1, kImxsig);
+      const int c_lo = max(((il2 == il) ? il - 1 : il2) + 1, k_lo), c_hi = min(((ir2 == ir) ? ir + 1 : ir2) - 1, k_hi);
+      const int e0 = max(k3lo, c_lo), e1 = min(k3hi, c_hi);
+      const int n3 = (act && k3lo <= k3hi) ? max(e1 - e0 + 1, 0) : 0;
+      if (__any(n3 > 0)) {
+        const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
+        const double x0 = z.x0, dwp = z.dwp, inv_dwp = z.inv_dwp, ryf = z.ryf, wa = r.wabs, we = r.wemi;
+        const int ibase = j1 - 1 - wlo;
+        for (int t = 0; __any(t < n3); ++t) {
+          if (t < n3) {
+            const int k = e0 + t;
+            const double d = fabs(xf(k) - x0);
+            double rx = d * inv_dwp; // |x(k)-x0|/dw correctly rounded: one residual correction
+            rx = fma(fma(-dwp, rx, d), inv_dwp, rx);
+            const double y = core_region3(ryf, (double)(float)(-rx));
+            atomicAdd(&s_a[k + ibase], wa * y);
+            atomicAdd(&s_e[k + ibase], we * y);
+          }
+        }
+      }
     }
     unsigned long long todo = __ballot(act);
     while (todo) {
@@ -735,7 +763,9 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
       const int k_lo = max(wlo - j1 + 1, 1), k_hi = min(whi - j1 + 1, kImxsig); // group & window, as k
       const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
       const double wa = r.wabs, we = r.wemi;
-      // ---- region 2: [il, il2] (if il < il2) then [ir2, ir] (if ir2 < ir), lineshape.f:503-522
+      // ---- region 2: [il, il2] (if il < il2) then [ir2, ir] (if ir2 < ir), lineshape.f:503-522: one run
+      // of consecutive lanes (lanes = lines was tried for it too: 300 ds_add_f64 per 64 lines at
+      // scattered addresses cost more than the chunks' idle lanes)
       {
         const int a0 = max(il, k_lo), a1 = il < il2 ? min(il2, k_hi) : a0 - 1;
         const int b0 = max(ir2, k_lo), b1 = ir2 < ir ? min(ir, k_hi) : b0 - 1;
@@ -745,7 +775,8 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
           if (t < na + nb) {
             const bool lf = t < na;
             const int k = lf ? a0 + t : b0 + (t - na);
-            const double x = lf ? fma(-(double)(k - il), r.xstep, z.xs2l) : fma((double)(k - ir2), r.xstep, z.xs2r);
+            // -(k - il) xstep + xs2l (left run) or (k - ir2) xstep + xs2r (right run), branch-free
+            const double x = fma((double)(lf ? il - k : k - ir2), r.xstep, lf ? z.xs2l : z.xs2r);
             const double y = region2_val(z.q2, x);
             const int idx = k + j1 - 1 - wlo;
             s_a[idx] = fma(wa, y, s_a[idx]);
@@ -753,8 +784,8 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
           }
         }
       }
-      // ---- core (il2a, ir2a), lineshape.f:524-562: region 3 = [k3lo, k3hi], region 4 on both sides.
-      // These points join the pending chunks (evaluated whenever 64 are waiting).
+      // ---- region 4: the core (il2a, ir2a), lineshape.f:524-562, without its region-3 interval
+      // [k3lo, k3hi].  The points join the pending chunk (evaluated whenever 64 are waiting).
       {
         const int c_lo = max(((il2 == il) ? il - 1 : il2) + 1, k_lo), c_hi = min(((ir2 == ir) ? ir + 1 : ir2) - 1, k_hi);
         const int k3lo = z.k3lo(), k3hi = z.k3hi();
@@ -765,15 +796,10 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
         const int base_idx = j1 - 1 - wlo;
         core_push<4>(p4, fill4, lane, a0, max(a1 - a0 + 1, 0), b0, max(b1 - b0 + 1, 0), base_idx, xf.gc, z, wa, we, gp,
                      s_a, s_e);
-        if (has3) {
-          const int e0 = max(k3lo, c_lo), e1 = min(k3hi, c_hi);
-          core_push<3>(p3, fill3, lane, e0, max(e1 - e0 + 1, 0), 0, 0, base_idx, xf.gc, z, wa, we, gp, s_a, s_e);
-        }
       }
     }
   }
   core_eval<4>(p4, lane < fill4, gp, s_a, s_e); // what is still waiting
-  core_eval<3>(p3, lane < fill3, gp, s_a, s_e);
   const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
 #pragma unroll
   for (int p = 0; p < WT / 64; ++p) {
@@ -807,15 +833,15 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcInde
     // 1e5 points x 80 layers with 512 instead of 256) as long as the waves still fill the chip
     // several times over (1024: 9.3 ms, too few waves and 16 KB LDS each).
     const long waves512 = (long)((g_hi - g_lo + 511) / 512) * n_layers;
-    if (waves512 >= 3 * 4096) {
-      const int n_t = (g_hi - g_lo + 511) / 512;
-      hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel<512>, dim3((unsigned)(n_t * n_layers)), dim3(64), 0, st, fast,
-                         cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, abs_out, emi_out);
-    } else {
-      const int n_t = (g_hi - g_lo + 255) / 256;
-      hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel<256>, dim3((unsigned)(n_t * n_layers)), dim3(64), 0, st, fast,
-                         cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, abs_out, emi_out);
-    }
+    const bool wide = waves512 >= 3 * 4096;
+    const int n_t = (g_hi - g_lo + (wide ? 511 : 255)) / (wide ? 512 : 256);
+    const dim3 gz((unsigned)(n_t * n_layers));
+    if (wide)
+      hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel<512>, gz, dim3(64), 0, st, fast, cold, ix, zmax, n_sub, n_t,
+                         g_lo, g_hi, gp, abs_out, emi_out);
+    else
+      hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel<256>, gz, dim3(64), 0, st, fast, cold, ix, zmax, n_sub, n_t,
+                         g_lo, g_hi, gp, abs_out, emi_out);
   }
   return (int)hipGetLastError();
 }

@@ -142,8 +142,8 @@ class LineSet(object):
 
     def last_kernel_ms(self):
         """Kernel times (ms) of the last abscoeff_layers call: (prep, farfield|wings,
-        near-wing|cores, near-general|0), see sr_last_kernel_ms."""
-        ms = (C.c_float * 4)()
+        near wings|cores, near zones|0, reserved), see sr_last_kernel_ms."""
+        ms = (C.c_float * 5)()
         check(lib.sr_last_kernel_ms(self._h, ms), "sr_last_kernel_ms")
         return tuple(ms)
 

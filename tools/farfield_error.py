@@ -37,13 +37,13 @@ def main():
     for _ in range(2):
         ls.abscoeff_layers(T, P, tvib=tv)
     torch.cuda.synchronize()
-    ms = np.zeros(4)
+    ms = np.zeros(5)
     for _ in range(5):
         ls.abscoeff_layers(T, P, tvib=tv)
         torch.cuda.synchronize()
         ms += np.array(ls.last_kernel_ms())
     ms /= 5
-    print("kernel ms (prep, far field, near wings, near zones): " + " ".join(f"{x:.2f}" for x in ms),
+    print("kernel ms (prep, far field, near wings, near zones, -): " + " ".join(f"{x:.2f}" for x in ms),
           f"sum {ms.sum():.2f}")
 
 
