@@ -129,7 +129,7 @@ __device__ inline double region2_val(const double (&q)[8], double x) {
   const double x2 = x * x;
   const double num = fma(x2, fma(x2, fma(q[3], x2, q[2]), q[1]), q[0]);
   const double den = fma(x2, fma(x2, fma(x2, x2 + q[7], q[6]), q[5]), q[4]);
-  return num * fast_rcp<2>(den);
+  return num * fast_rcp<1>(den);
 }
 
 // ---- regions 3 / 4: lineshape.f:526-561 ----
