@@ -718,12 +718,17 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
   for (int base = l0; base < l1; base += 64) {
     const int lv = min(base + lane, l1 - 1);
     bool act;
+    // runs of the lane's line inside this group, start | count << 16 (window indices <= 13010):
+    // region 2 left / right (lineshape.f:503-522), region 4 left / right of the region-3 interval
+    unsigned run2l, run2r, run4l, run4r;
     {
-      // ---- lane = line: which lines have work here, and their REGION 3 (lineshape.f:554-560), the
-      // ~15 points around the centre.  All lanes step through their own interval together (the
-      // intervals of neighbouring lines are equally long), the line's data sit in the lane's
-      // registers and die before the walk below; sums by ds_add_f64.  Walked line by line with
-      // lanes = points these few points cost a whole 64-lane chunk per line (1.1 of 6.6 ms).
+      // ---- lane = line: which lines have work here, the interval arithmetic of every line (the walk
+      // below reads it back with v_readlane: done there it was ~70 scalar instructions per line), and
+      // REGION 3 (lineshape.f:554-560), the ~15 points around the centre: all lanes step through
+      // their own interval together (the intervals of neighbouring lines are equally long), the
+      // line's data sit in the lane's registers and die before the walk; sums by ds_add_f64.  Walked
+      // line by line with lanes = points these few points cost a whole 64-lane chunk per line (1.1
+      // of 6.6 ms).
       const FastRec &r = frow[lv];
       const int j1 = r.j1, il = r.il(), ir = r.ir();
       const int zl = max(j1 + il - 1, j1), zh = min(j1 + ir - 1, j1 + (kImxsig - 1));
@@ -732,10 +737,24 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
       const ColdRec &z = crow[lv];
       const int k3lo = z.k3lo(), k3hi = z.k3hi();
       const int il2 = z.il2(), ir2 = z.ir2();
-      const int k_lo = max(wlo - j1 + 1, 1), k_hi = min(whi - j1 + 1, kImxsig);
+      const int k_lo = max(wlo - j1 + 1, 1), k_hi = min(whi - j1 + 1, kImxsig); // group & window, as k
+      {
+        const int a0 = max(il, k_lo), a1 = il < il2 ? min(il2, k_hi) : a0 - 1;
+        const int b0 = max(ir2, k_lo), b1 = ir2 < ir ? min(ir, k_hi) : b0 - 1;
+        run2l = (unsigned)a0 | ((unsigned)max(a1 - a0 + 1, 0) << 16);
+        run2r = (unsigned)b0 | ((unsigned)max(b1 - b0 + 1, 0) << 16);
+      }
+      // the core (il2a, ir2a), lineshape.f:524-562: region 3 = [k3lo, k3hi], region 4 on both sides
       const int c_lo = max(((il2 == il) ? il - 1 : il2) + 1, k_lo), c_hi = min(((ir2 == ir) ? ir + 1 : ir2) - 1, k_hi);
+      const bool has3 = k3lo <= k3hi;
+      {
+        const int a0 = c_lo, a1 = has3 ? min(k3lo - 1, c_hi) : c_hi;
+        const int b0 = has3 ? max(k3hi + 1, c_lo) : c_hi + 1, b1 = c_hi;
+        run4l = (unsigned)a0 | ((unsigned)max(a1 - a0 + 1, 0) << 16);
+        run4r = (unsigned)b0 | ((unsigned)max(b1 - b0 + 1, 0) << 16);
+      }
       const int e0 = max(k3lo, c_lo), e1 = min(k3hi, c_hi);
-      const int n3 = (act && k3lo <= k3hi) ? max(e1 - e0 + 1, 0) : 0;
+      const int n3 = (act && has3) ? max(e1 - e0 + 1, 0) : 0;
       if (__any(n3 > 0)) {
         const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
         const double x0 = z.x0, dwp = z.dwp, inv_dwp = z.inv_dwp, ryf = z.ryf, wa = r.wabs, we = r.wemi;
@@ -759,17 +778,16 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
       todo &= todo - 1;
       const FastRec r = frow[base + i];
       const ColdRec z = crow[base + i];
-      const int j1 = r.j1, il = r.il(), ir = r.ir(), il2 = z.il2(), ir2 = z.ir2();
-      const int k_lo = max(wlo - j1 + 1, 1), k_hi = min(whi - j1 + 1, kImxsig); // group & window, as k
+      const int j1 = r.j1, il = r.il(), ir2 = z.ir2();
       const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
       const double wa = r.wabs, we = r.wemi;
-      // ---- region 2: [il, il2] (if il < il2) then [ir2, ir] (if ir2 < ir), lineshape.f:503-522: one run
-      // of consecutive lanes (lanes = lines was tried for it too: 300 ds_add_f64 per 64 lines at
-      // scattered addresses cost more than the chunks' idle lanes)
+      const int base_idx = j1 - 1 - wlo;
+      // ---- region 2: the left then the right run as one run of consecutive lanes (lanes = lines was
+      // tried for it too: 300 ds_add_f64 per 64 lines at scattered addresses cost more than the
+      // chunks' idle lanes)
       {
-        const int a0 = max(il, k_lo), a1 = il < il2 ? min(il2, k_hi) : a0 - 1;
-        const int b0 = max(ir2, k_lo), b1 = ir2 < ir ? min(ir, k_hi) : b0 - 1;
-        const int na = max(a1 - a0 + 1, 0), nb = max(b1 - b0 + 1, 0);
+        const unsigned ul = __builtin_amdgcn_readlane(run2l, i), ur = __builtin_amdgcn_readlane(run2r, i);
+        const int a0 = (int)(ul & 0xffffu), na = (int)(ul >> 16), b0 = (int)(ur & 0xffffu), nb = (int)(ur >> 16);
         for (int t0 = 0; t0 < na + nb; t0 += 64) {
           const int t = t0 + lane;
           if (t < na + nb) {
@@ -778,24 +796,17 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
             // -(k - il) xstep + xs2l (left run) or (k - ir2) xstep + xs2r (right run), branch-free
             const double x = fma((double)(lf ? il - k : k - ir2), r.xstep, lf ? z.xs2l : z.xs2r);
             const double y = region2_val(z.q2, x);
-            const int idx = k + j1 - 1 - wlo;
+            const int idx = k + base_idx;
             s_a[idx] = fma(wa, y, s_a[idx]);
             s_e[idx] = fma(we, y, s_e[idx]);
           }
         }
       }
-      // ---- region 4: the core (il2a, ir2a), lineshape.f:524-562, without its region-3 interval
-      // [k3lo, k3hi].  The points join the pending chunk (evaluated whenever 64 are waiting).
+      // ---- region 4: its points join the pending chunk (evaluated whenever 64 are waiting)
       {
-        const int c_lo = max(((il2 == il) ? il - 1 : il2) + 1, k_lo), c_hi = min(((ir2 == ir) ? ir + 1 : ir2) - 1, k_hi);
-        const int k3lo = z.k3lo(), k3hi = z.k3hi();
-        const bool has3 = k3lo <= k3hi;
-        // region 4: [c_lo, k3lo-1] and [k3hi+1, c_hi] (the whole core if region 3 is empty)
-        const int a0 = c_lo, a1 = has3 ? min(k3lo - 1, c_hi) : c_hi;
-        const int b0 = has3 ? max(k3hi + 1, c_lo) : c_hi + 1, b1 = c_hi;
-        const int base_idx = j1 - 1 - wlo;
-        core_push<4>(p4, fill4, lane, a0, max(a1 - a0 + 1, 0), b0, max(b1 - b0 + 1, 0), base_idx, xf.gc, z, wa, we, gp,
-                     s_a, s_e);
+        const unsigned ul = __builtin_amdgcn_readlane(run4l, i), ur = __builtin_amdgcn_readlane(run4r, i);
+        core_push<4>(p4, fill4, lane, (int)(ul & 0xffffu), (int)(ul >> 16), (int)(ur & 0xffffu), (int)(ur >> 16),
+                     base_idx, xf.gc, z, wa, we, gp, s_a, s_e);
       }
     }
   }
