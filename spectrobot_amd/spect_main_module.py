@@ -6,6 +6,8 @@ calc_shapes_lines + LutSet.add_PT per (P,T) + a pickle round trip + the
 population-weighted combine, it makes ONE call into the HIP engine, which
 returns the abs/emi coefficient spectra of every LOS step.
 """
+import copy
+
 import numpy as np
 
 from . import engine
@@ -139,3 +141,263 @@ def inversion_algebra(obs, sims, noise, bayes_set, lambda_LM=0.1, L1_reg=False, 
     bayes_set.update_params(deltax)
     bayes_set.store_avk(AVK)
     bayes_set.store_VCM(S_x)
+
+
+# ----------------------------------------------------------------------------
+# retrieval parameter space (spect_main_module.py:169-665) and FOV integration
+# (N2; spect_main_module.py:3342-3374).  Host-side bookkeeping around the GPU forward model: the VMR
+# profile of a gas is sum_p mask_p(z) * x_p, so the absorber columns are linear in the parameters and
+# engine.radiance_jacobian (sr_radiance_jac_dev) returns d(radiance)/dx_p from dcol[s][p].
+# The reference builds its masks on spect_base_module.AtmGrid / AtmGridMask, which are not in the
+# tree; GridMask is the minimal stand-in (coordinates, mask values, interpolation tag).
+# ----------------------------------------------------------------------------
+class GridMask(object):
+    def __init__(self, coords, mask, interp):
+        self.grid = np.asarray(coords, dtype=float)
+        self.mask = np.asarray(mask, dtype=float)
+        self.interp = interp
+
+    def __mul__(self, value):
+        return self.mask * value
+
+    __rmul__ = __mul__
+
+
+def alt_triangle(alt_grid, node_alt, step=None, node_lo=None, node_up=None, first=False, last=False):
+    """Triangular weight of one altitude node on alt_grid (spect_main_module.py:319-351): 1 at the
+    node, linear to 0 at the neighbouring nodes; the first (last) node keeps weight 1 below (above)."""
+    z = np.asarray(alt_grid, dtype=float)
+    if step is not None:
+        node_lo, node_up = node_alt - step, node_alt + step
+    w = np.zeros(z.shape)
+    if first:
+        up = (z >= node_alt) & (z < node_up)
+        w[z < node_alt] = 1.0
+        w[up] = 1.0 - (z[up] - node_alt) / (node_up - node_alt)
+    elif last:
+        lo = (z <= node_alt) & (z > node_lo)
+        w[z > node_alt] = 1.0
+        w[lo] = 1.0 - (node_alt - z[lo]) / (node_alt - node_lo)
+    else:
+        up = (z >= node_alt) & (z <= node_up)
+        lo = (z < node_alt) & (z >= node_lo)
+        w[up] = 1.0 - (z[up] - node_alt) / (node_up - node_alt)
+        w[lo] = 1.0 - (node_alt - z[lo]) / (node_alt - node_lo)
+    return GridMask(z, w, 'lin')
+
+
+def lat_box(lat_limits, lat_ok):
+    """Box mask over latitude bands that start at lat_limits (spect_main_module.py:354-373): 1 for the
+    band holding lat_ok; the last band is open-ended and, as in the reference, excludes its own start."""
+    lim = np.asarray(lat_limits, dtype=float)
+    w = np.zeros(len(lim))
+    w[:-1] = (lat_ok >= lim[:-1]) & (lat_ok < lim[1:])
+    w[-1] = lat_ok > lim[-1]
+    return GridMask(lim, w, 'box')
+
+
+def centre_boxes(lat_limits):
+    """Band centres of consecutive limits (spect_main_module.py:376-384)."""
+    lim = np.asarray(lat_limits, dtype=float)
+    return list((lim[:-1] + lim[1:]) / 2.0)
+
+
+class RetParam(object):
+    """One retrieved parameter (spect_main_module.py:587-644)."""
+
+    def __init__(self, nameset, key, maskgrid, apriori, apriori_err, first_guess=None, constrain_positive=True):
+        self.nameset, self.key = nameset, key
+        self.maskgrid = copy.deepcopy(maskgrid)
+        self.value = apriori if first_guess is None else first_guess
+        self.apriori, self.apriori_err = apriori, apriori_err
+        self.derivatives, self.old_values = [], []
+        self.constrain_positive = constrain_positive
+        self.not_involved = False
+        self.is_used = False
+
+    def set_not_involved(self):
+        self.not_involved = True
+
+    def set_involved(self):
+        self.not_involved = False
+
+    def set_used(self):
+        self.is_used = True
+
+    def update_par(self, delta_par):
+        """value += delta; a step that would leave a positive-constrained parameter <= 0 is halved
+        until it does not (spect_main_module.py:616-624)."""
+        self.old_values.append(self.value)
+        if self.constrain_positive:
+            while self.value + delta_par <= 0.0:
+                delta_par /= 2
+        self.value = self.value + delta_par
+
+    def add_hires_deriv(self, derivative):
+        self.hires_deriv = copy.deepcopy(derivative)
+
+    def erase_hires_deriv(self):
+        self.hires_deriv = None
+
+    def store_deriv(self, derivative, num):
+        """Derivative spectrum of observation `num` (replaces an existing entry, else appends)."""
+        if 0 <= num < len(self.derivatives):
+            self.derivatives[num] = copy.deepcopy(derivative)
+        else:
+            self.derivatives.append(copy.deepcopy(derivative))
+
+
+class RetSet(object):
+    """Parameters of one quantity, e.g. the nodes of a VMR profile (spect_main_module.py:256-283)."""
+
+    def __init__(self, name, params):
+        self.name = name
+        self.set = [copy.deepcopy(p) for p in params]
+        self.n_par = len(self.set)
+
+    def keys(self):
+        return [p.key for p in self.set]
+
+    def items(self):
+        return list(zip(self.keys(), self.set))
+
+
+class LinearProfile_1D_new(RetSet):
+    """Profile by linear interpolation between altitude nodes (spect_main_module.py:450-492):
+    one RetParam per node, triangular masks on alt_grid."""
+
+    def __init__(self, name, alt_grid, alt_nodes, apriori_prof, apriori_prof_err, first_guess_prof=None):
+        z = np.asarray(alt_grid.grid[0] if hasattr(alt_grid, 'grid') else alt_grid, dtype=float)
+        nodes = list(alt_nodes)
+        fg = apriori_prof if first_guess_prof is None else first_guess_prof
+        self.name, self.alts, self.n_par, self.set = name, nodes, len(nodes), []
+        for i, node in enumerate(nodes):
+            if i == 0:
+                mask = alt_triangle(z, node, node_up=nodes[1], first=True)
+            elif i == len(nodes) - 1:
+                mask = alt_triangle(z, node, node_lo=nodes[-2], last=True)
+            else:
+                mask = alt_triangle(z, node, node_lo=nodes[i - 1], node_up=nodes[i + 1])
+            self.set.append(RetParam(name, node, mask, apriori_prof[i], apriori_prof_err[i], first_guess=fg[i]))
+
+    def profile(self):
+        """sum_p mask_p * value_p on the altitude grid."""
+        return sum(p.maskgrid * p.value for p in self.set)
+
+    def mask_matrix(self):
+        """[n_par, n_alt] weights: d(profile)/d(parameter), the input of the column Jacobian."""
+        return np.array([p.maskgrid.mask for p in self.set])
+
+    def check_involved(self, parkey, coord_range):
+        """A node is not involved in a path that starts above the next node (spect_main_module.py:482-492)."""
+        i = self.alts.index(parkey)
+        return i == len(self.alts) - 1 or not coord_range['alt'][0] > self.alts[i + 1]
+
+
+class BayesSet(object):
+    """The full parameter space of a retrieval: ordered RetSets (spect_main_module.py:169-253)."""
+
+    def __init__(self, tag=None):
+        self.tag = tag
+        self.sets, self.order, self.old_params = dict(), [], []
+        self.n_tot = 0
+
+    def add_set(self, set_):
+        self.sets[set_.name] = copy.deepcopy(set_)
+        self.order.append(set_.name)
+        self.n_tot += set_.n_par
+
+    def params(self):
+        return [p for name in self.order for p in self.sets[name].set]
+
+    def values(self):
+        return [p.value for p in self.params()]
+
+    def param_vector(self):
+        return np.array(self.values())
+
+    def apriori_vector(self):
+        return np.array([p.apriori for p in self.params()])
+
+    def VCM_apriori(self):
+        return np.diag(np.array([p.apriori_err for p in self.params()], dtype=float) ** 2)
+
+    def n_used_par(self):
+        return sum(p.is_used for p in self.params())
+
+    def build_jacobian(self, masks=None):
+        """[n_obs_total, n_tot]: per parameter the derivative spectra of all observations, concatenated
+        (and masked like the observation vector of genvec)."""
+        rows = [np.concatenate([np.asarray(d.spectrum, dtype=float) for d in p.derivatives]) for p in self.params()]
+        jac = np.array(rows)
+        if masks is not None:
+            jac = jac[:, np.concatenate([np.asarray(m, dtype=bool) for m in masks])]
+        self.jacobian = jac.T
+        return self.jacobian
+
+    def update_params(self, delta_x):
+        self.old_params.append(self.values())
+        for p, d in zip(self.params(), delta_x):
+            p.update_par(d)
+
+    def store_avk(self, av_kernel):
+        self.av_kernel = copy.deepcopy(av_kernel)
+
+    def store_VCM(self, VCM):
+        self.VCM = copy.deepcopy(VCM)
+
+    def update_parerror(self):
+        for i, p in enumerate(self.params()):
+            p.ret_error = np.sqrt(self.VCM[i, i])
+
+
+def retrieval_converged(chi, chi_old, chi_threshold=0.01):
+    """Stopping rule of the retrieval loop (spect_main_module.py:2960-2973): relative change of the
+    reduced chi square below the threshold, or chi square increased.  Returns '' (continue),
+    'converged' or 'raised'."""
+    if chi_old is None:
+        return ''
+    if abs(chi - chi_old) / chi_old < chi_threshold:
+        return 'converged'
+    return 'raised' if chi > chi_old else ''
+
+
+def FOV_integr_1D(radtrans, pixel_rot=0.0, closed_form=False):
+    """Field-of-view integration over a square pixel rotated by pixel_rot degrees, from the spectra of
+    three lines of sight at -dmax, 0, +dmax across it (spect_main_module.py:3342-3374): the spectrum
+    is interpolated across the pixel by a degree-2 spline through the three points -- the parabola
+    q(x) = s1 + b x + c x^2 -- and integrated with the weight esse for |x| <= delta, falling
+    linearly to 0 at |x| = dmax.
+
+    The reference integrates with scipy's quad at its default tolerances (epsabs 1.49e-8).  For
+    radiances of ~1e-6 that absolute tolerance is met by the first 21-point Gauss-Kronrod pass, which
+    does not resolve the kinks of the weight at +-delta: the reference's value is 2.5e-4 below the
+    integral for a 20-degree rotation.  Parity is with the reference, so the default path runs the
+    same quadrature on the same integrand; closed_form=True returns the integral itself,
+    I = esse [ 2 (s1 delta + c delta^3/3) + s1 e + 2 c (dmax (dmax^3-delta^3)/3 - (dmax^4-delta^4)/4)/e ],
+    e = dmax - delta (the odd term of q drops out)."""
+    rot = abs(np.deg2rad(pixel_rot))
+    dmax = np.sqrt(2.0) / 2.0 * np.cos(np.pi / 4 - rot)
+    delta = dmax - np.sin(rot)
+    esse = 1.0 / np.cos(rot)
+    s0, s1, s2 = (np.asarray(r.spectrum, dtype=float) for r in radtrans)
+    b = (s2 - s0) / (2.0 * dmax)
+    c = (s0 + s2 - 2.0 * s1) / (2.0 * dmax ** 2)
+    edge = dmax - delta
+    if closed_form:
+        total = 2.0 * (s1 * delta + c * delta ** 3 / 3.0)
+        if edge > 1e-14 * dmax:
+            m2 = dmax * (dmax ** 3 - delta ** 3) / 3.0 - (dmax ** 4 - delta ** 4) / 4.0  # int x^2 (dmax - x)
+            total = total + s1 * edge + 2.0 * c * m2 / edge
+        spet_fov = esse * total
+    else:
+        from scipy import integrate
+
+        def weighted(x, j):
+            q = s1[j] + x * (b[j] + x * c[j])
+            return q * esse if abs(x) <= delta else q * esse * abs(dmax - abs(x)) / edge
+
+        spet_fov = np.array([integrate.quad(weighted, -dmax, dmax, args=(j,))[0] for j in range(len(s1))])
+    out = copy.deepcopy(radtrans[0])
+    out.spectrum = spet_fov
+    return out

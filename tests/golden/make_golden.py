@@ -314,7 +314,7 @@ def main():
     print("e2e_co_all: abs max %.3e" % abc.max())
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--lowres", "--hitran", "--inversion")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--lowres", "--hitran", "--inversion", "--retrieval")):
     main()
 
 
@@ -436,3 +436,110 @@ def golden_inversion():
 
 if __name__ == "__main__" and "--inversion" in sys.argv:
     golden_inversion()
+
+
+def golden_retrieval():
+    """N4 (parameter space) and N2 (FOV): the reference's own BayesSet / RetSet / RetParam /
+    LinearProfile_1D_new / alt_triangle / lat_box / centre_boxes (spect_main_module.py:169-665) and
+    FOV_integr_1D (:3342-3374), run under Python 3.  The absent spect_base_module is stubbed with the
+    least that these call: AtmGrid / AtmGridMask as plain holders, rad = degrees -> radians."""
+    spcl, RF = import_reference_spcl()
+    m_mp = types.ModuleType("memory_profiler")
+    m_mp.profile = lambda f: f
+    sys.modules["memory_profiler"] = m_mp
+    sbm = sys.modules["spect_base_module"]
+
+    class AtmGrid(object):
+        def __init__(self, name, coords):
+            self.grid = [np.array(coords, dtype=float)]
+            self.coords = {name: self.grid[0]}
+
+    class AtmGridMask(object):
+        def __init__(self, grid, mask, interp):
+            self.grid, self.mask, self.interp = grid, np.array(mask, dtype=float), interp
+
+    sbm.AtmGrid, sbm.AtmGridMask = AtmGrid, AtmGridMask
+    sbm.rad = lambda deg: deg * np.pi / 180.0
+    import spect_main_module as smm
+    rng = np.random.default_rng(20260005)
+    out = {}
+
+    alts = np.linspace(100.0, 890.0, 80)
+    alt_grid = AtmGrid("alt", alts)
+    nodes_a = [150.0, 300.0, 450.0, 600.0, 800.0]
+    ap_a = [1.5e-2, 1.4e-2, 1.2e-2, 1.0e-2, 0.8e-2]
+    er_a = [0.5e-2, 0.5e-2, 0.4e-2, 0.4e-2, 0.3e-2]
+    fg_a = [1.2e-2, 1.5e-2, 1.1e-2, 1.2e-2, 0.7e-2]
+    nodes_b = [200.0, 500.0, 700.0]
+    ap_b = [2e-7, 5e-7, 9e-7]
+    er_b = [1e-7, 3e-7, 5e-7]
+    pa = smm.LinearProfile_1D_new("CH4", alt_grid, nodes_a, ap_a, er_a, first_guess_prof=fg_a)
+    pb = smm.LinearProfile_1D_new("HCN", alt_grid, nodes_b, ap_b, er_b)
+    out["alts"], out["nodes_a"], out["nodes_b"] = alts, np.array(nodes_a), np.array(nodes_b)
+    out["ap_a"], out["er_a"], out["fg_a"], out["ap_b"], out["er_b"] = map(np.array, (ap_a, er_a, fg_a, ap_b, er_b))
+    out["masks_a"] = np.array([p.maskgrid.mask for p in pa.set])
+    out["masks_b"] = np.array([p.maskgrid.mask for p in pb.set])
+    out["tri_step"] = smm.alt_triangle(alts, 420.0, step=75.0).mask
+    out["involved_a"] = np.array([[pa.check_involved(k, {"alt": (lo, lo + 50.0)}) for lo in (100.0, 320.0, 650.0, 850.0)]
+                                  for k in nodes_a], dtype=bool)
+    lat_limits = [-90.0, -60.0, -30.0, 30.0, 60.0]
+    out["lat_limits"] = np.array(lat_limits)
+    out["lat_boxes"] = np.array([smm.lat_box(lat_limits, la).mask for la in (-75.0, -30.0, 10.0, 59.9, 75.0)])
+    out["lat_centres"] = np.array(smm.centre_boxes(lat_limits))
+
+    bs = smm.BayesSet(tag="golden")
+    bs.add_set(pa)
+    bs.add_set(pb)
+    n_par, n_pix, n_low = bs.n_tot, 2, 24
+
+    class Sp(object):
+        def __init__(self, v):
+            self.spectrum = np.array(v, dtype=float)
+
+    ders = rng.standard_normal((n_par, n_pix, n_low)) * 1e-7
+    for ip, par in enumerate(bs.params()):
+        for num in range(n_pix):
+            par.store_deriv(Sp(ders[ip, num]), num)
+    masks = [rng.random(n_low) > 0.2 for _ in range(n_pix)]
+    out["ders"], out["pix_masks"] = ders, np.array(masks)
+    out["jac"] = bs.build_jacobian()
+    out["jac_masked"] = bs.build_jacobian(masks=masks)
+    out["S_ap"], out["x_ap"], out["x0"] = bs.VCM_apriori(), bs.apriori_vector(), bs.param_vector()
+    # positivity: parameters 1 and 6 are pushed below zero and have their step halved until positive
+    dx = np.array([1e-3, -4.9e-2, 2e-3, -3e-3, 1e-3, 1e-7, -9e-7, 2e-7])
+    bs.update_params(dx)
+    out["dx_pos"], out["x_after_pos"] = dx, bs.param_vector()
+    out["old_params_0"] = np.array(bs.old_params[0])
+    # one Levenberg-Marquardt step with the reference's algebra on this parameter space
+    sim = [Sp(np.abs(rng.standard_normal(n_low)) * 1e-6) for _ in range(n_pix)]
+    noi = [Sp(np.abs(rng.standard_normal(n_low)) * 1e-8 + 2e-8) for _ in range(n_pix)]
+    obs = [Sp(s_.spectrum + 3e-8 * rng.standard_normal(n_low)) for s_ in sim]
+    for par in bs.params():
+        par.set_used()
+    out["sim"], out["noi"], out["obs"] = (np.array([o.spectrum for o in x]) for x in (sim, noi, obs))
+    out["chi"] = smm.chicalc(obs, sim, noi, masks, bs.n_used_par())
+    smm.inversion_algebra(obs, sim, noi, bs, lambda_LM=0.1, masks=masks)
+    bs.update_parerror()
+    out["x_after_lm"], out["vcm"], out["avk"] = bs.param_vector(), np.array(bs.VCM), np.array(bs.av_kernel)
+    out["ret_error"] = np.array([p.ret_error for p in bs.params()])
+
+    # FOV integration of three LOS spectra (lower, centre, upper) for three pixel rotations
+    class Grid(object):
+        def __init__(self, g):
+            self.grid = g
+
+    class Rad(object):
+        def __init__(self, g, v):
+            self.spectral_grid, self.spectrum = Grid(g), np.array(v, dtype=float)
+
+    wl = np.linspace(3.2, 3.45, 17)
+    spe = np.array([1e-6 * (1.0 + 0.3 * np.sin(7 * wl + ph)) * sc for ph, sc in ((0.0, 0.7), (0.4, 1.0), (0.9, 1.6))])
+    out["fov_wl"], out["fov_spe"], out["fov_rot"] = wl, spe, np.array([0.0, 20.0, -45.0])
+    out["fov_out"] = np.array([smm.FOV_integr_1D([Rad(wl, v) for v in spe], pixel_rot=r).spectrum
+                               for r in out["fov_rot"]])
+    np.savez_compressed(os.path.join(HERE, "retrieval_classes.npz"), **out)
+    print("retrieval: x_after_pos", out["x_after_pos"][:3], "fov", out["fov_out"][:, 0])
+
+
+if __name__ == "__main__" and "--retrieval" in sys.argv:
+    golden_retrieval()

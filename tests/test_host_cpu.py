@@ -224,3 +224,65 @@ def test_inversion_algebra_against_reference(golden):
         assert np.allclose(bs.avk, g["avk_" + lam], rtol=1e-9, atol=1e-14)
         assert np.allclose(bs.vcm, g["vcm_" + lam], rtol=1e-9, atol=0)
     assert abs(smm.chicalc(o, s, nz, None, len(g["xi"])) - float(g["chi"])) < 1e-12 * float(g["chi"])
+
+
+def test_retrieval_parameter_space_against_reference(golden):
+    """BayesSet / RetParam / LinearProfile_1D_new / alt_triangle / lat_box (smm:169-665) and
+    FOV_integr_1D (smm:3342-3374) against the reference's own classes run under Python 3
+    (tests/golden/make_golden.py --retrieval)."""
+    from spectrobot_amd import spect_main_module as smm
+    g = golden("retrieval_classes")
+    alts = g["alts"]
+    pa = smm.LinearProfile_1D_new("CH4", alts, list(g["nodes_a"]), g["ap_a"], g["er_a"], first_guess_prof=g["fg_a"])
+    pb = smm.LinearProfile_1D_new("HCN", alts, list(g["nodes_b"]), g["ap_b"], g["er_b"])
+    assert np.array_equal(pa.mask_matrix(), g["masks_a"]) and np.array_equal(pb.mask_matrix(), g["masks_b"])
+    assert np.array_equal(smm.alt_triangle(alts, 420.0, step=75.0).mask, g["tri_step"])
+    assert np.allclose(pa.mask_matrix().sum(0), 1.0)  # the triangles are a partition of unity
+    inv = np.array([[pa.check_involved(k, {"alt": (lo, lo + 50.0)}) for lo in (100.0, 320.0, 650.0, 850.0)]
+                    for k in g["nodes_a"]])
+    assert np.array_equal(inv, g["involved_a"])
+    lat = list(g["lat_limits"])
+    boxes = np.array([smm.lat_box(lat, la).mask for la in (-75.0, -30.0, 10.0, 59.9, 75.0)])
+    assert np.array_equal(boxes, g["lat_boxes"]) and np.allclose(smm.centre_boxes(lat), g["lat_centres"])
+
+    class Sp(object):
+        def __init__(self, v):
+            self.spectrum = np.array(v, dtype=float)
+
+    bs = smm.BayesSet(tag="golden")
+    bs.add_set(pa)
+    bs.add_set(pb)
+    assert bs.n_tot == 8 and np.array_equal(bs.param_vector(), g["x0"])
+    for ip, par in enumerate(bs.params()):
+        for num in range(g["ders"].shape[1]):
+            par.store_deriv(Sp(g["ders"][ip, num]), num)
+    masks = [m for m in g["pix_masks"]]
+    assert np.array_equal(bs.build_jacobian(), g["jac"])
+    assert np.array_equal(bs.build_jacobian(masks=masks), g["jac_masked"])
+    assert np.array_equal(bs.VCM_apriori(), g["S_ap"]) and np.array_equal(bs.apriori_vector(), g["x_ap"])
+    bs.update_params(g["dx_pos"])  # two steps are halved until the parameter stays positive
+    assert np.array_equal(bs.param_vector(), g["x_after_pos"]) and np.array_equal(bs.old_params[0], g["old_params_0"])
+    assert (bs.param_vector() > 0).all()
+    for par in bs.params():
+        par.set_used()
+    sim, noi, obs = ([Sp(v) for v in g[k]] for k in ("sim", "noi", "obs"))
+    assert abs(smm.chicalc(obs, sim, noi, masks, bs.n_used_par()) - float(g["chi"])) < 1e-12 * float(g["chi"])
+    smm.inversion_algebra(obs, sim, noi, bs, lambda_LM=0.1, masks=masks)
+    bs.update_parerror()
+    assert np.allclose(bs.param_vector(), g["x_after_lm"], rtol=1e-9, atol=0)
+    assert np.allclose(bs.VCM, g["vcm"], rtol=1e-8, atol=0) and np.allclose(bs.av_kernel, g["avk"], rtol=1e-7, atol=1e-12)
+    assert np.allclose([p.ret_error for p in bs.params()], g["ret_error"], rtol=1e-8)
+    assert smm.retrieval_converged(1.0, None) == "" and smm.retrieval_converged(1.005, 1.0) == "converged"
+    assert smm.retrieval_converged(1.3, 1.0) == "raised" and smm.retrieval_converged(0.7, 1.0) == ""
+
+    class Rad(object):
+        def __init__(self, v):
+            self.spectrum = np.array(v, dtype=float)
+
+    for rot, want in zip(g["fov_rot"], g["fov_out"]):
+        rads = [Rad(v) for v in g["fov_spe"]]
+        got = smm.FOV_integr_1D(rads, pixel_rot=float(rot)).spectrum
+        assert np.allclose(got, want, rtol=1e-12, atol=0), (rot, np.abs(got / want - 1).max())
+        # the reference's quadrature error at its default tolerance: 2.5e-4 for a rotated pixel
+        exact = smm.FOV_integr_1D(rads, pixel_rot=float(rot), closed_form=True).spectrum
+        assert np.abs(exact / want - 1).max() < (1e-12 if rot == 0 else 1.5e-3)
