@@ -328,9 +328,9 @@ class SpectLine(object):
     def MakeShapeLine(self, Temp, Pres, grid=None, MM=None, Strength=1.0, verbose=False, keep_memory=False):
         """spect_classes.py:174-206.  The pressure shift is computed but, as in the
         reference (line 197), not applied; self broadening is not used (line 190)."""
-        if MM is None:
-            raise ValueError('MM (molar mass) is required: spect_base_module.find_molec_metadata is not part '
-                             'of the reference tree')
+        if MM is None:  # spect_classes.py:178-179: from molparam.txt
+            from . import spect_base_module as sbm
+            MM = sbm.find_molec_metadata(self.Mol, self.Iso)['iso_MM']
         if grid is None:
             sp_step = 5.e-4
             grid = np.arange(-imxsig * sp_step / 2, imxsig * sp_step / 2, sp_step, dtype=float)

@@ -286,3 +286,39 @@ def test_retrieval_parameter_space_against_reference(golden):
         # the reference's quadrature error at its default tolerance: 2.5e-4 for a rotated pixel
         exact = smm.FOV_integr_1D(rads, pixel_rot=float(rot), closed_form=True).spectrum
         assert np.abs(exact / want - 1).max() < (1e-12 if rot == 0 else 1.5e-3)
+
+
+def test_molparam_and_key_input_readers(tmp_path, monkeypatch):
+    """N3: HITRAN molparam.txt -> MM / isotopic ratio, and the drivers' [key] input files.  Both readers
+    belong to the absent spect_base_module: checked against the files themselves and the values the
+    reference hard-codes from them (spect_main.py:152: CH4 ratio 0.98827; SURVEY 8-d: MM 16.0313)."""
+    from spectrobot_amd import spect_base_module as sbm
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    mp = os.path.join(here, "molparam_first7.txt")
+    tab = sbm.read_molparam(mp)
+    assert len([k for k in tab if k[0] == 1]) == 6 and len([k for k in tab if k[0] == 2]) == 11
+    ch4 = sbm.find_molec_metadata(6, 1, filename=mp)
+    assert ch4["mol_name"] == "CH4" and ch4["iso_name"] == "211" and ch4["iso_MM"] == 16.0313
+    assert abs(ch4["iso_ratio"] - 0.98827) < 5e-6 and ch4["gj"] == 1 and ch4["Q_296"] == 590.52
+    co = sbm.find_molec_metadata(5, 1, filename=mp)
+    assert co["iso_MM"] == 27.994915 and co["iso_name"] == "26"
+    monkeypatch.setenv("SPECTROBOT_MOLPARAM", mp)
+    assert sbm.find_molec_metadata(6, 3)["iso_MM"] == 17.037475
+    with pytest.raises(ValueError):
+        sbm.find_molec_metadata(6, 9)
+    monkeypatch.delenv("SPECTROBOT_MOLPARAM")
+    with pytest.raises(ValueError):
+        sbm.find_molec_metadata(6, 1)
+
+    keys = "cart_atm cart_LUTS hitran_db n_threads test n_split wn_range tangent_alts".split()
+    itype = [str, str, str, int, bool, int, [float, float], float]
+    defaults = ["/a/", "/luts/", None, 4, False, None, None, None]
+    inp = sbm.read_inputs(os.path.join(here, "sample_inputs.in"), keys, itype=itype, defaults=defaults,
+                          n_lines=[1, 1, 1, 1, 1, 1, 1, 3])
+    assert inp["cart_atm"] == "/data/titan/atm/" and inp["cart_LUTS"] == "/luts/" and inp["n_threads"] == 8
+    assert inp["test"] is True and inp["n_split"] is None and inp["wn_range"] == [2850.0, 3450.0]
+    assert inp["tangent_alts"] == [150.0, 300.0, 450.0]
+    bad = tmp_path / "bad.in"
+    bad.write_text("[n_threads]\n[test]\nTrue\n")
+    with pytest.raises(ValueError):
+        sbm.read_inputs(str(bad), ["n_threads"], itype=[int])
