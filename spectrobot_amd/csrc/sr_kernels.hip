@@ -788,15 +788,17 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
       {
         const unsigned ul = __builtin_amdgcn_readlane(run2l, i), ur = __builtin_amdgcn_readlane(run2r, i);
         const int a0 = (int)(ul & 0xffffu), na = (int)(ul >> 16), b0 = (int)(ur & 0xffffu), nb = (int)(ur >> 16);
+        // item t of the run: left k = a0 + t, x = xs2l - (k - il) xstep; right k = b0 + (t - na),
+        // x = xs2r + (k - ir2) xstep.  Only x^2 enters, so both are t xstep + c with a per-line c
+        const double c_left = fma((double)(a0 - il), r.xstep, -z.xs2l);
+        const double c_right = fma((double)(b0 - na - ir2), r.xstep, z.xs2r);
+        const int i_left = a0 + base_idx, i_right = b0 - na + base_idx;
         for (int t0 = 0; t0 < na + nb; t0 += 64) {
           const int t = t0 + lane;
           if (t < na + nb) {
             const bool lf = t < na;
-            const int k = lf ? a0 + t : b0 + (t - na);
-            // -(k - il) xstep + xs2l (left run) or (k - ir2) xstep + xs2r (right run), branch-free
-            const double x = fma((double)(lf ? il - k : k - ir2), r.xstep, lf ? z.xs2l : z.xs2r);
-            const double y = region2_val(z.q2, x);
-            const int idx = k + base_idx;
+            const double y = region2_val(z.q2, fma((double)t, r.xstep, lf ? c_left : c_right));
+            const int idx = t + (lf ? i_left : i_right);
             s_a[idx] = fma(wa, y, s_a[idx]);
             s_e[idx] = fma(we, y, s_e[idx]);
           }
