@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -525,7 +526,9 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   HIPCHK(hipMemsetAsync(ls->d_zmax.p, 0, sizeof(int) * (size_t)nl, st));
 
   HIPCHK(hipEventRecord(ls->ev[0], st));
-  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, line_lo, n_sub, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(),
+  // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
+  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, line_lo, n_sub, g_far_field ? (int)g_lo : INT_MIN / 2,
+                        g_far_field ? (int)g_hi - 1 : INT_MAX / 2, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(),
                         ls->d_zmax.as<int>(), st));
   HIPCHK(hipEventRecord(ls->ev[1], st));
   if (g_far_field) {

@@ -22,7 +22,7 @@ namespace sr {
 //       spect_main_module.py:2049-2080 (population weights), lineshape.f:443-490
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, GridParams gp,
-                                                      int line_lo, int n_sub,
+                                                      int line_lo, int n_sub, int cold_lo, int cold_hi,
                                                       FastRec *__restrict__ fast,
                                                       ColdRec *__restrict__ cold,
                                                       int *__restrict__ zmax) {
@@ -79,7 +79,6 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
   r.wemi = wemi / fac;
   r.j1 = ic - kHalf;
   r.ilir = (uint32_t)B.il | ((uint32_t)B.ir << 16);
-  const ColdRec c = make_cold(B, dwp, x0, xf);
   {
     const int lane = threadIdx.x & 63, n_valid = min(64, n_sub - wave_first);
     uint4 *buf = s_rec[threadIdx.x >> 6];
@@ -95,15 +94,23 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
     for (int q = 0; q < NF; ++q)
       if (q * 64 + lane < n_valid * NF) gf[q * 64 + lane] = buf[q * 64 + lane];
     __builtin_amdgcn_wave_barrier();
-    const uint4 *cp = reinterpret_cast<const uint4 *>(&c);
+    // The cold record (regions 2-4) is read only for lines whose zone meets [cold_lo, cold_hi]: in
+    // far-field mode that is the shard, so the halo lines of a multi-GPU shard (half of its lines
+    // at 8 GPUs) skip its computation and its 128 B; exact mode reads it for window ends too and
+    // passes the whole index range.
+    const int zl = r.j1 + B.il - 1, zh = r.j1 + B.ir - 1;
+    if (__any(valid && zl <= cold_hi && zh >= cold_lo)) {
+      const ColdRec c = make_cold(B, dwp, x0, xf);
+      const uint4 *cp = reinterpret_cast<const uint4 *>(&c);
 #pragma unroll
-    for (int q = 0; q < NC; ++q) buf[lane * NC + q] = cp[q];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    uint4 *gc = reinterpret_cast<uint4 *>(cold + o);
+      for (int q = 0; q < NC; ++q) buf[lane * NC + q] = cp[q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      uint4 *gc = reinterpret_cast<uint4 *>(cold + o);
 #pragma unroll
-    for (int q = 0; q < NC; ++q)
-      if (q * 64 + lane < n_valid * NC) gc[q * 64 + lane] = buf[q * 64 + lane];
+      for (int q = 0; q < NC; ++q)
+        if (q * 64 + lane < n_valid * NC) gc[q * 64 + lane] = buf[q * 64 + lane];
+    }
   }
   // widest region-2/3/4 zone of the layer, in grid points from the window centre
   // (k = 6506): tells sr_abscoeff_cores_kernel how far to look for candidates
@@ -859,11 +866,12 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcInde
   return (int)hipGetLastError();
 }
 
-int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub,
-                FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st) {
+int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub, int cold_lo,
+                int cold_hi, FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st) {
   if (n_sub <= 0 || A.n_layers <= 0) return 0;
   dim3 grid((n_sub + 255) / 256, A.n_layers);
-  hipLaunchKernelGGL(sr_prep_kernel, grid, dim3(256), 0, st, L, A, gp, line_lo, n_sub, fast, cold, zmax);
+  hipLaunchKernelGGL(sr_prep_kernel, grid, dim3(256), 0, st, L, A, gp, line_lo, n_sub, cold_lo, cold_hi, fast, cold,
+                     zmax);
   return (int)hipGetLastError();
 }
 

@@ -57,8 +57,8 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcInde
                 int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp, double *abs_out,
                 double *emi_out, hipStream_t st);
 
-int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub,
-                FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st);
+int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub, int cold_lo,
+                int cold_hi, FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st);
 int abscoeff_tile_points(int variant);
 // which = 0: wings kernel (writes abs/emi), 1: cores kernel (adds into them)
 int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *cold, const IcIndex &ix,
