@@ -557,8 +557,9 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   for (int rg = 0; rg < 3; ++rg) {
     for (int base = rs[rg]; base < re[rg]; base += 64) {
       const int lv = base + lane;
-      // bits 0-3: slot lies wholly in one wing; bit 4: all four do, same wing; bits 5-8: slot has
-      // region-1 points but also zone points or a window end
+      // bits 0-3: slot lies wholly in one wing; bit 4: all four do, same wing.  Slots that also hold
+      // zone points, a window end or the grid end have region-1 points on one side only (bits 5-8
+      // left wing, 9-12 right wing) unless a zone narrower than the slot lies inside it (13-16)
       int flags = 0;
       if (lv < re[rg]) {
         const int j1 = frow[lv].j1;
@@ -568,8 +569,13 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
         for (int p = 0; p < 4; ++p) {
           const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
           if (slo <= whi && jN >= slo && j1 <= shi && !ff_admissible(j1, il, ir, slo, slo + 63, thr0)) {
-            if (classify(j1, il, ir, slo, shi) != 0) flags |= 1 << p;
-            else if (slo < j1 + il - 1 || shi > j1 + ir - 1) flags |= 32 << p; // some point outside the zone
+            if (classify(j1, il, ir, slo, shi) != 0) {
+              flags |= 1 << p;
+            } else {
+              const bool has_l = max(slo, j1) <= min(shi, j1 + il - 2); // points with 1 <= k < il
+              const bool has_r = max(slo, j1 + ir) <= min(shi, jN);     // points with ir < k <= 13010
+              flags |= (has_l && has_r ? 8192 : (has_l ? 32 : (has_r ? 512 : 0))) << p;
+            }
           }
         }
         if (flags == 15 && classify(j1, il, ir, wlo, whi) != 0) flags = 16;
@@ -594,14 +600,36 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
           acc_a[p] = fma(r.wabs, y, acc_a[p]);
           acc_e[p] = fma(r.wemi, y, acc_e[p]);
         }
-        // slot with zone points, a window end or the grid end: per-lane mask (branch-free body)
+        // left-wing points only, k in [1, min(il - 1, end of the group)]: x = (k - 1) xstep - xl (= -x)
         for (unsigned long long todo = __ballot((flags & (32 << p)) != 0); todo; todo &= todo - 1) {
+          const FastRec r = frow[base + __builtin_ctzll(todo)];
+          const int km1 = lp[p] + (wlo - r.j1); // k - 1
+          const double x = fma((double)km1, r.xstep, -r.xl);
+          const double x2 = x * x;
+          double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma3s(x2, fma3s(x2, 4.0, r.d), r.c));
+          y = (unsigned)km1 <= (unsigned)(min(r.il() - 1, whi - r.j1 + 1) - 1) ? y : 0.0;
+          acc_a[p] = fma(r.wabs, y, acc_a[p]);
+          acc_e[p] = fma(r.wemi, y, acc_e[p]);
+        }
+        // right-wing points only, k in [ir + 1, min(13010, end of the group)]: x = (k - ir) xstep + xr
+        for (unsigned long long todo = __ballot((flags & (512 << p)) != 0); todo; todo &= todo - 1) {
+          const FastRec r = frow[base + __builtin_ctzll(todo)];
+          const int ir = r.ir();
+          const int kmr = lp[p] + (wlo - r.j1 + 1 - ir); // k - ir
+          const double x = fma((double)kmr, r.xstep, r.xr);
+          const double x2 = x * x;
+          double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma3s(x2, fma3s(x2, 4.0, r.d), r.c));
+          y = (unsigned)(kmr - 1) <= (unsigned)(min(kImxsig, whi - r.j1 + 1) - ir - 1) ? y : 0.0;
+          acc_a[p] = fma(r.wabs, y, acc_a[p]);
+          acc_e[p] = fma(r.wemi, y, acc_e[p]);
+        }
+        // both wings in one slot (a zone narrower than the slot): per-lane side
+        for (unsigned long long todo = __ballot((flags & (8192 << p)) != 0); todo; todo &= todo - 1) {
           const FastRec r = frow[base + __builtin_ctzll(todo)];
           const int j1 = r.j1, il = r.il(), ir = r.ir();
           const int klo = max(1, wlo - j1 + 1), khi = min(kImxsig, whi - j1 + 1); // window and group, as k
           const int k = lp[p] + (wlo - j1 + 1);                                   // 1-based window index
           const bool left = k < il; // region 1: k < il or k > ir (lineshape.f:461-477, last writer wins)
-          // x = (k - 1) xstep - xl (left, = -x) or (k - ir) xstep + xr (right): wing_x_at per lane
           const double x = fma((double)(k - (left ? 1 : ir)), r.xstep, left ? -r.xl : r.xr);
           const double x2 = x * x;
           double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma3s(x2, fma3s(x2, 4.0, r.d), r.c));
