@@ -527,14 +527,16 @@ __device__ inline void near_ranges(const IcIndex &ix, int wlo, int width, int zm
   rs[2] = max(b0, re[1]); re[2] = max(b1, rs[2]);
 }
 
-// One group of 256 points (4 slots) per wave (two groups per wave measured slower: occupancy, SGPR
-// spills).  The walk is per SLOT: a ballot per slot and kind, and a loop body without flag tests --
+// NS slots of 64 points per wave: 4 (two groups of 4 per wave measured slower: occupancy, SGPR
+// spills), or 2 for small shards, where 4 leave wave slots empty and a wave's own latency is the
+// kernel time.  The walk is per SLOT: a ballot per slot and kind, and a loop body without flag tests --
 // the shared scalar unit is what bounds this kernel (walking the lines once with per-slot flag
 // tests and a record prefetch cost 117 scalar instructions per line against 100 vector ones).
+template <int NS>
 __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
     const FastRec *__restrict__ fast, IcIndex ix, const int *__restrict__ zmax, int n_sub,
     int n_tiles, int g_lo, int g_hi, FarParams fp, double *__restrict__ abs_out, double *__restrict__ emi_out) {
-  constexpr int NS = 4, WT = kGroup;
+  constexpr int WT = 64 * NS;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
   const int wlo = g_lo + tile * WT;
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
         const unsigned ilir = frow[lv].ilir;
         const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NS; ++p) {
           const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
           if (slo <= whi && jN >= slo && j1 <= shi && !ff_admissible(j1, il, ir, slo, slo + 63, thr0)) {
             if (classify(j1, il, ir, slo, shi) != 0) {
@@ -578,17 +580,19 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
             }
           }
         }
-        if (flags == 15 && classify(j1, il, ir, wlo, whi) != 0) flags = 16;
+        if (NS == 4 && flags == 15 && classify(j1, il, ir, wlo, whi) != 0) flags = 16;
       }
       if (__ballot(flags != 0) == 0) continue;
       // four whole slots in one wing: shared reciprocal
-      for (unsigned long long todo = __ballot(flags == 16); todo; todo &= todo - 1) {
-        const FastRec r = frow[base + __builtin_ctzll(todo)];
-        const int cls = wlo < r.j1 + kHalf ? 1 : 2; // the group lies before / after the line centre
-        wing_eval4(wing_x_at(r, cls, r.j1, wlo), r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl, acc_a, acc_e);
+      if constexpr (NS == 4) {
+        for (unsigned long long todo = __ballot(flags == 16); todo; todo &= todo - 1) {
+          const FastRec r = frow[base + __builtin_ctzll(todo)];
+          const int cls = wlo < r.j1 + kHalf ? 1 : 2; // the group lies before / after the line centre
+          wing_eval4(wing_x_at(r, cls, r.j1, wlo), r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl, acc_a, acc_e);
+        }
       }
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < NS; ++p) {
         const int slo = wlo + 64 * p;
         // whole slot in one wing
         for (unsigned long long todo = __ballot((flags & (1 << p)) != 0); todo; todo &= todo - 1) {
@@ -874,8 +878,10 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcInde
   const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
   const dim3 grid((unsigned)(n_groups * n_layers));
   if (part == 1) {
-    hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel, grid, dim3(64), 0, st, fast, ix, zmax, n_sub, n_groups,
-                       g_lo, g_hi, fp, abs_out, emi_out);
+    // slots per wave: 4 (256-point groups) measured 2.53 ms on config 2, 2: 2.31 ms, 1: see DESIGN.md
+    const int n_g1 = (g_hi - g_lo + 63) / 64;
+    hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<1>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st, fast,
+                       ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, abs_out, emi_out);
   } else {
     // Image width: wider images cut fewer zones in two (fewer (line, group) pairs: 7.1 -> 6.7 ms on
     // 1e5 points x 80 layers with 512 instead of 256) as long as the waves still fill the chip
