@@ -7,7 +7,7 @@
 //   matrix, coalesced fp64 stores; fp64 VALU bound, no MFMA: not a contraction):
 //     default  sr_farfield_kernel            far region-1 wings as per-box Taylor sums
 //              sr_abscoeff_near_wings_kernel  exact region 1 of the near lines + polynomials
-//              sr_abscoeff_near_zones_kernel  regions 2/3/4, lanes packed by region
+//              sr_abscoeff_near_zones_kernel  regions 2/3/4 through an LDS image of the group
 //     exact    sr_abscoeff_wings_kernel / sr_abscoeff_cores_kernel: every evaluation
 //   sr_radiance_kernel / sr_radiance_jac_kernel   limb recursion (+ Jacobian) per (point, ray)
 //   sr_lowres_kernel    Gaussian ILS onto low-resolution bands (hires_to_lowres)
@@ -493,20 +493,19 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
     fp.coef[((size_t)layer * fp.n_boxes_total + fp.box_off[level] + b) * (2 * kFC) + n_out] = v[0];
 }
 
-// Exact near field + evaluation of the far-field polynomials: one wave per group of
-// 256 points.  The scalar unit is shared by the CU's four SIMDs, so ownership tests
-// run on the VALU, 64 candidate lines at a time (lane = line); a ballot marks the
-// lines with work and only those are walked, their records fetched by scalar loads.
+// Exact near field + evaluation of the far-field polynomials.  The scalar unit is shared by
+// the CU's four SIMDs, so ownership tests and interval arithmetic run on the VALU, 64 candidate
+// lines at a time (lane = line); ballots mark the lines with work and only those are walked,
+// their records fetched by scalar loads.
 //
-// sr_abscoeff_near_wings_kernel: every REGION-1 point of the lines that no
-//   far-field level owns for a slot (whole slots with one reciprocal per four
-//   points where possible; slots that also hold zone points or a window end with
-//   a per-lane mask), plus one far-field polynomial per level; writes abs/emi.
-// sr_abscoeff_near_zones_kernel: the region-2/3/4 points.  Lanes are packed by
-//   REGION, not by position: the region-2 points of a line (two intervals), its
-//   region-4 points (two intervals) and its region-3 points each form one run of
-//   consecutive lanes executing uniform code; the sums go through a 256-point LDS
-//   image of the group (one wave per block: read-modify-write is race-free).
+// sr_abscoeff_near_wings_kernel (one 64-point slot per wave): every REGION-1 point of the
+//   lines that no far-field level owns for the slot -- whole slots, and slots that also hold
+//   zone points, a window end or the grid end with a one-sided per-lane mask -- plus one
+//   far-field polynomial per level; writes abs/emi.
+// sr_abscoeff_near_zones_kernel (one 256/512-point LDS image per wave; adds to abs/emi):
+//   region 3 (~15 points per line) with lanes = lines in the chunk phase; region 2 as one run
+//   of consecutive lanes per line; region 4 packed ACROSS lines into full 64-lane chunks
+//   (pending points carry their line's parameters; LDS atomics).
 // ------------------------------------------------------------------------
 __device__ inline void near_ranges(const IcIndex &ix, int wlo, int width, int zm,
                                    int rs[3], int re[3]) {
