@@ -536,6 +536,7 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     fp.n_levels = kMaxFarLevels;
     fp.n_layers = nl;
     fp.n_boxes_total = 0;
+    fp.top_first = n_pts <= 16384 ? 1 : 0; // see sr_farfield_kernel
     for (int lv = 0; lv < kMaxFarLevels; ++lv) {
       const int W = 64 << lv;
       fp.box_count[lv] = (int)((n_pts + W - 1) / W);

@@ -385,16 +385,40 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
                                                          IcIndex ix,
                                                          const int *__restrict__ zmax, int n_sub, int g_lo,
                                                          int /*g_hi*/, FarParams fp) {
-  // block -> (layer, level, box).  Layer-major, each XCD working through its own run of
-  // layers (xcd_remap): the blocks resident on an XCD then share one stretch of one layer's
-  // record row, which its L2 holds; within a layer the widest (longest-running) boxes first.
+  // block -> (layer, level, box).  Layers are taken in groups of ceil(n_layers / 8); xcd_remap
+  // gives each XCD a contiguous run of work ids, i.e. (about) one group.  Inside a group: first
+  // the two widest levels of ALL its layers (a 1024-point box runs ~100 us; left to the end of
+  // the last layer, as in a plain layer-major order, those were the tail of the kernel: 0.36 vs
+  // 0.27 ms expected on a 1/8 shard), then layer by layer the narrower levels, widest first, so
+  // that the blocks resident on an XCD share one stretch of one layer's record row, which its
+  // L2 holds.  On the full grid that locality is worth more than the tail (2.14 ms against 2.66 with
+  // the wide levels first, 2.76 fully level-major), so the host asks for it on small shards only.
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
-  const int layer = wid / fp.n_boxes_total;
-  int idx = wid - layer * fp.n_boxes_total;
-  int level = fp.n_levels - 1;
-  while (level > 0 && idx >= fp.box_count[level]) {
-    idx -= fp.box_count[level];
-    --level;
+  const int lg = (fp.n_layers + 7) / 8;                       // layers per group
+  const int grp = wid / (lg * fp.n_boxes_total);
+  const int l_first = grp * lg, l_cnt = min(lg, fp.n_layers - l_first);
+  int idx = wid - grp * lg * fp.n_boxes_total;                // within the group
+  const int n_top = fp.top_first ? min(2, fp.n_levels - 1) : 0; // levels taken first (small shards only)
+  int level = fp.n_levels - 1, layer = -1;
+  for (int t = 0; t < n_top && layer < 0; ++t, --level) {
+    const int cnt = l_cnt * fp.box_count[level];
+    if (idx < cnt) {
+      layer = l_first + idx / fp.box_count[level];
+      idx -= (layer - l_first) * fp.box_count[level];
+      ++level; // undo the loop's decrement
+    } else {
+      idx -= cnt;
+    }
+  }
+  if (layer < 0) { // the narrower levels, layer-major
+    int per_layer = 0;
+    for (int lv = 0; lv <= level; ++lv) per_layer += fp.box_count[lv];
+    layer = l_first + idx / per_layer;
+    idx -= (layer - l_first) * per_layer;
+    while (level > 0 && idx >= fp.box_count[level]) {
+      idx -= fp.box_count[level];
+      --level;
+    }
   }
   const int b = idx;
   const int lane = threadIdx.x;

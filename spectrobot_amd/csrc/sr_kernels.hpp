@@ -46,6 +46,7 @@ constexpr int kFC = kFD + 1;   // coefficients per box and output
 constexpr int kMaxFarLevels = 5;
 struct FarParams {
   int n_levels, n_layers, n_boxes_total;
+  int top_first; // block order of sr_farfield_kernel: widest two levels of a layer group first
   int box_count[kMaxFarLevels], box_off[kMaxFarLevels];
   const int *pm; // [n_layers] pole margin in grid points
   double *coef;  // [n_layers][n_boxes_total][2][kFC]
