@@ -754,17 +754,21 @@ __device__ inline void core_push(CorePend &P, int &fill, int lane, int a0, int n
 
 // WT points per wave (a multiple of 64): the wider the image, the fewer zones are cut in two by
 // its ends (a zone is ~280 points), i.e. the fewer partially filled lane runs.
-template <int WT>
-__global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
+template <int WT, int NW>
+__global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, IcIndex ix,
     const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp,
     double *__restrict__ abs_out, double *__restrict__ emi_out) {
-  __shared__ double s_a[WT], s_e[WT];
+  __shared__ double s_img[NW][2][WT]; // one private image per wave: abs, emi
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_groups, grp = wg - layer * n_groups;
   const int wlo = g_lo + grp * WT;
   const int whi = min(wlo + WT, g_hi) - 1;
-  const int lane = threadIdx.x;
+  // NW waves work on the same group and take its 64-line chunks in turn, each into its own image
+  // (added up in wave order at the end: the result does not depend on timing).  For small shards,
+  // where one wave per 512-point image leaves wave slots empty and 256-point images cut more zones.
+  const int lane = NW == 1 ? threadIdx.x : threadIdx.x & 63, wave = NW == 1 ? 0 : threadIdx.x >> 6;
+  double *const s_a = s_img[wave][0], *const s_e = s_img[wave][1];
   const int zm = min(zmax[layer], kHalf - 1);
 #pragma unroll
   for (int p = 0; p < WT / 64; ++p) s_a[lane + 64 * p] = s_e[lane + 64 * p] = 0.;
@@ -777,7 +781,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
   const int l0 = lower_bound_ic(ix, wlo - zm), l1 = lower_bound_ic(ix, whi + zm + 1);
   const FastRec *frow = fast + (size_t)layer * n_sub;
   const ColdRec *crow = cold + (size_t)layer * n_sub;
-  for (int base = l0; base < l1; base += 64) {
+  for (int base = l0 + 64 * wave; base < l1; base += 64 * NW) {
     const int lv = min(base + lane, l1 - 1);
     bool act;
     // runs of the lane's line inside this group, start | count << 16 (window indices <= 13010):
@@ -875,13 +879,19 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_zones_kernel(
     }
   }
   core_eval<4>(p4, lane < fill4, gp, s_a, s_e); // what is still waiting
+  if (NW > 1) __syncthreads();
   const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
-#pragma unroll
-  for (int p = 0; p < WT / 64; ++p) {
-    const int j = wlo + lane + 64 * p;
+  for (int p = threadIdx.x; p < WT; p += 64 * NW) {
+    const int j = wlo + p;
     if (j <= whi) {
-      abs_out[row + (j - g_lo)] += s_a[lane + 64 * p];
-      emi_out[row + (j - g_lo)] += s_e[lane + 64 * p];
+      double ta = s_img[0][0][p], te = s_img[0][1][p];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        ta += s_img[w][0][p];
+        te += s_img[w][1][p];
+      }
+      abs_out[row + (j - g_lo)] += ta;
+      emi_out[row + (j - g_lo)] += te;
     }
   }
 }
@@ -910,15 +920,17 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcInde
     // 1e5 points x 80 layers with 512 instead of 256) as long as the waves still fill the chip
     // several times over (1024: 9.3 ms, too few waves and 16 KB LDS each).
     const long waves512 = (long)((g_hi - g_lo + 511) / 512) * n_layers;
-    const bool wide = waves512 >= 3 * 4096;
-    const int n_t = (g_hi - g_lo + (wide ? 511 : 255)) / (wide ? 512 : 256);
+    const int n_t = (g_hi - g_lo + 511) / 512;
     const dim3 gz((unsigned)(n_t * n_layers));
-    if (wide)
-      hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel<512>, gz, dim3(64), 0, st, fast, cold, ix, zmax, n_sub, n_t,
-                         g_lo, g_hi, gp, abs_out, emi_out);
+    if (waves512 >= 3 * 4096)
+      hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 1>), gz, dim3(64), 0, st, fast, cold, ix, zmax, n_sub,
+                         n_t, g_lo, g_hi, gp, abs_out, emi_out);
+    else if (waves512 >= 3 * 2048)
+      hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 2>), gz, dim3(128), 0, st, fast, cold, ix, zmax, n_sub,
+                         n_t, g_lo, g_hi, gp, abs_out, emi_out);
     else
-      hipLaunchKernelGGL(sr_abscoeff_near_zones_kernel<256>, gz, dim3(64), 0, st, fast, cold, ix, zmax, n_sub, n_t,
-                         g_lo, g_hi, gp, abs_out, emi_out);
+      hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 4>), gz, dim3(256), 0, st, fast, cold, ix, zmax, n_sub,
+                         n_t, g_lo, g_hi, gp, abs_out, emi_out);
   }
   return (int)hipGetLastError();
 }
