@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--exact", action="store_true", help="evaluate every (line, point) exactly (no far-field expansions)")
     args = ap.parse_args()
 
+    import __graft_entry__
+    __graft_entry__.ensure_built(builder=int(os.environ.get("LOCAL_RANK", "0")) == 0)  # fresh checkouts carry no library
     import torch
     from spectrobot_amd import engine, synthetic as syn, distributed as sd
     from spectrobot_amd._lib import lib, dp

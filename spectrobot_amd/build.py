@@ -25,10 +25,27 @@ def build(force=False, verbose=False, extra=()):
     if not force and up_to_date():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [HIPCC] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    tmp = "%s.tmp.%d" % (OUT, os.getpid())  # other processes never see a half-written library
+    cmd = [HIPCC] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(cmd).replace(tmp, OUT))
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, OUT)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    return OUT
+
+
+def wait_until_built(timeout=600.0):
+    """For the ranks that do not build: wait for the building rank's library."""
+    import time
+    t0 = time.time()
+    while not up_to_date():
+        if time.time() - t0 > timeout:
+            raise RuntimeError("libspectrobot_hip.so was not built within %.0f s" % timeout)
+        time.sleep(0.5)
     return OUT
 
 
