@@ -94,11 +94,14 @@ def test_all_gather_spectrum_gloo_world2(tmp_path):
         "sys.path.insert(0, %r)\n"
         "from spectrobot_amd import distributed as sd\n"
         "rank, local, world = sd.init_from_env(backend='gloo')\n"
-        "n, rays = 1001, 3\n"
-        "full = torch.arange(rays * n, dtype=torch.float64).reshape(rays, n)\n"
-        "lo, hi = sd.shard_bounds(n, world, rank)\n"
-        "out = sd.all_gather_spectrum(full[:, lo:hi].contiguous(), n, world, rank)\n"
-        "assert torch.equal(out, full), rank\n"
+        "for n, rays in ((1001, 3), (1000, 1), (1000, 3)):   # ragged shards; equal shards: in place / one copy\n"
+        "    full = torch.arange(rays * n, dtype=torch.float64).reshape(rays, n)\n"
+        "    lo, hi = sd.shard_bounds(n, world, rank)\n"
+        "    out = sd.all_gather_spectrum(full[:, lo:hi].contiguous(), n, world, rank)\n"
+        "    assert torch.equal(out, full), (rank, n, rays)\n"
+        "    buf = torch.zeros((rays, n), dtype=torch.float64)\n"
+        "    assert sd.all_gather_spectrum(full[:, lo:hi].contiguous(), n, world, rank, out=buf) is buf\n"
+        "    assert torch.equal(buf, full), (rank, n, rays)\n"
         "torch.distributed.barrier()\n"
         "print('rank', rank, 'ok')\n" % ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
