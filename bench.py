@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s mea
 FLOP_PER_EVAL = 16             # SURVEY 8-d flop model per (line, layer, grid point)
 
 
-def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total):
+def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total, gpu=None):
     """Oracle (kind 'port', mode 1 = direct accumulate) on all host cores over a bounded
     sample of the SAME workload: all lines, full grid, the first `ns` layers."""
     from oracle import oracle as O
@@ -49,13 +49,21 @@ def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total):
     sel = np.linspace(0, n_layers_total - 1, ns).round().astype(int)
     tv = None if atm["tvib"] is None else atm["tvib"][:, sel]
     t0 = time.time()
-    O.abscoeff_layers(L, mm, e_lev, atm["temps"][sel], atm["press"][sel], q_part[sel], tv, grid, mode=1,
-                      n_threads=cores)
+    abo, emo = O.abscoeff_layers(L, mm, e_lev, atm["temps"][sel], atm["press"][sel], q_part[sel], tv, grid, mode=1,
+                                 n_threads=cores)
     dt = time.time() - t0
     out = {"value": (ns / n_layers_total) / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
            "sample": "%d of %d layers (evenly spaced), all %d lines, full %d-point grid, coefficients only, "
                      "%.1f s wall; extrapolated x%d/%d" % (ns, n_layers_total, len(L["freq"]), len(grid), dt,
                                                           n_layers_total, ns)}
+    if gpu is not None:  # the checker: the timed GPU result against the oracle at the BASELINE size
+        ab, em = (t[sel].cpu().numpy() for t in gpu)
+        out["parity_vs_oracle"] = {
+            "layers": int(ns), "points": int(abo.size),
+            "max_rel_err_abs": float(np.max(np.abs(ab - abo) / np.abs(abo))),
+            "max_rel_err_emi": float(np.max(np.abs(em - emo) / np.abs(emo))),
+            "note": "coefficient spectra of the timed far-field run vs the CPU oracle on the sampled layers, "
+                    "full grid, all lines; requirement 1e-6"}
     # reference's own Fortran kernel (oracle/_ref, compiled from the reference sources), 1 core
     try:
         from oracle import ref_fortran as RF
@@ -248,8 +256,13 @@ def main():
                                "sr_abscoeff_cores_kernel": float(exact_kms[2])},
                 "checksum": exact_checksum}
         if world == 1 and args.cpu_seconds > 0:
+            gpu = None
+            if not args.shard:  # ab / em hold the last exact-mode step: recompute the timed mode's result
+                step()
+                torch.cuda.synchronize()
+                gpu = (ab, em)
             out["cpu_baseline"] = cpu_baseline(L, atm, grid, syn.CH4_MM, e_lev, q_part, args.cpu_seconds,
-                                               args.layers)
+                                               args.layers, gpu=gpu)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
