@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
   // 80 / 128 B stride across the lanes, which the memory side handles badly (1.8 TB/s); the
   // wave's 64 records are contiguous in the table, so they are transposed and stored 1 KB per
   // instruction instead.
-  __shared__ uint4 s_rec[4][64 * sizeof(ColdRec) / 16];
+  __shared__ uint4 s_rec[4][64 * sizeof(FastRec) / 16]; // the 128-byte cold record goes in two halves
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
   const int wave_first = i0 - (threadIdx.x & 63);
@@ -102,14 +102,22 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
     if (__any(valid && zl <= cold_hi && zh >= cold_lo)) {
       const ColdRec c = make_cold(B, dwp, x0, xf);
       const uint4 *cp = reinterpret_cast<const uint4 *>(&c);
-#pragma unroll
-      for (int q = 0; q < NC; ++q) buf[lane * NC + q] = cp[q];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
       uint4 *gc = reinterpret_cast<uint4 *>(cold + o);
+      constexpr int NH = NC / 2; // 16-byte pieces per half record
 #pragma unroll
-      for (int q = 0; q < NC; ++q)
-        if (q * 64 + lane < n_valid * NC) gc[q * 64 + lane] = buf[q * 64 + lane];
+      for (int half = 0; half < 2; ++half) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < NH; ++q) buf[lane * NH + q] = cp[half * NH + q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // piece m of the half-record table: record m / NH, piece m % NH of this half
+#pragma unroll
+        for (int q = 0; q < NH; ++q) {
+          const int m = q * 64 + lane;
+          if (m < n_valid * NH) gc[(m / NH) * NC + half * NH + (m % NH)] = buf[m];
+        }
+      }
     }
   }
   // widest region-2/3/4 zone of the layer, in grid points from the window centre
