@@ -992,13 +992,29 @@ __global__ __launch_bounds__(256) void sr_radiance_kernel(const double *__restri
   if (j >= n_pts) return;
   double I = init_from_rad ? rad[(size_t)ray * n_pts + j] : 0.0;
   const int s0 = seg_off[ray], s1 = seg_off[ray + 1];
-  for (int s = s0; s < s1; ++s) {
-    const size_t o = (size_t)seg_layer[s] * n_pts + j;
-    const double u = seg_col[s];
-    const double tau = abs_c[o] * u;
-    const double em1 = -expm1(-tau);
-    const double src = fabs(tau) > 1e-12 ? (emi_c[o] * u) * (em1 / tau) : emi_c[o] * u;
-    I = I * exp(-tau) + src;
+  // The recursion is sequential in the segments and a 1-ray launch has only ~1.5 waves per SIMD,
+  // so the coefficient loads of kB segments are issued together ahead of their use (one memory
+  // latency per kB segments instead of one per segment: 147 -> ~40 us for 160 segments x 1e5 points)
+  constexpr int kB = 8;
+  for (int sb = s0; sb < s1; sb += kB) {
+    double a[kB], e[kB], u[kB];
+#pragma unroll
+    for (int t = 0; t < kB; ++t) {
+      const int s = min(sb + t, s1 - 1);
+      const size_t o = (size_t)seg_layer[s] * n_pts + j;
+      a[t] = abs_c[o];
+      e[t] = emi_c[o];
+      u[t] = seg_col[s];
+    }
+#pragma unroll
+    for (int t = 0; t < kB; ++t) {
+      if (sb + t < s1) {
+        const double tau = a[t] * u[t];
+        const double em1 = -expm1(-tau);
+        const double src = fabs(tau) > 1e-12 ? (e[t] * u[t]) * (em1 / tau) : e[t] * u[t];
+        I = I * exp(-tau) + src;
+      }
+    }
   }
   rad[(size_t)ray * n_pts + j] = I;
 }
