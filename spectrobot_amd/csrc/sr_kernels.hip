@@ -1040,20 +1040,33 @@ __global__ __launch_bounds__(256) void sr_radiance_jac_kernel(const double *__re
 #pragma unroll
   for (int q = 0; q < NP; ++q) J[q] = 0.0;
   const int s0 = seg_off[ray], s1 = seg_off[ray + 1];
-  for (int s = s0; s < s1; ++s) {
-    const size_t o = (size_t)seg_layer[s] * n_pts + j;
-    const double u = seg_col[s], a = abs_c[o], e = emi_c[o];
-    const double tau = a * u;
-    const double t = exp(-tau);
-    const double em1 = -expm1(-tau);
-    const double src = fabs(tau) > 1e-12 ? (e * u) * (em1 / tau) : e * u;
-    const double g = t * (e - a * I);
+  constexpr int kB = 8; // coefficient loads of kB segments ahead of the recursion, as in sr_radiance_kernel
+  for (int sb = s0; sb < s1; sb += kB) {
+    double av[kB], ev[kB];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const double d = (p0 + q < n_par) ? dcol[(size_t)s * n_par + p0 + q] : 0.0;
-      J[q] = fma(J[q], t, g * d);
+    for (int t = 0; t < kB; ++t) {
+      const size_t o = (size_t)seg_layer[min(sb + t, s1 - 1)] * n_pts + j;
+      av[t] = abs_c[o];
+      ev[t] = emi_c[o];
     }
-    I = I * t + src;
+#pragma unroll
+    for (int k = 0; k < kB; ++k) {
+      const int s = sb + k;
+      if (s < s1) {
+        const double u = seg_col[s], a = av[k], e = ev[k];
+        const double tau = a * u;
+        const double t = exp(-tau);
+        const double em1 = -expm1(-tau);
+        const double src = fabs(tau) > 1e-12 ? (e * u) * (em1 / tau) : e * u;
+        const double g = t * (e - a * I);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const double d = (p0 + q < n_par) ? dcol[(size_t)s * n_par + p0 + q] : 0.0;
+          J[q] = fma(J[q], t, g * d);
+        }
+        I = I * t + src;
+      }
+    }
   }
   if (blockIdx.z == 0) rad[(size_t)ray * n_pts + j] = I;
 #pragma unroll
