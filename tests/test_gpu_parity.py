@@ -469,3 +469,28 @@ def test_vmr_retrieval_loop(eng):
     assert (dev[well] < 4.0).all(), dev
     assert (np.abs(out["x_ret"] - out["x_true"])[well] < np.abs(out["x_ap"] - out["x_true"])[well]).all()
     assert 1.5 < out["avk_trace"] <= 5.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_grid,n_layers", [(50000, 64), (101000, 63), (20000, 5)])
+def test_zones_kernel_wave_sharing_paths(eng, n_grid, n_layers):
+    """The zones kernel runs 1, 2 or 4 waves per 512-point group depending on ceil(n_pts/512)*n_layers
+    (>= 12288: 1; >= 6144: 2; else 4, each wave with a private image merged in wave order).  Every
+    path against the exact mode, twice (the result must not depend on timing)."""
+    from spectrobot_amd import synthetic as syn
+    waves512 = -(-n_grid // 512) * n_layers
+    assert (waves512 >= 12288, 6144 <= waves512 < 12288, waves512 < 6144) == \
+        {(50000, 64): (False, True, False), (101000, 63): (True, False, False), (20000, 5): (False, False, True)}[(n_grid, n_layers)]
+    grid = syn.make_grid(2980.0, 5e-4, n_grid)
+    L = syn.make_lines(2500, grid, seed=77, n_levels=12)
+    atm = syn.make_atmosphere(n_layers, 12)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    eng.set_far_field(0)
+    a0, e0 = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
+    eng.set_far_field(1)
+    a1, e1 = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
+    a2, e2 = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
+    assert bool((a1 == a2).all()) and bool((e1 == e2).all())
+    assert float(((e1 - e0).abs() / e0.abs()).max()) < 2e-11
+    nz = a0 != 0
+    assert float(((a1 - a0)[nz].abs() / a0[nz].abs()).max()) < 1e-9   # absorption: populations may cancel
