@@ -202,6 +202,11 @@ int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double 
  * line's own contribution), near field exact.  0: every (line, point) evaluated
  * exactly (sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel). */
 int sr_set_far_field(int on);
+/* Far-field mode only.  1 (default): sr_abscoeff_near_zones_kernel runs on a second, internal
+ * stream beside sr_farfield_kernel (it needs the record tables only) and the wings kernel joins
+ * both; the caller's stream sees the op complete in order as before.  0: the four kernels one
+ * after the other on the caller's stream (per-kernel times for sr_last_kernel_ms). */
+int sr_set_overlap(int on);
 /* Memory knob: the per-(line, layer) record tables (208 B each) of one launch are kept
  * under this many bytes (default 48 GiB of the 288 GB); a longer layer stack (the reference
  * allows imxstp = 8000 LOS steps) is processed in batches of layers. */
@@ -211,11 +216,12 @@ int sr_set_points_per_lane(int p);
 
 /* Timing hook for bench.py: HIP-event times (ms) of the kernels of the most
  * recent sr_abscoeff_layers* call on this lineset, measured on the stream they
- * were launched on: ms5[0] sr_prep_kernel; far-field mode: ms5[1]
- * sr_farfield_kernel, ms5[2] sr_abscoeff_near_wings_kernel, ms5[3]
- * sr_abscoeff_near_zones_kernel; exact mode: ms5[1] sr_abscoeff_wings_kernel,
- * ms5[2] sr_abscoeff_cores_kernel; unused entries 0 (ms5[4] is reserved).
- * Synchronises. */
+ * were launched on.  ms5[0] sr_prep_kernel.  Far-field mode with overlap (the
+ * default): ms5[1] = the whole coefficient op (far field + near wings + near
+ * zones, which run partly side by side), rest 0.  Far-field mode without overlap:
+ * ms5[1] sr_farfield_kernel, ms5[2] sr_abscoeff_near_wings_kernel, ms5[3]
+ * sr_abscoeff_near_zones_kernel.  Exact mode: ms5[1] sr_abscoeff_wings_kernel,
+ * ms5[2] sr_abscoeff_cores_kernel.  Unused entries 0.  Synchronises. */
 int sr_last_kernel_ms(sr_lineset *ls, float *ms5);
 
 #ifdef __cplusplus

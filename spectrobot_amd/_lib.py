@@ -76,6 +76,7 @@ SYMBOLS = {
                                          C.c_double, C.c_int, dp, C.c_void_p]),
     "sr_set_points_per_lane": (C.c_int, [C.c_int]),
     "sr_set_far_field": (C.c_int, [C.c_int]),
+    "sr_set_overlap": (C.c_int, [C.c_int]),
     "sr_set_table_budget": (C.c_int, [C.c_int64]),
     "sr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
 }

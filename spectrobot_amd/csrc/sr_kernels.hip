@@ -566,7 +566,8 @@ __device__ inline void near_ranges(const IcIndex &ix, int wlo, int width, int zm
 template <int NS>
 __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
     const FastRec *__restrict__ fast, IcIndex ix, const int *__restrict__ zmax, int n_sub,
-    int n_tiles, int g_lo, int g_hi, FarParams fp, double *__restrict__ abs_out, double *__restrict__ emi_out) {
+    int n_tiles, int g_lo, int g_hi, FarParams fp, int add, double *__restrict__ abs_out,
+    double *__restrict__ emi_out) {
   constexpr int WT = 64 * NS;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
@@ -703,8 +704,13 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   for (int p = 0; p < NS; ++p) {
     const int j = wlo + lane + 64 * p;
     if (j <= whi) {
-      abs_out[row + (j - g_lo)] = acc_a[p];
-      emi_out[row + (j - g_lo)] = acc_e[p];
+      if (add) { // the zones kernel ran first (overlapped with the far-field kernel) and stored its sums
+        abs_out[row + (j - g_lo)] += acc_a[p];
+        emi_out[row + (j - g_lo)] += acc_e[p];
+      } else {
+        abs_out[row + (j - g_lo)] = acc_a[p];
+        emi_out[row + (j - g_lo)] = acc_e[p];
+      }
     }
   }
 }
@@ -765,7 +771,7 @@ __device__ inline void core_push(CorePend &P, int &fill, int lane, int a0, int n
 template <int WT, int NW>
 __global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, IcIndex ix,
-    const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp,
+    const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp, int add,
     double *__restrict__ abs_out, double *__restrict__ emi_out) {
   __shared__ double s_img[NW][2][WT]; // one private image per wave: abs, emi
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -898,8 +904,13 @@ __global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
         ta += s_img[w][0][p];
         te += s_img[w][1][p];
       }
-      abs_out[row + (j - g_lo)] += ta;
-      emi_out[row + (j - g_lo)] += te;
+      if (add) {
+        abs_out[row + (j - g_lo)] += ta;
+        emi_out[row + (j - g_lo)] += te;
+      } else {
+        abs_out[row + (j - g_lo)] = ta;
+        emi_out[row + (j - g_lo)] = te;
+      }
     }
   }
 }
@@ -912,9 +923,9 @@ int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int
   return (int)hipGetLastError();
 }
 
-int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax, int n_sub,
-                int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp, double *abs_out,
-                double *emi_out, hipStream_t st) {
+int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
+                int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp,
+                double *abs_out, double *emi_out, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
   const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
   const dim3 grid((unsigned)(n_groups * n_layers));
@@ -922,7 +933,7 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcInde
     // slots per wave: 4 (256-point groups) measured 2.53 ms on config 2, 2: 2.31 ms, 1: see DESIGN.md
     const int n_g1 = (g_hi - g_lo + 63) / 64;
     hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<1>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st, fast,
-                       ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, abs_out, emi_out);
+                       ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, abs_out, emi_out);
   } else {
     // Image width: wider images cut fewer zones in two (fewer (line, group) pairs: 7.1 -> 6.7 ms on
     // 1e5 points x 80 layers with 512 instead of 256) as long as the waves still fill the chip
@@ -932,13 +943,13 @@ int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcInde
     const dim3 gz((unsigned)(n_t * n_layers));
     if (waves512 >= 3 * 4096)
       hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 1>), gz, dim3(64), 0, st, fast, cold, ix, zmax, n_sub,
-                         n_t, g_lo, g_hi, gp, abs_out, emi_out);
+                         n_t, g_lo, g_hi, gp, add, abs_out, emi_out);
     else if (waves512 >= 3 * 2048)
       hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 2>), gz, dim3(128), 0, st, fast, cold, ix, zmax, n_sub,
-                         n_t, g_lo, g_hi, gp, abs_out, emi_out);
+                         n_t, g_lo, g_hi, gp, add, abs_out, emi_out);
     else
       hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 4>), gz, dim3(256), 0, st, fast, cold, ix, zmax, n_sub,
-                         n_t, g_lo, g_hi, gp, abs_out, emi_out);
+                         n_t, g_lo, g_hi, gp, add, abs_out, emi_out);
   }
   return (int)hipGetLastError();
 }

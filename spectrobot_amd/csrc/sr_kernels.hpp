@@ -54,9 +54,9 @@ struct FarParams {
 int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo,
                     int g_hi, const FarParams &fp, hipStream_t st);
 // part 1: wing-only pairs + far-field polynomials (writes); part 2: general pairs (adds)
-int launch_near(int part, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax, int n_sub,
-                int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp, double *abs_out,
-                double *emi_out, hipStream_t st);
+int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
+                int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp,
+                double *abs_out, double *emi_out, hipStream_t st);
 
 int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub, int cold_lo,
                 int cold_hi, FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st);

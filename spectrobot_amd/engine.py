@@ -142,7 +142,8 @@ class LineSet(object):
 
     def last_kernel_ms(self):
         """Kernel times (ms) of the last abscoeff_layers call: (prep, farfield|wings,
-        near wings|cores, near zones|0, reserved), see sr_last_kernel_ms."""
+        near wings|cores, near zones|0, reserved); with overlap (default, far-field mode): (prep, whole
+        coefficient op, 0, 0, 0).  See sr_last_kernel_ms."""
         ms = (C.c_float * 5)()
         check(lib.sr_last_kernel_ms(self._h, ms), "sr_last_kernel_ms")
         return tuple(ms)
@@ -194,6 +195,12 @@ def radiance_jacobian(abs_c, emi_c, seg_off, seg_layer, seg_col, dcol_dpar):
 
 def set_points_per_lane(p):
     check(lib.sr_set_points_per_lane(int(p)), "sr_set_points_per_lane")
+
+
+def set_overlap(on):
+    """1 (default): the zones kernel runs beside the far-field kernel on an internal stream;
+    0: kernels one after the other (per-kernel times in last_kernel_ms)."""
+    check(lib.sr_set_overlap(int(bool(on))), "sr_set_overlap")
 
 
 def set_far_field(on):

@@ -12,15 +12,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
-    # a fresh checkout has no libspectrobot_hip.so (built artefacts are not in history): build it
-    # (hipcc cross-compiles gfx950 without a GPU).  Loaded by path -- the package refuses to import
-    # without its library.
-    if not os.path.exists(os.path.join(ROOT, "spectrobot_amd", "lib", "libspectrobot_hip.so")):
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("_sr_build", os.path.join(ROOT, "spectrobot_amd", "build.py"))
-        b = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(b)
-        b.build()
+    # a fresh checkout has no libspectrobot_hip.so (built artefacts are not in history) and an edited
+    # source tree has a stale one: (re)build it when it is missing or older than its sources (hipcc
+    # cross-compiles gfx950 without a GPU).  Loaded by path -- the package refuses to import without
+    # a library that exports every symbol of the header.
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_sr_build", os.path.join(ROOT, "spectrobot_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build()
 
 
 @pytest.fixture(scope="session")

@@ -34,6 +34,7 @@ def main():
     print("far-field vs exact, max rel err per layer (emi):", " ".join(f"{x:.1e}" for x in re))
     del a0, e0, a1, e1
     T, P, tv = atm["temps"], atm["press"], atm["tvib"]
+    eng.set_overlap(0)  # per-kernel times
     for _ in range(2):
         ls.abscoeff_layers(T, P, tvib=tv)
     torch.cuda.synchronize()
@@ -45,6 +46,13 @@ def main():
     ms /= 5
     print("kernel ms (prep, far field, near wings, near zones, -): " + " ".join(f"{x:.2f}" for x in ms),
           f"sum {ms.sum():.2f}")
+    eng.set_overlap(1)
+    ls.abscoeff_layers(T, P, tvib=tv)
+    tot = 0.0
+    for _ in range(5):
+        ls.abscoeff_layers(T, P, tvib=tv)
+        tot += sum(ls.last_kernel_ms())
+    print(f"with overlap (default): prep + coefficient op {tot / 5:.2f} ms")
 
 
 if __name__ == "__main__":
