@@ -85,8 +85,8 @@ def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total, 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lines", type=int, default=100000)
     ap.add_argument("--grid", type=int, default=100000)
     ap.add_argument("--layers", type=int, default=80)
@@ -159,17 +159,14 @@ def main():
     barrier()
     kms = np.zeros(5)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps):   # no host synchronisation inside: consecutive steps pipeline on the GPU
         spec = step()
-        if world == 1:
-            kms += np.array(ls.last_kernel_ms())   # HIP events on the launch stream (syncs that step)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:  # per-kernel times of this rank's shard, outside the timed region
-        for _ in range(args.steps):
-            step()
-            kms += np.array(ls.last_kernel_ms())
-        barrier()
+    for _ in range(args.steps):   # HIP-event times of this rank's kernels (each query synchronises that step)
+        step()
+        kms += np.array(ls.last_kernel_ms())
+    barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")

@@ -168,11 +168,18 @@ struct sr_lineset {
   double freq_max = 0.0;
   DevBuf d_lines;      // one allocation, carved below
   LinesDev L{};
-  Stager s_layers;
-  DevBuf d_fast, d_cold, d_zmax, d_coef, d_first;
+  // [2]: with sr_set_overlap(1) the tables of call c+1 are prepared (on prep_st) while the kernels
+  // of call c still read theirs
+  Stager s_layers[2];
+  DevBuf d_fast[2], d_cold[2], d_zmax[2], d_coef, d_first;
   int first_x0 = 0, first_n = 0; // IcIndex table domain
   hipStream_t aux = nullptr;     // second stream: zones kernel beside the far-field kernel
+  hipStream_t prep_st = nullptr; // third stream: staging copy + sr_prep_kernel of the NEXT call
+  hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_tables_free[2] = {nullptr, nullptr}, ev_op0 = nullptr;
+  bool free_recorded[2] = {false, false};
+  int parity = 0;
   bool overlapped = false;       // last call ran that way (timing hook)
+  bool pipelined = false;        // last call prepared its tables on prep_st
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int n_timed = 0; // kernels timed in the last call
@@ -415,11 +422,18 @@ int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, cons
 
 int sr_lineset_destroy(sr_lineset *ls) {
   if (!ls) return SR_OK;
+  (void)hipDeviceSynchronize(); // work of the last calls may still be in flight on the internal streams
   ls->d_lines.release();
-  ls->s_layers.release();
-  ls->d_fast.release();
-  ls->d_cold.release();
-  ls->d_zmax.release();
+  for (int b = 0; b < 2; ++b) {
+    ls->s_layers[b].release();
+    ls->d_fast[b].release();
+    ls->d_cold[b].release();
+    ls->d_zmax[b].release();
+    if (ls->ev_prep_done[b]) (void)hipEventDestroy(ls->ev_prep_done[b]);
+    if (ls->ev_tables_free[b]) (void)hipEventDestroy(ls->ev_tables_free[b]);
+  }
+  if (ls->ev_op0) (void)hipEventDestroy(ls->ev_op0);
+  if (ls->prep_st) (void)hipStreamDestroy(ls->prep_st);
   ls->d_coef.release();
   ls->d_first.release();
   if (ls->ev_fork) (void)hipEventDestroy(ls->ev_fork);
@@ -445,7 +459,7 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   // imxstp = 8000 steps) is processed in layer batches that keep them under g_table_budget.
   {
     const size_t per_layer = (size_t)std::max<int64_t>(ls->n_lines, 1) * (sizeof(FastRec) + sizeof(ColdRec));
-    const int nl_max = (int)std::max<size_t>(1, g_table_budget / per_layer);
+    const int nl_max = (int)std::max<size_t>(1, g_table_budget / (g_overlap ? 2 : 1) / per_layer); // two table sets
     if (nl > nl_max) {
       const size_t n_pts_all = (size_t)(g_hi - g_lo);
       for (int k0 = 0; k0 < nl; k0 += nl_max) {
@@ -473,9 +487,27 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   // per-layer scalars (host, fp64)
   const size_t hl_doubles = (size_t)nl * (4 + npop);
   const size_t hl_bytes = sizeof(double) * hl_doubles + sizeof(int) * (size_t)nl;
-  int rc = ls->s_layers.prepare(hl_bytes);
+  // Table set of this call and the stream its preparation runs on.  With overlap, call c + 1
+  // prepares set (c + 1) % 2 on prep_st while the kernels of call c (which the caller's stream is
+  // still running) read set c % 2: the HBM-write-bound prep kernel hides behind the VALU-bound ones.
+  const int b = g_overlap ? (ls->parity ^= 1) : 0;
+  hipStream_t pst = st;
+  if (g_overlap) {
+    if (!ls->prep_st) {
+      HIPCHK(hipStreamCreateWithFlags(&ls->prep_st, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&ls->ev_op0, hipEventDefault));
+      for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&ls->ev_prep_done[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ls->ev_tables_free[i], hipEventDisableTiming));
+      }
+    }
+    pst = ls->prep_st;
+  }
+  Stager &SL = ls->s_layers[b];
+  DevBuf &d_fast = ls->d_fast[b], &d_cold = ls->d_cold[b], &d_zmax = ls->d_zmax[b];
+  int rc = SL.prepare(hl_bytes);
   if (rc) return rc;
-  double *T = ls->s_layers.host<double>(), *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *pop = sq + nl;
+  double *T = SL.host<double>(), *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *pop = sq + nl;
   std::vector<double> q(nl);
   if (atm->q_part) {
     std::copy(atm->q_part, atm->q_part + nl, q.begin());
@@ -504,10 +536,12 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
       pop[k] = 1 / q[k]; // smm:2054
     }
   }
-  rc = ls->s_layers.push(hl_bytes, st);
+  // set b was last read by the kernels of the call before the previous one
+  if (g_overlap && ls->free_recorded[b]) HIPCHK(hipStreamWaitEvent(pst, ls->ev_tables_free[b], 0));
+  rc = SL.push(hl_bytes, pst);
   if (rc) return rc;
   LayersDev A;
-  const double *dl = ls->s_layers.d.as<double>();
+  const double *dl = SL.d.as<double>();
   A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.pop = dl + 4 * nl;
   A.n_layers = nl; A.n_pop = npop;
   const int *d_pm = reinterpret_cast<const int *>(dl + hl_doubles);
@@ -530,21 +564,26 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     HIPCHK(hipMemsetAsync(emi_out, 0, sizeof(double) * n_pts * nl, st));
     return SR_OK;
   }
-  rc = ls->d_fast.ensure(sizeof(FastRec) * ((size_t)n_sub * nl + 1)); // +1: the wings kernel prefetches one ahead
+  rc = d_fast.ensure(sizeof(FastRec) * ((size_t)n_sub * nl + 1));
   if (rc) return rc;
-  rc = ls->d_cold.ensure(sizeof(ColdRec) * ((size_t)n_sub * nl + 1));
+  rc = d_cold.ensure(sizeof(ColdRec) * ((size_t)n_sub * nl + 1));
   if (rc) return rc;
 
-  rc = ls->d_zmax.ensure(sizeof(int) * (size_t)nl);
+  rc = d_zmax.ensure(sizeof(int) * (size_t)nl);
   if (rc) return rc;
-  HIPCHK(hipMemsetAsync(ls->d_zmax.p, 0, sizeof(int) * (size_t)nl, st));
+  HIPCHK(hipMemsetAsync(d_zmax.p, 0, sizeof(int) * (size_t)nl, pst));
 
-  HIPCHK(hipEventRecord(ls->ev[0], st));
+  HIPCHK(hipEventRecord(ls->ev[0], pst));
   // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
   LAUNCHCHK(launch_prep(ls->L, A, ls->gp, line_lo, n_sub, g_far_field ? (int)g_lo : INT_MIN / 2,
-                        g_far_field ? (int)g_hi - 1 : INT_MAX / 2, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(),
-                        ls->d_zmax.as<int>(), st));
-  HIPCHK(hipEventRecord(ls->ev[1], st));
+                        g_far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(),
+                        d_zmax.as<int>(), pst));
+  HIPCHK(hipEventRecord(ls->ev[1], pst));
+  if (g_overlap) { // the caller's stream takes over once the tables are ready
+    HIPCHK(hipEventRecord(ls->ev_prep_done[b], pst));
+    HIPCHK(hipStreamWaitEvent(st, ls->ev_prep_done[b], 0));
+    HIPCHK(hipEventRecord(ls->ev_op0, st));
+  }
   if (g_far_field) {
     FarParams fp;
     fp.n_levels = kMaxFarLevels;
@@ -573,26 +612,26 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
       }
       HIPCHK(hipEventRecord(ls->ev_fork, st));
       HIPCHK(hipStreamWaitEvent(ls->aux, ls->ev_fork, 0));
-      LAUNCHCHK(launch_near(2, 0, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), ix, ls->d_zmax.as<int>(), n_sub,
+      LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, d_zmax.as<int>(), n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, ls->aux));
       HIPCHK(hipEventRecord(ls->ev_join, ls->aux));
-      LAUNCHCHK(launch_farfield(ls->d_fast.as<FastRec>(), ix, ls->d_zmax.as<int>(), n_sub, nl,
+      LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, d_zmax.as<int>(), n_sub, nl,
                                 (int)g_lo, (int)g_hi, fp, st));
       HIPCHK(hipEventRecord(ls->ev[2], st));
       HIPCHK(hipStreamWaitEvent(st, ls->ev_join, 0));
-      LAUNCHCHK(launch_near(1, 1, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), ix, ls->d_zmax.as<int>(), n_sub,
+      LAUNCHCHK(launch_near(1, 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, d_zmax.as<int>(), n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, st));
       HIPCHK(hipEventRecord(ls->ev[3], st));
       HIPCHK(hipEventRecord(ls->ev[4], st));
       ls->overlapped = true;
     } else {
       ls->overlapped = false;
-      LAUNCHCHK(launch_farfield(ls->d_fast.as<FastRec>(), ix, ls->d_zmax.as<int>(), n_sub, nl,
+      LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, d_zmax.as<int>(), n_sub, nl,
                                 (int)g_lo, (int)g_hi, fp, st));
       HIPCHK(hipEventRecord(ls->ev[2], st));
       for (int part = 1; part <= 2; ++part) {
-        LAUNCHCHK(launch_near(part, part == 2, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(), ix,
-                              ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out,
+        LAUNCHCHK(launch_near(part, part == 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix,
+                              d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out,
                               st));
         HIPCHK(hipEventRecord(ls->ev[2 + part], st));
       }
@@ -601,12 +640,17 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   } else {
     ls->n_timed = 3;
     for (int which = 0; which < 2; ++which) {
-      LAUNCHCHK(launch_abscoeff(g_variant, which, ls->d_fast.as<FastRec>(), ls->d_cold.as<ColdRec>(),
-                                ix, ls->d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
+      LAUNCHCHK(launch_abscoeff(g_variant, which, d_fast.as<FastRec>(), d_cold.as<ColdRec>(),
+                                ix, d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
                                 abs_out, emi_out, st));
       HIPCHK(hipEventRecord(ls->ev[2 + which], st));
     }
   }
+  if (g_overlap) {
+    HIPCHK(hipEventRecord(ls->ev_tables_free[b], st));
+    ls->free_recorded[b] = true;
+  }
+  ls->pipelined = g_overlap != 0;
   ls->timed = true;
   return SR_OK;
 }
@@ -633,12 +677,16 @@ int sr_last_kernel_ms(sr_lineset *ls, float *ms5) {
   if (!ls || !ls->timed || !ms5) return SR_ERR_ARG;
   HIPCHK(hipEventSynchronize(ls->ev[ls->n_timed]));
   for (int i = 0; i < 5; ++i) ms5[i] = 0.f;
+  // ev[1] (end of prep) is on the prep stream when the call was pipelined: the kernels that follow
+  // are measured from ev_op0, recorded on the caller's stream once it has the tables
+  hipEvent_t first = ls->pipelined ? ls->ev_op0 : ls->ev[1];
+  HIPCHK(hipEventElapsedTime(&ms5[0], ls->ev[0], ls->ev[1]));
   if (ls->overlapped) { // kernels run side by side: only the whole coefficient op has a duration
-    HIPCHK(hipEventElapsedTime(&ms5[0], ls->ev[0], ls->ev[1]));
-    HIPCHK(hipEventElapsedTime(&ms5[1], ls->ev[1], ls->ev[4]));
+    HIPCHK(hipEventElapsedTime(&ms5[1], first, ls->ev[4]));
     return SR_OK;
   }
-  for (int i = 0; i < ls->n_timed; ++i) HIPCHK(hipEventElapsedTime(&ms5[i], ls->ev[i], ls->ev[i + 1]));
+  for (int i = 1; i < ls->n_timed; ++i)
+    HIPCHK(hipEventElapsedTime(&ms5[i], i == 1 ? first : ls->ev[i], ls->ev[i + 1]));
   return SR_OK;
 }
 
