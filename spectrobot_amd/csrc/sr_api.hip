@@ -704,7 +704,11 @@ int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers,
   for (int s = 0; s < n_seg; ++s)
     if (seg_layer[s] < 0 || seg_layer[s] >= n_layers) return SR_ERR_ARG; // would read out of bounds
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static thread_local Stager s_seg;
+  // a small ring of staging buffers: reusing one would make every call wait for the previous
+  // call's copy, i.e. for the GPU to reach it, and keep the host at most one step ahead
+  static thread_local Stager s_ring[4];
+  static thread_local unsigned s_next = 0;
+  Stager &s_seg = s_ring[s_next++ & 3];
   const size_t b_off = sizeof(int) * (size_t)(n_rays + 1), b_lay = sizeof(int) * (size_t)std::max(n_seg, 1);
   const size_t o_lay = (b_off + 15) / 16 * 16, o_col = (o_lay + b_lay + 15) / 16 * 16;
   const size_t total = o_col + sizeof(double) * (size_t)std::max(n_seg, 1);
@@ -739,7 +743,9 @@ int sr_radiance_jac_dev(const double *abs_c, const double *emi_c, int n_layers, 
   for (int s = 0; s < n_seg; ++s)
     if (seg_layer[s] < 0 || seg_layer[s] >= n_layers) return SR_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static thread_local Stager s_seg;
+  static thread_local Stager s_ring[4]; // as in sr_radiance_rays_dev
+  static thread_local unsigned s_next = 0;
+  Stager &s_seg = s_ring[s_next++ & 3];
   const size_t b_off = sizeof(int) * (size_t)(n_rays + 1), b_lay = sizeof(int) * (size_t)n_seg;
   const size_t o_lay = (b_off + 15) / 16 * 16, o_col = (o_lay + b_lay + 15) / 16 * 16;
   const size_t o_d = o_col + sizeof(double) * (size_t)n_seg;
