@@ -171,7 +171,7 @@ struct sr_lineset {
   // [2]: with sr_set_overlap(1) the tables of call c+1 are prepared (on prep_st) while the kernels
   // of call c still read theirs
   Stager s_layers[2];
-  DevBuf d_fast[2], d_cold[2], d_zmax[2], d_coef, d_first;
+  DevBuf d_fast[2], d_cold[2], d_zmax[2], d_coef, d_first, d_zone;
   int first_x0 = 0, first_n = 0; // IcIndex table domain
   hipStream_t aux = nullptr;     // second stream: zones kernel beside the far-field kernel
   hipStream_t prep_st = nullptr; // third stream: staging copy + sr_prep_kernel of the NEXT call
@@ -436,6 +436,7 @@ int sr_lineset_destroy(sr_lineset *ls) {
   if (ls->prep_st) (void)hipStreamDestroy(ls->prep_st);
   ls->d_coef.release();
   ls->d_first.release();
+  ls->d_zone.release();
   if (ls->ev_fork) (void)hipEventDestroy(ls->ev_fork);
   if (ls->ev_join) (void)hipEventDestroy(ls->ev_join);
   if (ls->aux) (void)hipStreamDestroy(ls->aux);
@@ -612,16 +613,31 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
       }
       HIPCHK(hipEventRecord(ls->ev_fork, st));
       HIPCHK(hipStreamWaitEvent(ls->aux, ls->ev_fork, 0));
+      // Small shards do not fill the chip: there the wings kernel need not wait for the zones kernel
+      // either -- zones writes a private buffer, one pass adds it at the end (on the full grid the
+      // VALU is saturated and this variant measured slower: 9.26 vs 9.06 ms).
+      const bool small = n_pts * (size_t)nl <= (size_t)3000000;
+      double *z_abs = abs_out, *z_emi = emi_out;
+      if (small) {
+        rc = ls->d_zone.ensure(sizeof(double) * 2 * n_pts * nl);
+        if (rc) return rc;
+        z_abs = ls->d_zone.as<double>();
+        z_emi = z_abs + n_pts * nl;
+      }
       LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, d_zmax.as<int>(), n_sub,
-                            nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, ls->aux));
+                            nl, (int)g_lo, (int)g_hi, ls->gp, fp, z_abs, z_emi, ls->aux));
       HIPCHK(hipEventRecord(ls->ev_join, ls->aux));
       LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, d_zmax.as<int>(), n_sub, nl,
                                 (int)g_lo, (int)g_hi, fp, st));
       HIPCHK(hipEventRecord(ls->ev[2], st));
-      HIPCHK(hipStreamWaitEvent(st, ls->ev_join, 0));
-      LAUNCHCHK(launch_near(1, 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, d_zmax.as<int>(), n_sub,
+      if (!small) HIPCHK(hipStreamWaitEvent(st, ls->ev_join, 0));
+      LAUNCHCHK(launch_near(1, small ? 0 : 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, d_zmax.as<int>(), n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, st));
       HIPCHK(hipEventRecord(ls->ev[3], st));
+      if (small) {
+        HIPCHK(hipStreamWaitEvent(st, ls->ev_join, 0));
+        LAUNCHCHK(launch_add2(abs_out, z_abs, emi_out, z_emi, n_pts * nl, st));
+      }
       HIPCHK(hipEventRecord(ls->ev[4], st));
       ls->overlapped = true;
     } else {

@@ -915,6 +915,21 @@ __global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
   }
 }
 
+// a += za, e += ze (small shards: the zones kernel's private result joins the wings kernel's)
+__global__ __launch_bounds__(256) void sr_add2_kernel(double *__restrict__ a, const double *__restrict__ za,
+                                                      double *__restrict__ e, const double *__restrict__ ze, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    a[i] += za[i];
+    e[i] += ze[i];
+  }
+}
+int launch_add2(double *a, const double *za, double *e, const double *ze, size_t n, hipStream_t st) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sr_add2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, za, e, ze, n);
+  return (int)hipGetLastError();
+}
+
 int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo,
                     int g_hi, const FarParams &fp, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;

@@ -51,6 +51,7 @@ struct FarParams {
   const int *pm; // [n_layers] pole margin in grid points
   double *coef;  // [n_layers][n_boxes_total][2][kFC]
 };
+int launch_add2(double *a, const double *za, double *e, const double *ze, size_t n, hipStream_t st);
 int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo,
                     int g_hi, const FarParams &fp, hipStream_t st);
 // part 1: wing-only pairs + far-field polynomials (writes); part 2: general pairs (adds)
