@@ -962,8 +962,11 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
     else if (waves512 >= 3 * 2048)
       hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 2>), gz, dim3(128), 0, st, fast, cold, ix, zmax, n_sub,
                          n_t, g_lo, g_hi, gp, add, abs_out, emi_out);
-    else
+    else if (waves512 >= 3 * 1024)
       hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 4>), gz, dim3(256), 0, st, fast, cold, ix, zmax, n_sub,
+                         n_t, g_lo, g_hi, gp, add, abs_out, emi_out);
+    else
+      hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 8>), gz, dim3(512), 0, st, fast, cold, ix, zmax, n_sub,
                          n_t, g_lo, g_hi, gp, add, abs_out, emi_out);
   }
   return (int)hipGetLastError();

@@ -472,15 +472,15 @@ def test_vmr_retrieval_loop(eng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_grid,n_layers", [(50000, 64), (101000, 63), (20000, 5)])
+@pytest.mark.parametrize("n_grid,n_layers", [(50000, 64), (101000, 63), (30000, 60), (20000, 5)])
 def test_zones_kernel_wave_sharing_paths(eng, n_grid, n_layers):
-    """The zones kernel runs 1, 2 or 4 waves per 512-point group depending on ceil(n_pts/512)*n_layers
-    (>= 12288: 1; >= 6144: 2; else 4, each wave with a private image merged in wave order).  Every
-    path against the exact mode, twice (the result must not depend on timing)."""
+    """The zones kernel runs 1, 2, 4 or 8 waves per 512-point group depending on ceil(n_pts/512)*n_layers
+    (>= 12288: 1; >= 6144: 2; >= 3072: 4; else 8, each wave with a private image merged in wave order).
+    Every path against the exact mode, twice (the result must not depend on timing)."""
     from spectrobot_amd import synthetic as syn
     waves512 = -(-n_grid // 512) * n_layers
-    assert (waves512 >= 12288, 6144 <= waves512 < 12288, waves512 < 6144) == \
-        {(50000, 64): (False, True, False), (101000, 63): (True, False, False), (20000, 5): (False, False, True)}[(n_grid, n_layers)]
+    path = 1 if waves512 >= 12288 else 2 if waves512 >= 6144 else 4 if waves512 >= 3072 else 8
+    assert path == {(50000, 64): 2, (101000, 63): 1, (30000, 60): 4, (20000, 5): 8}[(n_grid, n_layers)]
     grid = syn.make_grid(2980.0, 5e-4, n_grid)
     L = syn.make_lines(2500, grid, seed=77, n_levels=12)
     atm = syn.make_atmosphere(n_layers, 12)
