@@ -182,6 +182,16 @@ int sr_radiance_jac_dev(const double *abs_c, const double *emi_c, int n_layers, 
                         const int32_t *seg_off, const int32_t *seg_layer, const double *seg_col,
                         const double *dcol_dpar, int n_par, double *rad, double *jac, void *stream);
 
+/* Radiance Jacobian with respect to one scalar per layer that acts through the layer's own
+ * coefficients -- its temperature (BASELINE configs[3]: "Jacobians w.r.t. T ... per layer"; the
+ * reference has no temperature Jacobian, spect_main_module.py:300-306 is commented out: build's
+ * definition, parity unpinned, checked against finite differences of the whole chain).
+ * dabs / demi: DEVICE [n_layers][n_pts] = d(abs, emi of layer k)/d(parameter of layer k), e.g. central
+ * differences of two sr_abscoeff_layers_dev calls at T +- dT; jac: DEVICE [n_rays][n_layers][n_pts]. */
+int sr_radiance_jac_layer_dev(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
+                              int n_layers, int64_t n_pts, int n_rays, const int32_t *seg_off,
+                              const int32_t *seg_layer, const double *seg_col, double *jac, void *stream);
+
 /* Instrument step that follows the path: what
  * SpectralIntensity.hires_to_lowres(lowres_obs, spectral_widths) does
  * (spect_classes.py:1180-1191) for a hi-res spectrum on the cm^-1 grid

@@ -72,6 +72,8 @@ SYMBOLS = {
                                        C.c_void_p, C.c_void_p]),
     "sr_radiance_jac_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, ip, ip, dp, dp, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sr_radiance_jac_layer_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                            C.c_int, ip, ip, dp, C.c_void_p, C.c_void_p]),
     "sr_hires_to_lowres_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, dp, dp, C.c_int,
                                          C.c_double, C.c_int, dp, C.c_void_p]),
     "sr_set_points_per_lane": (C.c_int, [C.c_int]),

@@ -745,6 +745,42 @@ int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers,
 }
 
 // ------------------------------------------------------------------------
+int sr_radiance_jac_layer_dev(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
+                              int n_layers, int64_t n_pts, int n_rays, const int32_t *seg_off,
+                              const int32_t *seg_layer, const double *seg_col, double *jac, void *stream) {
+  if (!abs_c || !emi_c || !dabs || !demi || !jac || !seg_off || n_layers <= 0 || n_pts <= 0 || n_rays <= 0)
+    return SR_ERR_ARG;
+  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  const int n_seg = seg_off[n_rays];
+  if (seg_off[0] != 0 || n_seg <= 0 || !seg_layer || !seg_col) return SR_ERR_ARG;
+  for (int r = 0; r < n_rays; ++r)
+    if (seg_off[r + 1] < seg_off[r]) return SR_ERR_ARG;
+  for (int s = 0; s < n_seg; ++s)
+    if (seg_layer[s] < 0 || seg_layer[s] >= n_layers) return SR_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static thread_local Stager s_ring[4]; // as in sr_radiance_rays_dev
+  static thread_local unsigned s_next = 0;
+  Stager &s_seg = s_ring[s_next++ & 3];
+  const size_t b_off = sizeof(int) * (size_t)(n_rays + 1), b_lay = sizeof(int) * (size_t)n_seg;
+  const size_t o_lay = (b_off + 15) / 16 * 16, o_col = (o_lay + b_lay + 15) / 16 * 16;
+  const size_t total = o_col + sizeof(double) * (size_t)n_seg;
+  int rc = s_seg.prepare(total);
+  if (rc) return rc;
+  char *h = s_seg.host<char>();
+  std::memcpy(h, seg_off, b_off);
+  std::memcpy(h + o_lay, seg_layer, b_lay);
+  std::memcpy(h + o_col, seg_col, sizeof(double) * (size_t)n_seg);
+  rc = s_seg.push(total, st);
+  if (rc) return rc;
+  char *base = s_seg.d.as<char>();
+  LAUNCHCHK(launch_radiance_jac_layer(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, n_rays,
+                                      reinterpret_cast<const int *>(base),
+                                      reinterpret_cast<const int *>(base + o_lay),
+                                      reinterpret_cast<const double *>(base + o_col), jac, st));
+  return SR_OK;
+}
+
+// ------------------------------------------------------------------------
 int sr_radiance_jac_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, int n_rays,
                         const int32_t *seg_off, const int32_t *seg_layer, const double *seg_col,
                         const double *dcol_dpar, int n_par, double *rad, double *jac, void *stream) {

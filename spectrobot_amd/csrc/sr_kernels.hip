@@ -1103,6 +1103,62 @@ __global__ __launch_bounds__(256) void sr_radiance_jac_kernel(const double *__re
     if (p0 + q < n_par) jac[((size_t)ray * n_par + p0 + q) * n_pts + j] = J[q];
 }
 
+// Radiance derivatives with respect to ONE scalar per layer (its temperature, ...) through the
+// layer's own coefficients: dabs[k][j], demi[k][j] = d(abs, emi of layer k)/d(parameter of layer k).
+// Forward sensitivity of the recursion I <- I t + src, t = e^-tau, src = emi u f(tau), f = (1 - e^-tau)/tau:
+//   dt = -u t dabs,  dsrc = u f demi + emi u^2 f'(tau) dabs,  f' = (tau e^-tau - (1 - e^-tau))/tau^2
+//   J_k <- J_k t + [seg_layer == k] (I_prev dt + dsrc).
+// Thread = (point, ray, chunk of NP layers); build's definition like the recursion itself.
+template <int NP>
+__global__ __launch_bounds__(256) void sr_radiance_jac_layer_kernel(
+    const double *__restrict__ abs_c, const double *__restrict__ emi_c, const double *__restrict__ dabs,
+    const double *__restrict__ demi, int n_pts, int n_layers, const int *__restrict__ seg_off,
+    const int *__restrict__ seg_layer, const double *__restrict__ seg_col, double *__restrict__ jac) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ray = blockIdx.y, p0 = blockIdx.z * NP;
+  if (j >= n_pts) return;
+  double I = 0.0, J[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) J[q] = 0.0;
+  const int s0 = seg_off[ray], s1 = seg_off[ray + 1];
+  for (int s = s0; s < s1; ++s) {
+    const int k = seg_layer[s];
+    const size_t o = (size_t)k * n_pts + j;
+    const double u = seg_col[s], a = abs_c[o], e = emi_c[o];
+    const double tau = a * u;
+    const double t = exp(-tau);
+    const double em1 = -expm1(-tau);
+    const bool thin = !(fabs(tau) > 1e-12);
+    const double f = thin ? 1.0 : em1 / tau;
+    const double src = (e * u) * f;
+    if (k >= p0 && k < p0 + NP) { // this segment's layer is one of this thread's parameters
+      const double fp = thin ? -0.5 : (tau * t - em1) / (tau * tau);
+      const double da = dabs[o], de = demi[o];
+      const double d = I * (-u * t * da) + u * f * de + e * u * u * fp * da;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) J[q] = fma(J[q], t, (k == p0 + q) ? d : 0.0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) J[q] *= t;
+    }
+    I = I * t + src;
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+    if (p0 + q < n_layers) jac[((size_t)ray * n_layers + p0 + q) * n_pts + j] = J[q];
+}
+
+int launch_radiance_jac_layer(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
+                              int n_pts, int n_layers, int n_rays, const int *seg_off, const int *seg_layer,
+                              const double *seg_col, double *jac, hipStream_t st) {
+  if (n_pts <= 0 || n_rays <= 0 || n_layers <= 0) return 0;
+  constexpr int NP = 4;
+  dim3 grid((n_pts + 255) / 256, n_rays, (n_layers + NP - 1) / NP);
+  hipLaunchKernelGGL(sr_radiance_jac_layer_kernel<NP>, grid, dim3(256), 0, st, abs_c, emi_c, dabs, demi, n_pts,
+                     n_layers, seg_off, seg_layer, seg_col, jac);
+  return (int)hipGetLastError();
+}
+
 int launch_radiance_jac(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                         const int *seg_layer, const double *seg_col, const double *dcol, int n_par, double *rad,
                         double *jac, hipStream_t st) {

@@ -69,6 +69,9 @@ int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                     const int *seg_layer, const double *seg_col, int init_from_rad, double *rad,
                     hipStream_t st);
+int launch_radiance_jac_layer(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
+                              int n_pts, int n_layers, int n_rays, const int *seg_off, const int *seg_layer,
+                              const double *seg_col, double *jac, hipStream_t st);
 int launch_radiance_jac(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                         const int *seg_layer, const double *seg_col, const double *dcol, int n_par, double *rad,
                         double *jac, hipStream_t st);

@@ -193,6 +193,42 @@ def radiance_jacobian(abs_c, emi_c, seg_off, seg_layer, seg_col, dcol_dpar):
     return rad, jac
 
 
+def radiance_layer_jacobian(abs_c, emi_c, dabs, demi, seg_off, seg_layer, seg_col):
+    """d rad / d (one scalar per layer) [n_rays, n_layers, n_pts], the scalar acting through the layer's own
+    coefficients: dabs, demi [n_layers, n_pts] = d(abs, emi of layer k)/d(parameter of layer k)
+    (sr_radiance_jac_layer_dev)."""
+    for t in (abs_c, emi_c, dabs, demi):
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.shape == abs_c.shape
+    n_layers, n_pts = abs_c.shape
+    seg_off, op = _i(seg_off)
+    seg_layer, lp = _i(seg_layer)
+    seg_col, cp = _d(seg_col)
+    n_rays = seg_off.size - 1
+    jac = torch.empty((n_rays, n_layers, n_pts), dtype=torch.float64, device="cuda")
+    check(lib.sr_radiance_jac_layer_dev(C.c_void_p(abs_c.data_ptr()), C.c_void_p(emi_c.data_ptr()),
+                                        C.c_void_p(dabs.data_ptr()), C.c_void_p(demi.data_ptr()), n_layers, n_pts,
+                                        n_rays, op, lp, cp, C.c_void_p(jac.data_ptr()), _stream_ptr()),
+          "sr_radiance_jac_layer_dev")
+    return jac
+
+
+def temperature_jacobian(ls, temps, press, seg_off, seg_layer, seg_col, tvib=None, q_part=None, dT=0.05,
+                         g_lo=0, g_hi=None, coeffs=None):
+    """d rad / d T_k [n_rays, n_layers, n_pts] for the kinetic temperature of every layer (pressure,
+    columns and, in non-LTE, the vibrational temperatures held fixed): the coefficient op at T + dT
+    and T - dT (central differences of the layer's own abs / emi; with q_part=None the partition sum
+    follows T), then the forward sensitivity of the radiance recursion.  `coeffs` = (abs, emi) at T
+    if already computed.  The reference has no temperature Jacobian: build's definition."""
+    temps = np.ascontiguousarray(temps, dtype=np.float64)
+    if coeffs is None:
+        coeffs = ls.abscoeff_layers(temps, press, tvib=tvib, q_part=q_part, g_lo=g_lo, g_hi=g_hi)
+    a_p, e_p = ls.abscoeff_layers(temps + dT, press, tvib=tvib, q_part=q_part, g_lo=g_lo, g_hi=g_hi)
+    a_m, e_m = ls.abscoeff_layers(temps - dT, press, tvib=tvib, q_part=q_part, g_lo=g_lo, g_hi=g_hi)
+    dabs = (a_p - a_m) / (2.0 * dT)
+    demi = (e_p - e_m) / (2.0 * dT)
+    return radiance_layer_jacobian(coeffs[0], coeffs[1], dabs, demi, seg_off, seg_layer, seg_col)
+
+
 def set_points_per_lane(p):
     check(lib.sr_set_points_per_lane(int(p)), "sr_set_points_per_lane")
 

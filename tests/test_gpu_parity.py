@@ -494,3 +494,42 @@ def test_zones_kernel_wave_sharing_paths(eng, n_grid, n_layers):
     assert float(((e1 - e0).abs() / e0.abs()).max()) < 2e-11
     nz = a0 != 0
     assert float(((a1 - a0)[nz].abs() / a0[nz].abs()).max()) < 1e-9   # absorption: populations may cancel
+
+
+@pytest.mark.gpu
+def test_temperature_jacobian_finite_differences(eng):
+    """d rad / d T per layer (sr_radiance_jac_layer_dev + central differences of the coefficient op)
+    against finite differences of the whole chain (coefficients + recursion recomputed at T_k +- h)
+    for several layers and rays, LTE and non-LTE.  No reference counterpart: unpinned."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2991.0, 5e-4, 6000)
+    for nlev in (0, 12):
+        L = syn.make_lines(500, grid, seed=31, n_levels=nlev)
+        atm = syn.make_atmosphere(12, max(nlev, 1))
+        T, P = atm["temps"], atm["press"] * 50.0   # optically thicker: both terms of the sensitivity matter
+        tv = atm["tvib"] if nlev else None
+        ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES[:nlev])
+        nd = syn.number_density(P, T)
+        offs, lays, cols = [0], [], []
+        for zt in (atm["z"][0] + 3.0, atm["z"][4] + 2.0):
+            sl, ln = syn.limb_path(atm["z"], zt)
+            lays += list(sl)
+            cols += list(ln * 1e5 * nd[sl] * 0.0148)
+            offs.append(len(lays))
+        jac = eng.temperature_jacobian(ls, T, P, offs, lays, cols, tvib=tv, dT=0.02)
+        assert tuple(jac.shape) == (2, 12, 6000)
+        h = 0.02
+        for k in (0, 4, 5, 11):
+            Tp, Tm = T.copy(), T.copy()
+            Tp[k] += h
+            Tm[k] -= h
+            rp = eng.radiance_rays(*ls.abscoeff_layers(Tp, P, tvib=tv), offs, lays, cols)
+            rm = eng.radiance_rays(*ls.abscoeff_layers(Tm, P, tvib=tv), offs, lays, cols)
+            fd = (rp - rm) / (2 * h)
+            scale = fd.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+            err = float(((jac[:, k] - fd).abs() / scale).max())
+            assert err < 1e-5, (nlev, k, err)   # both sides carry O(h^2) truncation (~1e-6 here) + cancellation noise
+        # the lowest ray does not reach above... every ray crosses all layers >= its tangent layer: a layer
+        # below the tangent height of ray 1 (layers 0-3) has no influence on it
+        assert float(jac[1, :4].abs().max()) == 0.0
