@@ -212,6 +212,29 @@ def radiance_layer_jacobian(abs_c, emi_c, dabs, demi, seg_off, seg_layer, seg_co
     return jac
 
 
+def mix_gases(coeffs, ratios):
+    """Coefficients of a gas mixture on the column scale of a reference absorber: the column of gas g in
+    a segment of layer k is ratios[g][k] times the reference column (VMR_g / VMR_ref of the layer), so
+    tau = (sum_g ratios[g][k] abs_g[k]) * u_ref.  coeffs: [(abs_g, emi_g)] CUDA [n_layers, n_pts] on one
+    grid; ratios: [n_gas][n_layers].  Returns (abs_mix, emi_mix)."""
+    a_mix = e_mix = None
+    for (a, e), r in zip(coeffs, ratios):
+        w = torch.as_tensor(np.ascontiguousarray(r, dtype=np.float64), device=a.device)[:, None]
+        a_mix = a * w if a_mix is None else a_mix + a * w
+        e_mix = e * w if e_mix is None else e_mix + e * w
+    return a_mix.contiguous(), e_mix.contiguous()
+
+
+def gas_layer_jacobian(abs_mix, emi_mix, abs_g, emi_g, dratio_dx, seg_off, seg_layer, seg_col):
+    """d rad / d x_k [n_rays, n_layers, n_pts] for one scalar per layer that scales gas g's amount in
+    that layer inside a mixture (its VMR): the mixture's coefficients depend on it through
+    d abs_mix[k]/d x_k = dratio_dx[k] * abs_g[k] (same for emi), which is the layer Jacobian's input.
+    Profile parameters follow by the chain rule: J_p = sum_k mask_p[k] * J_k."""
+    w = torch.as_tensor(np.ascontiguousarray(dratio_dx, dtype=np.float64), device=abs_g.device)[:, None]
+    return radiance_layer_jacobian(abs_mix, emi_mix, (abs_g * w).contiguous(), (emi_g * w).contiguous(),
+                                   seg_off, seg_layer, seg_col)
+
+
 def temperature_jacobian(ls, temps, press, seg_off, seg_layer, seg_col, tvib=None, q_part=None, dT=0.05,
                          g_lo=0, g_hi=None, coeffs=None):
     """d rad / d T_k [n_rays, n_layers, n_pts] for the kinetic temperature of every layer (pressure,

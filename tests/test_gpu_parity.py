@@ -571,3 +571,45 @@ def test_pipelined_calls_of_changing_shape_and_stream(eng):
     for i, (a, e) in enumerate(got):
         ra, re_ = ref[i % len(cases)]
         assert bool((a == ra).all()) and bool((e == re_).all()), i
+
+
+@pytest.mark.gpu
+def test_two_gas_mixture_and_per_gas_jacobian(eng):
+    """BASELINE configs[4] shape (two gases on one grid): mixture coefficients on a reference column
+    scale and the per-layer VMR Jacobian of one gas inside the mixture, against finite differences."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(3280.0, 5e-4, 5000)
+    atm = syn.make_atmosphere(10, 1)
+    T, P = atm["temps"], atm["press"] * 3.0
+    g1 = eng.LineSet(syn.make_lines(300, grid, seed=1, n_levels=0), grid, 6, 1, syn.CH4_MM)
+    g2 = eng.LineSet(syn.make_lines(200, grid, seed=2, n_levels=0, co_like=True), grid, 5, 1, syn.CO_MM)
+    c1 = g1.abscoeff_layers(T, P)
+    c2 = g2.abscoeff_layers(T, P)
+    vmr1 = np.full(10, 0.0148)
+    vmr2 = np.linspace(5e-3, 1.5e-2, 10)
+    nd = syn.number_density(P, T)
+    sl, ln = syn.limb_path(atm["z"], atm["z"][2] + 1.0)
+    offs, lays, col_ref = [0, len(sl)], sl, ln * 1e5 * nd[sl] * vmr1[sl]      # columns of gas 1
+    am, em = eng.mix_gases([c1, c2], [np.ones(10), vmr2 / vmr1])
+    rad = eng.radiance_rays(am, em, offs, lays, col_ref)
+    # reference: the same recursion with explicit per-gas optical depths, in numpy
+    a1, e1, a2, e2 = (t.cpu().numpy() for t in (*c1, *c2))
+    I = np.zeros(grid.size)
+    for k, u1 in zip(lays, col_ref):
+        u2 = u1 * vmr2[k] / vmr1[k]
+        tau = a1[k] * u1 + a2[k] * u2
+        I = I * np.exp(-tau) + (e1[k] * u1 + e2[k] * u2) * (-np.expm1(-tau)) / tau
+    assert relerr(rad[0].cpu().numpy(), I) < 1e-12
+    # d rad / d vmr2[k]: ratio = vmr2 / vmr1, d ratio / d vmr2 = 1 / vmr1
+    jac = eng.gas_layer_jacobian(am, em, c2[0], c2[1], 1.0 / vmr1, offs, lays, col_ref)
+    for k in (2, 5, 9):
+        h = 1e-3 * vmr2[k]   # the central difference's own error is ~(h/x)^2 tau^2 at a line centre
+        vp, vm = vmr2.copy(), vmr2.copy()
+        vp[k] += h
+        vm[k] -= h
+        rp = eng.radiance_rays(*eng.mix_gases([c1, c2], [np.ones(10), vp / vmr1]), offs, lays, col_ref)
+        rm = eng.radiance_rays(*eng.mix_gases([c1, c2], [np.ones(10), vm / vmr1]), offs, lays, col_ref)
+        fd = (rp - rm)[0] / (2 * h)
+        assert float(((jac[0, k] - fd).abs() / fd.abs().max()).max()) < 2e-5, k
+    assert float(jac[0, :2].abs().max()) == 0.0   # layers below the tangent height
