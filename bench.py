@@ -278,6 +278,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(L, atm, grid, syn.CH4_MM, e_lev, q_part, args.cpu_seconds,
                                                args.layers, gpu=gpu)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            # the shipped Python path, quoted separately.  2.3 ms per (line, layer)
+            # per core was measured in the survey container, not on this box; ideal
+            # scaling over this box's cores is assumed.
+            pairs = float(args.lines) * args.layers
+            py_sps = out["cpu_baseline"]["cores"] / (pairs * 2.3e-3)
+            out["cpu_baseline"]["reference_python_path_extrapolated"] = {
+                "value": py_sps, "unit": "spectra/s", "speedup": out["value"] / py_sps,
+                "note": "shape + pickle + accumulate = 2.3 ms per (line, layer) per core (BASELINE.md 2, survey "
+                        "container), x ideal scaling over the cores above"}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()
