@@ -558,6 +558,101 @@ __device__ inline void near_ranges(const IcIndex &ix, int wlo, int width, int zm
   rs[2] = max(b0, re[1]); re[2] = max(b1, rs[2]);
 }
 
+// ------------------------------------------------------------------------
+// Window ends.  Every line has two, and in the slot holding one it contributes region-1 values to the
+// points up to (from) its last (first) window point only -- nothing beyond, exactly as the
+// reference's 13010-point window.  Walked line by line these partial slots were half of the near
+// wings kernel (64 ends + 64 starts per slot at one line per point).  They are 6441+ points from
+// the line centre, where the wing is so smooth over 64 points (Taylor ratio 32/6441) that degree 5
+// is exact to 2e-14 of the term; so: lanes = lines, each lane expands its own line about the slot
+// centre, a suffix (ends) / prefix (starts) sum over the lanes -- the lines are sorted by window
+// position -- gives for every cut-off position the polynomial of all lines still (already) inside
+// their window, and each point evaluates the one for its own position.
+// ------------------------------------------------------------------------
+// DPP row move of a double (two dwords): CTRL 0x101..0x10f row_shl:n (lane i reads lane i + n of its row of
+// 16), 0x111..0x11f row_shr:n; lanes whose source lies outside the row get 0.
+template <int CTRL>
+__device__ inline double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double lane_value(double v, int src_lane) { // wave-uniform: the value lane src_lane holds
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+constexpr int kWE = 6; // series coefficients of the window-end expansions
+__device__ inline void wing_series6(double xc, double e, const FastRec &r, double f[kWE]) {
+  const double u0 = xc * xc, u1 = 2. * xc * e, u2 = e * e;
+  const double n0 = fma(r.b, u0, r.a), n1 = r.b * u1, n2 = r.b * u2;
+  const double d0 = fma(u0, fma(4., u0, r.d), r.c);
+  const double d1 = u1 * fma(8., u0, r.d);
+  const double d2 = fma(u2, r.d, 4. * fma(u1, u1, 2. * u0 * u2));
+  const double d3 = 8. * u1 * u2, d4 = 4. * u2 * u2;
+  const double r0 = fast_rcp<2>(d0);
+  const double D1 = d1 * r0, D2 = d2 * r0, D3 = d3 * r0, D4 = d4 * r0;
+  f[0] = n0 * r0;
+  f[1] = fma(-D1, f[0], n1 * r0);
+  f[2] = fma(-D1, f[1], fma(-D2, f[0], n2 * r0));
+  f[3] = -fma(D1, f[2], fma(D2, f[1], D3 * f[0]));
+#pragma unroll
+  for (int n = 4; n < kWE; ++n) f[n] = -fma(D1, f[n - 1], fma(D2, f[n - 2], fma(D3, f[n - 3], D4 * f[n - 4])));
+}
+// Sum over the lanes' lines of (value at this lane's point, 0 outside the line's window) for one chunk
+// of 64 lines.  ends: line of lane i is valid at points p <= pos_i; starts: at p >= pos_i; pos is
+// non-decreasing over the lanes (lines sorted by window centre); lanes without such a line carry
+// zero coefficients.  c: [0, kWE) abs, [kWE, 2 kWE) emi series coefficients of the lane's line.
+__device__ inline void window_end_sum(bool ends, int pos, double c[2 * kWE], int lane, double &out_a, double &out_e) {
+  // inclusive suffix (ends) or prefix (starts) sums over the lanes: inside each row of 16 lanes by DPP
+  // row shifts (plain VALU moves, zero shifted in at the row end), then the totals of the other rows
+  const int row = lane >> 4;
+#pragma unroll
+  for (int n = 0; n < 2 * kWE; ++n) {
+    double v = c[n];
+    if (ends) {
+      v += dpp_move<0x101>(v); // row_shl:1  lane i <- lane i + 1
+      v += dpp_move<0x102>(v);
+      v += dpp_move<0x104>(v);
+      v += dpp_move<0x108>(v);
+      const double t1 = lane_value(v, 16), t2 = lane_value(v, 32), t3 = lane_value(v, 48); // row totals
+      const double t23 = t2 + t3;
+      v += row == 0 ? t1 + t23 : (row == 1 ? t23 : (row == 2 ? t3 : 0.0));
+    } else {
+      v += dpp_move<0x111>(v); // row_shr:1  lane i <- lane i - 1
+      v += dpp_move<0x112>(v);
+      v += dpp_move<0x114>(v);
+      v += dpp_move<0x118>(v);
+      const double t0 = lane_value(v, 15), t1 = lane_value(v, 31), t2 = lane_value(v, 47);
+      const double t01 = t0 + t1;
+      v += row == 3 ? t01 + t2 : (row == 2 ? t01 : (row == 1 ? t0 : 0.0));
+    }
+    c[n] = v;
+  }
+  // this lane as a POINT p = lane: ends: first line with pos >= p; starts: last line with pos <= p
+  int lo = 0, hi = 64; // 65 possible answers: 7 halvings
+#pragma unroll
+  for (int it = 0; it < 7; ++it) {
+    const int mid = min((lo + hi) >> 1, 63);
+    const int v = __shfl(pos, mid);
+    const bool right = lo < hi && (ends ? v < lane : v <= lane);
+    const bool left = lo < hi && !right;
+    lo = right ? mid + 1 : lo;
+    hi = left ? mid : hi;
+  }
+  const int src = ends ? lo : lo - 1; // lo = number of lines with pos < p (ends) / pos <= p (starts)
+  const bool any = ends ? src < 64 : src >= 0;
+  const double t = (double)(2 * lane - 63) * (1.0 / 64);
+  double pa = 0., pe = 0.;
+#pragma unroll
+  for (int n = kWE - 1; n >= 0; --n) {
+    const double ca = __shfl(c[n], src & 63), ce = __shfl(c[kWE + n], src & 63);
+    pa = fma(pa, t, any ? ca : 0.0);
+    pe = fma(pe, t, any ? ce : 0.0);
+  }
+  out_a += pa;
+  out_e += pe;
+}
+
 // NS slots of 64 points per wave: 4 (two groups of 4 per wave measured slower: occupancy, SGPR
 // spills), or 2 for small shards, where 4 leave wave slots empty and a wave's own latency is the
 // kernel time.  The walk is per SLOT: a ballot per slot and kind, and a loop body without flag tests --
@@ -615,6 +710,44 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
         if (NS == 4 && flags == 15 && classify(j1, il, ir, wlo, whi) != 0) flags = 16;
       }
       if (__ballot(flags != 0) == 0) continue;
+      if constexpr (NS == 1) {
+        // window ends (range 0) / starts (range 2) of this slot, when there are enough of them
+        if (rg != 1) {
+          const bool ends = rg == 0;
+          bool fastl = false;
+          int pos = ends ? 64 : 64; // lanes without a line: never selected
+          double c[2 * kWE];
+#pragma unroll
+          for (int n = 0; n < 2 * kWE; ++n) c[n] = 0.;
+          if (lv < re[rg]) {
+            const int j1 = frow[lv].j1;
+            const unsigned ilir = frow[lv].ilir;
+            const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
+            // the slot's region-1 points are cut by the window end (and the grid end) only, not by the zone
+            fastl = ends ? (flags == 512 && j1 + ir <= wlo) : (flags == 32 && j1 + il - 2 >= wlo + 63);
+            pos = ends ? min(max(jN - wlo, -1), 64) : min(max(j1 - wlo, 0), 64);
+          }
+          const unsigned long long fm = __ballot(fastl);
+          if (__builtin_popcountll(fm) >= 12) {
+            if (fastl) {
+              const FastRec r = frow[lv];
+              // -x (starts: left wing) or x (ends: right wing) at the slot centre wlo + 31.5
+              const double xc = ends ? fma(0.5 * (double)(2 * (wlo - (r.j1 + r.ir() - 1)) + 63), r.xstep, r.xr)
+                                     : fma(0.5 * (double)(2 * (wlo - r.j1) + 63), r.xstep, -r.xl);
+              double f[kWE];
+              wing_series6(xc, 32.0 * r.xstep, r, f);
+#pragma unroll
+              for (int n = 0; n < kWE; ++n) {
+                c[n] = r.wabs * f[n];
+                c[kWE + n] = r.wemi * f[n];
+              }
+              flags = 0; // done here
+            }
+            window_end_sum(ends, pos, c, lane, acc_a[0], acc_e[0]);
+            if (__ballot(flags != 0) == 0) continue;
+          }
+        }
+      }
       // four whole slots in one wing: shared reciprocal
       if constexpr (NS == 4) {
         for (unsigned long long todo = __ballot(flags == 16); todo; todo &= todo - 1) {
