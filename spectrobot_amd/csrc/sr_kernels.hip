@@ -531,9 +531,10 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
 // their records fetched by scalar loads.
 //
 // sr_abscoeff_near_wings_kernel (one 64-point slot per wave): every REGION-1 point of the
-//   lines that no far-field level owns for the slot -- whole slots, and slots that also hold
-//   zone points, a window end or the grid end with a one-sided per-lane mask -- plus one
-//   far-field polynomial per level; writes abs/emi.
+//   lines that no far-field level owns for the slot -- whole slots; slots that also hold zone
+//   points or the grid end with a one-sided per-lane mask; the slots holding a window end or
+//   start by per-line expansions and a lane scan (window_end_sum) -- plus one far-field
+//   polynomial per level; writes abs/emi (or adds, when the zones kernel stored first).
 // sr_abscoeff_near_zones_kernel (one 256/512-point LDS image per wave; adds to abs/emi):
 //   region 3 (~15 points per line) with lanes = lines in the chunk phase; region 2 as one run
 //   of consecutive lanes per line; region 4 packed ACROSS lines into full 64-lane chunks
