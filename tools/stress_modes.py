@@ -3,7 +3,7 @@ many small configurations: grids, shard offsets, line densities, molar masses, p
 Doppler to the Lorentz regime, with and without non-LTE levels.  GPU only (the oracle is not used:
 tests/test_gpu_parity.py pins 16 such configurations to the oracle; this sweeps hundreds).
 
-  python tools/stress_modes.py [first_seed] [n_seeds]
+  python tools/stress_modes.py [first_seed] [n_seeds] [--large]
 """
 import os
 import sys
@@ -14,13 +14,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spectrobot_amd import engine as eng, synthetic as syn  # noqa: E402
 
 
+LARGE = False   # --large: grids up to 1.2e5 points, up to 70 layers, up to one line per point (all kernel paths)
+
+
 def one(seed):
     rng = np.random.default_rng(50000 + seed)
     step = float(rng.choice([2.5e-4, 5e-4, 1e-3, 2e-3]))
-    n_grid = int(rng.integers(300, 40000))
+    n_grid = int(rng.integers(300, 40000)) if not LARGE else int(rng.integers(20000, 120000))
     w0 = float(rng.choice([650.0, 2100.0, 2990.0, 4300.0]))
     grid = syn.make_grid(w0, step, n_grid)
-    n_lines = int(rng.integers(1, 3000))
+    n_lines = int(rng.integers(1, 3000)) if not LARGE else int(rng.integers(2000, n_grid))
     nlev = int(rng.choice([0, 3, 12]))
     L = syn.make_lines(n_lines, grid, seed=60000 + seed, n_levels=nlev)
     if n_lines > 4 and rng.random() < 0.5:   # clustered lines: many share a grid point
@@ -28,7 +31,7 @@ def one(seed):
         order = np.argsort(L["freq"], kind="stable")
         L = {k: v[order] for k, v in L.items()}
     mm = float(rng.choice([16.0313, 27.994915, 2.0159, 44.0]))
-    nl = int(rng.integers(1, 5))
+    nl = int(rng.integers(1, 5)) if not LARGE else int(rng.integers(8, 70))
     T = rng.uniform(70, 300, nl)
     P = 10.0 ** rng.uniform(-7, 3.3, nl)
     tv = None if nlev == 0 else np.array([T + 2.0 * i for i in range(nlev)])
@@ -50,6 +53,9 @@ def one(seed):
 
 
 if __name__ == "__main__":
+    if "--large" in sys.argv:
+        LARGE = True
+        sys.argv.remove("--large")
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     worst = 0.0
