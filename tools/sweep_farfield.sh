@@ -16,7 +16,7 @@ for pair in "$@"; do
   sed -e "s/^constexpr int kTheta = [0-9]*;/constexpr int kTheta = $th;/" \
       -e "s/^constexpr int kFD = [0-9]*;/constexpr int kFD = $fd;/" /tmp/sr_kernels.hpp.orig > "$hpp"
   echo "=== theta=$th degree=$fd" | tee -a "$out"
-  python -c "import spectrobot_amd.build as b; b.build(force=True)" >> "$out" 2>&1 || { echo "build failed" | tee -a "$out"; continue; }
+  python spectrobot_amd/build.py --force >> "$out" 2>&1 || { echo "build failed" | tee -a "$out"; continue; }
   timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -q -x -m gpu \
       -k "far_field_vs_exact or randomized or e2e_ch4" 2>&1 | tail -4 | tee -a "$out"
   timeout -k 10 200 python tools/farfield_error.py 2>&1 | tee -a "$out"
