@@ -2,20 +2,22 @@
 """bench.py -- limb spectra/s of the SpectRobot spectral hot path on MI355X.
 
 A "step" is one pass of the hot path over one synthetic limb case: per-layer
-abs/emi coefficient spectra (prep + gather kernels), the radiance recursion of
-the ray batch and, for N > 1, the all-gather of the spectral shards.  Default
-workload = BASELINE.json configs[1]: CH4 Titan limb, 1e5 lines x 1e5 nu-grid x 80
-layers, 1 ray, fp64.  Inputs are uploaded before the timed region (HBM resident).
+abs/emi coefficient spectra (prep + gather kernels), the LOS columns and radiance
+recursion of the ray batch and, for N > 1, the all-gather of the spectral shards.
+Default workload = BASELINE.json configs[1]: CH4 Titan limb, 1e5 lines x 1e5 nu-grid
+x 80 layers, 1 ray, fp64.  Inputs are uploaded before the timed region (HBM resident).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --config 2|3|4      extra lines for BASELINE configs[2..4] (bench_configs.py; not the headline)
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
-(dominant kernel, HIP-event timed inside the timed region) and `cpu_baseline`
-(the oracle, i.e. the CPU restatement of the reference, on the host cores;
-N = 1 only).
+(dominant kernel: EXECUTED flops, counted on the device, over its HIP-event time)
+and `cpu_baseline` (the oracle, i.e. the CPU restatement of the reference, on the
+host cores; N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,13 +30,30 @@ sys.path.insert(0, ROOT)
 
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (= fp64 matrix) dense peak, SURVEY 8-d / AMD datasheet
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
-FLOP_PER_EVAL = 16             # SURVEY 8-d flop model per (line, layer, grid point)
+FLOP_PER_EVAL = 16             # SURVEY 8-d flop model per (line, layer, grid point), brute force
+# Executed-work flop model.  Per evaluation, SURVEY 8-d: region 1 = 9, region 2 = 17,
+# core = 140, + 6 for the weighted accumulations.  Per far-field (line, box) expansion: counted from
+# sr_farfield_kernel's source (setup 42, reciprocal 9, f0..f3 14, 23 coefficients x 2 outputs).  Per
+# (point, level) polynomial: 2 outputs x degree 22 Horner.  Per window-end expansion: series + its share
+# of the lane scan.
+FLOP = {"region1_evals": 15, "region2_evals": 23, "region3_evals": 146, "region4_evals": 146,
+        "farfield_expansions": 281, "poly_point_levels": 93, "window_end_expansions": 187}
+KERNEL_COUNTERS = {
+    "sr_farfield_kernel": ("farfield_expansions",),
+    "sr_abscoeff_near_wings_kernel": ("region1_evals", "window_end_expansions", "poly_point_levels"),
+    "sr_abscoeff_near_zones_kernel": ("region2_evals", "region3_evals", "region4_evals"),
+}
 
 
-def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total, gpu=None):
-    """Oracle (kind 'port', mode 1 = direct accumulate) on all host cores over a bounded
-    sample of the SAME workload: all lines, full grid, the first `ns` layers."""
-    from oracle import oracle as O
+def kernel_sources_sha256():
+    """Hash of the kernel sources: a PMC traffic figure is only reported for the build it was measured on."""
+    h = hashlib.sha256()
+    for f in ("sr_kernels.hip", "sr_api.hip", "sr_device.hpp", "sr_kernels.hpp"):
+        h.update(open(os.path.join(ROOT, "spectrobot_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # the GPU box gives each job a CPU share through the cgroup quota (16 cores for one GPU)
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -42,20 +61,67 @@ def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total, 
             cores = max(1, min(cores, int(round(int(quota) / int(period)))))
     except Exception:
         pass
-    # ~50 us per (line, layer) per core
-    per_layer_core_s = 55e-6 * len(L["freq"])
+    return cores
+
+
+def reference_kernel_timing():
+    """The reference's own compiled humliv_bb (oracle/_ref, built from the reference's Fortran by
+    oracle/Makefile), ONE pinned core, 2000 calls after 200 warm-up calls, median and min.  Run before the
+    threaded oracle leg so that its threads do not disturb it."""
+    try:
+        from oracle import ref_fortran as RF
+        if not RF.available():
+            return {"available": False}
+        aff = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+        try:
+            if aff:
+                os.sched_setaffinity(0, {sorted(aff)[len(aff) // 2]})
+            out = RF.time_humliv_bb()
+        finally:
+            if aff:
+                os.sched_setaffinity(0, aff)
+        out["available"] = True
+        out["cores"] = 1
+        return out
+    except Exception as e:  # the reference build is optional on the box
+        return {"available": False, "note": str(e)[:100]}
+
+
+def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total, rays, gpu=None):
+    """Oracle (kind 'port', mode 1 = direct accumulate) on all host cores over a bounded sample of the
+    SAME workload: all lines, full grid, `ns` evenly spaced layers -- coefficients AND the radiance
+    recursion of the ray batch over those layers."""
+    from oracle import oracle as O
+    ref = reference_kernel_timing()
+    cores = host_cores()
+    per_layer_core_s = 55e-6 * len(L["freq"])   # ~50 us per (line, layer) per core
     ns = int(max(1, min(n_layers_total, round(seconds_hint * cores / max(per_layer_core_s, 1e-9)))))
     ns = max(min(ns, n_layers_total), min(cores, n_layers_total))
     sel = np.linspace(0, n_layers_total - 1, ns).round().astype(int)
     tv = None if atm["tvib"] is None else atm["tvib"][:, sel]
+    offs, lays, cols = rays
     t0 = time.time()
     abo, emo = O.abscoeff_layers(L, mm, e_lev, atm["temps"][sel], atm["press"][sel], q_part[sel], tv, grid, mode=1,
                                  n_threads=cores)
-    dt = time.time() - t0
-    out = {"value": (ns / n_layers_total) / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
-           "sample": "%d of %d layers (evenly spaced), all %d lines, full %d-point grid, coefficients only, "
-                     "%.1f s wall; extrapolated x%d/%d" % (ns, n_layers_total, len(L["freq"]), len(grid), dt,
-                                                          n_layers_total, ns)}
+    t_coef = time.time() - t0
+    # the recursion over the sampled layers only (segments of the other layers skipped): same share of the work
+    pos = {int(k): i for i, k in enumerate(sel)}
+    t0 = time.time()
+    for r in range(len(offs) - 1):
+        sl = [s for s in range(offs[r], offs[r + 1]) if int(lays[s]) in pos]
+        O.radiance_ray(abo, emo, [pos[int(lays[s])] for s in sl], cols[sl])
+    t_rad = time.time() - t0
+    dt = t_coef + t_rad
+    out = {"value": (ns / n_layers_total) / dt * (len(offs) - 1), "unit": "spectra/s", "cores": cores, "kind": "port",
+           "sample": "%d of %d layers (evenly spaced), all %d lines, full %d-point grid: coefficients %.1f s on %d "
+                     "threads + radiance recursion of %d ray(s) over those layers %.2f s (1 thread); extrapolated "
+                     "x%d/%d" % (ns, n_layers_total, len(L["freq"]), len(grid), t_coef, cores, len(offs) - 1, t_rad,
+                                 n_layers_total, ns),
+           "reference_humliv_bb": ref}
+    if ref.get("available"):
+        # the reference's own kernel beside the port: n_lines * n_layers calls of humliv_bb, nothing else
+        pairs = float(len(L["freq"])) * n_layers_total
+        out["reference_humliv_bb"]["kernel_only_spectra_per_s_all_cores_ideal"] = cores / (pairs * ref["median_us"] * 1e-6)
     if gpu is not None:  # the checker: the timed GPU result against the oracle at the BASELINE size
         ab, em = (t[sel].cpu().numpy() for t in gpu)
         out["parity_vs_oracle"] = {
@@ -63,23 +129,22 @@ def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total, 
             "max_rel_err_abs": float(np.max(np.abs(ab - abo) / np.abs(abo))),
             "max_rel_err_emi": float(np.max(np.abs(em - emo) / np.abs(emo))),
             "note": "coefficient spectra of the timed far-field run vs the CPU oracle on the sampled layers, "
-                    "full grid, all lines; requirement 1e-6"}
-    # reference's own Fortran kernel (oracle/_ref, compiled from the reference sources), 1 core
-    try:
-        from oracle import ref_fortran as RF
-        if RF.available():
-            st = grid[1] - grid[0]
-            lin = np.arange(-13010 * st / 2, 13010 * st / 2, st)
-            x = lin + grid[len(grid) // 2]
-            n = 300
-            t0 = time.time()
-            for i in range(n):
-                RF.humliv_bb(x, 1, 13010, float(x[6505] + 1e-4), 1e-4 * (1 + i % 7), 4e-3)
-            out["reference_humliv_bb_us_per_call"] = (time.time() - t0) / n * 1e6
-    except Exception as e:  # the reference build is optional on the box
-        out["reference_humliv_bb_us_per_call"] = None
-        out["reference_note"] = str(e)[:100]
+                    "full grid, all lines; requirement 1e-6 (the pytest of the same comparison: "
+                    "tests/test_gpu_configs.py::test_config1_full_size_vs_oracle)"}
     return out
+
+
+def build_rays(syn, atm, n_rays, vmr=0.0148):
+    """Tangent heights z_t = 100 + 12.5 r km; per segment the layer and the column
+    n * vmr * iso_ratio * ds (cm^-2)."""
+    offs, lays, cols = [0], [], []
+    nd = syn.number_density(atm["press"], atm["temps"])
+    for r in range(n_rays):
+        sl, ln = syn.limb_path(atm["z"], 100.0 + 12.5 * r + 1e-3)
+        lays += list(sl)
+        cols += list(ln * 1e5 * nd[sl] * vmr * syn.CH4_ISO_RATIO)
+        offs.append(len(lays))
+    return np.array(offs, np.int32), np.array(lays, np.int32), np.array(cols, np.float64)
 
 
 def main():
@@ -87,6 +152,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=1, help="1 (default): BASELINE configs[1], the headline; "
+                    "2, 3, 4: extra lines for configs[2..4] (bench_configs.py)")
     ap.add_argument("--lines", type=int, default=100000)
     ap.add_argument("--grid", type=int, default=100000)
     ap.add_argument("--layers", type=int, default=80)
@@ -100,6 +167,9 @@ def main():
 
     import __graft_entry__
     __graft_entry__.ensure_built(builder=int(os.environ.get("LOCAL_RANK", "0")) == 0)  # fresh checkouts carry no library
+    if args.config != 1:
+        import bench_configs
+        return bench_configs.main(args)
     import torch
     from spectrobot_amd import engine, synthetic as syn, distributed as sd
     from spectrobot_amd._lib import lib, dp
@@ -120,15 +190,7 @@ def main():
     q_part = np.zeros(args.layers)
     tt = np.ascontiguousarray(atm["temps"])
     assert lib.sr_calc_partition_sum(6, 1, tt.ctypes.data_as(dp), args.layers, q_part.ctypes.data_as(dp)) == 0
-    # rays: tangent heights z_t = 100 + 12.5 r km; columns n*vmr*iso_ratio*ds
-    offs, lays, cols = [0], [], []
-    nd = syn.number_density(atm["press"], atm["temps"])
-    for r in range(args.rays):
-        sl, ln = syn.limb_path(atm["z"], 100.0 + 12.5 * r + 1e-3)
-        lays += list(sl)
-        cols += list(ln * 1e5 * nd[sl] * 0.0148 * syn.CH4_ISO_RATIO)
-        offs.append(len(lays))
-    offs, lays, cols = np.array(offs, np.int32), np.array(lays, np.int32), np.array(cols, np.float64)
+    offs, lays, cols = build_rays(syn, atm, args.rays)
 
     ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)     # lines -> HBM (outside the timed region)
     g_lo, g_hi = sd.shard_bounds(args.grid, world, rank)
@@ -176,15 +238,20 @@ def main():
     prep_ms = float(kms[0])
     main_ms = float(kms[1:].sum())   # far-field mode: the coefficient op as a whole (its kernels overlap)
     checksum = float(spec.sum().item())
-    # outside the timed region: the kernels of the coefficient op one after the other, for the breakdown
-    serial_kms = None
+    # outside the timed region: the kernels of the coefficient op one after the other (HIP events on the
+    # stream they run on), and the work each one executes (counting instantiations, device counters)
+    serial_kms = counts = None
     if not args.exact:
         engine.set_overlap(0)
         step()
         serial_kms = np.zeros(5)
-        for _ in range(3):
+        for _ in range(5):
             step()
-            serial_kms += np.array(ls.last_kernel_ms()) / 3
+            serial_kms += np.array(ls.last_kernel_ms()) / 5
+        engine.set_counting(1)
+        step()
+        counts = ls.last_eval_counts()
+        engine.set_counting(0)
         engine.set_overlap(1)
     # outside the timed region: the brute-force kernels (every evaluation exact) for reference
     exact_kms = None
@@ -201,20 +268,56 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = args.steps / elapsed  # one limb spectrum (x rays) per step, whole job
-        # dominant kernel: sr_abscoeff_kernel, one launch per step on this rank's shard
-        n_sub = args.lines if world == 1 else None
         evals = float(args.lines) * 13010.0 * args.layers / world           # SURVEY 8-d, per launch
-        flops = FLOP_PER_EVAL * evals
+        flops_bf = FLOP_PER_EVAL * evals
         alg_bytes = (8.0 * args.grid * args.layers * 2 + 80.0 * args.lines) / world
-        tf = flops / (main_ms * 1e-3) / 1e12
         gbs = alg_bytes / (main_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-        if os.path.exists(pmc) and world == 1 and args.lines == 100000 and args.grid == 100000:
+        # HBM traffic from the PMC counters: only for the build it was measured on (sources hash)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")
+        if os.path.exists(pmc) and world == 1 and args.lines == 100000 and args.grid == 100000 and not args.shard:
             try:
-                traffic = json.load(open(pmc)).get("coefficient_kernels_hbm_bytes_per_step")
+                pj = json.load(open(pmc))
+                if pj.get("kernel_sources_sha256") == kernel_sources_sha256():
+                    traffic = pj.get("coefficient_kernels_hbm_bytes_per_step")
+                    traffic_src = {"file": "profiles/r02_pmc_hbm.json", "profile_tag": pj.get("profile_tag"),
+                                   "kernel_sources_sha256": pj.get("kernel_sources_sha256")[:16]}
+                else:
+                    traffic_src = {"file": "profiles/r02_pmc_hbm.json", "stale": True,
+                                   "note": "measured on other kernel sources than this build: not reported"}
             except Exception:
                 traffic = None
+        if args.exact:
+            xm = float(kms[1] + kms[2])
+            roofline = {"bound": "fp64-valu", "achieved": flops_bf / (xm * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": flops_bf / (xm * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                        "traffic": None, "kernel": "sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel",
+                        "kernels_ms": dict(zip(["sr_prep_kernel", "sr_abscoeff_wings_kernel",
+                                                "sr_abscoeff_cores_kernel"], [float(v) for v in kms[:3]])),
+                        "flops_per_launch": flops_bf, "mode": "exact"}
+        else:
+            names = ["sr_farfield_kernel", "sr_abscoeff_near_wings_kernel", "sr_abscoeff_near_zones_kernel"]
+            per_kernel = {}
+            for nm, ms in zip(names, serial_kms[1:4]):
+                fl = float(sum(FLOP[c] * counts[c] for c in KERNEL_COUNTERS[nm]))
+                per_kernel[nm] = {"ms": float(ms), "executed_flops": fl,
+                                  "achieved_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                                  "frac": fl / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if ms > 0 else None}
+            dom = max(names, key=lambda n: per_kernel[n]["ms"])
+            d = per_kernel[dom]
+            roofline = {
+                "bound": "fp64-valu", "achieved": d["achieved_tflops"], "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": dom, "kernel_ms": d["ms"], "flops_per_launch": d["executed_flops"],
+                "executed_counts": counts, "flop_model": FLOP, "kernels": per_kernel,
+                "sr_prep_kernel_ms": float(serial_kms[0]),
+                "coefficient_op_ms_in_timed_steps": main_ms, "mode": "far-field",
+                "note": "dominant kernel of the step; achieved = flops it EXECUTES (evaluations counted on the device "
+                        "by the counting instantiations of the same kernels x the per-region flops of SURVEY 8-d) / "
+                        "its average HIP-event duration over 5 launches with the kernels one after the other on the "
+                        "caller's stream (in the timed steps the zones kernel overlaps the far-field kernel on a "
+                        "second stream); peak 78.6 TFLOP/s = fp64 vector = fp64 MFMA dense peak of MI355X (no MFMA "
+                        "use: not a contraction).  HBM is not the bound: arithmetic intensity ~1e3 flop/B"}
         out = {
             "metric": "limb spectra/sec (1e5 lines x 1e5 nu-grid, 80 layers)",
             "value": value * args.rays, "unit": "spectra/s", "n_gpus": world, "steps": args.steps,
@@ -227,43 +330,24 @@ def main():
                                     ("ONLY shard %s timed (tuning aid)" % args.shard if args.shard else "none")),
                        "mode": "exact" if args.exact else "far-field", "device": info["name"],
                        "cu_count": info["cu_count"]},
-            "roofline": {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": ("sr_farfield_kernel + sr_abscoeff_near_wings_kernel + sr_abscoeff_near_zones_kernel" if not args.exact else
-                                    "sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel") +
-                                   " (the coefficient op; achieved = algorithmic flops / its HIP-event duration in the "
-                                   "timed steps: in far-field mode the zones kernel runs on a second stream beside "
-                                   "the far-field kernel, so the op is shorter than the sum of its kernels, which "
-                                   "kernels_ms.serial_run lists from a separate non-overlapped pass)",
-                         "kernel_ms": main_ms,
-                         "kernels_ms": (dict(zip(["sr_prep_kernel", "sr_abscoeff_wings_kernel",
-                                                  "sr_abscoeff_cores_kernel"], [float(v) for v in kms]))
-                                        if args.exact else
-                                        {"sr_prep_kernel": prep_ms, "coefficient_op_overlapped": main_ms,
-                                         "serial_run": dict(zip(["sr_prep_kernel", "sr_farfield_kernel",
-                                                                 "sr_abscoeff_near_wings_kernel",
-                                                                 "sr_abscoeff_near_zones_kernel"],
-                                                                [float(v) for v in serial_kms]))}),
-                         "mode": "exact" if args.exact else "far-field",
-                         "flops_per_launch": flops,
-                         "note": "fp64-vector bound (arithmetic intensity ~1e4 flop/B, no MFMA: not a "
-                                 "contraction); algorithmic flops = 16 per (line, layer, point) x "
-                                 "n_lines*13010*n_layers evaluations of the reference formulation (SURVEY 8-d); "
-                                 "peak 78.6 TFLOP/s = fp64 vector = fp64 MFMA dense peak of MI355X.  In far-field "
-                                 "mode ~90 % of those evaluations are replaced by per-box Taylor expansions, so "
-                                 "the algorithmic rate can exceed what brute force could reach; run with --exact "
-                                 "for the brute-force kernels (VALU-busy figures: DESIGN.md, profiles/)"},
+            "roofline": roofline,
             "roofline_hbm": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": alg_bytes,
-                             "note": "algorithmic bytes 8*n_grid*n_layers*2 + 80*n_lines (SURVEY 8-d); expected "
-                                     "<<1 because the kernel is compute bound"},
+                             "note": "the BASELINE-named figure: algorithmic bytes 8*n_grid*n_layers*2 + 80*n_lines "
+                                     "(SURVEY 8-d) / coefficient-op time; <<1 by construction (compute bound)"},
+            "algorithmic_speedup_vs_brute_force": {
+                "brute_force_flops": flops_bf, "equivalent_tflops": flops_bf / (main_ms * 1e-3) / 1e12,
+                "ratio_to_fp64_peak": flops_bf / (main_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                "note": "16 flop x n_lines*13010*n_layers evaluations of the reference formulation / coefficient-op "
+                        "time: NOT a roofline fraction -- in far-field mode ~94 % of those evaluations are replaced "
+                        "by per-box Taylor expansions, so this exceeds what brute force could reach"},
             "checksum": checksum,
         }
         if exact_kms is not None:
             xm = float(exact_kms[1] + exact_kms[2])
             out["roofline_exact_mode"] = {
-                "bound": "fp64-valu", "achieved": flops / (xm * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": flops / (xm * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                "bound": "fp64-valu", "achieved": flops_bf / (xm * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": flops_bf / (xm * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                 "kernel": "sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel (every (line, layer, point) "
                           "evaluated; same results to ~1e-13)",
                 "kernels_ms": {"sr_prep_kernel": float(exact_kms[0]), "sr_abscoeff_wings_kernel": float(exact_kms[1]),
@@ -276,7 +360,7 @@ def main():
                 torch.cuda.synchronize()
                 gpu = (ab, em)
             out["cpu_baseline"] = cpu_baseline(L, atm, grid, syn.CH4_MM, e_lev, q_part, args.cpu_seconds,
-                                               args.layers, gpu=gpu)
+                                               args.layers, (offs, lays, cols), gpu=gpu)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             # the shipped Python path, quoted separately.  2.3 ms per (line, layer)
             # per core was measured in the survey container, not on this box; ideal

@@ -145,6 +145,13 @@ typedef struct {
   const double *q_part;
 } sr_layers_desc;
 
+/* Stream contract of the coarse-grained calls: work is enqueued on `stream` and returns without
+ * synchronising.  A lineset owns scratch that consecutive calls share; every call therefore first
+ * orders `stream` after the end of the previous sr_abscoeff_layers* / sr_gcoeff_* call on the SAME
+ * lineset (an event wait, free when both use one stream), so calls on unrelated streams are safe.
+ * Calls on one lineset must still be ISSUED from one host thread at a time.  The sr_set_* mode
+ * switches are process-wide atomics; a call reads them once at entry. */
+
 /* abs/emi coefficient spectra for every layer over the grid shard
  * [g_lo, g_hi): what make_abscoeff_isomolec(..., useLUTs=False) returns as
  * AbsSetLOS lists (spect_main_module.py:2128-2131), i.e. calc_shapes_lines +
@@ -223,6 +230,16 @@ int sr_set_overlap(int on);
 int sr_set_table_budget(int64_t bytes);
 /* Tuning knob of the exact wings kernel: grid points per lane (4 or 8; default 8). */
 int sr_set_points_per_lane(int p);
+
+/* Executed-work accounting for bench.py's roofline (far-field mode only).  sr_set_counting(1): the
+ * following sr_abscoeff_layers* calls run the counting instantiations of the three coefficient kernels
+ * (same results; one atomic per wave and counter) -- not for timed runs.  sr_last_eval_counts: the
+ * counters of the most recent such call on this lineset, counts8[0] (line, box) far-field expansions,
+ * [1] region-1 evaluations done point by point, [2] window-end expansions, [3] (point, level)
+ * far-field polynomial evaluations, [4] region-2, [5] region-3, [6] region-4 evaluations, [7] 0.
+ * Synchronises. */
+int sr_set_counting(int on);
+int sr_last_eval_counts(sr_lineset *ls, uint64_t *counts8);
 
 /* Timing hook for bench.py: HIP-event times (ms) of the kernels of the most
  * recent sr_abscoeff_layers* call on this lineset, measured on the stream they

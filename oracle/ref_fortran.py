@@ -83,3 +83,29 @@ def curgod(which, nd, x, vmr=None, f=None):
     ptrs = [a.ctypes.data_as(_dp) for a in args]
     getattr(_lib("curgods"), "curgod_fort_%d_" % which)(*ptrs, _r(n_p, C.c_int), C.byref(res))
     return res.value
+
+
+def time_humliv_bb(n_calls=2000, n_warm=200, x0_off=1e-4, lw=1e-4, dw=4e-3, step=5e-4, centre=3000.0):
+    """Per-call wall time (microseconds) of the reference's compiled humliv_bb on one 13010-point window
+    (i1=1, i2=13010: what MakeShape passes, spect_classes.py:1999), arguments prepared once so that only
+    the Fortran call itself (through ctypes, by reference) is inside the timed region.  Returns
+    dict(median_us, min_us, n_calls, params)."""
+    import time
+    lin = np.arange(-IMXSIG * step / 2, IMXSIG * step / 2, step)
+    x = np.ascontiguousarray(lin + centre)
+    y = np.zeros(IMXSIG)
+    f = _lib("lineshape").humliv_bb_
+    xp, yp = x.ctypes.data_as(_dp), y.ctypes.data_as(_dp)
+    i1, i2 = C.c_int(1), C.c_int(IMXSIG)
+    a0, a1, a2 = C.c_double(float(x[IMXSIG // 2] + x0_off)), C.c_double(lw), C.c_double(dw)
+    args = (xp, C.byref(i1), C.byref(i2), C.byref(a0), C.byref(a1), C.byref(a2), yp)
+    for _ in range(n_warm):
+        f(*args)
+    t = np.empty(n_calls)
+    for i in range(n_calls):
+        t0 = time.perf_counter()
+        f(*args)
+        t[i] = time.perf_counter() - t0
+    return dict(median_us=float(np.median(t) * 1e6), min_us=float(t.min() * 1e6), n_calls=int(n_calls),
+                params=dict(window=IMXSIG, step=step, centre=centre, x0_offset=x0_off, lw=lw, dw_over_sqrt_ln2=dw,
+                            ry=lw / dw))

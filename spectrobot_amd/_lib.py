@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspectrobot_hip.so")
+# SPECTROBOT_HIP_LIB: a variant library built by build.py --out (tuning sweeps); default = the in-tree build
+LIB_PATH = os.environ.get("SPECTROBOT_HIP_LIB") or os.path.join(_HERE, "lib", "libspectrobot_hip.so")
 
 SR_OK = 0
 SR_ERR_ARG, SR_ERR_LIMIT, SR_ERR_HIP, SR_ERR_NODEVICE, SR_ERR_UNSUPPORTED, SR_ERR_TABLE = -1, -2, -3, -4, -5, -6
@@ -81,6 +82,8 @@ SYMBOLS = {
     "sr_set_overlap": (C.c_int, [C.c_int]),
     "sr_set_table_budget": (C.c_int, [C.c_int64]),
     "sr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "sr_set_counting": (C.c_int, [C.c_int]),
+    "sr_last_eval_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
 }
 
 if not os.path.exists(LIB_PATH):

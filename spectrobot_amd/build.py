@@ -21,9 +21,18 @@ def up_to_date():
         os.path.getmtime(os.path.abspath(__file__)) <= t
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and up_to_date():
+def build(force=False, verbose=False, extra=(), out=None):
+    """out: build a variant (extra flags, e.g. -DSR_KTHETA=5) to another path, for
+    SPECTROBOT_HIP_LIB=<path>; the default library is never overwritten by a variant."""
+    if out is None and extra:
+        raise ValueError("a build with extra flags needs its own output path (out=...)")
+    if out is None and not force and up_to_date():
         return OUT
+    OUT_ = OUT if out is None else os.path.abspath(out)
+    return _compile(OUT_, verbose, extra)
+
+
+def _compile(OUT, verbose, extra):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     tmp = "%s.tmp.%d" % (OUT, os.getpid())  # other processes never see a half-written library
     cmd = [HIPCC] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
@@ -50,6 +59,12 @@ def wait_until_built(timeout=600.0):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True,
-          extra=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])
-    print(OUT)
+    # python build.py [--force] [--out PATH -DSR_KTHETA=5 ...]
+    argv = sys.argv[1:]
+    out = None
+    if "--out" in argv:
+        i = argv.index("--out")
+        out = argv[i + 1]
+        del argv[i:i + 2]
+    print(build(force="--force" in argv, verbose=True,
+                extra=[a for a in argv if a.startswith("-") and a != "--force"], out=out))

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -151,10 +152,13 @@ double lagrange4(const double *tg, const double *qg, int n, double temp) {
   return y;
 }
 
-int g_variant = 8; // points per lane in the exact wings kernel
-int g_far_field = 1; // 1: far wings by local expansions (default), 0: every evaluation exact
-int g_overlap = 1;   // 1: zones kernel on a second stream beside the far-field kernel (default)
-size_t g_table_budget = (size_t)48 << 30; // bytes of FastRec + ColdRec tables per layer batch
+// Process-wide mode switches (sr_set_*).  Atomic: a call reads each ONCE at entry and works with that
+// snapshot, so flipping a switch from another thread never changes a call half way.
+std::atomic<int> g_variant{8};   // points per lane in the exact wings kernel
+std::atomic<int> g_far_field{1}; // 1: far wings by local expansions (default), 0: every evaluation exact
+std::atomic<int> g_overlap{1};   // 1: zones kernel on a second stream beside the far-field kernel (default)
+std::atomic<int> g_counting{0};  // 1: counting instantiations of the far-field-mode kernels (sr_set_counting)
+std::atomic<size_t> g_table_budget{(size_t)48 << 30}; // bytes of FastRec + ColdRec tables per layer batch
 
 } // namespace
 
@@ -184,6 +188,13 @@ struct sr_lineset {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int n_timed = 0; // kernels timed in the last call
   bool timed = false;
+  // d_coef / d_zone / d_counts and (without overlap) the single table set are shared by consecutive
+  // calls: every call first makes its streams wait for the end of the previous call on this handle,
+  // whatever stream that one ran on (ev_last_done), so calls on unrelated caller streams are safe.
+  hipEvent_t ev_last_done = nullptr;
+  bool last_done_recorded = false;
+  DevBuf d_counts; // kCntN executed-work counters of the last counting call
+  bool counted = false;
 };
 
 extern "C" {
@@ -229,23 +240,28 @@ int sr_device_info(char *name, int name_len, int *cu_count, double *hbm_gib) {
 
 int sr_set_table_budget(int64_t bytes) {
   if (bytes < (int64_t)(sizeof(FastRec) + sizeof(ColdRec))) return SR_ERR_ARG;
-  g_table_budget = (size_t)bytes;
+  g_table_budget.store((size_t)bytes);
   return SR_OK;
 }
 
 int sr_set_far_field(int on) {
-  g_far_field = on ? 1 : 0;
+  g_far_field.store(on ? 1 : 0);
   return SR_OK;
 }
 
 int sr_set_overlap(int on) {
-  g_overlap = on ? 1 : 0;
+  g_overlap.store(on ? 1 : 0);
+  return SR_OK;
+}
+
+int sr_set_counting(int on) {
+  g_counting.store(on ? 1 : 0);
   return SR_OK;
 }
 
 int sr_set_points_per_lane(int p) {
   if (p != 4 && p != 8) return SR_ERR_ARG;
-  g_variant = p;
+  g_variant.store(p);
   return SR_OK;
 }
 
@@ -415,6 +431,8 @@ int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, cons
     e = hipEventCreate(&ev);
     if (e != hipSuccess) { sr_lineset_destroy(ls); return hip_fail(e, "hipEventCreate"); }
   }
+  e = hipEventCreateWithFlags(&ls->ev_last_done, hipEventDisableTiming);
+  if (e != hipSuccess) { sr_lineset_destroy(ls); return hip_fail(e, "hipEventCreate"); }
   if (n_kept) *n_kept = m;
   *out = ls;
   return SR_OK;
@@ -433,6 +451,8 @@ int sr_lineset_destroy(sr_lineset *ls) {
     if (ls->ev_tables_free[b]) (void)hipEventDestroy(ls->ev_tables_free[b]);
   }
   if (ls->ev_op0) (void)hipEventDestroy(ls->ev_op0);
+  if (ls->ev_last_done) (void)hipEventDestroy(ls->ev_last_done);
+  ls->d_counts.release();
   if (ls->prep_st) (void)hipStreamDestroy(ls->prep_st);
   ls->d_coef.release();
   ls->d_first.release();
@@ -455,12 +475,16 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   const int nl = atm->n_layers, nlev = ls->n_levels, npop = nlev > 0 ? nlev : 1;
   for (int k = 0; k < nl; ++k)
     if (!(atm->temps[k] > 0.0) || !(atm->press[k] >= 0.0)) return SR_ERR_ARG;
+  // one snapshot of the mode switches per call
+  const int far_field = g_far_field.load(), overlap = g_overlap.load(), variant = g_variant.load();
+  const bool counting = g_counting.load() != 0 && far_field;
+  const size_t table_budget = g_table_budget.load();
 
   // The per-(line, layer) record tables cost 208 B each; a long LOS (the reference allows
   // imxstp = 8000 steps) is processed in layer batches that keep them under g_table_budget.
   {
     const size_t per_layer = (size_t)std::max<int64_t>(ls->n_lines, 1) * (sizeof(FastRec) + sizeof(ColdRec));
-    const int nl_max = (int)std::max<size_t>(1, g_table_budget / (g_overlap ? 2 : 1) / per_layer); // two table sets
+    const int nl_max = (int)std::max<size_t>(1, table_budget / (overlap ? 2 : 1) / per_layer); // two table sets
     if (nl > nl_max) {
       const size_t n_pts_all = (size_t)(g_hi - g_lo);
       for (int k0 = 0; k0 < nl; k0 += nl_max) {
@@ -491,9 +515,12 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   // Table set of this call and the stream its preparation runs on.  With overlap, call c + 1
   // prepares set (c + 1) % 2 on prep_st while the kernels of call c (which the caller's stream is
   // still running) read set c % 2: the HBM-write-bound prep kernel hides behind the VALU-bound ones.
-  const int b = g_overlap ? (ls->parity ^= 1) : 0;
+  const int b = overlap ? (ls->parity ^= 1) : 0;
   hipStream_t pst = st;
-  if (g_overlap) {
+  // Order this call after the previous one on this handle (see ev_last_done): a no-op when both use
+  // the same stream.  The next call's table preparation (pst) needs only its own table set to be free.
+  if (ls->last_done_recorded) HIPCHK(hipStreamWaitEvent(st, ls->ev_last_done, 0));
+  if (overlap) {
     if (!ls->prep_st) {
       HIPCHK(hipStreamCreateWithFlags(&ls->prep_st, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&ls->ev_op0, hipEventDefault));
@@ -538,7 +565,7 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     }
   }
   // set b was last read by the kernels of the call before the previous one
-  if (g_overlap && ls->free_recorded[b]) HIPCHK(hipStreamWaitEvent(pst, ls->ev_tables_free[b], 0));
+  if (overlap && ls->free_recorded[b]) HIPCHK(hipStreamWaitEvent(pst, ls->ev_tables_free[b], 0));
   rc = SL.push(hl_bytes, pst);
   if (rc) return rc;
   LayersDev A;
@@ -560,6 +587,14 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
 
   ls->timed = false;
   ls->overlapped = false;
+  ls->counted = false;
+  unsigned long long *d_cnt = nullptr;
+  if (counting) {
+    rc = ls->d_counts.ensure(sizeof(unsigned long long) * kCntN);
+    if (rc) return rc;
+    d_cnt = ls->d_counts.as<unsigned long long>();
+    HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * kCntN, st));
+  }
   if (n_sub <= 0) {
     HIPCHK(hipMemsetAsync(abs_out, 0, sizeof(double) * n_pts * nl, st));
     HIPCHK(hipMemsetAsync(emi_out, 0, sizeof(double) * n_pts * nl, st));
@@ -576,16 +611,16 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
 
   HIPCHK(hipEventRecord(ls->ev[0], pst));
   // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
-  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, line_lo, n_sub, g_far_field ? (int)g_lo : INT_MIN / 2,
-                        g_far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(),
+  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
+                        far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(),
                         d_zmax.as<int>(), pst));
   HIPCHK(hipEventRecord(ls->ev[1], pst));
-  if (g_overlap) { // the caller's stream takes over once the tables are ready
+  if (overlap) { // the caller's stream takes over once the tables are ready
     HIPCHK(hipEventRecord(ls->ev_prep_done[b], pst));
     HIPCHK(hipStreamWaitEvent(st, ls->ev_prep_done[b], 0));
     HIPCHK(hipEventRecord(ls->ev_op0, st));
   }
-  if (g_far_field) {
+  if (far_field) {
     FarParams fp;
     fp.n_levels = kMaxFarLevels;
     fp.n_layers = nl;
@@ -601,7 +636,7 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     if (rc) return rc;
     fp.pm = d_pm;
     fp.coef = ls->d_coef.as<double>();
-    if (g_overlap) {
+    if (overlap) {
       // The zones kernel needs only the record tables, the wings kernel needs the far-field
       // coefficients: zones runs on a second stream beside the far-field kernel and STORES its sums,
       // the wings kernel waits for both and adds (9.9 -> 9.2 ms on config 2: the two VALU-bound
@@ -625,14 +660,14 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
         z_emi = z_abs + n_pts * nl;
       }
       LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, d_zmax.as<int>(), n_sub,
-                            nl, (int)g_lo, (int)g_hi, ls->gp, fp, z_abs, z_emi, ls->aux));
+                            nl, (int)g_lo, (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, ls->aux));
       HIPCHK(hipEventRecord(ls->ev_join, ls->aux));
       LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, d_zmax.as<int>(), n_sub, nl,
-                                (int)g_lo, (int)g_hi, fp, st));
+                                (int)g_lo, (int)g_hi, fp, d_cnt, st));
       HIPCHK(hipEventRecord(ls->ev[2], st));
       if (!small) HIPCHK(hipStreamWaitEvent(st, ls->ev_join, 0));
       LAUNCHCHK(launch_near(1, small ? 0 : 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, d_zmax.as<int>(), n_sub,
-                            nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, st));
+                            nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st));
       HIPCHK(hipEventRecord(ls->ev[3], st));
       if (small) {
         HIPCHK(hipStreamWaitEvent(st, ls->ev_join, 0));
@@ -643,12 +678,12 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     } else {
       ls->overlapped = false;
       LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, d_zmax.as<int>(), n_sub, nl,
-                                (int)g_lo, (int)g_hi, fp, st));
+                                (int)g_lo, (int)g_hi, fp, d_cnt, st));
       HIPCHK(hipEventRecord(ls->ev[2], st));
       for (int part = 1; part <= 2; ++part) {
         LAUNCHCHK(launch_near(part, part == 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix,
                               d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out,
-                              st));
+                              d_cnt, st));
         HIPCHK(hipEventRecord(ls->ev[2 + part], st));
       }
     }
@@ -656,18 +691,21 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   } else {
     ls->n_timed = 3;
     for (int which = 0; which < 2; ++which) {
-      LAUNCHCHK(launch_abscoeff(g_variant, which, d_fast.as<FastRec>(), d_cold.as<ColdRec>(),
+      LAUNCHCHK(launch_abscoeff(variant, which, d_fast.as<FastRec>(), d_cold.as<ColdRec>(),
                                 ix, d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
                                 abs_out, emi_out, st));
       HIPCHK(hipEventRecord(ls->ev[2 + which], st));
     }
   }
-  if (g_overlap) {
+  if (overlap) {
     HIPCHK(hipEventRecord(ls->ev_tables_free[b], st));
     ls->free_recorded[b] = true;
   }
-  ls->pipelined = g_overlap != 0;
+  HIPCHK(hipEventRecord(ls->ev_last_done, st));
+  ls->last_done_recorded = true;
+  ls->pipelined = overlap != 0;
   ls->timed = true;
+  ls->counted = counting;
   return SR_OK;
 }
 
@@ -687,6 +725,14 @@ int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, 
   a.release();
   e.release();
   return rc;
+}
+
+int sr_last_eval_counts(sr_lineset *ls, uint64_t *counts8) {
+  if (!ls || !counts8 || !ls->counted) return SR_ERR_ARG;
+  HIPCHK(hipEventSynchronize(ls->ev_last_done));
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
+  HIPCHK(hipMemcpy(counts8, ls->d_counts.p, sizeof(uint64_t) * kCntN, hipMemcpyDeviceToHost));
+  return SR_OK;
 }
 
 int sr_last_kernel_ms(sr_lineset *ls, float *ms5) {

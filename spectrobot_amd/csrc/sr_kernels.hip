@@ -161,6 +161,15 @@ __device__ inline int xcd_remap(int b, int nb) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// Executed-work counters (counting instantiations only): sum a per-lane count over the wave, one
+// atomic per wave and counter.
+__device__ inline void count_add(unsigned long long *cnt, int which, unsigned per_lane, int lane) {
+  unsigned v = per_lane;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  if (lane == 0 && v) atomicAdd(&cnt[which], (unsigned long long)v);
+}
+
 // 1: every point of [lo, hi] is strictly left of il (region 1, running x from
 // k = 1) and inside the window; 2: strictly right of ir; 0: anything else.
 __device__ inline int classify(int j1, int il, int ir, int lo, int hi) {
@@ -389,10 +398,15 @@ __device__ inline int lane_reduce_index(int lane, bool &primary) {
   }
 }
 
+// COUNT: the instantiation sr_set_counting(1) selects; it adds the number of (line, box) expansions
+// this launch performs to cnt[kCntExpansions] (bench.py's executed-work accounting).  The timed
+// instantiation carries no counting code.
+template <bool COUNT>
 __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restrict__ fast,
                                                          IcIndex ix,
                                                          const int *__restrict__ zmax, int n_sub, int g_lo,
-                                                         int /*g_hi*/, FarParams fp) {
+                                                         int /*g_hi*/, FarParams fp,
+                                                         unsigned long long *__restrict__ cnt) {
   // block -> (layer, level, box).  Layers are taken in groups of ceil(n_layers / 8); xcd_remap
   // gives each XCD a contiguous run of work ids, i.e. (about) one group.  Inside a group: first
   // the two widest levels of ALL its layers (a 1024-point box runs ~100 us; left to the end of
@@ -475,6 +489,7 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
   for (int n = 0; n < 2 * kFC; ++n) v[n] = 0.;
   const FastRec *frow = fast + (size_t)layer * n_sub;
   const double hw = (double)h;
+  unsigned n_exp = 0;
   for (int i = 0; i < nr; ++i) {
     for (int base = rs[i]; base < re[i]; base += 64) {
       const int l = base + lane;
@@ -484,6 +499,7 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
       if (!ff_admissible(j1, il, ir, blo, bhi, thr2)) continue;
       if (!top && ff_admissible(j1, il, ir, plo, phi, thr2p)) continue; // owned by a wider box
       const int cls = classify(j1, il, ir, blo, bhi);
+      if (COUNT) ++n_exp;
       // x (or -x) at the box centre blo + h - 1/2, and the half-width in x units
       const double xc = cls == 1 ? fma(0.5 * (double)(2 * (blo - j1) + W - 1), r.xstep, -r.xl)
                                  : fma(0.5 * (double)(2 * (blo - (j1 + ir - 1)) + W - 1), r.xstep, r.xr);
@@ -523,6 +539,7 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
   const int n_out = lane_reduce_index<2 * kFC, 32>(lane, primary);
   if (primary)
     fp.coef[((size_t)layer * fp.n_boxes_total + fp.box_off[level] + b) * (2 * kFC) + n_out] = v[0];
+  if (COUNT) count_add(cnt, kCntExpansions, n_exp, lane);
 }
 
 // Exact near field + evaluation of the far-field polynomials.  The scalar unit is shared by
@@ -659,11 +676,11 @@ __device__ inline void window_end_sum(bool ends, int pos, double c[2 * kWE], int
 // kernel time.  The walk is per SLOT: a ballot per slot and kind, and a loop body without flag tests --
 // the shared scalar unit is what bounds this kernel (walking the lines once with per-slot flag
 // tests and a record prefetch cost 117 scalar instructions per line against 100 vector ones).
-template <int NS>
+template <int NS, bool COUNT>
 __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
     const FastRec *__restrict__ fast, IcIndex ix, const int *__restrict__ zmax, int n_sub,
     int n_tiles, int g_lo, int g_hi, FarParams fp, int add, double *__restrict__ abs_out,
-    double *__restrict__ emi_out) {
+    double *__restrict__ emi_out, unsigned long long *__restrict__ cnt) {
   constexpr int WT = 64 * NS;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
@@ -684,6 +701,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
 #pragma unroll
   for (int p = 0; p < 4; ++p) lp[p] = lane + 64 * p;
   const FastRec *frow = fast + (size_t)layer * n_sub;
+  unsigned n_r1 = 0, n_we = 0; // COUNT: region-1 evaluations of this lane, window-end expansions
   for (int rg = 0; rg < 3; ++rg) {
     for (int base = rs[rg]; base < re[rg]; base += 64) {
       const int lv = base + lane;
@@ -737,6 +755,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
                                      : fma(0.5 * (double)(2 * (wlo - r.j1) + 63), r.xstep, -r.xl);
               double f[kWE];
               wing_series6(xc, 32.0 * r.xstep, r, f);
+              if (COUNT) ++n_we;
 #pragma unroll
               for (int n = 0; n < kWE; ++n) {
                 c[n] = r.wabs * f[n];
@@ -755,6 +774,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
           const FastRec r = frow[base + __builtin_ctzll(todo)];
           const int cls = wlo < r.j1 + kHalf ? 1 : 2; // the group lies before / after the line centre
           wing_eval4(wing_x_at(r, cls, r.j1, wlo), r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl, acc_a, acc_e);
+          if (COUNT) n_r1 += 4;
         }
       }
 #pragma unroll
@@ -769,6 +789,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
           const double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
           acc_a[p] = fma(r.wabs, y, acc_a[p]);
           acc_e[p] = fma(r.wemi, y, acc_e[p]);
+          if (COUNT) ++n_r1;
         }
         // left-wing points only, k in [1, min(il - 1, end of the group)]: x = (k - 1) xstep - xl (= -x)
         for (unsigned long long todo = __ballot((flags & (32 << p)) != 0); todo; todo &= todo - 1) {
@@ -777,7 +798,9 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
           const double x = fma((double)km1, r.xstep, -r.xl);
           const double x2 = x * x;
           double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma3s(x2, fma3s(x2, 4.0, r.d), r.c));
-          y = (unsigned)km1 <= (unsigned)(min(r.il() - 1, whi - r.j1 + 1) - 1) ? y : 0.0;
+          const bool on = (unsigned)km1 <= (unsigned)(min(r.il() - 1, whi - r.j1 + 1) - 1);
+          y = on ? y : 0.0;
+          if (COUNT) n_r1 += on;
           acc_a[p] = fma(r.wabs, y, acc_a[p]);
           acc_e[p] = fma(r.wemi, y, acc_e[p]);
         }
@@ -789,7 +812,9 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
           const double x = fma((double)kmr, r.xstep, r.xr);
           const double x2 = x * x;
           double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma3s(x2, fma3s(x2, 4.0, r.d), r.c));
-          y = (unsigned)(kmr - 1) <= (unsigned)(min(kImxsig, whi - r.j1 + 1) - ir - 1) ? y : 0.0;
+          const bool on = (unsigned)(kmr - 1) <= (unsigned)(min(kImxsig, whi - r.j1 + 1) - ir - 1);
+          y = on ? y : 0.0;
+          if (COUNT) n_r1 += on;
           acc_a[p] = fma(r.wabs, y, acc_a[p]);
           acc_e[p] = fma(r.wemi, y, acc_e[p]);
         }
@@ -805,11 +830,19 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
           double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma3s(x2, fma3s(x2, 4.0, r.d), r.c));
           const bool on = ((unsigned)(k - klo) <= (unsigned)(khi - klo)) & ((unsigned)(k - il) > (unsigned)(ir - il));
           y = on ? y : 0.0;
+          if (COUNT) n_r1 += on;
           acc_a[p] = fma(r.wabs, y, acc_a[p]);
           acc_e[p] = fma(r.wemi, y, acc_e[p]);
         }
       }
     }
+  }
+  if (COUNT) {
+    count_add(cnt, kCntRegion1, n_r1, lane);
+    count_add(cnt, kCntWindowEnds, n_we, lane);
+    unsigned n_poly = 0;
+    for (int p = 0; p < NS; ++p) n_poly += (wlo + 64 * p + lane <= whi) ? (unsigned)fp.n_levels : 0u;
+    count_add(cnt, kCntPolyPoints, n_poly, lane);
   }
   // far field: one polynomial per level and slot
   const double *cl = fp.coef + (size_t)layer * fp.n_boxes_total * (2 * kFC);
@@ -902,11 +935,11 @@ __device__ inline void core_push(CorePend &P, int &fill, int lane, int a0, int n
 
 // WT points per wave (a multiple of 64): the wider the image, the fewer zones are cut in two by
 // its ends (a zone is ~280 points), i.e. the fewer partially filled lane runs.
-template <int WT, int NW>
+template <int WT, int NW, bool COUNT>
 __global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, IcIndex ix,
     const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp, int add,
-    double *__restrict__ abs_out, double *__restrict__ emi_out) {
+    double *__restrict__ abs_out, double *__restrict__ emi_out, unsigned long long *__restrict__ cnt) {
   __shared__ double s_img[NW][2][WT]; // one private image per wave: abs, emi
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_groups, grp = wg - layer * n_groups;
@@ -925,6 +958,7 @@ __global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
   p4.base = 0;
   p4.gc = p4.x0 = p4.dwp = p4.inv_dwp = p4.ryf = p4.wa = p4.we = 0.;
   int fill4 = 0;
+  unsigned n_r2 = 0, n_r3 = 0, n_r4 = 0; // COUNT: evaluations of this lane per region
   // lines whose zone [ic - zm, ic + zm] can meet the group
   const int l0 = lower_bound_ic(ix, wlo - zm), l1 = lower_bound_ic(ix, whi + zm + 1);
   const FastRec *frow = fast + (size_t)layer * n_sub;
@@ -980,6 +1014,7 @@ __global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
             double rx = d * inv_dwp; // |x(k)-x0|/dw correctly rounded: one residual correction
             rx = fma(fma(-dwp, rx, d), inv_dwp, rx);
             const double y = core_region3(ryf, (double)(float)(-rx));
+            if (COUNT) ++n_r3;
             atomicAdd(&s_a[k + ibase], wa * y);
             atomicAdd(&s_e[k + ibase], we * y);
           }
@@ -1012,6 +1047,7 @@ __global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
           if (t < na + nb) {
             const bool lf = t < na;
             const double y = region2_val(z.q2, fma((double)t, r.xstep, lf ? c_left : c_right));
+            if (COUNT) ++n_r2;
             const int idx = t + (lf ? i_left : i_right);
             s_a[idx] = fma(wa, y, s_a[idx]);
             s_e[idx] = fma(we, y, s_e[idx]);
@@ -1021,12 +1057,18 @@ __global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
       // ---- region 4: its points join the pending chunk (evaluated whenever 64 are waiting)
       {
         const unsigned ul = __builtin_amdgcn_readlane(run4l, i), ur = __builtin_amdgcn_readlane(run4r, i);
+        if (COUNT && lane == 0) n_r4 += (ul >> 16) + (ur >> 16);
         core_push<4>(p4, fill4, lane, (int)(ul & 0xffffu), (int)(ul >> 16), (int)(ur & 0xffffu), (int)(ur >> 16),
                      base_idx, xf.gc, z, wa, we, gp, s_a, s_e);
       }
     }
   }
   core_eval<4>(p4, lane < fill4, gp, s_a, s_e); // what is still waiting
+  if (COUNT) {
+    count_add(cnt, kCntRegion2, n_r2, lane);
+    count_add(cnt, kCntRegion3, n_r3, lane);
+    count_add(cnt, kCntRegion4, n_r4, lane);
+  }
   if (NW > 1) __syncthreads();
   const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
   for (int p = threadIdx.x; p < WT; p += 64 * NW) {
@@ -1065,24 +1107,39 @@ int launch_add2(double *a, const double *za, double *e, const double *ze, size_t
 }
 
 int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo,
-                    int g_hi, const FarParams &fp, hipStream_t st) {
+                    int g_hi, const FarParams &fp, unsigned long long *cnt, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
-  hipLaunchKernelGGL(sr_farfield_kernel, dim3((unsigned)(fp.n_boxes_total * n_layers)), dim3(64), 0, st, fast,
-                     ix, zmax, n_sub, g_lo, g_hi, fp);
+  const dim3 grid((unsigned)(fp.n_boxes_total * n_layers));
+  if (cnt)
+    hipLaunchKernelGGL(sr_farfield_kernel<true>, grid, dim3(64), 0, st, fast, ix, zmax, n_sub, g_lo, g_hi, fp, cnt);
+  else
+    hipLaunchKernelGGL(sr_farfield_kernel<false>, grid, dim3(64), 0, st, fast, ix, zmax, n_sub, g_lo, g_hi, fp, cnt);
   return (int)hipGetLastError();
+}
+
+template <int NW, bool COUNT>
+static void launch_zones(dim3 gz, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
+                         int n_sub, int n_t, int g_lo, int g_hi, const GridParams &gp, int add, double *abs_out,
+                         double *emi_out, unsigned long long *cnt, hipStream_t st) {
+  hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, NW, COUNT>), gz, dim3(64 * NW), 0, st, fast, cold, ix, zmax,
+                     n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt);
 }
 
 int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
                 int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp,
-                double *abs_out, double *emi_out, hipStream_t st) {
+                double *abs_out, double *emi_out, unsigned long long *cnt, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
   const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
   const dim3 grid((unsigned)(n_groups * n_layers));
   if (part == 1) {
     // slots per wave: 4 (256-point groups) measured 2.53 ms on config 2, 2: 2.31 ms, 1: see DESIGN.md
     const int n_g1 = (g_hi - g_lo + 63) / 64;
-    hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<1>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st, fast,
-                       ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, abs_out, emi_out);
+    if (cnt)
+      hipLaunchKernelGGL((sr_abscoeff_near_wings_kernel<1, true>), dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
+                         fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, abs_out, emi_out, cnt);
+    else
+      hipLaunchKernelGGL((sr_abscoeff_near_wings_kernel<1, false>), dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
+                         fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, abs_out, emi_out, cnt);
   } else {
     // Image width: wider images cut fewer zones in two (fewer (line, group) pairs: 7.1 -> 6.7 ms on
     // 1e5 points x 80 layers with 512 instead of 256) as long as the waves still fill the chip
@@ -1090,18 +1147,18 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
     const long waves512 = (long)((g_hi - g_lo + 511) / 512) * n_layers;
     const int n_t = (g_hi - g_lo + 511) / 512;
     const dim3 gz((unsigned)(n_t * n_layers));
+#define SR_ZONES(NW)                                                                                         \
+  (cnt ? launch_zones<NW, true>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st) \
+       : launch_zones<NW, false>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st))
     if (waves512 >= 3 * 4096)
-      hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 1>), gz, dim3(64), 0, st, fast, cold, ix, zmax, n_sub,
-                         n_t, g_lo, g_hi, gp, add, abs_out, emi_out);
+      SR_ZONES(1);
     else if (waves512 >= 3 * 2048)
-      hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 2>), gz, dim3(128), 0, st, fast, cold, ix, zmax, n_sub,
-                         n_t, g_lo, g_hi, gp, add, abs_out, emi_out);
+      SR_ZONES(2);
     else if (waves512 >= 3 * 1024)
-      hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 4>), gz, dim3(256), 0, st, fast, cold, ix, zmax, n_sub,
-                         n_t, g_lo, g_hi, gp, add, abs_out, emi_out);
+      SR_ZONES(4);
     else
-      hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, 8>), gz, dim3(512), 0, st, fast, cold, ix, zmax, n_sub,
-                         n_t, g_lo, g_hi, gp, add, abs_out, emi_out);
+      SR_ZONES(8);
+#undef SR_ZONES
   }
   return (int)hipGetLastError();
 }

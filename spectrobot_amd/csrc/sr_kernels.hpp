@@ -40,8 +40,14 @@ struct IcIndex {
 // (8,14) 18.2 ms and (5,19) 17.2 ms with the first far-field kernel; with the streamed
 // recurrence (6,17) 13.8, (5,19) 13.4, (4,22) 12.8, (4,24) 13.2, (3,28) 13.2.
 // (4, 22): bound 2.6e-13.
-constexpr int kTheta = 4;      // admissible distance, in box half-widths
-constexpr int kFD = 22;        // expansion degree
+#ifndef SR_KTHETA // tools/sweep_farfield.sh builds variants with -DSR_KTHETA= -DSR_KFD= into a separate file
+#define SR_KTHETA 4
+#endif
+#ifndef SR_KFD
+#define SR_KFD 22
+#endif
+constexpr int kTheta = SR_KTHETA; // admissible distance, in box half-widths
+constexpr int kFD = SR_KFD;       // expansion degree
 constexpr int kFC = kFD + 1;   // coefficients per box and output
 constexpr int kMaxFarLevels = 5;
 struct FarParams {
@@ -52,12 +58,24 @@ struct FarParams {
   double *coef;  // [n_layers][n_boxes_total][2][kFC]
 };
 int launch_add2(double *a, const double *za, double *e, const double *ze, size_t n, hipStream_t st);
+// Executed-work counters of the counting instantiations (sr_set_counting): index into cnt[kCntN].
+enum {
+  kCntExpansions = 0, // (line, box) far-field expansions          sr_farfield_kernel
+  kCntRegion1 = 1,    // region-1 evaluations done point by point  sr_abscoeff_near_wings_kernel
+  kCntWindowEnds = 2, // per-line degree-5 window-end expansions   sr_abscoeff_near_wings_kernel
+  kCntPolyPoints = 3, // (point, level) far-field polynomial evaluations, two outputs each
+  kCntRegion2 = 4,    // region-2 evaluations                      sr_abscoeff_near_zones_kernel
+  kCntRegion3 = 5,    // region-3 evaluations
+  kCntRegion4 = 6,    // region-4 evaluations
+  kCntN = 8
+};
+// cnt: device counters [kCntN] or nullptr (the timed instantiations: no counting code)
 int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo,
-                    int g_hi, const FarParams &fp, hipStream_t st);
+                    int g_hi, const FarParams &fp, unsigned long long *cnt, hipStream_t st);
 // part 1: wing-only pairs + far-field polynomials (writes); part 2: general pairs (adds)
 int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
                 int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp,
-                double *abs_out, double *emi_out, hipStream_t st);
+                double *abs_out, double *emi_out, unsigned long long *cnt, hipStream_t st);
 
 int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub, int cold_lo,
                 int cold_hi, FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st);

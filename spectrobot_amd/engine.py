@@ -149,6 +149,21 @@ class LineSet(object):
         return tuple(ms)
 
 
+    def last_eval_counts(self):
+        """Executed-work counters of the last abscoeff_layers call made under set_counting(1)
+        (sr_last_eval_counts): dict name -> count."""
+        c = (C.c_uint64 * 8)()
+        check(lib.sr_last_eval_counts(self._h, c), "sr_last_eval_counts")
+        names = ("farfield_expansions", "region1_evals", "window_end_expansions", "poly_point_levels",
+                 "region2_evals", "region3_evals", "region4_evals")
+        return dict(zip(names, (int(v) for v in c)))
+
+
+def set_counting(on):
+    """1: the next coefficient ops run the counting instantiations (executed-work accounting, untimed)."""
+    check(lib.sr_set_counting(int(bool(on))), "sr_set_counting")
+
+
 def radiance_rays(abs_c, emi_c, seg_off, seg_layer, seg_col, rad0=None):
     """Limb radiance recursion for a batch of rays (include/spectrobot_hip.h).
     abs_c/emi_c: CUDA float64 [n_layers, n_pts]; returns CUDA float64 [n_rays, n_pts]."""

@@ -169,40 +169,37 @@ class SpectralObject(object):
     add_to_spectrum / integrate."""
 
     def __init__(self, spectrum, spectral_grid, direction=None, units='', link_grid=False):
-        self.spectrum = copy.deepcopy(spectrum)
-        self.direction = copy.deepcopy(direction)
+        # link_grid=True shares the caller's grid object (one grid for all the steps of a LOS)
         self.spectral_grid = spectral_grid if link_grid else copy.deepcopy(spectral_grid)
+        self.spectrum = np.array(spectrum, dtype=float) if isinstance(spectrum, np.ndarray) else copy.deepcopy(spectrum)
+        self.direction = copy.deepcopy(direction)
         self.units = units
 
     def n_points(self):
         return len(self.spectrum)
 
-    def __add__(self, obj2):
-        coso = copy.deepcopy(self)
-        if isinstance(obj2, SpectralObject):
-            if len(obj2.spectrum) == len(self.spectrum):
-                coso.spectrum += obj2.spectrum
-            else:
-                coso.add_to_spectrum(obj2)
+    def _combined(self, other, sign):
+        """self + sign * other on a copy: same-length operands point by point, a shorter spectrum is
+        placed by its grid (add_to_spectrum), anything else is broadcast by numpy."""
+        out = copy.deepcopy(self)
+        if not isinstance(other, SpectralObject):
+            out.spectrum = out.spectrum + sign * other
+        elif len(other.spectrum) == len(self.spectrum):
+            out.spectrum = out.spectrum + sign * other.spectrum
         else:
-            coso.spectrum += obj2
-        return coso
+            out.add_to_spectrum(other, Strength=sign)
+        return out
+
+    def __add__(self, obj2):
+        return self._combined(obj2, 1.0)
 
     def __sub__(self, obj2):
-        coso = copy.deepcopy(self)
-        if isinstance(obj2, SpectralObject):
-            if len(obj2.spectrum) == len(self.spectrum):
-                coso.spectrum -= obj2.spectrum
-            else:
-                coso.add_to_spectrum(obj2, Strength=-1.0)
-        else:
-            coso.spectrum -= obj2
-        return coso
+        return self._combined(obj2, -1.0)
 
     def __mul__(self, obj2):
-        coso = copy.deepcopy(self)
-        coso.spectrum *= obj2.spectrum if isinstance(obj2, SpectralObject) else obj2
-        return coso
+        out = copy.deepcopy(self)
+        out.spectrum = out.spectrum * (obj2.spectrum if isinstance(obj2, SpectralObject) else obj2)
+        return out
 
     def multiply(self, factor, save=True):
         if save:

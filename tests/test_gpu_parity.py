@@ -613,3 +613,86 @@ def test_two_gas_mixture_and_per_gas_jacobian(eng):
         fd = (rp - rm)[0] / (2 * h)
         assert float(((jac[0, k] - fd).abs() / fd.abs().max()).max()) < 2e-5, k
     assert float(jac[0, :2].abs().max()) == 0.0   # layers below the tangent height
+
+
+@pytest.mark.gpu
+def test_calls_on_unsynchronised_streams(eng):
+    """Consecutive calls on ONE lineset from caller streams that are NOT ordered against each other (no
+    wait_stream): the handle's shared scratch (far-field coefficients, zone sums, record tables) is
+    protected by the library's own end-of-previous-call event.  Both overlap settings."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2987.0, 5e-4, 60000)
+    L = syn.make_lines(6000, grid, seed=92, n_levels=12)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    atm = syn.make_atmosphere(24, 12)
+    cases = [(atm["temps"] + 3.0 * i, atm["press"] * (1.0 + 0.5 * i), atm["tvib"] + 3.0 * i) for i in range(6)]
+    try:
+        for overlap in (1, 0):
+            eng.set_overlap(0)
+            ref = [ls.abscoeff_layers(T, P, tvib=tv) for T, P, tv in cases]
+            torch.cuda.synchronize()
+            eng.set_overlap(overlap)
+            streams = [torch.cuda.Stream() for _ in range(3)]
+            got = []
+            for i, (T, P, tv) in enumerate(cases):
+                with torch.cuda.stream(streams[i % 3]):          # no wait_stream anywhere
+                    got.append(ls.abscoeff_layers(T, P, tvib=tv))
+            torch.cuda.synchronize()
+            for i, (a, e) in enumerate(got):
+                assert bool((a == ref[i][0]).all()) and bool((e == ref[i][1]).all()), (overlap, i)
+    finally:
+        eng.set_overlap(1)
+
+
+def _humliv_bounds_np(xwin, x0, lw, dwp):
+    """Region boundaries of the middle branch (lineshape.f:443-490), 1-based, in numpy."""
+    nint0 = lambda v: int(max(np.floor(v + 0.5), 0)) if v > 0 else 0
+    n = len(xwin)
+    ry, xs = lw / dwp, (xwin[1] - xwin[0]) / dwp
+    rx = (x0 - xwin[0]) / dwp
+    il = 1 + nint0((rx - ry - 15.0) / xs) if rx + ry >= 15.0 else 1
+    rx = (xwin[-1] - x0) / dwp
+    ir = n - nint0((rx - ry - 15.0) / xs) if rx + ry >= 15.0 else n
+    return il, ir
+
+
+@pytest.mark.gpu
+def test_executed_work_counters(eng):
+    """sr_set_counting: the counting instantiations give bit-identical spectra, and the zone counters
+    (regions 2 + 3 + 4) equal the number of (line, layer, point) triples inside [il, ir] -- computed
+    here from the reference's boundary formulas -- that fall into the shard."""
+    from spectrobot_amd import synthetic as syn, spect_classes as spcl
+    grid = syn.make_grid(2990.0, 5e-4, 40000)
+    L = syn.make_lines(300, grid, seed=17, n_levels=0)
+    T = np.array([160.0, 120.0])
+    P = np.array([3.0, 1e-3])
+    q = np.array([200.0, 150.0])
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM)
+    lo, hi = 3000, 38011
+    a0, e0 = ls.abscoeff_layers(T, P, q_part=q, g_lo=lo, g_hi=hi)
+    eng.set_counting(1)
+    try:
+        a1, e1 = ls.abscoeff_layers(T, P, q_part=q, g_lo=lo, g_hi=hi)
+        c = ls.last_eval_counts()
+    finally:
+        eng.set_counting(0)
+    assert bool((a0 == a1).all()) and bool((e0 == e1).all())
+    step = grid[1] - grid[0]
+    lin = np.arange(-13010 * step / 2, 13010 * step / 2, step)
+    want = 0
+    for k in range(2):
+        for f, ga, na in zip(L["freq"], L["air_broad"], L["t_dep_broad"]):
+            ic = int(np.argmin(np.abs(grid - f)))
+            xwin = lin + grid[ic]
+            lw = spcl.Lorenz_width(T[k], spcl.convert_to_atm(P[k]), na, ga)
+            dwp = spcl.Doppler_width(T[k], syn.CH4_MM, f) / np.sqrt(np.log(2.0))
+            il, ir = _humliv_bounds_np(xwin, f, lw, dwp)
+            j_lo, j_hi = ic - 6505 + il - 1, ic - 6505 + ir - 1       # grid indices of k = il .. ir
+            want += max(0, min(j_hi, hi - 1) - max(j_lo, lo) + 1)
+    assert c["region2_evals"] + c["region3_evals"] + c["region4_evals"] == want
+    assert c["region3_evals"] > 0 and c["region4_evals"] > 0 and c["region2_evals"] > 0
+    assert c["farfield_expansions"] > 0 and c["poly_point_levels"] == 5 * 2 * (hi - lo)
+    # every (line, layer, point) inside window and shard is either a zone point, a region-1 evaluation,
+    # or covered by an expansion: the point-by-point part must be a small share of the brute-force count
+    assert c["region1_evals"] < 0.5 * 300 * 2 * 13010
