@@ -127,7 +127,10 @@ typedef struct sr_lineset sr_lineset; /* opaque, device resident */
  * handed to calc_shapes_lines (spect_classes.py:1378).  Applies the reference's
  * line filter (spect_classes.py:1384-1388 with LinkToMolec 122-150), finds each
  * line's window centre (closest_grid, spect_classes.py:1937-1943) and sorts by
- * centre.  n_kept (may be NULL) receives the number of lines retained. */
+ * centre.  n_kept (may be NULL) receives the number of lines retained.
+ * Lines farther than half a window (~3.25 cm^-1 at the default step) from the grid are kept too:
+ * their window sits on the first / last grid point, humliv_bb takes one of its outer branches
+ * (lineshape.f:272-442) and their far wing inside the grid is added, as in the reference. */
 int sr_lineset_create(const sr_lines_desc *lines, const sr_isomolec_desc *iso,
                       const sr_grid_desc *grid, sr_lineset **out,
                       int64_t *n_kept);
@@ -163,6 +166,26 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm,
 /* Same with HOST output buffers (copies back; PCIe-inclusive). */
 int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo,
                        int64_t g_hi, double *abs_out, double *emi_out);
+
+/* Per-level, per-ctype G-coefficient spectra: what LutSet.add_PT -> SpectralGcoeff.BuildCoeff(lines,
+ * Temp, Pres, preCalc_shapes=True) produce for ONE level at every (P, T) of the layer stack
+ * (spect_main_module.py:1122-1168, spect_classes.py:1277-1337; called per level from
+ * LookUpTable.make, spect_main_module.py:770-774, and make_abscoeff_isomolec, :1983-1990):
+ *   sp_emission, ind_emission: sum over the lines whose UPPER level is `level` of G_ctype * shape,
+ *   absorption:                sum over the lines whose LOWER level is `level` (spect_classes.py:1304-1313);
+ * for an iso-molecule without levels (the 'all' set, spect_classes.py:1316-1319) level must be 0 and
+ * every line counts.  No population enters (that is the caller's combine, spect_main_module.py:2073-2080).
+ * g_out: DEVICE [3][n_layers][g_hi-g_lo], ctype 0 'sp_emission', 1 'ind_emission', 2 'absorption'.
+ * atm->tvib / q_part are not used.  Lines of the level are cut into a sub-lineset on first use. */
+int sr_gcoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, int64_t g_lo, int64_t g_hi,
+                         double *g_out, void *stream);
+
+/* One level's share of the abs / emi coefficients, the reference's track_levels output
+ * (spect_main_module.py:2083-2087): abs = pop_L (Gabs_L - Gind_L), emi = pop_L Gsp_L with
+ * pop_L = exp(-c2 E_L / Tvib_L) / Q(T).  Summed over the levels this is sr_abscoeff_layers_dev.
+ * abs_out / emi_out: DEVICE [n_layers][g_hi-g_lo]. */
+int sr_abscoeff_level_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, int64_t g_lo, int64_t g_hi,
+                          double *abs_out, double *emi_out, void *stream);
 
 /* Limb radiance recursion for a batch of rays over the shard (the build's own
  * definition standing in for the absent sbm LineOfSight.radtran_fast, call

@@ -74,6 +74,9 @@ def lib():
         L.sro_abscoeff_layers.argtypes = [C.POINTER(_Lines), C.c_double, C.c_int, _dp, C.c_int,
                                           _dp, _dp, _dp, _dp, _dp, C.c_long, C.c_int, C.c_int,
                                           _dp, _dp]
+        L.sro_gcoeff_layers.restype = C.c_int
+        L.sro_gcoeff_layers.argtypes = [C.POINTER(_Lines), C.c_double, C.c_int, _dp, C.c_int,
+                                        _dp, _dp, _dp, _dp, _dp, C.c_long, C.c_int, _dp, _dp, _dp]
         L.sro_hires_to_lowres.restype = None
         L.sro_hires_to_lowres.argtypes = [_dp, _dp, C.c_long, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp]
         L.sro_radiance_ray.restype = None
@@ -216,6 +219,38 @@ def abscoeff_layers(lines, mm, e_lev, temps, press, q_part, tvib, grid, mode=0, 
     if rc:
         raise ValueError("sro_abscoeff_layers rc=%d" % rc)
     return ab, em
+
+
+def gcoeff_layers(lines, mm, e_lev, temps, press, q_part, tvib, grid, n_threads=1):
+    """abscoeff_layers(mode=0) that also returns the per-level G spectra it materialises:
+    (abs, emi, G[n_layers, max(n_levels, 1), 3, n_grid]); ctype 0 sp_emission, 1 ind_emission, 2 absorption."""
+    keep = {}
+    st = _Lines()
+    st.n_lines = len(lines["freq"])
+    for n in ("freq", "a_coeff", "e_lower", "g_up", "g_lo", "air_broad", "t_dep_broad"):
+        keep[n], p = _d(lines[n])
+        setattr(st, n, p)
+    for n in ("lev_up", "lev_lo"):
+        keep[n], p = _i(lines.get(n, np.zeros(st.n_lines)))
+        setattr(st, n, p)
+    e_lev = np.ascontiguousarray(e_lev if e_lev is not None else [], dtype=np.float64)
+    temps, tp = _d(temps)
+    press, pp = _d(press)
+    q_part, qp = _d(q_part)
+    grid, gp = _d(grid)
+    nlay = temps.size
+    tvp = None
+    if tvib is not None:
+        tvib, tvp = _d(tvib)
+    ab = np.zeros((nlay, grid.size))
+    em = np.zeros((nlay, grid.size))
+    G = np.zeros((nlay, max(e_lev.size, 1), 3, grid.size))
+    rc = lib().sro_gcoeff_layers(C.byref(st), mm, e_lev.size, e_lev.ctypes.data_as(_dp), nlay, tp, pp, qp, tvp, gp,
+                                 grid.size, n_threads, ab.ctypes.data_as(_dp), em.ctypes.data_as(_dp),
+                                 G.ctypes.data_as(_dp))
+    if rc:
+        raise ValueError("sro_gcoeff_layers rc=%d" % rc)
+    return ab, em, G
 
 
 def radiance_ray(abs_c, emi_c, seg_layer, col, rad0=None):

@@ -534,6 +534,7 @@ typedef struct {
   long n_grid;
   int mode;
   double *abs_out, *emi_out;
+  double *g_out;        /* mode 0 only: [n_layers][n_set][3][n_grid] per-level G spectra, or NULL */
   const long *ic;       /* closest grid index per line */
   const double *lin_grid; /* np.arange(-imxsig*s/2, imxsig*s/2, s) */
   int layer_lo, layer_hi;
@@ -616,6 +617,8 @@ static void layer_run(job_t *J, int k, double *xwin, double *shape,
       }
     }
   }
+  if (J->mode == 0 && J->g_out)
+    memcpy(J->g_out + (long)k * nset * 3 * n, gbuf, sizeof(double) * nset * 3 * n);
   if (J->mode == 0) {
     /* smm:2052-2080 */
     for (int lv = 0; lv < nset; lv++) {
@@ -648,12 +651,39 @@ static void *worker(void *arg) {
   return NULL;
 }
 
+static int abscoeff_impl(const sro_lines *L, double mm, int n_levels,
+                         const double *e_lev, int n_layers, const double *temps,
+                         const double *press, const double *q_part,
+                         const double *tvib, const double *grid, long n_grid,
+                         int mode, int n_threads, double *abs_out,
+                         double *emi_out, double *g_out);
+
 int sro_abscoeff_layers(const sro_lines *L, double mm, int n_levels,
                         const double *e_lev, int n_layers, const double *temps,
                         const double *press, const double *q_part,
                         const double *tvib, const double *grid, long n_grid,
                         int mode, int n_threads, double *abs_out,
                         double *emi_out) {
+  return abscoeff_impl(L, mm, n_levels, e_lev, n_layers, temps, press, q_part, tvib, grid, n_grid, mode,
+                       n_threads, abs_out, emi_out, NULL);
+}
+
+int sro_gcoeff_layers(const sro_lines *L, double mm, int n_levels,
+                      const double *e_lev, int n_layers, const double *temps,
+                      const double *press, const double *q_part,
+                      const double *tvib, const double *grid, long n_grid,
+                      int n_threads, double *abs_out, double *emi_out,
+                      double *g_out) {
+  return abscoeff_impl(L, mm, n_levels, e_lev, n_layers, temps, press, q_part, tvib, grid, n_grid, 0,
+                       n_threads, abs_out, emi_out, g_out);
+}
+
+static int abscoeff_impl(const sro_lines *L, double mm, int n_levels,
+                         const double *e_lev, int n_layers, const double *temps,
+                         const double *press, const double *q_part,
+                         const double *tvib, const double *grid, long n_grid,
+                         int mode, int n_threads, double *abs_out,
+                         double *emi_out, double *g_out) {
   if (n_levels > 64 || n_grid < 2) return -3;
   long *ic = (long *)malloc(sizeof(long) * (L->n_lines > 0 ? L->n_lines : 1));
   for (long i = 0; i < L->n_lines; i++) {
@@ -691,6 +721,7 @@ int sro_abscoeff_layers(const sro_lines *L, double mm, int n_levels,
     J->n_layers = n_layers; J->temps = temps; J->press = press;
     J->q_part = q_part; J->tvib = tvib; J->grid = grid; J->n_grid = n_grid;
     J->mode = mode; J->abs_out = abs_out; J->emi_out = emi_out; J->ic = ic;
+    J->g_out = g_out;
     J->lin_grid = lin_grid;
     J->layer_lo = (int)((long)n_layers * t / n_threads);
     J->layer_hi = (int)((long)n_layers * (t + 1) / n_threads);

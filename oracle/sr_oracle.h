@@ -121,6 +121,17 @@ int sro_abscoeff_layers(const sro_lines *L, double mm, int n_levels,
                         int mode, int n_threads, double *abs_out,
                         double *emi_out);
 
+/* As sro_abscoeff_layers in mode 0, also returning the per-level, per-ctype G-coefficient spectra it
+ * builds on the way -- what LutSet.add_PT / SpectralGcoeff.BuildCoeff produce (spect_main_module.py:1122-1168,
+ * spect_classes.py:1277-1337): g_out[n_layers][n_set][3][n_grid], n_set = max(n_levels, 1), ctype 0
+ * sp_emission, 1 ind_emission, 2 absorption. */
+int sro_gcoeff_layers(const sro_lines *L, double mm, int n_levels,
+                      const double *e_lev, int n_layers, const double *temps,
+                      const double *press, const double *q_part,
+                      const double *tvib, const double *grid, long n_grid,
+                      int n_threads, double *abs_out, double *emi_out,
+                      double *g_out);
+
 /* Build's own definition of the limb radiance recursion (reference source
  * absent: parity unpinned).  For one ray crossing n_seg segments in photon
  * order; seg_layer[s] indexes the layer whose coefficients apply, col[s] is

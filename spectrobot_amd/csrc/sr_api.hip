@@ -152,6 +152,15 @@ double lagrange4(const double *tg, const double *qg, int n, double temp) {
   return y;
 }
 
+// Host copy of a (filtered, centre-sorted) line list in the layout of the device SoA: 12 double
+// arrays then 3 int arrays of length md.
+struct HostLines {
+  size_t md = 1;   // array stride (>= 1)
+  int64_t m = 0;   // lines
+  std::vector<double> d;
+  std::vector<int> i;
+};
+
 // Process-wide mode switches (sr_set_*).  Atomic: a call reads each ONCE at entry and works with that
 // snapshot, so flipping a switch from another thread never changes a call half way.
 std::atomic<int> g_variant{8};   // points per lane in the exact wings kernel
@@ -163,7 +172,15 @@ std::atomic<size_t> g_table_budget{(size_t)48 << 30}; // bytes of FastRec + Cold
 } // namespace
 
 struct sr_lineset {
-  int64_t n_lines = 0; // kept
+  int64_t n_lines = 0; // main lines (centre inside its own window)
+  HostLines host, host_outer; // host copies: per-level subsets are cut from them (level_set)
+  int n_outer = 0;            // lines whose centre lies outside their window (outer branches)
+  DevBuf d_lines_outer, d_outer_recs;
+  LinesDev Lo{};
+  // per-level sub-linesets (lines whose upper or lower level is L), built on first use by the
+  // G-coefficient / tracked-level entry points; nullptr until then
+  std::vector<sr_lineset *> level_sets;
+  DevBuf d_gscratch;          // second output channel of the ind_emission pass
   GridParams gp{};
   int mol = 0, iso = 0, n_levels = 0;
   double mm = 0.0;
@@ -283,7 +300,82 @@ int sr_calc_partition_sum(int mol, int iso, const double *temps, int n, double *
   return SR_OK;
 }
 
+} // extern "C"
+
 // ------------------------------------------------------------------------
+namespace {
+
+int upload_soa(const HostLines &H, DevBuf &buf, LinesDev &L) {
+  const size_t bytes_d = H.d.size() * sizeof(double), bytes_i = H.i.size() * sizeof(int);
+  int rc = buf.ensure(bytes_d + bytes_i);
+  if (rc) return rc;
+  char *base = buf.as<char>();
+  HIPCHK(hipMemcpy(base, H.d.data(), bytes_d, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(base + bytes_d, H.i.data(), bytes_i, hipMemcpyHostToDevice));
+  const double *dd = reinterpret_cast<const double *>(base);
+  const int *di = reinterpret_cast<const int *>(base + bytes_d);
+  const size_t md = H.md;
+  L.freq = dd + 0 * md; L.hcf = dd + 1 * md; L.a_coeff = dd + 2 * md; L.b21 = dd + 3 * md;
+  L.b12 = dd + 4 * md; L.e_lower = dd + 5 * md; L.g_up = dd + 6 * md; L.g_lo = dd + 7 * md;
+  L.air_broad = dd + 8 * md; L.t_dep = dd + 9 * md; L.evib_up = dd + 10 * md; L.evib_lo = dd + 11 * md;
+  L.ic = di + 0 * md; L.lev_up = di + 1 * md; L.lev_lo = di + 2 * md;
+  L.n_lines = (int)H.m;
+  return SR_OK;
+}
+
+// rows `sel` of H (ascending, so the subset stays sorted by window centre)
+HostLines subset(const HostLines &H, const std::vector<int64_t> &sel) {
+  HostLines S;
+  S.m = (int64_t)sel.size();
+  S.md = (size_t)std::max<int64_t>(S.m, 1);
+  S.d.assign(12 * S.md, 0.0);
+  S.i.assign(3 * S.md, 0);
+  for (int64_t q = 0; q < S.m; ++q) {
+    for (int a = 0; a < 12; ++a) S.d[a * S.md + q] = H.d[a * H.md + sel[q]];
+    for (int a = 0; a < 3; ++a) S.i[a * S.md + q] = H.i[a * H.md + sel[q]];
+  }
+  return S;
+}
+
+} // namespace
+
+// Device side of a lineset from its host line lists (main: centre inside its window; outer: not).
+static int lineset_upload(sr_lineset *ls) {
+  const HostLines &H = ls->host;
+  ls->n_lines = H.m;
+  ls->ic.assign(H.i.begin(), H.i.begin() + H.m);
+  ls->freq_max = 0.0;
+  for (int64_t q = 0; q < H.m; ++q) ls->freq_max = std::max(ls->freq_max, H.d[q]);
+  for (int64_t q = 0; q < ls->host_outer.m; ++q) ls->freq_max = std::max(ls->freq_max, ls->host_outer.d[q]);
+  int rc = upload_soa(H, ls->d_lines, ls->L);
+  if (rc) return rc;
+  ls->n_outer = (int)ls->host_outer.m;
+  if (ls->n_outer > 0) {
+    rc = upload_soa(ls->host_outer, ls->d_lines_outer, ls->Lo);
+    if (rc) return rc;
+  }
+  { // direct index into the sorted centres (IcIndex)
+    const int64_t m = H.m;
+    const int x0 = m > 0 ? ls->ic.front() : 0, n_tab = m > 0 ? ls->ic.back() - x0 + 2 : 1;
+    std::vector<int> first((size_t)n_tab);
+    size_t q = 0;
+    for (int t = 0; t < n_tab; ++t) {
+      while (q < (size_t)m && ls->ic[q] < x0 + t) ++q;
+      first[(size_t)t] = (int)q;
+    }
+    rc = ls->d_first.ensure(sizeof(int) * (size_t)n_tab);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(ls->d_first.p, first.data(), sizeof(int) * (size_t)n_tab, hipMemcpyHostToDevice));
+    ls->first_x0 = x0;
+    ls->first_n = n_tab;
+  }
+  for (auto &ev : ls->ev) HIPCHK(hipEventCreate(&ev));
+  HIPCHK(hipEventCreateWithFlags(&ls->ev_last_done, hipEventDisableTiming));
+  return SR_OK;
+}
+
+extern "C" {
+
 int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, const sr_grid_desc *gd,
                       sr_lineset **out, int64_t *n_kept) {
   if (!ld || !iso || !gd || !out) return SR_ERR_ARG;
@@ -330,6 +422,7 @@ int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, cons
   }
   const int64_t m = (int64_t)keep.size();
   std::vector<int> ic(m);
+  std::vector<char> is_outer(m, 0);
   const int ng = gp.n_grid;
   for (int64_t q = 0; q < m; ++q) {
     const double f = ld->freq[keep[q]];
@@ -346,31 +439,32 @@ int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, cons
       if (v < bv) { bv = v; best = j; }
     }
     ic[q] = (int)best;
+    // A line farther than half a window (~3.25 cm-1) from the grid has its centre outside its own
+    // window: humliv_bb takes an outer branch (lineshape.f:272, 358).  Kept apart, see launch_outer.
     WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, (int)best)};
-    if (!(xf(1) < f && f < xf(kImxsig))) {
-      g_err = "line centre outside its 13010-point window (line farther than 3.25 cm-1 from the grid): "
-              "the reference reaches humliv_bb's outer branches here, not supported";
-      return SR_ERR_UNSUPPORTED;
-    }
+    is_outer[q] = !(xf(1) < f && f < xf(kImxsig));
   }
   std::vector<int64_t> ord(m);
   std::iota(ord.begin(), ord.end(), 0);
   std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return ic[x] < ic[y]; });
 
   sr_lineset *ls = new sr_lineset();
-  ls->n_lines = m;
   ls->gp = gp;
   ls->mol = iso->mol;
   ls->iso = iso->iso;
   ls->mm = iso->mm;
   ls->n_levels = nlev;
   ls->e_lev.assign(iso->level_energy, iso->level_energy + nlev);
-  ls->ic.resize(m);
 
-  const size_t md = (size_t)std::max<int64_t>(m, 1);
-  std::vector<double> hd(12 * md, 0.0);
-  std::vector<int> hi(3 * md, 0);
+  // the line list in device layout, main and outer lines apart (both in centre order)
+  HostLines all;
+  all.m = m;
+  all.md = (size_t)std::max<int64_t>(m, 1);
+  all.d.assign(12 * all.md, 0.0);
+  all.i.assign(3 * all.md, 0);
+  const size_t md = all.md;
   const double h = kHcgs, c = kCcgs;
+  std::vector<int64_t> sel_main, sel_outer;
   for (int64_t q = 0; q < m; ++q) {
     const int64_t s = keep[ord[q]];
     const double f = ld->freq[s];
@@ -378,7 +472,7 @@ int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, cons
     const double b21 = ld->a_coeff[s] / fact_2;               // :1750
     const double b12 = ld->g_lo[s] != 0.0 ? b21 * ld->g_up[s] / ld->g_lo[s] : 0.0; // :1783
     const int lu = nlev > 0 ? ld->lev_up[s] : 0, ll = nlev > 0 ? ld->lev_lo[s] : 0;
-    double *d = hd.data();
+    double *d = all.d.data();
     d[0 * md + q] = f;
     d[1 * md + q] = h * c * f;
     d[2 * md + q] = ld->a_coeff[s];
@@ -391,48 +485,15 @@ int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, cons
     d[9 * md + q] = ld->t_dep_broad[s];
     d[10 * md + q] = nlev > 0 ? iso->level_energy[lu] : 0.0; // spect_classes.py:318-324
     d[11 * md + q] = nlev > 0 ? iso->level_energy[ll] : 0.0;
-    hi[0 * md + q] = ic[ord[q]];
-    hi[1 * md + q] = lu;
-    hi[2 * md + q] = ll;
-    ls->ic[q] = ic[ord[q]];
-    ls->freq_max = std::max(ls->freq_max, f);
+    all.i[0 * md + q] = ic[ord[q]];
+    all.i[1 * md + q] = lu;
+    all.i[2 * md + q] = ll;
+    (is_outer[ord[q]] ? sel_outer : sel_main).push_back(q);
   }
-  const size_t bytes_d = hd.size() * sizeof(double), bytes_i = hi.size() * sizeof(int);
-  int rc = ls->d_lines.ensure(bytes_d + bytes_i);
-  if (rc) { delete ls; return rc; }
-  char *base = ls->d_lines.as<char>();
-  hipError_t e = hipMemcpy(base, hd.data(), bytes_d, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(base + bytes_d, hi.data(), bytes_i, hipMemcpyHostToDevice);
-  if (e != hipSuccess) { ls->d_lines.release(); delete ls; return hip_fail(e, "upload lines"); }
-  const double *dd = reinterpret_cast<const double *>(base);
-  const int *di = reinterpret_cast<const int *>(base + bytes_d);
-  LinesDev &L = ls->L;
-  L.freq = dd + 0 * md; L.hcf = dd + 1 * md; L.a_coeff = dd + 2 * md; L.b21 = dd + 3 * md;
-  L.b12 = dd + 4 * md; L.e_lower = dd + 5 * md; L.g_up = dd + 6 * md; L.g_lo = dd + 7 * md;
-  L.air_broad = dd + 8 * md; L.t_dep = dd + 9 * md; L.evib_up = dd + 10 * md; L.evib_lo = dd + 11 * md;
-  L.ic = di + 0 * md; L.lev_up = di + 1 * md; L.lev_lo = di + 2 * md;
-  L.n_lines = (int)m;
-  { // direct index into the sorted centres (IcIndex)
-    const int x0 = m > 0 ? ls->ic.front() : 0, n_tab = m > 0 ? ls->ic.back() - x0 + 2 : 1;
-    std::vector<int> first((size_t)n_tab);
-    size_t q = 0;
-    for (int t = 0; t < n_tab; ++t) {
-      while (q < (size_t)m && ls->ic[q] < x0 + t) ++q;
-      first[(size_t)t] = (int)q;
-    }
-    rc = ls->d_first.ensure(sizeof(int) * (size_t)n_tab);
-    if (rc) { sr_lineset_destroy(ls); return rc; }
-    e = hipMemcpy(ls->d_first.p, first.data(), sizeof(int) * (size_t)n_tab, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { sr_lineset_destroy(ls); return hip_fail(e, "upload index"); }
-    ls->first_x0 = x0;
-    ls->first_n = n_tab;
-  }
-  for (auto &ev : ls->ev) {
-    e = hipEventCreate(&ev);
-    if (e != hipSuccess) { sr_lineset_destroy(ls); return hip_fail(e, "hipEventCreate"); }
-  }
-  e = hipEventCreateWithFlags(&ls->ev_last_done, hipEventDisableTiming);
-  if (e != hipSuccess) { sr_lineset_destroy(ls); return hip_fail(e, "hipEventCreate"); }
+  ls->host = subset(all, sel_main);
+  ls->host_outer = subset(all, sel_outer);
+  const int rc = lineset_upload(ls);
+  if (rc) { sr_lineset_destroy(ls); return rc; }
   if (n_kept) *n_kept = m;
   *out = ls;
   return SR_OK;
@@ -441,6 +502,11 @@ int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, cons
 int sr_lineset_destroy(sr_lineset *ls) {
   if (!ls) return SR_OK;
   (void)hipDeviceSynchronize(); // work of the last calls may still be in flight on the internal streams
+  for (sr_lineset *child : ls->level_sets) sr_lineset_destroy(child);
+  ls->level_sets.clear();
+  ls->d_lines_outer.release();
+  ls->d_outer_recs.release();
+  ls->d_gscratch.release();
   ls->d_lines.release();
   for (int b = 0; b < 2; ++b) {
     ls->s_layers[b].release();
@@ -466,8 +532,12 @@ int sr_lineset_destroy(sr_lineset *ls) {
   return SR_OK;
 }
 
-int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi,
-                           double *abs_out, double *emi_out, void *stream) {
+} // extern "C"
+
+// The coefficient op with the output weights of `W` (sr_kernels.hpp); the public entry points below
+// choose W.  abs_out / emi_out: DEVICE [n_layers][g_hi - g_lo].
+static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *abs_out,
+                   double *emi_out, void *stream, const WeightMode W) {
   if (!ls || !atm || !abs_out || !emi_out) return SR_ERR_ARG;
   if (atm->n_layers <= 0 || !atm->temps || !atm->press) return SR_ERR_ARG;
   if (g_lo < 0 || g_hi > ls->gp.n_grid || g_lo >= g_hi) return SR_ERR_ARG;
@@ -501,8 +571,8 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
                       tv.begin() + (size_t)lv * sub.n_layers);
           sub.tvib = tv.data();
         }
-        const int rc = sr_abscoeff_layers_dev(ls, &sub, g_lo, g_hi, abs_out + (size_t)k0 * n_pts_all,
-                                              emi_out + (size_t)k0 * n_pts_all, stream);
+        const int rc = coef_op(ls, &sub, g_lo, g_hi, abs_out + (size_t)k0 * n_pts_all,
+                               emi_out + (size_t)k0 * n_pts_all, stream, W);
         if (rc) return rc;
       }
       return SR_OK;
@@ -595,9 +665,33 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
     d_cnt = ls->d_counts.as<unsigned long long>();
     HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * kCntN, st));
   }
+  // lines with their centre outside their own window: added after the main kernels (launch_outer)
+  auto add_outer = [&]() -> int {
+    if (ls->n_outer <= 0) return SR_OK;
+    int rc2 = ls->d_outer_recs.ensure(sizeof(OuterRec) * (size_t)ls->n_outer * nl);
+    if (rc2) return rc2;
+    LAUNCHCHK(launch_outer(ls->Lo, ls->n_outer, A, ls->gp, W, ls->d_outer_recs.as<OuterRec>(), (int)g_lo, (int)g_hi,
+                           abs_out, emi_out, st));
+    return SR_OK;
+  };
   if (n_sub <= 0) {
     HIPCHK(hipMemsetAsync(abs_out, 0, sizeof(double) * n_pts * nl, st));
     HIPCHK(hipMemsetAsync(emi_out, 0, sizeof(double) * n_pts * nl, st));
+    if (ls->n_outer > 0) {
+      // the layer scalars were pushed on pst: the caller's stream must see them
+      if (overlap) {
+        HIPCHK(hipEventRecord(ls->ev_prep_done[b], pst));
+        HIPCHK(hipStreamWaitEvent(st, ls->ev_prep_done[b], 0));
+      }
+      rc = add_outer();
+      if (rc) return rc;
+      if (overlap) {
+        HIPCHK(hipEventRecord(ls->ev_tables_free[b], st));
+        ls->free_recorded[b] = true;
+      }
+      HIPCHK(hipEventRecord(ls->ev_last_done, st));
+      ls->last_done_recorded = true;
+    }
     return SR_OK;
   }
   rc = d_fast.ensure(sizeof(FastRec) * ((size_t)n_sub * nl + 1));
@@ -611,7 +705,7 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
 
   HIPCHK(hipEventRecord(ls->ev[0], pst));
   // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
-  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
+  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, W, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
                         far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(),
                         d_zmax.as<int>(), pst));
   HIPCHK(hipEventRecord(ls->ev[1], pst));
@@ -697,6 +791,8 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
       HIPCHK(hipEventRecord(ls->ev[2 + which], st));
     }
   }
+  rc = add_outer(); // after the timing events: not part of the per-kernel times
+  if (rc) return rc;
   if (overlap) {
     HIPCHK(hipEventRecord(ls->ev_tables_free[b], st));
     ls->free_recorded[b] = true;
@@ -707,6 +803,72 @@ int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_
   ls->timed = true;
   ls->counted = counting;
   return SR_OK;
+}
+
+// Sub-lineset of the lines whose upper or lower level is `level` (same grid, iso-molecule and level
+// table), built on first use.  For the 'all' set (no levels) the lineset itself.
+static int level_set(sr_lineset *ls, int level, sr_lineset **out) {
+  if (ls->n_levels == 0) {
+    if (level != 0) return SR_ERR_ARG;
+    *out = ls;
+    return SR_OK;
+  }
+  if (level < 0 || level >= ls->n_levels) return SR_ERR_ARG;
+  if (ls->level_sets.empty()) ls->level_sets.assign((size_t)ls->n_levels, nullptr);
+  if (!ls->level_sets[(size_t)level]) {
+    sr_lineset *c = new sr_lineset();
+    c->gp = ls->gp;
+    c->mol = ls->mol;
+    c->iso = ls->iso;
+    c->mm = ls->mm;
+    c->n_levels = ls->n_levels;
+    c->e_lev = ls->e_lev;
+    for (int which = 0; which < 2; ++which) {
+      const HostLines &H = which ? ls->host_outer : ls->host;
+      std::vector<int64_t> sel;
+      for (int64_t q = 0; q < H.m; ++q)
+        if (H.i[1 * H.md + q] == level || H.i[2 * H.md + q] == level) sel.push_back(q);
+      (which ? c->host_outer : c->host) = subset(H, sel);
+    }
+    const int rc = lineset_upload(c);
+    if (rc) { sr_lineset_destroy(c); return rc; }
+    ls->level_sets[(size_t)level] = c;
+  }
+  *out = ls->level_sets[(size_t)level];
+  return SR_OK;
+}
+
+extern "C" {
+
+int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi,
+                           double *abs_out, double *emi_out, void *stream) {
+  return coef_op(ls, atm, g_lo, g_hi, abs_out, emi_out, stream, WeightMode{kWeightFolded, 0});
+}
+
+int sr_gcoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, int64_t g_lo, int64_t g_hi,
+                         double *g_out, void *stream) {
+  if (!ls || !atm || !g_out || atm->n_layers <= 0 || g_lo < 0 || g_lo >= g_hi) return SR_ERR_ARG;
+  sr_lineset *c = nullptr;
+  int rc = level_set(ls, level, &c);
+  if (rc) return rc;
+  const size_t plane = (size_t)atm->n_layers * (size_t)(g_hi - g_lo);
+  rc = c->d_gscratch.ensure(sizeof(double) * plane);
+  if (rc) return rc;
+  // pass 1: abs channel = absorption (lines whose LOWER level is `level`), emi channel = sp_emission
+  // (UPPER level); pass 2: abs channel = ind_emission (UPPER level), emi channel unused
+  rc = coef_op(c, atm, g_lo, g_hi, g_out + 2 * plane, g_out + 0 * plane, stream, WeightMode{kWeightGabsGsp, level});
+  if (rc) return rc;
+  return coef_op(c, atm, g_lo, g_hi, g_out + 1 * plane, c->d_gscratch.as<double>(), stream,
+                 WeightMode{kWeightGind, level});
+}
+
+int sr_abscoeff_level_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, int64_t g_lo, int64_t g_hi,
+                          double *abs_out, double *emi_out, void *stream) {
+  if (!ls) return SR_ERR_ARG;
+  sr_lineset *c = nullptr;
+  const int rc = level_set(ls, level, &c);
+  if (rc) return rc;
+  return coef_op(c, atm, g_lo, g_hi, abs_out, emi_out, stream, WeightMode{kWeightTracked, level});
 }
 
 int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi,

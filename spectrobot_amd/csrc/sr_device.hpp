@@ -88,6 +88,22 @@ struct __attribute__((aligned(16))) ColdRec {
 };
 static_assert(sizeof(ColdRec) == 128, "ColdRec must be 128 bytes");
 
+// One (line, layer) of a line whose centre lies outside its own window: humliv_bb's sequential
+// outer branches (lineshape.f:272-357 for x0 <= x(i1), :358-442 for x0 >= x(i2)) reduced to three
+// index segments, each with the running value at the first index the Fortran visits there:
+// value(k) = x_ref + dir * (k - k_ref) * xstep.  Window points in no segment keep y = 0.
+struct OuterRec {
+  double ry, ryf, xstep;
+  double a, b, c, d;         // region 1 (lineshape.f:335-339)
+  double q2[8];              // region 2 (:316-325)
+  double wabs, wemi;
+  double x_core, x_r2, x_r1; // running rx / x at c_ref, r2_lo, r1_lo
+  int dir;                   // +1: x0 <= x(i1);  -1: x0 >= x(i2)
+  int j1;                    // grid index of window point k = 1
+  int c_ref, c_lo, c_hi;     // core (while loop): k in [c_lo, c_hi], running rx starts at c_ref
+  int r2_lo, r2_hi, r1_lo, r1_hi; // 1-based inclusive; lo > hi: empty
+};
+
 // max(nint(v), 0) of lineshape.f:448,453,484,489 (nint rounds half away from zero)
 __device__ inline int nint_clamp0(double v) { return v <= 0.0 ? 0 : (int)round(v); }
 

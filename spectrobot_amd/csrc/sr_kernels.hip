@@ -21,7 +21,57 @@ namespace sr {
 // prep: spect_classes.py:174-206 (MakeShapeLine), 312-343 (Calc_Gcoeffs),
 //       spect_main_module.py:2049-2080 (population weights), lineshape.f:443-490
 // ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, GridParams gp,
+// Widths, normalisation and the two output weights of line ln in layer k.
+//   lw, dw' (= dw / sqrt(ln2)), fac        spect_classes.py:1972, 1984, 1997-1999
+//   G coefficients                         spect_classes.py:326-337, 1806-1853
+//   weights by W.mode (sr_kernels.hpp: WeightMode), already divided by fac (shape = y / fac, :2003)
+struct LinePhys {
+  double lw, dwp, wabs, wemi;
+};
+__device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, const WeightMode W, int ln, int k) {
+  LinePhys P;
+  const double T = A.temps[k];
+  const double x0 = L.freq[ln];
+  P.lw = pow(A.trat[k], L.t_dep[ln]) * (L.air_broad[ln] * A.p_atm[k]);
+  const double dw = x0 / kCcgs * A.sqk[k];
+  P.dwp = dw / A.sqrt_ln2;
+  const double fac = dw * A.sqrt_pi_ln2;
+  double g_sp = 0., g_in = 0., g_ab = 0.;
+  const double a_co = L.a_coeff[ln], gu = L.g_up[ln], gl = L.g_lo[ln];
+  if (a_co != 0.0 && gl != 0.0 && gu != 0.0) {
+    const double four_pi = 4 * kPi;
+    const double el = L.e_lower[ln];
+    const double rot_up = gu * exp(-kC2 * (el + x0 - L.evib_up[ln]) / T);
+    const double rot_lo = gl * exp(-kC2 * (el - L.evib_lo[ln]) / T);
+    const double hcf = L.hcf[ln];
+    g_sp = hcf * rot_up * a_co / four_pi;
+    g_in = hcf * rot_up * L.b21[ln] / four_pi;
+    g_ab = hcf * rot_lo * L.b12[ln] / four_pi;
+  }
+  const int lu = L.lev_up[ln], ll = L.lev_lo[ln];
+  const double *pop = A.pop + (size_t)k * A.n_pop;
+  double wabs, wemi;
+  if (W.mode == kWeightFolded) { // spect_main_module.py:2073-2080 folded per line
+    const double pu = pop[lu], pl = pop[ll];
+    wabs = pl * g_ab - pu * g_in;
+    wemi = pu * g_sp;
+  } else if (W.mode == kWeightGabsGsp) { // BuildCoeff of level W.level: absorption | sp_emission (spcl:1304-1313)
+    wabs = ll == W.level ? g_ab : 0.0;
+    wemi = lu == W.level ? g_sp : 0.0;
+  } else if (W.mode == kWeightGind) {    // ... ind_emission | nothing
+    wabs = lu == W.level ? g_in : 0.0;
+    wemi = 0.0;
+  } else {                               // kWeightTracked: one level's share of abs / emi (smm:2083-2087)
+    const double pu = pop[lu], pl = pop[ll];
+    wabs = (ll == W.level ? pl * g_ab : 0.0) - (lu == W.level ? pu * g_in : 0.0);
+    wemi = lu == W.level ? pu * g_sp : 0.0;
+  }
+  P.wabs = wabs / fac;
+  P.wemi = wemi / fac;
+  return P;
+}
+
+__global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, GridParams gp, WeightMode W,
                                                       int line_lo, int n_sub, int cold_lo, int cold_hi,
                                                       FastRec *__restrict__ fast,
                                                       ColdRec *__restrict__ cold,
@@ -38,45 +88,21 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
   const bool valid = i0 < n_sub;
   const int i = valid ? i0 : n_sub - 1;
   const int ln = line_lo + i;
-  const double T = A.temps[k];
   const double x0 = L.freq[ln];
-
-  // spect_classes.py:1972, 1984, 1997-1999
-  const double lw = pow(A.trat[k], L.t_dep[ln]) * (L.air_broad[ln] * A.p_atm[k]);
-  const double dw = x0 / kCcgs * A.sqk[k];
-  const double dwp = dw / A.sqrt_ln2;
-  const double fac = dw * A.sqrt_pi_ln2;
+  const LinePhys ph = line_physics(L, A, W, ln, k);
+  const double lw = ph.lw, dwp = ph.dwp;
 
   const int ic = L.ic[ln];
   WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, ic)};
   const Bounds B = humliv_bounds(xf, kImxsig, x0, lw, dwp);
-
-  // spect_classes.py:326-337, 1806-1853
-  double g_sp = 0., g_in = 0., g_ab = 0.;
-  const double a_co = L.a_coeff[ln], gu = L.g_up[ln], gl = L.g_lo[ln];
-  if (a_co != 0.0 && gl != 0.0 && gu != 0.0) {
-    const double four_pi = 4 * kPi;
-    const double el = L.e_lower[ln];
-    const double rot_up = gu * exp(-kC2 * (el + x0 - L.evib_up[ln]) / T);
-    const double rot_lo = gl * exp(-kC2 * (el - L.evib_lo[ln]) / T);
-    const double hcf = L.hcf[ln];
-    g_sp = hcf * rot_up * a_co / four_pi;
-    g_in = hcf * rot_up * L.b21[ln] / four_pi;
-    g_ab = hcf * rot_lo * L.b12[ln] / four_pi;
-  }
-  // spect_main_module.py:2073-2080 folded per line
-  const double *pop = A.pop + (size_t)k * A.n_pop;
-  const double pu = pop[L.lev_up[ln]], pl = pop[L.lev_lo[ln]];
-  const double wabs = pl * g_ab - pu * g_in;
-  const double wemi = pu * g_sp;
 
   FastRec r;
   r.xl = B.xl;
   r.xr = B.xr;
   r.xstep = B.xstep;
   region1_coef(B.ry, r.a, r.b, r.c, r.d);
-  r.wabs = wabs / fac; // shape = y/fac, spect_classes.py:2003
-  r.wemi = wemi / fac;
+  r.wabs = ph.wabs;
+  r.wemi = ph.wemi;
   r.j1 = ic - kHalf;
   r.ilir = (uint32_t)B.il | ((uint32_t)B.ir << 16);
   {
@@ -126,6 +152,132 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) hw = max(hw, __shfl_xor(hw, m));
   if ((threadIdx.x & 63) == 0) atomicMax(&zmax[k], hw);
+}
+
+// ------------------------------------------------------------------------
+// Lines whose centre lies outside their own 13010-point window (farther than ~3.25 cm-1 from the
+// grid): closest_grid puts their window on the first / last grid point (spect_classes.py:1941) and
+// humliv_bb takes one of its two sequential outer branches; the part of the window inside the grid
+// is added to the spectrum like any other line (spect_classes.py:1113-1120).  They are few: one
+// thread per (line, layer) walks the Fortran's control flow for the segment bounds, then one thread
+// per (grid point, layer) adds the lines in list order (gather: deterministic, no atomics).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sr_outer_prep_kernel(LinesDev L, int n_out, LayersDev A, GridParams gp,
+                                                           WeightMode W, OuterRec *__restrict__ recs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (i >= n_out) return;
+  const LinePhys ph = line_physics(L, A, W, i, k);
+  const double x0 = L.freq[i], dw = ph.dwp;
+  const int ic = L.ic[i], n = kImxsig;
+  const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, ic)};
+  OuterRec r;
+  r.ry = ph.lw / dw;                        // lineshape.f:261
+  r.ryf = (double)(float)r.ry;
+  r.xstep = (xf(2) - xf(1)) / dw;           // :265-266
+  region1_coef(r.ry, r.a, r.b, r.c, r.d);
+  region2_coef(r.ry, r.q2);
+  r.wabs = ph.wabs;
+  r.wemi = ph.wemi;
+  r.j1 = ic - kHalf;
+  r.c_lo = r.r2_lo = r.r1_lo = 1;
+  r.c_hi = r.r2_hi = r.r1_hi = 0;
+  r.c_ref = 1;
+  r.x_core = r.x_r2 = r.x_r1 = 0.0;
+  const double ry = r.ry, xstep = r.xstep;
+  if (x0 <= xf(1)) {                        // :272-357
+    r.dir = 1;
+    int j = 1;
+    double rx = (xf(j) - x0) / dw;
+    r.x_core = rx;
+    while ((rx + ry < 5.5) && (j <= n)) { j = j + 1; rx = rx + xstep; }
+    r.c_lo = 1; r.c_hi = j - 1; r.c_ref = 1;
+    if (j <= n) {
+      int l = max((int)round((15.0 - ry - rx) / xstep), 0) + j;
+      l = min(l, n);
+      if (l > j) {
+        r.r2_lo = j; r.r2_hi = l;
+        r.x_r2 = (xf(j) - x0) / dw;
+        l = l + 1;
+      }
+      if (l < j) l = j;
+      if (l < n) {
+        r.r1_lo = l; r.r1_hi = n;
+        r.x_r1 = (xf(l) - x0) / dw;
+      }
+    }
+  } else {                                  // x0 >= x(i2), :358-442
+    r.dir = -1;
+    int j = n;
+    double rx = (x0 - xf(j)) / dw;
+    r.x_core = rx;
+    while ((rx + ry < 5.5) && (j >= 1)) { j = j - 1; rx = rx + xstep; }
+    r.c_lo = j + 1; r.c_hi = n; r.c_ref = n;
+    if (j >= 1) {
+      int l = j - max((int)round((15.0 - ry - rx) / dw / xstep), 0); // sic, :404
+      l = max(l, 1);
+      if (l == n) l = n + 1;
+      if (l < j) {
+        r.r2_lo = l; r.r2_hi = j;
+        r.x_r2 = (x0 - xf(l)) / dw;
+      }
+      if (l >= 1) {
+        r.r1_lo = 1; r.r1_hi = l - 1;
+        r.x_r1 = (x0 - xf(1)) / dw;
+      }
+    }
+  }
+  recs[(size_t)k * n_out + i] = r;
+}
+
+__global__ __launch_bounds__(256) void sr_outer_add_kernel(const OuterRec *__restrict__ recs, int n_out, int p_lo,
+                                                           int p_hi, int g_lo, int g_hi,
+                                                           double *__restrict__ abs_out,
+                                                           double *__restrict__ emi_out) {
+  const int j = p_lo + blockIdx.x * blockDim.x + threadIdx.x, layer = blockIdx.y;
+  if (j >= p_hi) return;
+  const OuterRec *row = recs + (size_t)layer * n_out;
+  double acc_a = 0., acc_e = 0.;
+  for (int i = 0; i < n_out; ++i) {
+    const OuterRec &r = row[i]; // wave-uniform address
+    const int k = j - r.j1 + 1;
+    if (k < 1 || k > kImxsig) continue;
+    const double s = (double)r.dir;
+    double y;
+    // the Fortran writes core, region 2, region 1 in this order over disjoint index ranges
+    if (k >= r.c_lo && k <= r.c_hi) {
+      y = core_point(fma(s * (double)(k - r.c_ref), r.xstep, r.x_core), r.ry, r.ryf);
+    } else if (k >= r.r2_lo && k <= r.r2_hi) {
+      y = region2_val(r.q2, fma(s * (double)(k - r.r2_lo), r.xstep, r.x_r2));
+    } else if (k >= r.r1_lo && k <= r.r1_hi) {
+      const double x = fma(s * (double)(k - r.r1_lo), r.xstep, r.x_r1);
+      const double x2 = x * x;
+      y = fma(x2, r.b, r.a) * fast_rcp<2>(fma(x2, fma(x2, 4.0, r.d), r.c));
+    } else {
+      continue;
+    }
+    acc_a = fma(r.wabs, y, acc_a);
+    acc_e = fma(r.wemi, y, acc_e);
+  }
+  const size_t o = (size_t)layer * (size_t)(g_hi - g_lo) + (size_t)(j - g_lo);
+  abs_out[o] += acc_a;
+  emi_out[o] += acc_e;
+}
+
+int launch_outer(const LinesDev &Lo, int n_out, const LayersDev &A, const GridParams &gp, const WeightMode &W,
+                 OuterRec *recs, int g_lo, int g_hi, double *abs_out, double *emi_out, hipStream_t st) {
+  if (n_out <= 0 || A.n_layers <= 0 || g_hi <= g_lo) return 0;
+  // their windows sit on the first / last grid point: only points within half a window of a grid end
+  const int ranges[2][2] = {{max(g_lo, 0), min(g_hi, kHalf)}, {max(g_lo, max(gp.n_grid - 1 - kHalf, kHalf)), g_hi}};
+  if (ranges[0][0] >= ranges[0][1] && ranges[1][0] >= ranges[1][1]) return 0;
+  hipLaunchKernelGGL(sr_outer_prep_kernel, dim3((n_out + 63) / 64, A.n_layers), dim3(64), 0, st, Lo, n_out, A, gp, W,
+                     recs);
+  for (int q = 0; q < 2; ++q) {
+    const int lo = ranges[q][0], hi = ranges[q][1];
+    if (lo >= hi) continue;
+    hipLaunchKernelGGL(sr_outer_add_kernel, dim3((hi - lo + 255) / 256, A.n_layers), dim3(256), 0, st, recs, n_out,
+                       lo, hi, g_lo, g_hi, abs_out, emi_out);
+  }
+  return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------
@@ -1163,12 +1315,12 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
   return (int)hipGetLastError();
 }
 
-int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub, int cold_lo,
-                int cold_hi, FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st) {
+int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, const WeightMode &W, int line_lo,
+                int n_sub, int cold_lo, int cold_hi, FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st) {
   if (n_sub <= 0 || A.n_layers <= 0) return 0;
   dim3 grid((n_sub + 255) / 256, A.n_layers);
-  hipLaunchKernelGGL(sr_prep_kernel, grid, dim3(256), 0, st, L, A, gp, line_lo, n_sub, cold_lo, cold_hi, fast, cold,
-                     zmax);
+  hipLaunchKernelGGL(sr_prep_kernel, grid, dim3(256), 0, st, L, A, gp, W, line_lo, n_sub, cold_lo, cold_hi, fast,
+                     cold, zmax);
   return (int)hipGetLastError();
 }
 

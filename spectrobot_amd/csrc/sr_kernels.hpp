@@ -22,6 +22,17 @@ struct LayersDev {
   double sqrt_ln2, sqrt_pi_ln2;
 };
 
+// What the two output channels ("abs", "emi") of the coefficient kernels accumulate, chosen per call:
+// the weights of line i in layer k, from its three G coefficients and its levels' populations.
+enum { kWeightFolded = 0, kWeightGabsGsp = 1, kWeightGind = 2, kWeightTracked = 3 };
+struct WeightMode {
+  int mode;  // kWeightFolded: abs = pop_lo G_abs - pop_up G_ind, emi = pop_up G_sp (smm:2073-2080)
+             // kWeightGabsGsp: abs = [lev_lo == level] G_abs, emi = [lev_up == level] G_sp   (BuildCoeff)
+             // kWeightGind:    abs = [lev_up == level] G_ind, emi = 0
+             // kWeightTracked: the folded weights restricted to `level` (smm:2083-2087)
+  int level;
+};
+
 // Direct index into the sorted window-centre list: first[x - x0] = number of lines with
 // centre < x, for x in [x0, x0 + n_tab) (x0 = smallest centre, last entry = n_lines), so a
 // kernel finds a candidate range with ONE load instead of a 17-step dependent binary search
@@ -77,8 +88,12 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
                 int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp,
                 double *abs_out, double *emi_out, unsigned long long *cnt, hipStream_t st);
 
-int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, int line_lo, int n_sub, int cold_lo,
-                int cold_hi, FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st);
+int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, const WeightMode &W, int line_lo,
+                int n_sub, int cold_lo, int cold_hi, FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st);
+// Lines whose centre lies outside their own window (humliv_bb's outer branches, lineshape.f:272-442):
+// records per (line, layer), then one thread per (grid point, layer) adds them in line order.
+int launch_outer(const LinesDev &Lo, int n_out, const LayersDev &A, const GridParams &gp, const WeightMode &W,
+                 OuterRec *recs, int g_lo, int g_hi, double *abs_out, double *emi_out, hipStream_t st);
 int abscoeff_tile_points(int variant);
 // which = 0: wings kernel (writes abs/emi), 1: cores kernel (adds into them)
 int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *cold, const IcIndex &ix,

@@ -130,6 +130,32 @@ class LineSet(object):
                                          C.c_void_p(em.data_ptr()), _stream_ptr()), "sr_abscoeff_layers_dev")
         return ab, em
 
+    def gcoeff_layers(self, temps, press, level=0, g_lo=0, g_hi=None):
+        """Per-ctype G-coefficient spectra of one level at every (P, T): CUDA float64
+        [3, n_layers, g_hi-g_lo], ctype 0 sp_emission, 1 ind_emission, 2 absorption
+        (sr_gcoeff_layers_dev = LutSet.add_PT / SpectralGcoeff.BuildCoeff)."""
+        g_hi = self.n_grid if g_hi is None else int(g_hi)
+        desc, keep, n = self._layers(temps, press, None, None)
+        npts = g_hi - int(g_lo)
+        if npts <= 0:
+            raise ValueError("empty shard")
+        g = torch.empty((3, n, npts), dtype=torch.float64, device="cuda")
+        check(lib.sr_gcoeff_layers_dev(self._h, C.byref(desc), int(level), int(g_lo), g_hi,
+                                       C.c_void_p(g.data_ptr()), _stream_ptr()), "sr_gcoeff_layers_dev")
+        return g
+
+    def abscoeff_level(self, temps, press, level, tvib=None, q_part=None, g_lo=0, g_hi=None):
+        """One level's share of abs / emi (track_levels, spect_main_module.py:2083-2087)."""
+        g_hi = self.n_grid if g_hi is None else int(g_hi)
+        desc, keep, n = self._layers(temps, press, tvib, q_part)
+        npts = g_hi - int(g_lo)
+        ab = torch.empty((n, npts), dtype=torch.float64, device="cuda")
+        em = torch.empty((n, npts), dtype=torch.float64, device="cuda")
+        check(lib.sr_abscoeff_level_dev(self._h, C.byref(desc), int(level), int(g_lo), g_hi,
+                                        C.c_void_p(ab.data_ptr()), C.c_void_p(em.data_ptr()), _stream_ptr()),
+              "sr_abscoeff_level_dev")
+        return ab, em
+
     def abscoeff_layers_host(self, temps, press, tvib=None, q_part=None, g_lo=0, g_hi=None):
         """Same through the host-buffer entry point (numpy in, numpy out)."""
         g_hi = self.n_grid if g_hi is None else int(g_hi)

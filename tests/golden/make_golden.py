@@ -314,7 +314,7 @@ def main():
     print("e2e_co_all: abs max %.3e" % abc.max())
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--lowres", "--hitran", "--inversion", "--retrieval")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--lowres", "--hitran", "--inversion", "--retrieval", "--gcoeff", "--outer")):
     main()
 
 
@@ -543,3 +543,162 @@ def golden_retrieval():
 
 if __name__ == "__main__" and "--retrieval" in sys.argv:
     golden_retrieval()
+
+
+def _patch_add_lines_py3(spcl, RF):
+    """SpectralObject.add_lines_to_spectrum (spect_classes.py:1016-1097) cannot run under Python 3 as it
+    lies: it slices with n_lines/n_threads (a float) and forks one process per slice.  The harness
+    replaces ONLY that fan-out: the rows are packed by the reference's own prepare_fortran_sum
+    (spect_classes.py:1100-1147, one call, a list standing in for the Queue) and summed by the reference's
+    compiled sum_all_lines (lineshape.f:2-25) on its fixed (40000, 13010) matrix and 2e6-point spectrum,
+    exactly as lines 1079-1095 arrange them.  BuildCoeff / LutSet.add_PT then run unmodified."""
+    import ctypes as C
+    lib = RF._lib("lineshape")
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    matrix = np.zeros((spcl.imxlines, spcl.imxsig), dtype=float, order="F")   # 4.16 GB, reused
+    state = {"rows": 0}
+
+    class Coda(object):
+        def put(self, v):
+            self.v = v
+
+    def add_lines_to_spectrum(self, lines, Strengths=None, fix_length=spcl.imxsig, n_threads=1):
+        n_lines = len(lines)
+        if n_lines == 0:
+            return self.spectrum
+        if n_lines > spcl.imxlines:
+            raise ValueError("too many lines")
+        lines_ok = []
+        if Strengths is not None:
+            for line, strength in zip(lines, Strengths):
+                lines_ok.append(line.multiply(strength, save=False))          # spcl:1040-1042
+        coda = Coda()
+        self.prepare_fortran_sum(lines_ok, 0, coda)
+        rows, initarr, finarr = coda.v
+        matrix[:state["rows"], :] = 0.0
+        matrix[:n_lines, :] = rows
+        state["rows"] = n_lines
+        init = np.zeros(spcl.imxlines, dtype=np.int32)
+        fin = np.zeros(spcl.imxlines, dtype=np.int32)
+        init[:n_lines], fin[:n_lines] = initarr, finarr
+        spe_ini = np.zeros(spcl.imxsig_long)
+        spe_ini[:self.n_points()] = self.spectrum
+        spe_fin = np.zeros(spcl.imxsig_long)
+        lib.sum_all_lines_(spe_ini.ctypes.data_as(dp), matrix.ctypes.data_as(dp), init.ctypes.data_as(ip),
+                           fin.ctypes.data_as(ip), C.byref(C.c_int(n_lines)), C.byref(C.c_int(self.n_points())),
+                           spe_fin.ctypes.data_as(dp))
+        self.spectrum = spe_fin[:self.n_points()]
+        return self.spectrum
+
+    spcl.SpectralObject.add_lines_to_spectrum = add_lines_to_spectrum
+
+
+def golden_gcoeff():
+    """A5: per-level, per-ctype G-coefficient spectra from the reference's own LutSet.add_PT
+    (spect_main_module.py:1122-1168) -> SpectralGcoeff.BuildCoeff(preCalc_shapes=True)
+    (spect_classes.py:1277-1337) on lines prepared by the reference's PrepareCalcShapes, for an
+    iso-molecule with levels and for the 'all' set; plus the tracked-level coefficients assembled as
+    make_abscoeff_isomolec does (spect_main_module.py:2073-2087) with the reference's operators."""
+    import io
+    spcl, RF = import_reference_spcl()
+    m_mp = types.ModuleType("memory_profiler")
+    m_mp.profile = lambda f: f
+    sys.modules["memory_profiler"] = m_mp
+    import spect_main_module as smm
+    from spectrobot_amd import synthetic as syn
+    _patch_add_lines_py3(spcl, RF)
+    ctypes_ = ["sp_emission", "ind_emission", "absorption"]
+    # longer than one 13010-point window: on a shorter grid prepare_fortran_sum shifts `init` below 1
+    # and sum_all_lines writes in front of its array (spect_classes.py:1132-1134)
+    n_grid = 14000
+    grid = syn.make_grid(2992.0, 5e-4, n_grid)
+    sg = spcl.SpectralGrid(grid, units="cm_1")
+    L = syn.make_lines(90, grid, config_id=102, n_levels=3)
+    L["lev_up"][4] = -1                      # dropped by the LinkToMolec filter
+    L["lev_lo"][7] = L["lev_up"][7]          # same-level line: dropped too
+    L["freq"][0] = grid[0] + 3e-7            # windows clipped at both grid ends
+    L["freq"][-1] = grid[-1] - 3e-7
+    L["freq"] = np.sort(L["freq"])
+    e_lev = np.array([0.0, 1311.0, 3019.0])
+    temps = np.array([168.4, 141.2])
+    press = np.array([4.0, 3.7e-3])
+    tvib = np.array([temps, temps + 14.0, temps + 31.5])
+    out = {}
+    for tag, levels in (("lev", e_lev), ("all", np.array([]))):
+        iso = IsoMolec(6, 1, syn.CH4_MM, levels)
+        G = np.zeros((len(temps), max(len(levels), 1), 3, n_grid))
+        for k, (P, T) in enumerate(zip(press, temps)):
+            lines = ref_lines(spcl, 6, 1, L, labels=len(levels) > 0)
+            if len(levels) > 0:
+                oks = [l.LinkToMolec(iso) for l in lines]                       # spcl:1384-1388
+                lines = [l for l, ok in zip(lines, oks) if ok]
+            lines = spcl.PrepareCalcShapes(sg, lines, T, P, iso)
+            names = iso.levels if len(levels) > 0 else [None]
+            for li, lev in enumerate(names):
+                ls = smm.LutSet(6, 1, syn.CH4_MM, level=None if lev is None else getattr(iso, lev), filename="unused")
+                ls.temp_file = io.BytesIO()                                      # add_PT pickles into it
+                ls.add_PT(sg, lines, P, T, keep_memory=True, n_threads=1)
+                for ci, ct in enumerate(ctypes_):
+                    G[k, li, ci] = ls.sets[0][ct].spectrum
+        out["G_" + tag] = G
+    # tracked level 1 (non-LTE populations), spect_main_module.py:2073-2087
+    iso = IsoMolec(6, 1, syn.CH4_MM, e_lev)
+    trk_abs, trk_emi = [], []
+    for k, T in enumerate(temps):
+        Q = spcl.CalcPartitionSum(6, 1, temp=T)
+        pop = spcl.Boltz_ratio_nodeg(e_lev[1], tvib[1][k]) / Q
+        mk = lambda v: spcl.SpectralObject(v.copy(), sg)
+        a = spcl.SpectralObject(np.zeros(n_grid), sg)
+        e = spcl.SpectralObject(np.zeros(n_grid), sg)
+        a += mk(out["G_lev"][k, 1, 2]) * pop
+        a -= mk(out["G_lev"][k, 1, 1]) * pop
+        e += mk(out["G_lev"][k, 1, 0]) * pop
+        trk_abs.append(a.spectrum.copy())
+        trk_emi.append(e.spectrum.copy())
+    qpart = np.array([float(spcl.CalcPartitionSum(6, 1, temp=t)) for t in temps])
+    np.savez_compressed(os.path.join(HERE, "gcoeff_levels.npz"), grid_w0=grid[0], grid_step=grid[1] - grid[0],
+                        grid_n=n_grid, mm=syn.CH4_MM, mol=6, iso=1, e_lev=e_lev, temps=temps, press=press, tvib=tvib,
+                        q_part=qpart, G_lev=out["G_lev"], G_all=out["G_all"], track_level=1,
+                        track_abs=np.array(trk_abs), track_emi=np.array(trk_emi),
+                        **{"line_" + k: v for k, v in L.items()})
+    print("gcoeff_levels: G_lev max per ctype", out["G_lev"].max(axis=(0, 1, 3)), "G_all", out["G_all"].max(axis=(0, 1, 3)))
+
+
+if __name__ == "__main__" and "--gcoeff" in sys.argv:
+    golden_gcoeff()
+
+
+def golden_outer():
+    """Lines 3.3 - 25 cm-1 OUTSIDE the grid (the usual far-wing margin of a HITRAN extraction): the
+    reference keeps them (make_abscoeff_isomolec filters on Mol / Iso only, spect_main_module.py:1968),
+    closest_grid puts their window on the first / last grid point and humliv_bb runs one of its outer
+    branches (lineshape.f:272-442).  Same route as the other end-to-end fixtures (ref_abscoeff)."""
+    spcl, RF = import_reference_spcl()
+    from spectrobot_amd import synthetic as syn
+    n_grid = 15000
+    grid = syn.make_grid(2100.0, 5e-4, n_grid)
+    L = syn.make_lines(60, grid, config_id=103, n_levels=0, co_like=True)
+    far = np.array([-25.0, -11.0, -6.0, -3.4, -3.26, -3.2531, 3.2527, 3.27, 3.6, 7.5, 14.0, 25.0])
+    for i, d in enumerate(far):
+        L["freq"][i] = (grid[0] + d) if d < 0 else (grid[-1] + d)
+        L["a_coeff"][i] *= 30.0
+    order = np.argsort(L["freq"])
+    L = {k: v[order] for k, v in L.items()}
+    iso = IsoMolec(5, 1, syn.CO_MM, [])
+    temps = np.array([150.0, 210.0, 120.0])
+    press = np.array([1013.25, 40.0, 0.02])       # Lorentz wings reach far at the first two
+    ab, em, _ = ref_abscoeff(spcl, grid, ref_lines(spcl, 5, 1, L, labels=False), iso, temps, press, None)
+    # the outer lines alone (their contribution is small next to the in-grid lines)
+    sel = (L["freq"] < grid[0] - 3.0) | (L["freq"] > grid[-1] + 3.0)
+    Lo = {k: v[sel] for k, v in L.items()}
+    abo, emo, _ = ref_abscoeff(spcl, grid, ref_lines(spcl, 5, 1, Lo, labels=False), iso, temps, press, None)
+    qp = np.array([float(spcl.CalcPartitionSum(5, 1, temp=t)) for t in temps])
+    np.savez_compressed(os.path.join(HERE, "e2e_outer_lines.npz"), grid_w0=grid[0], grid_step=grid[1] - grid[0],
+                        grid_n=n_grid, mm=syn.CO_MM, mol=5, iso=1, temps=temps, press=press, q_part=qp, abs=ab, emi=em,
+                        outer_sel=sel, abs_outer_only=abo, emi_outer_only=emo,
+                        **{"line_" + k: v for k, v in L.items()})
+    print("e2e_outer_lines: %d outer lines, outer-only abs max %.3e of %.3e" % (sel.sum(), abo.max(), ab.max()))
+
+
+if __name__ == "__main__" and "--outer" in sys.argv:
+    golden_outer()

@@ -217,13 +217,8 @@ def test_make_abscoeff_isomolec_api(eng, golden):
 
 def test_error_paths_on_device(eng):
     from spectrobot_amd import synthetic as syn
-    from spectrobot_amd._lib import SpectRobotHipError, SR_ERR_UNSUPPORTED, SR_ERR_ARG
+    from spectrobot_amd._lib import SpectRobotHipError, SR_ERR_ARG
     grid = syn.make_grid(2990.0, 5e-4, 5000)
-    L = syn.make_lines(10, grid, seed=3, n_levels=0)
-    L["freq"][0] = grid[0] - 5.0  # farther than half a window from the grid
-    with pytest.raises(SpectRobotHipError) as e:
-        eng.LineSet(L, grid, 6, 1, 16.0)
-    assert e.value.status == SR_ERR_UNSUPPORTED
     L = syn.make_lines(10, grid, seed=3, n_levels=0)
     ls = eng.LineSet(L, grid, 6, 1, 16.0)
     with pytest.raises(SpectRobotHipError) as e:
@@ -696,3 +691,91 @@ def test_executed_work_counters(eng):
     # every (line, layer, point) inside window and shard is either a zone point, a region-1 evaluation,
     # or covered by an expansion: the point-by-point part must be a small share of the brute-force count
     assert c["region1_evals"] < 0.5 * 300 * 2 * 13010
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("far", [1, 0])
+def test_outer_lines_golden_and_oracle(eng, oracle, golden, far):
+    """Lines whose centre lies outside their own window (3.3 - 25 cm-1 outside the grid): the coarse op
+    adds their far wings like the reference (humliv_bb's outer branches), in both evaluation modes;
+    against the reference run, against the oracle on a shard, and the outer lines alone."""
+    g = golden("e2e_outer_lines")
+    L, grid = _lines(g), _grid(g)
+    eng.set_far_field(far)
+    try:
+        ls = eng.LineSet(L, grid, int(g["mol"]), int(g["iso"]), float(g["mm"]))
+        assert ls.n_kept == len(L["freq"])
+        ab, em = ls.abscoeff_layers(g["temps"], g["press"], q_part=g["q_part"])
+        assert relerr(ab.cpu().numpy(), g["abs"]) < TOL and relerr(em.cpu().numpy(), g["emi"]) < TOL
+        lo, hi = 6000, 14999
+        ab2, em2 = ls.abscoeff_layers(g["temps"], g["press"], q_part=g["q_part"], g_lo=lo, g_hi=hi)
+        assert relerr(ab2.cpu().numpy(), g["abs"][:, lo:hi]) < TOL
+        Lo = {k: v[g["outer_sel"]] for k, v in L.items()}
+        lso = eng.LineSet(Lo, grid, int(g["mol"]), int(g["iso"]), float(g["mm"]))
+        abo, emo = lso.abscoeff_layers(g["temps"], g["press"], q_part=g["q_part"])
+        abo, emo = abo.cpu().numpy(), emo.cpu().numpy()
+        nz = g["abs_outer_only"] != 0
+        assert np.array_equal(abo != 0, nz)
+        # running sums of up to 13010 steps vs one fma: the drift of test_randomized_configs
+        assert relerr(abo[nz], g["abs_outer_only"][nz]) < 1e-9 and relerr(emo[nz], g["emi_outer_only"][nz]) < 1e-9
+    finally:
+        eng.set_far_field(1)
+    # a line close to the window: the sequential branches' core / region-2 segments (x0 within 5.5 dw')
+    grid2 = syn_grid = None
+    from spectrobot_amd import synthetic as syn
+    grid2 = syn.make_grid(2990.0, 5e-4, 20000)
+    L2 = syn.make_lines(6, grid2, seed=8, n_levels=0)
+    step = grid2[1] - grid2[0]
+    L2["freq"][:] = [grid2[0] - 6505 * step - 1e-3, grid2[0] - 6505 * step - 0.02, grid2[0] - 6505 * step,
+                     grid2[-1] + 6504 * step + 2e-3, grid2[-1] + 6504 * step + 0.05, grid2[-1] + 6504 * step]
+    T, P, q = np.array([150.0, 200.0]), np.array([1013.0, 0.5]), np.array([100.0, 120.0])
+    ls2 = eng.LineSet(L2, grid2, 6, 1, syn.CH4_MM)
+    a2, e2 = ls2.abscoeff_layers(T, P, q_part=q)
+    ao, eo = oracle.abscoeff_layers(L2, syn.CH4_MM, [], T, P, q, None, grid2, mode=1)
+    nz = ao != 0
+    assert np.array_equal(a2.cpu().numpy() != 0, nz)
+    assert relerr(a2.cpu().numpy()[nz], ao[nz]) < 1e-9 and relerr(e2.cpu().numpy()[nz], eo[nz]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_gcoeff_levels_golden(eng, oracle, golden):
+    """A5 on the GPU: per-level, per-ctype G spectra (sr_gcoeff_layers_dev) against the reference's own
+    LutSet.add_PT / BuildCoeff run, levels and 'all' set; their population-weighted sum is the abs / emi
+    output; the tracked-level entry point against the reference combine."""
+    g = golden("gcoeff_levels")
+    L, grid = _lines(g), _grid(g)
+    ls = eng.LineSet(L, grid, int(g["mol"]), int(g["iso"]), float(g["mm"]), g["e_lev"])
+    nlev = len(g["e_lev"])
+    G = np.stack([ls.gcoeff_layers(g["temps"], g["press"], level=lv).cpu().numpy() for lv in range(nlev)])  # [lev, 3, k, n]
+    G = G.transpose(2, 0, 1, 3)                                                                              # [k, lev, 3, n]
+    nz = g["G_lev"] != 0
+    assert np.array_equal(G != 0, nz)
+    assert relerr(G[nz], g["G_lev"][nz]) < TOL
+    # shard
+    lo, hi = 3000, 13999
+    Gs = ls.gcoeff_layers(g["temps"], g["press"], level=1, g_lo=lo, g_hi=hi).cpu().numpy()
+    assert relerr(Gs[:, :, :][g["G_lev"][:, 1].transpose(1, 0, 2)[:, :, lo:hi] != 0],
+                  g["G_lev"][:, 1].transpose(1, 0, 2)[:, :, lo:hi][g["G_lev"][:, 1].transpose(1, 0, 2)[:, :, lo:hi] != 0]) < TOL
+    # sum_L pop_L (Gabs_L - Gind_L) == abs, sum_L pop_L Gsp_L == emi (spect_main_module.py:2073-2080)
+    c2 = oracle.constants()["c2"]
+    pop = np.exp(-c2 * g["e_lev"][:, None] / g["tvib"]) / g["q_part"][None, :]          # [lev, k]
+    ab, em = ls.abscoeff_layers(g["temps"], g["press"], tvib=g["tvib"], q_part=g["q_part"])
+    want_a = sum(pop[lv][:, None] * (G[:, lv, 2] - G[:, lv, 1]) for lv in range(nlev))
+    want_e = sum(pop[lv][:, None] * G[:, lv, 0] for lv in range(nlev))
+    assert relerr(ab.cpu().numpy(), want_a) < 1e-9       # cancellation between absorption and induced emission
+    assert relerr(em.cpu().numpy(), want_e) < 1e-12
+    # tracked level
+    lv = int(g["track_level"])
+    ta, te = ls.abscoeff_level(g["temps"], g["press"], lv, tvib=g["tvib"], q_part=g["q_part"])
+    nzt = g["track_abs"] != 0
+    assert relerr(ta.cpu().numpy()[nzt], g["track_abs"][nzt]) < 1e-9
+    assert relerr(te.cpu().numpy()[g["track_emi"] != 0], g["track_emi"][g["track_emi"] != 0]) < TOL
+    # the levels' shares add up to the whole
+    sa = sum(ls.abscoeff_level(g["temps"], g["press"], l_, tvib=g["tvib"], q_part=g["q_part"])[0] for l_ in range(nlev))
+    assert float(((sa - ab).abs() / ab.abs()).max()) < 1e-9
+    # 'all' set
+    ls0 = eng.LineSet(L, grid, int(g["mol"]), int(g["iso"]), float(g["mm"]))
+    Ga = ls0.gcoeff_layers(g["temps"], g["press"], level=0).cpu().numpy().transpose(1, 0, 2)[:, None]   # [k, 1, 3, n]
+    nz = g["G_all"] != 0
+    assert np.array_equal(Ga != 0, nz)
+    assert relerr(Ga[nz], g["G_all"][nz]) < TOL

@@ -167,3 +167,47 @@ def test_hires_to_lowres(oracle, golden):
     for u in ("Wm2", "ergscm2", "nWcm2"):
         o = oracle.hires_to_lowres(grid, g["spectrum"], g["centers_nm"], g["widths_nm"], u)
         assert relerr(o, g["low_" + u]) < 1e-13
+
+
+def _glines(g):
+    return {k[5:]: g[k] for k in g.files if k.startswith("line_")}
+
+
+def _ggrid(g):
+    return float(g["grid_w0"]) + float(g["grid_step"]) * np.arange(int(g["grid_n"]))
+
+
+def test_gcoeff_levels_vs_reference_add_PT(oracle, golden):
+    """A5: per-level, per-ctype G spectra against the reference's own LutSet.add_PT -> BuildCoeff run
+    (tests/golden/make_golden.py --gcoeff), levels and the 'all' set, and the tracked-level combine."""
+    g = golden("gcoeff_levels")
+    L, grid = _glines(g), _ggrid(g)
+    ab, em, G = oracle.gcoeff_layers(L, float(g["mm"]), g["e_lev"], g["temps"], g["press"], g["q_part"], g["tvib"], grid)
+    nz = g["G_lev"] != 0
+    assert np.array_equal(G != 0, nz)
+    assert relerr(G[nz], g["G_lev"][nz]) < 1e-13
+    _, _, Ga = oracle.gcoeff_layers(L, float(g["mm"]), [], g["temps"], g["press"], g["q_part"], None, grid)
+    nz = g["G_all"] != 0
+    assert np.array_equal(Ga != 0, nz)
+    assert relerr(Ga[nz], g["G_all"][nz]) < 1e-13
+    lv = int(g["track_level"])
+    pop = np.exp(-oracle.constants()["c2"] * g["e_lev"][lv] / g["tvib"][lv]) / g["q_part"]
+    ta = G[:, lv, 2] * pop[:, None] - G[:, lv, 1] * pop[:, None]
+    assert relerr(ta, g["track_abs"]) < 1e-12
+    assert relerr(G[:, lv, 0] * pop[:, None], g["track_emi"]) < 1e-13
+
+
+def test_outer_lines_vs_reference(oracle, golden):
+    """Lines 3.3 - 25 cm-1 outside the grid (humliv_bb's outer branches through the whole coefficient
+    path) against the reference run (make_golden.py --outer)."""
+    g = golden("e2e_outer_lines")
+    L, grid = _glines(g), _ggrid(g)
+    for mode in (0, 1):
+        ab, em = oracle.abscoeff_layers(L, float(g["mm"]), [], g["temps"], g["press"], g["q_part"], None, grid,
+                                        mode=mode, n_threads=3)
+        assert relerr(ab, g["abs"]) < 1e-13 and relerr(em, g["emi"]) < 1e-13
+    Lo = {k: v[g["outer_sel"]] for k, v in L.items()}
+    ab, em = oracle.abscoeff_layers(Lo, float(g["mm"]), [], g["temps"], g["press"], g["q_part"], None, grid, mode=1)
+    nz = g["abs_outer_only"] != 0
+    assert np.array_equal(ab != 0, nz)
+    assert relerr(ab[nz], g["abs_outer_only"][nz]) < 1e-13 and relerr(em[nz], g["emi_outer_only"][nz]) < 1e-13
