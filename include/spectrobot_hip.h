@@ -174,7 +174,8 @@ int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo,
  *   sp_emission, ind_emission: sum over the lines whose UPPER level is `level` of G_ctype * shape,
  *   absorption:                sum over the lines whose LOWER level is `level` (spect_classes.py:1304-1313);
  * for an iso-molecule without levels (the 'all' set, spect_classes.py:1316-1319) level must be 0 and
- * every line counts.  No population enters (that is the caller's combine, spect_main_module.py:2073-2080).
+ * every line counts; level = -1 on an iso-molecule WITH levels sums every linked line with the G
+ * coefficients of its own levels (the 'all' LutSet of an LTE table, spect_main_module.py:742-748, 774).  No population enters (that is the caller's combine, spect_main_module.py:2073-2080).
  * g_out: DEVICE [3][n_layers][g_hi-g_lo], ctype 0 'sp_emission', 1 'ind_emission', 2 'absorption'.
  * atm->tvib / q_part are not used.  Lines of the level are cut into a sub-lineset on first use. */
 int sr_gcoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, int64_t g_lo, int64_t g_hi,
@@ -186,6 +187,20 @@ int sr_gcoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, i
  * abs_out / emi_out: DEVICE [n_layers][g_hi-g_lo]. */
 int sr_abscoeff_level_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, int64_t g_lo, int64_t g_hi,
                           double *abs_out, double *emi_out, void *stream);
+
+/* Look-up-table route: LutSet.calculate (spect_main_module.py:997-1066) for one level and
+ * n_steps LOS steps on a table of G spectra resident in HBM, g_tab: DEVICE [3][n_pt][n_pts] (ctype-major,
+ * one row per tabulated (P, T) couple, as sr_gcoeff_layers_dev writes them).  Per step, idx4[s] = table rows
+ * (P1,T1), (P1,T2), (P2,T1), (P2,T2) and wgt4[s] = (wP1, wP2, wT1, wT2): first linear in P at both
+ * temperatures, then linear in T (SpectralGcoeff.interpolate, spect_classes.py:1349-1375); idx4[s][2] < 0:
+ * T only between rows idx4[s][0], idx4[s][1] with (wT1, wT2) (below the lowest tabulated pressure, :1007-1025).
+ * combine == 0: out_a: DEVICE [3][n_steps][n_pts] receives the interpolated set (out_e unused);
+ * combine != 0: the population-weighted combine of make_abscoeff_isomolec (:2073-2080) is applied on the fly,
+ * out_a[s] += pop[s] G_abs; out_a[s] -= pop[s] G_ind; out_e[s] += pop[s] G_sp (DEVICE [n_steps][n_pts],
+ * zeroed by the caller before the first level).  idx4 / wgt4 / pop: HOST. */
+int sr_lut_interp_dev(const double *g_tab, int n_pt, int64_t n_pts, int n_steps, const int32_t *idx4,
+                      const double *wgt4, const double *pop, int combine, double *out_a, double *out_e,
+                      void *stream);
 
 /* Limb radiance recursion for a batch of rays over the shard (the build's own
  * definition standing in for the absent sbm LineOfSight.radtran_fast, call

@@ -73,6 +73,8 @@ SYMBOLS = {
                                        C.c_void_p]),
     "sr_abscoeff_level_dev": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int, C.c_int64, C.c_int64,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sr_lut_interp_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, ip, dp, dp, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
     "sr_radiance_rays_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, ip, ip, dp, C.c_int,
                                        C.c_void_p, C.c_void_p]),
     "sr_radiance_jac_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, ip, ip, dp, dp, C.c_int,

@@ -808,6 +808,10 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
 // Sub-lineset of the lines whose upper or lower level is `level` (same grid, iso-molecule and level
 // table), built on first use.  For the 'all' set (no levels) the lineset itself.
 static int level_set(sr_lineset *ls, int level, sr_lineset **out) {
+  if (level == -1) { // every line of the iso-molecule
+    *out = ls;
+    return SR_OK;
+  }
   if (ls->n_levels == 0) {
     if (level != 0) return SR_ERR_ARG;
     *out = ls;
@@ -856,10 +860,11 @@ int sr_gcoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, i
   if (rc) return rc;
   // pass 1: abs channel = absorption (lines whose LOWER level is `level`), emi channel = sp_emission
   // (UPPER level); pass 2: abs channel = ind_emission (UPPER level), emi channel unused
-  rc = coef_op(c, atm, g_lo, g_hi, g_out + 2 * plane, g_out + 0 * plane, stream, WeightMode{kWeightGabsGsp, level});
+  const int wl = ls->n_levels == 0 ? -1 : level; // no level table: lev_up = lev_lo = 0 for every line anyway
+  rc = coef_op(c, atm, g_lo, g_hi, g_out + 2 * plane, g_out + 0 * plane, stream, WeightMode{kWeightGabsGsp, wl});
   if (rc) return rc;
   return coef_op(c, atm, g_lo, g_hi, g_out + 1 * plane, c->d_gscratch.as<double>(), stream,
-                 WeightMode{kWeightGind, level});
+                 WeightMode{kWeightGind, wl});
 }
 
 int sr_abscoeff_level_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, int64_t g_lo, int64_t g_hi,
@@ -1024,6 +1029,42 @@ int sr_radiance_jac_dev(const double *abs_c, const double *emi_c, int n_layers, 
                                 reinterpret_cast<const int *>(base + o_lay),
                                 reinterpret_cast<const double *>(base + o_col),
                                 reinterpret_cast<const double *>(base + o_d), n_par, rad, jac, st));
+  return SR_OK;
+}
+
+// ------------------------------------------------------------------------
+int sr_lut_interp_dev(const double *g_tab, int n_pt, int64_t n_pts, int n_steps, const int32_t *idx4,
+                      const double *wgt4, const double *pop, int combine, double *out_a, double *out_e,
+                      void *stream) {
+  if (!g_tab || !idx4 || !wgt4 || !out_a || n_pt <= 0 || n_pts <= 0 || n_steps <= 0) return SR_ERR_ARG;
+  if (combine && (!pop || !out_e)) return SR_ERR_ARG;
+  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  for (int s = 0; s < n_steps; ++s) {
+    const int32_t *q = idx4 + 4 * s;
+    const bool bil = q[2] >= 0;
+    for (int i = 0; i < 4; ++i) {
+      if (!bil && i >= 2) { if (q[i] >= 0) return SR_ERR_ARG; continue; }
+      if (q[i] < 0 || q[i] >= n_pt) return SR_ERR_ARG; // would read out of the table
+    }
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static thread_local Stager s_ring[4];
+  static thread_local unsigned s_next = 0;
+  Stager &sg = s_ring[s_next++ & 3];
+  const size_t b_w = sizeof(double) * 4 * (size_t)n_steps, b_p = sizeof(double) * (size_t)n_steps;
+  const size_t b_i = sizeof(int) * 4 * (size_t)n_steps;
+  int rc = sg.prepare(b_w + b_p + b_i);
+  if (rc) return rc;
+  char *h = sg.host<char>();
+  std::memcpy(h, wgt4, b_w);
+  if (pop) std::memcpy(h + b_w, pop, b_p); else std::memset(h + b_w, 0, b_p);
+  std::memcpy(h + b_w + b_p, idx4, b_i);
+  rc = sg.push(b_w + b_p + b_i, st);
+  if (rc) return rc;
+  char *d = sg.d.as<char>();
+  LAUNCHCHK(launch_lut(combine, g_tab, n_pt, (int)n_pts, n_steps, reinterpret_cast<const int *>(d + b_w + b_p),
+                       reinterpret_cast<const double *>(d), reinterpret_cast<const double *>(d + b_w), out_a, out_e,
+                       st));
   return SR_OK;
 }
 

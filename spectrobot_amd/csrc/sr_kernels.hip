@@ -56,10 +56,10 @@ __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, c
     wabs = pl * g_ab - pu * g_in;
     wemi = pu * g_sp;
   } else if (W.mode == kWeightGabsGsp) { // BuildCoeff of level W.level: absorption | sp_emission (spcl:1304-1313)
-    wabs = ll == W.level ? g_ab : 0.0;
-    wemi = lu == W.level ? g_sp : 0.0;
+    wabs = (W.level < 0 || ll == W.level) ? g_ab : 0.0; // level < 0: every line (the 'all' LutSet of an LTE table)
+    wemi = (W.level < 0 || lu == W.level) ? g_sp : 0.0;
   } else if (W.mode == kWeightGind) {    // ... ind_emission | nothing
-    wabs = lu == W.level ? g_in : 0.0;
+    wabs = (W.level < 0 || lu == W.level) ? g_in : 0.0;
     wemi = 0.0;
   } else {                               // kWeightTracked: one level's share of abs / emi (smm:2083-2087)
     const double pu = pop[lu], pl = pop[ll];
@@ -1648,6 +1648,62 @@ int launch_sum_lines(double *spe, long n_spe, const double *rows, const int *ini
   if (n_spe <= 0) return 0;
   hipLaunchKernelGGL(sr_sum_lines_kernel, dim3((unsigned)((n_spe + 255) / 256)), dim3(256), 0, st, spe,
                      n_spe, rows, init, fin, n_lines, row_len);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// A9: look-up-table route.  LutSet.calculate (spect_main_module.py:997-1066) interpolates the three G
+// spectra of one level between tabulated (P, T) couples -- linear in P between the two nearest pressures
+// at each of the two nearest temperatures, then linear in T (SpectralGcoeff.interpolate,
+// spect_classes.py:1349-1375); below the lowest tabulated pressure in T only -- and
+// make_abscoeff_isomolec / make_abscoeff_LUTS_fast combine them with the level population
+// (spect_main_module.py:2073-2080, 2241-2249).  Thread = (grid point, LOS step); tab: [3][n_pt][n_pts].
+// idx[s][4]: table rows (P1,T1), (P1,T2), (P2,T1), (P2,T2), or (P1,TA), (P1,TB), -1, -1 for the T-only case.
+// COMBINE: abs += pop (Gabs - Gind), emi += pop Gsp; else the interpolated set itself, g_out[3][n_steps][n_pts].
+// ------------------------------------------------------------------------
+template <bool COMBINE>
+__global__ __launch_bounds__(256) void sr_lut_kernel(const double *__restrict__ tab, int n_pt, int n_pts,
+                                                     const int *__restrict__ idx, const double *__restrict__ wgt,
+                                                     const double *__restrict__ pop, double *__restrict__ out_a,
+                                                     double *__restrict__ out_e) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y, n_steps = gridDim.y;
+  if (j >= n_pts) return;
+  const int i1 = idx[4 * s + 0], i2 = idx[4 * s + 1], i3 = idx[4 * s + 2], i4 = idx[4 * s + 3];
+  const double wp1 = wgt[4 * s + 0], wp2 = wgt[4 * s + 1], wt1 = wgt[4 * s + 2], wt2 = wgt[4 * s + 3];
+  double v[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double *t = tab + (size_t)c * n_pt * n_pts + j;
+    if (i3 >= 0) {
+      const double c13 = wp1 * t[(size_t)i1 * n_pts] + wp2 * t[(size_t)i3 * n_pts];
+      const double c24 = wp1 * t[(size_t)i2 * n_pts] + wp2 * t[(size_t)i4 * n_pts];
+      v[c] = wt1 * c13 + wt2 * c24;
+    } else {
+      v[c] = wt1 * t[(size_t)i1 * n_pts] + wt2 * t[(size_t)i2 * n_pts];
+    }
+  }
+  const size_t o = (size_t)s * n_pts + j;
+  if (COMBINE) {
+    const double p = pop[s];
+    double a = out_a[o];
+    a = a + v[2] * p; // spect_main_module.py:2078-2080, in this order
+    a = a - v[1] * p;
+    out_a[o] = a;
+    out_e[o] = out_e[o] + v[0] * p;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out_a[(size_t)c * n_steps * n_pts + o] = v[c];
+  }
+}
+
+int launch_lut(int combine, const double *tab, int n_pt, int n_pts, int n_steps, const int *idx, const double *wgt,
+               const double *pop, double *out_a, double *out_e, hipStream_t st) {
+  if (n_pts <= 0 || n_steps <= 0) return 0;
+  const dim3 grid((n_pts + 255) / 256, n_steps);
+  if (combine)
+    hipLaunchKernelGGL(sr_lut_kernel<true>, grid, dim3(256), 0, st, tab, n_pt, n_pts, idx, wgt, pop, out_a, out_e);
+  else
+    hipLaunchKernelGGL(sr_lut_kernel<false>, grid, dim3(256), 0, st, tab, n_pt, n_pts, idx, wgt, pop, out_a, out_e);
   return (int)hipGetLastError();
 }
 

@@ -115,6 +115,8 @@ int launch_sum_lines(double *spe, long n_spe, const double *rows, const int *ini
                      int n_lines, int row_len, hipStream_t st);
 int launch_lowres(const double *rad, int n_pts, int n_rays, double w0, double gstep, const double *cen,
                   const double *wid, int n_bands, double n_sigma, int out_units, double *out, hipStream_t st);
+int launch_lut(int combine, const double *tab, int n_pt, int n_pts, int n_steps, const int *idx, const double *wgt,
+               const double *pop, double *out_a, double *out_e, hipStream_t st);
 int launch_curgod(int which, const double *nd, const double *vmr, const double *f, const double *x,
                   const int *off, int n_seg, double *res, hipStream_t st);
 

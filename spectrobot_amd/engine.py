@@ -185,6 +185,30 @@ class LineSet(object):
         return dict(zip(names, (int(v) for v in c)))
 
 
+def lut_interp(table, idx4, wgt4, pops=None, out=None):
+    """LutSet.calculate for n_steps LOS steps on a G table resident in HBM (sr_lut_interp_dev).
+    table: CUDA [3, n_PT, n_grid]; idx4 [n_steps, 4] rows, wgt4 [n_steps, 4] = (wP1, wP2, wT1, wT2).
+    pops None: returns the interpolated set [3, n_steps, n_grid]; else accumulates the population-weighted
+    combine into out = (abs, emi), CUDA [n_steps, n_grid]."""
+    assert table.is_cuda and table.dtype == torch.float64 and table.is_contiguous() and table.dim() == 3
+    idx4, ipp = _i(np.asarray(idx4).reshape(-1, 4))
+    wgt4, wp = _d(np.asarray(wgt4).reshape(-1, 4))
+    n_steps, n_pt, n_pts = idx4.shape[0], table.shape[1], table.shape[2]
+    if pops is None:
+        g = torch.empty((3, n_steps, n_pts), dtype=torch.float64, device="cuda")
+        check(lib.sr_lut_interp_dev(C.c_void_p(table.data_ptr()), n_pt, n_pts, n_steps, ipp, wp, None, 0,
+                                    C.c_void_p(g.data_ptr()), None, _stream_ptr()), "sr_lut_interp_dev")
+        return g
+    pops, pp = _d(pops)
+    ab, em = out
+    for t in (ab, em):
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.shape == (n_steps, n_pts)
+    check(lib.sr_lut_interp_dev(C.c_void_p(table.data_ptr()), n_pt, n_pts, n_steps, ipp, wp, pp, 1,
+                                C.c_void_p(ab.data_ptr()), C.c_void_p(em.data_ptr()), _stream_ptr()),
+          "sr_lut_interp_dev")
+    return ab, em
+
+
 def set_counting(on):
     """1: the next coefficient ops run the counting instantiations (executed-work accounting, untimed)."""
     check(lib.sr_set_counting(int(bool(on))), "sr_set_counting")

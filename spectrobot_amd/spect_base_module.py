@@ -12,6 +12,18 @@ def isclose(a, b, rtol=1e-9, atol=0.0):
     return bool(np.isclose(a, b, rtol=rtol, atol=atol))
 
 
+def weight(x, x1, x2, itype='lin'):
+    """(w1, w2) with w1 * f(x1) + w2 * f(x2) the interpolant at x (call sites spect_classes.py:1365, 1371;
+    the function itself is in the absent module): linear, or linear in log x for itype='exp'."""
+    if itype == 'lin':
+        w2 = (x - x1) / (x2 - x1)
+    elif itype == 'exp':
+        w2 = (np.log(x) - np.log(x1)) / (np.log(x2) - np.log(x1))
+    else:
+        raise ValueError('itype {} not recognized'.format(itype))
+    return 1.0 - w2, w2
+
+
 class Level(object):
     """A vibrational level: .energy (cm-1), .lev_string, .minimal_level_string(),
     .local_vibtemp (one vibrational temperature per LOS step, spect_main_module.py:2065)."""
@@ -23,6 +35,10 @@ class Level(object):
 
     def minimal_level_string(self):
         return self.lev_string.strip()
+
+    def equiv(self, lev_string):
+        """Same level as the one labelled lev_string (call site spect_main_module.py:711, 809)."""
+        return self.minimal_level_string() == lev_string.strip()
 
     def add_local_vibtemp(self, temp):
         self.local_vibtemp = np.asarray(temp, dtype=float)

@@ -139,14 +139,66 @@ def closest_grid(wn_arr, wn_0):
 # ----------------------------------------------------------------------------
 # containers
 # ----------------------------------------------------------------------------
+_C_SI = 299792458.0   # scipy.constants.c (spect_classes.py:409, 429)
+
+# Unit hub of SpectralGrid / SpectralObject conversions (spect_classes.py:395-432, 771-807): every
+# conversion goes through nm.  Per unit: (grid -> nm, grid reversed?, spectrum factor given the grid in
+# THAT unit) for "to nm", and the same from nm.  The expressions keep the reference's order of operations.
+_TO_NM = {
+    'nm': (lambda g: g, False, None),
+    'mum': (lambda g: g * 1.e3, False, lambda sp, g: sp * 1.e-3),
+    'cm_1': (lambda g: 1.e7 / g, True, lambda sp, g: sp * g ** 2 * 1.e-7),
+    'hz': (lambda g: _C_SI / (1.e-9 * g), True, lambda sp, g: sp * g ** 2 * 1.e-9 / _C_SI),
+}
+_FROM_NM = {
+    'nm': (lambda g: g, False, None),
+    'mum': (lambda g: g * 1.e-3, False, lambda sp, g: sp * 1.e3),
+    'cm_1': (lambda g: 1.e7 / g, True, lambda sp, g: sp * g ** 2 * 1.e-7),
+    'hz': (lambda g: _C_SI / (1.e-9 * g), True, lambda sp, g: sp * g ** 2 * 1.e-9 / _C_SI),
+}
+
+
 class SpectralGrid(object):
-    """spect_classes.py:354-432 (grid + units; conversions other than cm_1 are post-processing, not mirrored)"""
+    """spect_classes.py:354-432: grid + units with in-place conversions between 'nm', 'mum', 'cm_1', 'hz'
+    (a conversion that inverts the axis also reverses the array, so grids stay ascending)."""
 
     def __init__(self, spectral_grid, units='nm'):
         self.grid = copy.deepcopy(np.asarray(spectral_grid, dtype=float))
         self.units = units
         if len(spectral_grid) > imxsig_long:
             raise ValueError('Grid longer that the max value imxsig_long set to {}'.format(imxsig_long))
+
+    def _convert(self, units):
+        if units not in _FROM_NM:
+            raise ValueError('Cannot recognize units {}'.format(units))
+        if self.units != 'nm':
+            to_nm, rev, _ = _TO_NM[self.units]
+            g = to_nm(self.grid)
+            self.grid, self.units = (g[::-1].copy() if rev else g), 'nm'
+        if units != 'nm':
+            from_nm, rev, _ = _FROM_NM[units]
+            g = from_nm(self.grid)
+            self.grid, self.units = (g[::-1].copy() if rev else g), units
+        return self.grid
+
+    def convertto_nm(self):
+        return self._convert('nm')
+
+    def convertto_cm_1(self):
+        return self._convert('cm_1')
+
+    def convertto_mum(self):
+        return self._convert('mum')
+
+    def convertto_hz(self):
+        return self._convert('hz')
+
+    def half_precision(self):
+        """spect_classes.py:381-386 (float16 grid for saving)."""
+        self.grid = self.grid.astype(np.float16)
+
+    def double_precision(self):
+        self.grid = self.grid.astype(float)
 
     def step(self):
         return self.grid[1] - self.grid[0]
@@ -201,6 +253,129 @@ class SpectralObject(object):
         out.spectrum = out.spectrum * (obj2.spectrum if isinstance(obj2, SpectralObject) else obj2)
         return out
 
+    def __truediv__(self, obj2):
+        """spect_classes.py:493-499 (__div__ of the Python-2 reference)."""
+        out = copy.deepcopy(self)
+        out.spectrum = out.spectrum / (obj2.spectrum if isinstance(obj2, SpectralObject) else obj2)
+        return out
+
+    __div__ = __truediv__
+
+    def __getitem__(self, key):
+        """spectrum[(w1, w2)]: the part of the spectrum with w1 - step/2 < grid < w2 + step/2
+        (spect_classes.py:451-460); None when empty."""
+        half = self.spectral_grid.step() / 2.0
+        cond = (self.spectral_grid.grid > key[0] - half) & (self.spectral_grid.grid < key[1] + half)
+        if not np.any(cond):
+            return None
+        out = copy.deepcopy(self)
+        out.spectral_grid = SpectralGrid(self.spectral_grid.grid[cond], units=self.units)   # sic: the object's units
+        out.spectrum = self.spectrum[cond]
+        return out
+
+    def interp_to_grid(self, nugrid):
+        """Linear interpolation onto another SpectralGrid, zero outside (spect_classes.py:501-507)."""
+        out = copy.deepcopy(self)
+        out.spectrum = np.interp(nugrid.grid, self.spectral_grid.grid, self.spectrum, left=0.0, right=0.0)
+        out.spectral_grid = copy.deepcopy(nugrid)
+        return out
+
+    def max(self):
+        return np.max(self.spectrum)
+
+    def min(self):
+        return np.min(self.spectrum)
+
+    def convert_grid_to(self, units):
+        """Grid AND spectral density to `units` ('nm', 'mum', 'cm_1', 'hz'), in place: the density picks up
+        |d old / d new| and the arrays are reversed with the axis (spect_classes.py:757-807).
+        Returns (grid, spectrum)."""
+        if units not in _FROM_NM:
+            raise ValueError('Cannot recognize units {}'.format(units))
+        cur = self.spectral_grid.units
+        if cur != 'nm':
+            _, rev, fac = _TO_NM[cur]
+            sp = fac(self.spectrum, self.spectral_grid.grid)
+            self.spectrum = sp[::-1] if rev else sp
+            self.spectral_grid.convertto_nm()
+        if units != 'nm':
+            _, rev, fac = _FROM_NM[units]
+            sp = fac(self.spectrum, self.spectral_grid.grid)       # grid in nm here, as in the reference
+            self.spectrum = sp[::-1] if rev else sp
+            self.spectral_grid._convert(units)
+        return self.spectral_grid.grid, self.spectrum
+
+    def convertto_nm(self):
+        return self.convert_grid_to('nm')
+
+    def convertto_mum(self):
+        return self.convert_grid_to('mum')
+
+    def convertto_cm_1(self):
+        return self.convert_grid_to('cm_1')
+
+    def convertto_hz(self):
+        return self.convert_grid_to('hz')
+
+    def half_precision(self):
+        """spect_classes.py:722-737: float32 spectrum (sic), float16 grid."""
+        self.spectrum = self.spectrum.astype(np.float32)
+        if self.spectral_grid is not None:
+            self.spectral_grid.half_precision()
+
+    def double_precision(self):
+        self.spectrum = self.spectrum.astype(float)
+        if self.spectral_grid is not None:
+            self.spectral_grid.double_precision()
+
+    # ---- fine-grained drop-in of the reference's accumulate (the production path never materialises
+    # per-line shapes: engine.LineSet.abscoeff_layers / gcoeff_layers) ----
+    def prepare_fortran_sum(self, lines, fix_length=imxsig):
+        """Rows, init, fin for lineshape.sum_all_lines (spect_classes.py:1100-1147): every line's part
+        inside this grid, zero-padded to fix_length on the right -- or on the left, with init shifted,
+        when the padded row would pass the end of the grid.  1-based, inclusive."""
+        spino = self.spectral_grid.step() / 10.
+        g = self.spectral_grid.grid
+        rows = np.zeros((len(lines), fix_length))
+        init, fin = np.zeros(len(lines), np.int32), np.zeros(len(lines), np.int32)
+        for n, line in enumerate(lines):
+            lg = line.spectral_grid.grid
+            inside = np.flatnonzero((g > lg[0] - spino) & (g < lg[-1] + spino))
+            part = line.spectrum[(lg > g[0] - spino) & (lg < g[-1] + spino)]
+            first, last = inside[0] + 1, inside[-1] + 1
+            pad = fix_length - (last - first + 1)
+            if pad <= 0:
+                rows[n, :] = line.spectrum
+            elif last + pad < self.n_points():
+                rows[n, :len(part)] = part
+                last += pad
+            else:
+                rows[n, pad:] = part
+                first -= pad
+            init[n], fin[n] = first, last
+        return rows, init, fin
+
+    def add_lines_to_spectrum(self, lines, Strengths=None, fix_length=imxsig, n_threads=n_threads):
+        """spect_classes.py:1016-1097 with the sum on the GPU (compat lineshape.sum_all_lines, Fortran
+        summation order).  As in the reference the lines are only added when Strengths is given (:1038-1044)."""
+        n_lines = len(lines)
+        if n_lines == 0:
+            return self.spectrum
+        if n_lines > imxlines:
+            raise ValueError('{} are too many lines!! Increase the thresold imxlines (now {}) or decrease num of '
+                             'lines..'.format(n_lines, imxlines))
+        if self.n_points() > imxsig_long:
+            raise ValueError('The input spectrum is too long!! Increase the thresold imxsig_long or decrease num of wn..')
+        scaled = [] if Strengths is None else [ln.multiply(st, save=False) for ln, st in zip(lines, Strengths)]
+        if not scaled:
+            return self.spectrum
+        rows, init, fin = self.prepare_fortran_sum(scaled, fix_length=fix_length)
+        if init.min() < 1:
+            raise ValueError('grid shorter than one line window: the reference writes in front of its array here '
+                             '(spect_classes.py:1132-1134)')
+        self.spectrum = lineshape.sum_all_lines(self.spectrum, rows, init, fin, len(scaled), self.n_points())
+        return self.spectrum
+
     def multiply(self, factor, save=True):
         if save:
             self.spectrum = self.spectrum * factor
@@ -245,6 +420,39 @@ class SpectralIntensity(SpectralObject):
         self.spectral_grid = copy.deepcopy(spectral_grid)
         self.units = units
 
+    _TO_WM2 = {'Wm2': 1.0, 'ergscm2': 1.e-3, 'nWcm2': 1.e-5}      # spect_classes.py:1213-1223
+    _FROM_WM2 = {'Wm2': 1.0, 'ergscm2': 1.e3, 'nWcm2': 1.e5}      # :1225-1235
+
+    def convertto(self, new_units):
+        """In-place conversion between 'Wm2', 'ergscm2', 'nWcm2' through W m-2 (spect_classes.py:1200-1235)."""
+        if new_units not in self._FROM_WM2:
+            raise ValueError('No method for units ' + new_units)
+        if self.units != 'Wm2':
+            self.spectrum = self.spectrum * self._TO_WM2[self.units]
+            self.units = 'Wm2'
+        if new_units != 'Wm2':
+            self.spectrum = self.spectrum * self._FROM_WM2[new_units]
+            self.units = new_units
+        return self.spectrum
+
+    def convertto_Wm2(self):
+        return self.convertto('Wm2')
+
+    def convertto_ergscm2(self):
+        return self.convertto('ergscm2')
+
+    def convertto_nWcm2(self):
+        return self.convertto('nWcm2')
+
+    def add_noise(self, noise):
+        self.noise = copy.deepcopy(noise)
+
+    def add_mask(self, mask):
+        self.mask = copy.deepcopy(mask)
+
+    def add_bands(self, bands):
+        self.bands = copy.deepcopy(bands)
+
     def hires_to_lowres(self, lowres_obs, spectral_widths=None, keep_original_hires=True):
         """spect_classes.py:1180-1191.  self: hi-res on a cm_1 np.arange grid in 'ergscm2';
         lowres_obs: object with .spectral_grid (units 'nm') and .units; spectral_widths: Gaussian
@@ -266,6 +474,93 @@ class SpectralIntensity(SpectralObject):
         low = engine.hires_to_lowres(dev, self.spectral_grid.grid, lowres_obs.spectral_grid.grid, spectral_widths,
                                      out_units=lowres_obs.units)[0]
         return SpectralIntensity(low, lowres_obs.spectral_grid, units=lowres_obs.units)
+
+
+class SpectralGcoeff(SpectralObject):
+    """G_abs / G_spem / G_indem spectrum of ONE level of an iso-molecule at one (P, T)
+    (spect_classes.py:1247-1375): what the non-LTE look-up tables hold."""
+
+    ctypes = ('sp_emission', 'ind_emission', 'absorption')
+
+    def __init__(self, ctype, spectral_grid, mol, iso, MM, minimal_level_string, unidentified_lines=False,
+                 spectrum=None, Pres=None, Temp=None, link_grid=False):
+        self.mol, self.iso, self.MM = mol, iso, MM
+        self.unidentified_lines = bool(unidentified_lines)
+        self.lev_string = None if unidentified_lines else minimal_level_string
+        self.ctype = ctype
+        self.spectral_grid = spectral_grid if link_grid else copy.deepcopy(spectral_grid)
+        self.spectrum = np.zeros(len(spectral_grid.grid), dtype=float) if spectrum is None else spectrum
+        self.direction = None
+        self.units = ''
+        if Pres is not None and Temp is not None:
+            self.pres, self.temp = Pres, Temp
+
+    def BuildCoeff(self, lines, Temp, Pres, n_threads=n_threads, preCalc_shapes=False, debug=False, isomolec=None):
+        """Sum of G_ctype * shape over the lines of this level: upper level for the two emission types, lower
+        level for absorption; every line of the iso-molecule for the 'all' set (spect_classes.py:1277-1337).
+        `lines` carry .shape / .G_coeffs (calc_shapes_lines) when preCalc_shapes; otherwise they are computed
+        here, which needs `isomolec` (the reference's own call at :1302 is one argument short of :1340).
+        This is the per-line drop-in route (GPU shims); LutSet.add_PT with an engine.LineSet is the fast one."""
+        if self.ctype not in self.ctypes:
+            raise ValueError('ctype has to be one among {}, {} and {}. {} not recognized'.format(*self.ctypes, self.ctype))
+        self.temp, self.pres = Temp, Pres
+        if len(lines) == 0:
+            return self.spectrum
+        if preCalc_shapes:
+            if not (hasattr(lines[0], 'shape') and hasattr(lines[0], 'G_coeffs')):
+                raise ValueError('preCalc_shapes is set as True but the lines do not contain the attribute << shapes >>. '
+                                 'Are you sure you precalculated the line shapes? Run calc_shapes_lines on your line '
+                                 'set first.')
+        else:
+            if isomolec is None:
+                raise ValueError('BuildCoeff without preCalc_shapes needs isomolec= to run calc_shapes_lines')
+            lines = calc_shapes_lines(self.spectral_grid, lines, Temp, Pres, isomolec)
+        mine = [lin for lin in lines if lin.Mol == self.mol and lin.Iso == self.iso]
+        if not self.unidentified_lines:
+            if self.ctype == 'absorption':
+                mine = [lin for lin in mine if self.lev_string == lin.minimal_level_string_lo()]
+            else:
+                mine = [lin for lin in mine if self.lev_string == lin.minimal_level_string_up()]
+        if mine:
+            self.add_lines_to_spectrum([lin.shape for lin in mine], Strengths=[lin.G_coeffs[self.ctype] for lin in mine],
+                                       n_threads=n_threads)
+        return self.spectrum
+
+    def interpolate(self, coeff2, Pres=None, Temp=None):
+        """Linear interpolation between two G spectra that share T (give Pres) or P (give Temp)
+        (spect_classes.py:1349-1375; sbm.weight(.., itype='lin') is in the absent module: linear weights)."""
+        from . import spect_base_module as sbm
+        if coeff2 is None:
+            return None
+        same_t, same_p = sbm.isclose(self.temp, coeff2.temp), sbm.isclose(self.pres, coeff2.pres)
+        if not same_t and not same_p:
+            raise ValueError('The two coeffs have both different temperatures and pressures! cannot interpolate')
+        if Pres is not None:
+            if not same_t:
+                raise ValueError('The two coeffs have different temperatures! You should specify the interpolation '
+                                 'temperature, not the pressure')
+            w1, w2 = sbm.weight(Pres, self.pres, coeff2.pres, itype='lin')
+            new_p, new_t = Pres, self.temp
+        elif Temp is not None:
+            if not same_p:
+                raise ValueError('The two coeffs have different pressures! You should specify the interpolation '
+                                 'pressure, not the temperature')
+            w1, w2 = sbm.weight(Temp, self.temp, coeff2.temp, itype='lin')
+            new_p, new_t = self.pres, Temp
+        else:
+            raise ValueError('give Pres or Temp')
+        return SpectralGcoeff(self.ctype, self.spectral_grid, self.mol, self.iso, self.MM, self.lev_string,
+                              unidentified_lines=self.unidentified_lines,
+                              spectrum=w1 * self.spectrum + w2 * coeff2.spectrum, Pres=new_p, Temp=new_t)
+
+
+def Calc_BB(spectral_grid, T, units='ergscm2'):
+    """Planck spectrum on a cm_1 grid as a SpectralIntensity (spect_classes.py:1881-1892)."""
+    spectrum = 2 * h_cgs * c_cgs ** 2 * (spectral_grid.grid) ** 3 / (np.exp(c2 * spectral_grid.grid / T) - 1)
+    bb = SpectralIntensity(spectrum, spectral_grid, units='ergscm2')
+    if units != 'ergscm2':
+        bb.convertto(units)
+    return bb
 
 
 class SpectLine(object):

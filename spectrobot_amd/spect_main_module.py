@@ -7,6 +7,9 @@ population-weighted combine, it makes ONE call into the HIP engine, which
 returns the abs/emi coefficient spectra of every LOS step.
 """
 import copy
+import os
+import pickle
+import time
 
 import numpy as np
 
@@ -24,79 +27,485 @@ def prepare_spe_grid(wn_range, sp_step=5.e-4, units='cm_1'):
 
 
 class AbsSetLOS(object):
-    """Set of abs / emi coefficient spectra along a LOS (spect_main_module.py:1179-1258).
-    Kept in memory (.set); the reference's pickle streaming is a RAM workaround of its
-    CPU path and is not mirrored.  .device holds the same data as one CUDA tensor
-    [n_steps, n_grid] for consumers that stay on the GPU (radiance recursion)."""
+    """Set of abs / emi coefficient spectra along a LOS (spect_main_module.py:1179-1258): kept in memory
+    (.set, add_set) or streamed through a pickle file (prepare_export / add_dump / finalize_IO, then
+    prepare_read / read_one), the reference's way of saving RAM on long LOS.  read_one() serves both.
+    .device holds the same data as one CUDA tensor [n_steps, n_grid] for consumers that stay on the GPU."""
 
     def __init__(self, filename=None, spectral_grid=None, indices=None):
         self.indices = indices if indices is not None else []
         self.counter = 0
         self.remaining = 0
         self.filename = filename
+        self.temp_file = None
         self.set = []
         self.spectral_grid = spectral_grid
         self.device = None
+
+    def _open(self, mode):
+        if self.filename is None:
+            raise ValueError('ERROR!: NO filename set for LutSet.')
+        self.temp_file = open(self.filename, mode)
+
+    def prepare_export(self):
+        self._open('wb')
+        if self.spectral_grid is not None:
+            pickle.dump(self.spectral_grid, self.temp_file, protocol=-1)
+
+    def add_dump(self, set_, no_spectral_grid=True):
+        if no_spectral_grid:
+            for obj in (set_.values() if type(set_) is dict else [set_]):
+                obj.erase_grid()
+        pickle.dump(set_, self.temp_file, protocol=-1)
+        self.counter += 1
+
+    def finalize_IO(self):
+        self.temp_file.close()
+        self.temp_file = None
 
     def add_set(self, set_):
         self.set.append(set_)
         self.counter += 1
 
-    def read_one(self):
-        set_ = self.set[self.counter - self.remaining] if self.remaining else self.set[0]
-        self.remaining = max(self.remaining - 1, 0)
-        return set_
-
     def prepare_read(self, read_spectral_grid=True):
         self.remaining = self.counter
+        if self.set:            # in memory
+            return
+        self._open('rb')
+        if read_spectral_grid:
+            self.spectral_grid = pickle.load(self.temp_file)
+
+    def read_one(self):
+        if self.set:
+            if self.remaining <= 0:
+                self.remaining = self.counter
+            set_ = self.set[self.counter - self.remaining]
+            self.remaining -= 1
+            return set_
+        if self.temp_file is None:
+            self.prepare_read()
+        set_ = pickle.load(self.temp_file)
+        for obj in (set_.values() if type(set_) is dict else [set_]):
+            obj.restore_grid(self.spectral_grid, link_grid=True)
+        self.remaining -= 1
+        return set_
+
+
+def date_stamp():
+    t = time.ctime().split()
+    return '_' + t[2] + '-' + t[1] + '-' + t[4]          # spect_main_module.py:30-32
+
+
+def lut_name(mol, iso, LTE):
+    return 'LUT_mol{:02d}_iso{:1d}_{}'.format(mol, iso, 'LTE' if LTE else 'nonLTE')   # :659-664
+
+
+ctypes_G = ['sp_emission', 'ind_emission', 'absorption']
+
+
+def _as_lineset(lines, spectral_grid, isomolec):
+    """engine.LineSet of the iso-molecule's lines on the grid (lines: SpectLine list or a LineSet)."""
+    if isinstance(lines, engine.LineSet):
+        return lines
+    lines = [lin for lin in lines if lin.Mol == isomolec.mol and lin.Iso == isomolec.iso]
+    levels = [getattr(isomolec, lev) for lev in isomolec.levels]
+    return engine.LineSet(spcl.lines_to_soa(lines, isomolec), spectral_grid.grid, isomolec.mol, isomolec.iso,
+                          isomolec.MM, [lv.energy for lv in levels])
+
+
+class LutSet(object):
+    """Look-up table entry of ONE level of an iso-molecule: the three G spectra at every tabulated (P, T)
+    (spect_main_module.py:841-1176).  The table lives in HBM, .device = CUDA float64 [3, n_PT, n_grid]
+    (ctype order of ctypes_G); .sets[i][ctype] are host views created on demand.  The reference streams the
+    same content through pickle files to save RAM; filename is kept for that interface (add_dump / load)."""
+
+    def __init__(self, mol, iso, MM, level=None, filename=None, level_index=None):
+        self.mol, self.iso, self.MM = mol, iso, MM
+        self.level = copy.deepcopy(level)
+        self.unidentified_lines = level is None
+        self.level_index = level_index        # index into the engine's level table (-1 / None: every line)
+        self.filename = filename
+        self.filenames = [filename]
+        self.spectral_grid = None
+        self.PTcouples = None
+        self.device = None
+        self.temp_file = None
+        self._host = {}
+
+    # ---- table content ----
+    def _append(self, g3, PT):
+        import torch
+        g3 = g3 if g3.dim() == 3 else g3[:, None, :]
+        self.device = g3 if self.device is None else torch.cat([self.device, g3], dim=1)
+        if self.PTcouples is None:
+            self.PTcouples = []
+        self.PTcouples += [list(pt) for pt in PT]
+        self._host = {}
+
+    def add_PT(self, spectral_grid, lines, Pres, Temp, keep_memory=False, control=True, n_threads=n_threads):
+        """Adds one (P, T) couple (spect_main_module.py:1122-1168).  lines: an engine.LineSet -- one
+        sr_gcoeff_layers_dev call -- or SpectLine objects processed by spcl.calc_shapes_lines, which go
+        through SpectralGcoeff.BuildCoeff(preCalc_shapes=True) as in the reference (per-line drop-in route)."""
+        import torch
+        if self.spectral_grid is None:
+            self.spectral_grid = copy.deepcopy(spectral_grid)
+        if isinstance(lines, engine.LineSet):
+            lev = -1 if (self.unidentified_lines or self.level_index is None) else self.level_index
+            g3 = lines.gcoeff_layers([Temp], [Pres], level=0 if lines.level_energies.size == 0 else lev)
+        else:
+            mls = '' if self.unidentified_lines else self.level.minimal_level_string()
+            rows = []
+            for ctype in ctypes_G:
+                gigi = spcl.SpectralGcoeff(ctype, spectral_grid, self.mol, self.iso, self.MM, mls,
+                                           unidentified_lines=self.unidentified_lines, link_grid=True)
+                rows.append(gigi.BuildCoeff(lines, Temp, Pres, preCalc_shapes=True, n_threads=n_threads))
+            g3 = torch.as_tensor(np.array(rows), device='cuda')[:, None, :]
+        if self.temp_file is not None:
+            self.add_dump(self._host_set(g3[:, 0].cpu().numpy(), Pres, Temp, grid=False))
+        self._append(g3, [[Pres, Temp]])
+
+    def _host_set(self, rows, Pres, Temp, grid=True):
+        mls = '' if self.unidentified_lines else self.level.minimal_level_string()
+        return {ct: spcl.SpectralGcoeff(ct, self.spectral_grid, self.mol, self.iso, self.MM, mls,
+                                        unidentified_lines=self.unidentified_lines, spectrum=np.array(rows[c]),
+                                        Pres=Pres, Temp=Temp, link_grid=True) for c, ct in enumerate(ctypes_G)}
+
+    @property
+    def sets(self):
+        """[{ctype: SpectralGcoeff}] per PT couple, on the host (copied from HBM on first access)."""
+        if 'sets' not in self._host:
+            tab = self.device.cpu().numpy() if self.device is not None else np.zeros((3, 0, 0))
+            self._host['sets'] = [self._host_set(tab[:, i], pt[0], pt[1]) for i, pt in enumerate(self.PTcouples or [])]
+        return self._host['sets']
+
+    def free_memory(self):
+        self._host = {}
+
+    def find(self, Pres, Temp):
+        if [Pres, Temp] not in self.PTcouples:
+            raise ValueError('{} couple not found!'.format([Pres, Temp]))
+        return self.PTcouples.index([Pres, Temp])
+
+    # ---- interpolation (spect_main_module.py:997-1066) ----
+    def interp_plan(self, Pres, Temp):
+        """Table rows and weights of LutSet.calculate for one (P, T): ([i1, i2, i3, i4], [wP1, wP2, wT1, wT2])."""
+        from . import spect_base_module as sbm
+        Ps = np.unique(np.array([PT[0] for PT in self.PTcouples]))
+        Ts = np.unique(np.array([PT[1] for PT in self.PTcouples]))
+        order_t = np.argsort(np.abs(Ts - Temp))
+        T1, T2 = Ts[np.argmin(np.abs(Ts - Temp))], Ts[order_t[1]]
+        wt = sbm.weight(Temp, T1, T2, itype='lin')
+        if Pres <= np.min(Ps):
+            P1 = np.min(Ps)
+            return [self.find(P1, T1), self.find(P1, T2), -1, -1], [0.0, 0.0, wt[0], wt[1]]
+        if Pres <= np.max(Ps):
+            P1, P2 = Ps[np.argmin(np.abs(Ps - Pres))], Ps[np.argsort(np.abs(Ps - Pres))[1]]
+            wp = sbm.weight(Pres, P1, P2, itype='lin')
+            return ([self.find(P1, T1), self.find(P1, T2), self.find(P2, T1), self.find(P2, T2)],
+                    [wp[0], wp[1], wt[0], wt[1]])
+        raise ValueError('Extrapolating in P')
+
+    def _plan(self, Press, Temps):
+        plans = [self.interp_plan(P, T) for P, T in zip(Press, Temps)]
+        return (np.array([p[0] for p in plans], np.int32).reshape(-1, 4),
+                np.array([p[1] for p in plans], np.float64).reshape(-1, 4))
+
+    def calculate_steps(self, Press, Temps):
+        """Interpolated G spectra at every (Press[i], Temps[i]): CUDA [3, n_steps, n_grid]."""
+        return engine.lut_interp(self.device, *self._plan(Press, Temps))
+
+    def combine_steps(self, Press, Temps, pops, abs_dev, emi_dev):
+        """abs += pop (Gabs - Gind), emi += pop Gsp at every step (spect_main_module.py:2073-2080)."""
+        idx, w = self._plan(Press, Temps)
+        engine.lut_interp(self.device, idx, w, pops=pops, out=(abs_dev, emi_dev))
+
+    def calculate(self, Pres, Temp):
+        """{ctype: SpectralGcoeff} at (Pres, Temp), spect_main_module.py:997-1066."""
+        g3 = self.calculate_steps([Pres], [Temp])[:, 0].cpu().numpy()
+        return self._host_set(g3, Pres, Temp)
+
+    # ---- file streaming of the reference (RAM workaround), optional ----
+    def prepare_export(self, PTcouples, spectral_grid):
+        if self.filename is None:
+            raise ValueError('ERROR!: NO filename set for LutSet.')
+        self.temp_file = open(self.filename, 'wb')
+        self.spectral_grid = spectral_grid
+        pickle.dump([list(pt) for pt in PTcouples], self.temp_file, protocol=-1)
+
+    def add_dump(self, set_):
+        for obj in set_.values():
+            obj.erase_grid()
+        pickle.dump(set_, self.temp_file, protocol=-1)
+
+    def finalize_IO(self):
+        if self.temp_file is not None:
+            self.temp_file.close()
+        self.temp_file = None
+
+    def load_from_file(self, load_just_PT=False, spectral_grid=None):
+        """Reads a stream written by prepare_export / add_PT back into HBM."""
+        import torch
+        with open(self.filename, 'rb') as fh:
+            PT = pickle.load(fh)
+            if load_just_PT:
+                self.PTcouples = PT
+                return
+            rows = [[pickle.load(fh)[ct].spectrum for ct in ctypes_G] for _ in PT]
+        if spectral_grid is not None and self.spectral_grid is None:
+            self.spectral_grid = spectral_grid
+        self.device, self.PTcouples, self._host = None, None, {}
+        self._append(torch.as_tensor(np.array(rows, dtype=float).transpose(1, 0, 2).copy(), device='cuda'), PT)
+
+
+class LookUpTable(object):
+    """Look-up table of one iso-molecule: one LutSet per level in non-LTE, one 'all' set in LTE
+    (spect_main_module.py:682-838); built on the GPU, resident in HBM."""
+
+    def __init__(self, isomolec, wn_range, LTE):
+        self.tag = lut_name(isomolec.mol, isomolec.iso, LTE)
+        self.wn_range = copy.deepcopy(wn_range)
+        self.mol, self.iso, self.MM = isomolec.mol, isomolec.iso, isomolec.MM
+        self.isomolec = copy.deepcopy(isomolec)
+        self.sets = dict()
+        self.PTcouples = []
+        self.LTE = LTE
+
+    def make(self, spectral_grid, lines, PTcouples, export_levels=True, cartLUTs=None, control=True,
+             n_threads=n_threads, pt_batch=64):
+        """G spectra of every level at every [P, T] of PTcouples (spect_main_module.py:718-788): the
+        reference's loop over PT couples x levels x ctypes is one sr_gcoeff_layers_dev call per level and batch
+        of pt_batch couples.  cartLUTs: when given, every LutSet is also streamed to a file there."""
+        self.PTcouples = copy.deepcopy(PTcouples)
+        self.spectral_grid = copy.deepcopy(spectral_grid)
+        lineset = _as_lineset(lines, spectral_grid, self.isomolec)
+        Ps = np.array([pt[0] for pt in PTcouples], float)
+        Ts = np.array([pt[1] for pt in PTcouples], float)
+        if not self.LTE:
+            todo = [(lev, getattr(self.isomolec, lev), i) for i, lev in enumerate(self.isomolec.levels)]
+        else:
+            todo = [('all', None, -1 if self.isomolec.levels else 0)]
+        for name, level, index in todo:
+            fn = None if cartLUTs is None else cartLUTs + self.tag + '_' + (name if level is not None else 'alllev') + date_stamp() + '.pic'
+            st = LutSet(self.mol, self.iso, self.MM, level=level, filename=fn, level_index=index)
+            st.spectral_grid = self.spectral_grid
+            if fn is not None:
+                st.prepare_export(PTcouples, self.spectral_grid)
+            for b0 in range(0, len(PTcouples), pt_batch):
+                sl = slice(b0, b0 + pt_batch)
+                g3 = lineset.gcoeff_layers(Ts[sl], Ps[sl], level=index)
+                if fn is not None:
+                    gh = g3.cpu().numpy()
+                    for i, pt in enumerate(PTcouples[sl]):
+                        st.add_dump(st._host_set(gh[:, i], pt[0], pt[1], grid=False))
+                st._append(g3, PTcouples[sl])
+            st.finalize_IO()
+            self.sets[name] = st
+
+    def CPU_time_estimate(self, lines, PTcouples):
+        """The reference's own estimate for ITS path, minutes (spect_main_module.py:791-801)."""
+        n_lin = len([lin for lin in lines if (lin.Mol == self.mol and lin.Iso == self.iso)])
+        return n_lin * 3. / 30000. * len(PTcouples)
+
+    def find_lev(self, lev_string):
+        for lev in self.sets.keys():
+            if self.sets[lev].level is not None and self.sets[lev].level.equiv(lev_string):
+                return True, lev
+        return False, None
+
+    def merge(self, LUT):
+        """One table from two with different PT couples and the same levels (spect_main_module.py:699-716)."""
+        if self.wn_range != LUT.wn_range:
+            raise ValueError('Incompatible LUTs, different wn_ranges: {} {}'.format(self.wn_range, LUT.wn_range))
+        for lev_name in self.sets.keys():
+            lev1, lev2 = self.sets[lev_name], LUT.sets[lev_name]
+            if not self.LTE and not lev1.level.equiv(lev2.level.lev_string):
+                raise ValueError('Levels are different, cannot merge LUTs')
+            lev1._append(lev2.device, lev2.PTcouples)
+        self.PTcouples += LUT.PTcouples
+
+
+def calc_PT_couples_atmosphere(lines, molecs, atmosphere, pres_step_log=0.4, temp_step=5.0, max_pres=None, thres=0.01,
+                               add_lowpres=True):
+    """The [P, T] couples a look-up table needs to cover `atmosphere` (.pres [hPa], .temp [K] arrays):
+    pressure levels on a log grid, at each level the temperatures met within one level either side, rounded
+    outwards to temp_step; below the pressure where the most-broadened line is Doppler dominated
+    (lw < thres * dw) one low-pressure level stands for all (spect_main_module.py:1746-1844)."""
+    import math as mt
+    pres, temp = np.asarray(atmosphere.pres, float), np.asarray(atmosphere.temp, float)
+    top = np.log(np.max(pres)) if max_pres is None else np.log(max_pres)
+    log_hi = mt.ceil(top / pres_step_log) * pres_step_log
+    log_lo = mt.floor(np.log(np.min(pres)) / pres_step_log) * pres_step_log
+    pressures = np.exp(log_lo + np.arange(0, (log_hi - log_lo) + 0.5 * pres_step_log, pres_step_log))
+    windows = [(-np.inf, pressures[1])] + list(zip(pressures[:-2], pressures[2:])) + [(pressures[-2], pressures[-1])]
+    PTcouples = []
+    for p, (lo, hi) in zip(pressures, windows):
+        tt = temp[(pres >= lo) & (pres <= hi)]
+        t_0 = (np.floor(np.min(tt) / temp_step) - 1) * temp_step
+        t_1 = (np.ceil(np.max(tt) / temp_step) + 1) * temp_step
+        PTcouples += [[p, t] for t in np.arange(t_0, t_1 + 0.5 * temp_step, temp_step)]
+    mms = []
+    for mol in (molecs if type(molecs) is list else [molecs]):
+        if hasattr(mol, 'all_iso'):
+            mms += [getattr(mol, isom).MM for isom in mol.all_iso]
+        else:
+            mms.append(mol.MM)
+    widest = lines[int(np.argmax(np.array([lin.Air_broad for lin in lines])))]
+    keep, temps_lowpres, pres_0 = [], [], 1.e-8
+    for Pres, Temp in PTcouples:
+        dw, lw, _ = widest.CheckWidths(Temp, Pres, min(mms))
+        if lw < thres * dw:
+            pres_0 = max(pres_0, Pres)
+            if Temp not in temps_lowpres:
+                temps_lowpres.append(Temp)
+        else:
+            keep.append([Pres, Temp])
+    for Temp in temps_lowpres:
+        keep.insert(0, [pres_0, Temp])
+    if add_lowpres:
+        for Temp in temps_lowpres:
+            keep.insert(0, [np.exp(log_lo), Temp])
+    return keep
+
+
+def makeLUT_nonLTE_Gcoeffs(spectral_grid, lines, isomol, LTE, atmosphere=None, PTcouples=None, cartLUTs=None,
+                           pres_step_log=0.4, temp_step=5.0, save_LUTs=True, n_threads=n_threads, test=False, thres=0.01,
+                           max_pres=None, check_num_couples=False):
+    """spect_main_module.py:1847-1877: the look-up table of isomol over the atmosphere's (P, T) couples."""
+    if PTcouples is None:
+        PTcouples = calc_PT_couples_atmosphere(lines, isomol, atmosphere, pres_step_log=pres_step_log,
+                                               temp_step=temp_step, max_pres=max_pres, thres=thres)
+    if check_num_couples:
+        return PTcouples
+    if test:
+        PTcouples = PTcouples[:10]
+    LUT = LookUpTable(isomol, spectral_grid.wn_range(), LTE)
+    LUT.make(spectral_grid, lines, PTcouples, export_levels=True, cartLUTs=cartLUTs if save_LUTs else None,
+             n_threads=n_threads)
+    return LUT
+
+
+def _populations(isomolec, levels, Temps, LTE):
+    """[n_levels or 1, n_steps]: exp(-c2 E_L / Tvib_L) / Q(T), or 1 / Q(T) for the 'all' set
+    (spect_main_module.py:2049-2073)."""
+    Q = np.atleast_1d(spcl.CalcPartitionSum(isomolec.mol, isomolec.iso, temp=np.asarray(Temps, float)))
+    if not levels:
+        return (1 / Q)[None, :]
+    return np.array([spcl.Boltz_ratio_nodeg(lv.energy, np.asarray(Temps, float) if LTE else lv.local_vibtemp) / Q
+                     for lv in levels])
 
 
 def make_abscoeff_isomolec(wn_range_tot, isomolec, Temps, Press, LTE=True, allLUTs=None, useLUTs=False,
                            lines=None, store_in_memory=False, tagLOS=None, cartDROP=None, track_levels=None,
                            n_threads=n_threads, lineset=None, to_host=True):
     """Absorption and emission coefficients of `isomolec` at every (Press[i], Temps[i])
-    (spect_main_module.py:1880-2131, useLUTs=False route).  Non-LTE: every level of
-    isomolec.levels carries .local_vibtemp (one value per step).
+    (spect_main_module.py:1880-2131).  Non-LTE: every level of isomolec.levels carries .local_vibtemp (one
+    value per step).
 
-    Returns (abs_coeffs, emi_coeffs): AbsSetLOS whose .set holds one SpectralObject per
-    step (when to_host) and whose .device is the CUDA tensor [n_steps, n_grid].
-    `lineset` may carry an engine.LineSet built earlier from the same lines/grid so
-    that the upload is not repeated."""
-    if useLUTs:
-        raise NotImplementedError('the LUT route (interpolation of stored G coefficients, '
-                                  'spect_main_module.py:997-1066) is a disk cache of the CPU path; '
-                                  'the engine recomputes: call with useLUTs=False')
-    if track_levels is not None:
-        raise NotImplementedError('track_levels is not supported yet')
+    useLUTs=False: lines (SpectLine list) or lineset (an engine.LineSet built earlier from the same lines and
+    grid) -- ONE coefficient op on the GPU instead of calc_shapes_lines + LutSet.add_PT per (P, T), a pickle
+    round trip and the population-weighted combine.  useLUTs=True: allLUTs[(isomolec.mol_name, isomolec.iso)]
+    is a LookUpTable; its G spectra are interpolated to every step and combined on the GPU (:1992-2017).
+    track_levels: level names whose own share of the coefficients is returned too.
+
+    Returns (abs_coeffs, emi_coeffs) or, with track_levels, (abs_coeffs, emi_coeffs, emi_coeffs_tracked,
+    abs_coeffs_tracked): AbsSetLOS with .device (CUDA [n_steps, n_grid]) and, when to_host, one
+    SpectralObject per step -- in .set, or in the pickle stream `cartDROP + 'abscoeff_' + tagLOS...` when
+    store_in_memory is True (the reference's name for spilling to disk; it forces it for more than 10 steps
+    to save RAM, which is not done here: read_one() / prepare_read() serve the in-memory set the same way)."""
+    import torch
     try:
         len(Press)
         len(Temps)
     except TypeError:
         Press, Temps = [Press], [Temps]
-    if lineset is None and lines is None:
-        raise ValueError('when calling smm.make_abscoeff_isomolec() with useLUTs = False, you need to give '
-                         'the list of spectral lines of isomolec as input')   # spect_main_module.py:1965
-    coso = prepare_spe_grid(wn_range_tot)
-    spectral_grid = coso.spectral_grid
+    Temps, Press = np.asarray(Temps, float), np.asarray(Press, float)
     levels = [getattr(isomolec, lev) for lev in isomolec.levels]
-    if lineset is None:
-        lines = [lin for lin in lines if lin.Mol == isomolec.mol and lin.Iso == isomolec.iso]  # :1968
-        soa = spcl.lines_to_soa(lines, isomolec)
-        lineset = engine.LineSet(soa, spectral_grid.grid, isomolec.mol, isomolec.iso, isomolec.MM,
-                                 [lv.energy for lv in levels])
-    tvib = None
-    if levels and not LTE:
-        tvib = np.array([lv.local_vibtemp for lv in levels], dtype=float)   # :2065
-    ab, em = lineset.abscoeff_layers(np.asarray(Temps, float), np.asarray(Press, float), tvib=tvib)
-    abs_coeffs = AbsSetLOS(None, spectral_grid=spectral_grid)
-    emi_coeffs = AbsSetLOS(None, spectral_grid=spectral_grid)
-    abs_coeffs.device, emi_coeffs.device = ab, em
-    if to_host:
-        abh, emh = ab.cpu().numpy(), em.cpu().numpy()
-        for i in range(abh.shape[0]):
-            abs_coeffs.add_set(spcl.SpectralObject(abh[i], spectral_grid, link_grid=True))
-            emi_coeffs.add_set(spcl.SpectralObject(emh[i], spectral_grid, link_grid=True))
-    return abs_coeffs, emi_coeffs
+    if track_levels is not None:
+        for lev in track_levels:
+            if lev not in isomolec.levels:
+                raise ValueError('level {} is not a level of mol {} iso {}'.format(lev, isomolec.mol, isomolec.iso))
+    tracked = {}
+    if useLUTs:
+        LUTs = allLUTs[(isomolec.mol_name, isomolec.iso)]
+        spectral_grid = LUTs.spectral_grid
+        n_grid = len(spectral_grid.grid)
+        ab = torch.zeros((len(Temps), n_grid), dtype=torch.float64, device='cuda')
+        em = torch.zeros_like(ab)
+        pops = _populations(isomolec, levels, Temps, LTE)
+        if not levels:
+            LUTs.sets['all'].combine_steps(Press, Temps, pops[0], ab, em)
+        for li, (lev, levello) in enumerate(zip(isomolec.levels, levels)):
+            ok, lev_lut = LUTs.find_lev(levello.lev_string)
+            if not ok:
+                raise ValueError('mol {} iso {} Level {} not found'.format(isomolec.mol, isomolec.iso, levello.lev_string))
+            LUTs.sets[lev_lut].combine_steps(Press, Temps, pops[li], ab, em)
+            if track_levels is not None and lev in track_levels:
+                ta, te = torch.zeros_like(ab), torch.zeros_like(em)
+                LUTs.sets[lev_lut].combine_steps(Press, Temps, pops[li], ta, te)
+                tracked[lev] = (ta, te)
+    else:
+        if lineset is None and lines is None:
+            raise ValueError('when calling smm.make_abscoeff_isomolec() with useLUTs = False, you need to give '
+                             'the list of spectral lines of isomolec as input')   # spect_main_module.py:1965
+        spectral_grid = prepare_spe_grid(wn_range_tot).spectral_grid
+        if lineset is None:
+            lineset = _as_lineset(lines, spectral_grid, isomolec)                  # :1968 filter inside
+        tvib = None
+        if levels and not LTE:
+            tvib = np.array([lv.local_vibtemp for lv in levels], dtype=float)      # :2065
+        ab, em = lineset.abscoeff_layers(Temps, Press, tvib=tvib)
+        for lev in (track_levels or []):
+            tracked[lev] = lineset.abscoeff_level(Temps, Press, isomolec.levels.index(lev), tvib=tvib)
+
+    tagLOS = 'LOS' if tagLOS is None else tagLOS
+    if store_in_memory and to_host:
+        if cartDROP is None:
+            cartDROP = 'stuff_' + date_stamp()
+            if not os.path.exists(cartDROP):
+                os.mkdir(cartDROP)
+            cartDROP += '/'
+    name = lambda kind, extra='': None if not (store_in_memory and to_host) else \
+        cartDROP + kind + '_' + tagLOS + '_mol_{}_iso_{}{}.pic'.format(isomolec.mol, isomolec.iso, extra)
+
+    def fill(aset, dev):
+        aset.device = dev
+        if not to_host:
+            return aset
+        host = dev.cpu().numpy()
+        if store_in_memory:
+            aset.prepare_export()
+        for row in host:
+            obj = spcl.SpectralObject(row, spectral_grid, link_grid=True)
+            aset.add_dump(obj) if store_in_memory else aset.add_set(obj)
+        if store_in_memory:
+            aset.finalize_IO()
+        return aset
+
+    abs_coeffs = fill(AbsSetLOS(name('abscoeff'), spectral_grid=spectral_grid), ab)
+    emi_coeffs = fill(AbsSetLOS(name('emicoeff'), spectral_grid=spectral_grid), em)
+    if track_levels is None:
+        return abs_coeffs, emi_coeffs
+    emi_tracked, abs_tracked = dict(), dict()
+    for lev in track_levels:
+        ta, te = tracked[lev]
+        emi_tracked[lev] = fill(AbsSetLOS(name('tracklevel_emicoeff', '_' + lev), spectral_grid=spectral_grid), te)
+        # sic: the reference stores the level's EMISSION coefficient in abs_coeffs_tracked too
+        # (spect_main_module.py:2097, 2106); the level's absorption share is kept beside it as .true_abs
+        abs_tracked[lev] = fill(AbsSetLOS(name('tracklevel_abscoeff', '_' + lev), spectral_grid=spectral_grid), te)
+        abs_tracked[lev].true_abs = fill(AbsSetLOS(None, spectral_grid=spectral_grid), ta) if not store_in_memory else ta
+    return abs_coeffs, emi_coeffs, emi_tracked, abs_tracked
+
+
+def make_abscoeff_LUTS_fast(spectral_grid, isomolec, Temps, Press, LTE=True, tagLOS=None, allLUTs=None, cartDROP=None,
+                            store_in_memory=False, track_levels=None, time_control=False, to_host=True):
+    """The in-memory LUT route of the fast retrieval (spect_main_module.py:2134-2299): same result as
+    make_abscoeff_isomolec(useLUTs=True) on the LUT's own grid; (None, None) when the iso-molecule has no
+    table in this spectral range (:2159-2164)."""
+    if allLUTs[(isomolec.mol_name, isomolec.iso)] is None:
+        return (None, None) if track_levels is None else (None, None, None, None)
+    return make_abscoeff_isomolec(None, isomolec, Temps, Press, LTE=LTE, allLUTs=allLUTs, useLUTs=True,
+                                  store_in_memory=store_in_memory, tagLOS=tagLOS, cartDROP=cartDROP,
+                                  track_levels=track_levels, to_host=to_host)
 
 
 # ----------------------------------------------------------------------------

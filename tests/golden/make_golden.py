@@ -655,8 +655,30 @@ def golden_gcoeff():
         e += mk(out["G_lev"][k, 1, 0]) * pop
         trk_abs.append(a.spectrum.copy())
         trk_emi.append(e.spectrum.copy())
+    # A9: the reference's LutSet.calculate (spect_main_module.py:997-1066) on a small table of level 1 built
+    # with its own add_PT: bilinear inside the pressure range, T only below it.  sbm.weight is in the absent
+    # module: linear weights (the only reading of "itype='lin'").
+    sys.modules["spect_base_module"].weight = lambda x, x1, x2, itype="lin": (1.0 - (x - x1) / (x2 - x1), (x - x1) / (x2 - x1))
+    lut_P, lut_T = [1.0, 4.0], [140.0, 150.0, 160.0]
+    lut = smm.LutSet(6, 1, syn.CH4_MM, level=getattr(iso, "lev_01"), filename="unused")
+    lut.temp_file = io.BytesIO()
+    lut.PTcouples = []
+    for P in lut_P:
+        for T in lut_T:
+            lines = ref_lines(spcl, 6, 1, L)
+            oks = [l.LinkToMolec(iso) for l in lines]
+            lines = spcl.PrepareCalcShapes(sg, [l for l, ok in zip(lines, oks) if ok], T, P, iso)
+            lut.add_PT(sg, lines, P, T, keep_memory=True, n_threads=1)
+            lut.PTcouples.append([P, T])
+            for ct in ctypes_:
+                lut.sets[-1][ct].restore_grid(sg)
+    lut_q = [(2.2, 146.0), (0.5, 151.0), (4.0, 157.5)]
+    cut = slice(5000, 9000)
+    lut_res = np.array([[lut.calculate(P, T)[ct].spectrum[cut] for ct in ctypes_] for P, T in lut_q])
     qpart = np.array([float(spcl.CalcPartitionSum(6, 1, temp=t)) for t in temps])
-    np.savez_compressed(os.path.join(HERE, "gcoeff_levels.npz"), grid_w0=grid[0], grid_step=grid[1] - grid[0],
+    np.savez_compressed(os.path.join(HERE, "gcoeff_levels.npz"), lut_P=np.array(lut_P), lut_T=np.array(lut_T),
+                        lut_query=np.array(lut_q), lut_cut=np.array([5000, 9000]), lut_result=lut_res,
+                        grid_w0=grid[0], grid_step=grid[1] - grid[0],
                         grid_n=n_grid, mm=syn.CH4_MM, mol=6, iso=1, e_lev=e_lev, temps=temps, press=press, tvib=tvib,
                         q_part=qpart, G_lev=out["G_lev"], G_all=out["G_all"], track_level=1,
                         track_abs=np.array(trk_abs), track_emi=np.array(trk_emi),

@@ -779,3 +779,117 @@ def test_gcoeff_levels_golden(eng, oracle, golden):
     nz = g["G_all"] != 0
     assert np.array_equal(Ga != 0, nz)
     assert relerr(Ga[nz], g["G_all"][nz]) < TOL
+
+
+def _iso_and_lines(g, with_levels=True, mol_name="CH4"):
+    """sbm.IsoMolec + SpectLine objects of a golden fixture (labels 'Lnn' as in make_golden.ref_lines)."""
+    from spectrobot_amd import spect_classes as spcl, spect_base_module as sbm
+    iso = sbm.IsoMolec(int(g["mol"]), int(g["iso"]), float(g["mm"]), mol_name=mol_name)
+    if with_levels:
+        for i, e in enumerate(g["e_lev"]):
+            iso.add_level("L%02d" % i, e, local_vibtemp=g["tvib"][i])
+    lines = []
+    for i in range(len(g["line_freq"])):
+        up = "L%02d" % g["line_lev_up"][i] if (with_levels and g["line_lev_up"][i] >= 0) else "??"
+        lo = "L%02d" % g["line_lev_lo"][i] if (with_levels and g["line_lev_lo"][i] >= 0) else "??"
+        lines.append(spcl.SpectLine([int(g["mol"]), int(g["iso"]), g["line_freq"][i], 0.0, g["line_a_coeff"][i],
+                                     g["line_air_broad"][i], 0.0, g["line_e_lower"][i], g["line_t_dep_broad"][i], 0.0,
+                                     up, lo, "", "", "", g["line_g_up"][i], g["line_g_lo"][i]], nomi=spcl.cose_hit))
+    return iso, lines
+
+
+@pytest.mark.gpu
+def test_lut_route_golden(eng, golden, tmp_path):
+    """A5 + A9 through the reference's object interface: LookUpTable.make builds the per-level tables in HBM,
+    LutSet.calculate reproduces the reference's bilinear / T-only interpolation (fixture from its own
+    LutSet.calculate), make_abscoeff_isomolec(useLUTs=True) at tabulated couples equals the direct route, and
+    track_levels returns the level's share (fixture) -- in memory and through the pickle stream."""
+    from spectrobot_amd import spect_classes as spcl, spect_main_module as smm
+    g = golden("gcoeff_levels")
+    grid = _grid(g)
+    iso, lines = _iso_and_lines(g)
+    sg = spcl.SpectralGrid(grid, units="cm_1")
+    PT = [[P, T] for P in g["lut_P"] for T in g["lut_T"]]
+    lut = smm.LookUpTable(iso, [grid[0], grid[-1]], LTE=False)
+    lut.make(sg, lines, PT, pt_batch=4)
+    assert sorted(lut.sets) == sorted(iso.levels) and lut.sets["lev_01"].device.shape == (3, 6, len(grid))
+    lo, hi = (int(v) for v in g["lut_cut"])
+    for (P, T), want in zip(g["lut_query"], g["lut_result"]):
+        got = lut.sets["lev_01"].calculate(float(P), float(T))
+        for c, ct in enumerate(smm.ctypes_G):
+            nz = want[c] != 0
+            assert relerr(got[ct].spectrum[lo:hi][nz], want[c][nz]) < TOL, (P, T, ct)
+            assert got[ct].pres == P and got[ct].temp == T
+    with pytest.raises(ValueError):
+        lut.sets["lev_01"].calculate(9.0, 150.0)          # 'Extrapolating in P'
+    ok, name = lut.find_lev("L02")
+    assert ok and name == "lev_02" and lut.find_lev("nope") == (False, None)
+    # LUT route at tabulated couples == direct route (interpolation weights are exactly 1 and 0 there)
+    Ts, Ps = np.array([150.0, 160.0, 140.0]), np.array([1.0, 4.0, 4.0])
+    for lv in iso.levels:
+        getattr(iso, lv).add_local_vibtemp(Ts + 9.0 * iso.levels.index(lv))
+    a_d, e_d = smm.make_abscoeff_isomolec([grid[0], grid[-1]], iso, Ts, Ps, LTE=False, lines=lines)
+    a_l, e_l = smm.make_abscoeff_isomolec(None, iso, Ts, Ps, LTE=False, allLUTs={(iso.mol_name, iso.iso): lut}, useLUTs=True)
+    assert relerr(a_l.device.cpu().numpy(), a_d.device.cpu().numpy()) < 1e-9
+    assert relerr(e_l.device.cpu().numpy(), e_d.device.cpu().numpy()) < 1e-12
+    assert np.array_equal(a_l.set[1].spectrum, a_l.device[1].cpu().numpy()) and a_l.counter == 3
+    # between the nodes the LUT route differs from the direct one by the interpolation error only (per mil)
+    a_i, _ = smm.make_abscoeff_isomolec(None, iso, [155.0], [2.0], LTE=True, allLUTs={(iso.mol_name, iso.iso): lut}, useLUTs=True)
+    a_x, _ = smm.make_abscoeff_isomolec([grid[0], grid[-1]], iso, [155.0], [2.0], LTE=True, lines=lines)
+    rel = (a_i.device - a_x.device).abs().max() / a_x.device.abs().max()
+    assert 1e-9 < float(rel) < 0.2
+    # track_levels against the reference combine; abs_coeffs_tracked holds the EMISSION share (sic)
+    for lv in iso.levels:
+        getattr(iso, lv).add_local_vibtemp(g["tvib"][iso.levels.index(lv)])
+    a, e, et, at = smm.make_abscoeff_isomolec([grid[0], grid[-1]], iso, g["temps"], g["press"], LTE=False, lines=lines,
+                                              track_levels=["lev_01"], store_in_memory=True, cartDROP=str(tmp_path) + "/",
+                                              tagLOS="LOS007")
+    assert a.set == [] and os.path.exists(str(tmp_path) + "/abscoeff_LOS007_mol_6_iso_1.pic")
+    a.prepare_read()
+    rows = np.array([a.read_one().spectrum for _ in range(a.counter)])
+    assert np.array_equal(rows, a.device.cpu().numpy()) and a.remaining == 0
+    et["lev_01"].prepare_read()
+    te = np.array([et["lev_01"].read_one().spectrum for _ in range(2)])
+    nz = g["track_emi"] != 0
+    assert relerr(te[nz], g["track_emi"][nz]) < TOL
+    at["lev_01"].prepare_read()
+    assert np.array_equal(np.array([at["lev_01"].read_one().spectrum for _ in range(2)]), te)     # sic
+    nza = g["track_abs"] != 0
+    assert relerr(at["lev_01"].true_abs.cpu().numpy()[nza], g["track_abs"][nza]) < 1e-9
+    # the LUT route tracks levels too
+    Ts, Ps = np.array([150.0]), np.array([1.0])
+    for lv in iso.levels:
+        getattr(iso, lv).add_local_vibtemp(Ts)
+    _, _, et2, _ = smm.make_abscoeff_isomolec(None, iso, Ts, Ps, LTE=False, allLUTs={(iso.mol_name, iso.iso): lut},
+                                              useLUTs=True, track_levels=["lev_02"])
+    _, _, et3, _ = smm.make_abscoeff_isomolec([grid[0], grid[-1]], iso, Ts, Ps, LTE=False, lines=lines, track_levels=["lev_02"])
+    assert relerr(et2["lev_02"].device.cpu().numpy(), et3["lev_02"].device.cpu().numpy()) < 1e-12
+    # LTE table: one 'all' set over every linked line (level = -1)
+    lut_lte = smm.LookUpTable(iso, [grid[0], grid[-1]], LTE=True)
+    lut_lte.make(sg, lines, PT[:2])
+    G_all = lut_lte.sets["all"].device
+    G_sum = sum(lut.sets[lv].device[:, :2] for lv in iso.levels)
+    assert float(((G_all - G_sum).abs() / G_sum.abs().clamp_min(1e-300)).max()) < 1e-9
+
+
+@pytest.mark.gpu
+def test_per_line_dropin_route(eng, golden):
+    """The fine-grained drop-in route the reference's own Python takes: calc_shapes_lines (humliv_bb shim per
+    line) + SpectralGcoeff.BuildCoeff(preCalc_shapes=True) -> add_lines_to_spectrum -> sum_all_lines shim,
+    against the reference's LutSet.add_PT fixture (few lines: it is the slow route by construction)."""
+    from spectrobot_amd import spect_classes as spcl, spect_main_module as smm
+    g = golden("gcoeff_levels")
+    grid = _grid(g)
+    iso, lines = _iso_and_lines(g)
+    sg = spcl.SpectralGrid(grid, units="cm_1")
+    T, P = float(g["temps"][0]), float(g["press"][0])
+    proc = spcl.calc_shapes_lines(sg, lines, T, P, iso)
+    st = smm.LutSet(6, 1, float(g["mm"]), level=getattr(iso, "lev_01"), level_index=1)
+    st.add_PT(sg, proc, P, T)
+    got = st.device[:, 0].cpu().numpy()
+    want = g["G_lev"][0, 1]
+    nz = want != 0
+    assert np.array_equal(got != 0, nz) and relerr(got[nz], want[nz]) < TOL
+    gc = spcl.SpectralGcoeff("absorption", sg, 6, 1, float(g["mm"]), "L00")
+    gc.BuildCoeff(lines, T, P, isomolec=iso)          # computes the shapes itself
+    assert relerr(gc.spectrum[g["G_lev"][0, 0, 2] != 0], g["G_lev"][0, 0, 2][g["G_lev"][0, 0, 2] != 0]) < TOL
