@@ -216,6 +216,54 @@ int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers,
                          const int32_t *seg_layer, const double *seg_col,
                          int init_from_rad, double *rad, void *stream);
 
+/* ------------------------------------------------------------------------ *
+ * Device LOS pipeline: Curtis-Godson columns per segment on the device, then the      *
+ * recursion, for a batch of rays through n_gas gases.  Stands in for the absent sbm                    *
+ * LineOfSight.calc_radtran_steps + radtran_fast (call sites spect_main_module.py:2746-2767, 2834-2845, *
+ * radtran_3D_ch4.py:297-315); the build's own definition, parity unpinned (columns: curgod_fort_2,     *
+ * pinned).                                                                                             *
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  int n_rays, n_gas;        /* n_gas <= 4 */
+  const int32_t *seg_off;   /* HOST [n_rays+1]: ray r crosses segments seg_off[r] .. seg_off[r+1]-1 */
+  const int32_t *seg_layer; /* HOST [n_seg]: row of abs_c / emi_c (the LOS step's (P, T)) a segment applies */
+  const int32_t *pt_off;    /* HOST [n_seg+1]: LOS sample points of segment s: pt_off[s] .. pt_off[s+1]-1 (>= 2) */
+  const double *x;          /* HOST [n_pt] path coordinate of the sample points, cm, increasing inside a segment */
+  const double *nd;         /* HOST [n_pt] number density, cm^-3 (exponential between sample points, curgods.f) */
+  const double *vmr;        /* HOST [n_gas][n_pt] volume mixing ratio (linear between sample points) */
+  const double *col_scale;  /* HOST [n_gas] factor on each gas's columns (isotopic abundance), NULL = 1 */
+  int los_order;            /* 0 'photon': segments listed along the photon path (spect_main_module.py:2748);
+                               1: listed from the observer outwards (walked backwards by the recursion) */
+  int solo_absorption;      /* != 0: no emission term, I <- I exp(-tau) (radtran_3D_ch4.py:312) */
+  int init_mode;            /* 0: I = 0; 1: rad holds the initial_intensity; 2: Planck spectrum at t_init on the
+                               grid w0 + (g_lo + j) step (Calc_BB, spect_classes.py:1881-1892) */
+  double t_init, w0, step;
+  int64_t g_lo;             /* first grid index of the shard (Planck only) */
+} sr_los_desc;
+
+/* Curtis-Godson columns only: col_out HOST [n_gas][n_seg] = col_scale[g] * curgod_fort_2(nd, vmr_g, x) per segment
+ * (curgods.f:24-45), evaluated on the device.  Synchronises. */
+int sr_los_columns(const sr_los_desc *los, double *col_out);
+
+/* Radiances of the ray batch.  abs_c / emi_c: DEVICE [n_gas][n_layers][n_pts]; rad: DEVICE [n_rays][n_pts].
+ * Per-level partial radiances (single_rad[(gas, iso, lev)], spect_main_module.py:2883-2887): pass the level's
+ * emission share (sr_abscoeff_level_dev) as emi_c with the total abs_c. */
+int sr_limb_rays_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, const sr_los_desc *los,
+                     double *rad, void *stream);
+
+/* + Jacobian w.r.t. n_par VMR-profile parameters: the VMR of gas par_gas[p] at LOS sample point i is
+ * sum_p par_w[p][i] x_p (mask values of RetParam / LinearProfile at the point, spect_main_module.py:319-375), so
+ * d col_g[s] / d x_p = col_scale[g] curgod_fort_2(nd, par_w[p], x).  par_gas: HOST [n_par]; par_w: HOST
+ * [n_par][n_pt]; jac: DEVICE [n_rays][n_par][n_pts].  Checked against finite differences (unpinned). */
+int sr_limb_rays_jac_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts,
+                         const sr_los_desc *los, int n_par, const int32_t *par_gas, const double *par_w, double *rad,
+                         double *jac, void *stream);
+
+/* + Jacobian w.r.t. one scalar per layer acting through the coefficients (temperature; BASELINE configs[3]):
+ * dabs / demi: DEVICE [n_gas][n_layers][n_pts]; jac: DEVICE [n_rays][n_layers][n_pts].  init_mode 0 or 2. */
+int sr_limb_rays_jac_layer_dev(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
+                               int n_layers, int64_t n_pts, const sr_los_desc *los, double *jac, void *stream);
+
 /* Radiances and their Jacobian with respect to n_par retrieval parameters on which the absorber
  * columns depend linearly, col_s = sum_p dcol_dpar[s][p] * x_p (VMR profile parameters of the
  * reference's RetParam / LinearProfile classes, spect_main_module.py:319-375; the reference's own

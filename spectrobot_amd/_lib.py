@@ -51,6 +51,13 @@ class LayersDesc(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("temps", dp), ("press", dp), ("tvib", dp), ("q_part", dp)]
 
 
+class LosDesc(C.Structure):
+    _fields_ = [("n_rays", C.c_int), ("n_gas", C.c_int), ("seg_off", ip), ("seg_layer", ip), ("pt_off", ip),
+                ("x", dp), ("nd", dp), ("vmr", dp), ("col_scale", dp), ("los_order", C.c_int),
+                ("solo_absorption", C.c_int), ("init_mode", C.c_int), ("t_init", C.c_double), ("w0", C.c_double),
+                ("step", C.c_double), ("g_lo", C.c_int64)]
+
+
 # every symbol include/spectrobot_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "sr_strerror": (C.c_char_p, [C.c_int]),
@@ -75,6 +82,13 @@ SYMBOLS = {
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_lut_interp_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, ip, dp, dp, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "sr_los_columns": (C.c_int, [C.POINTER(LosDesc), dp]),
+    "sr_limb_rays_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(LosDesc), C.c_void_p,
+                                   C.c_void_p]),
+    "sr_limb_rays_jac_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(LosDesc), C.c_int, ip, dp,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sr_limb_rays_jac_layer_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                             C.POINTER(LosDesc), C.c_void_p, C.c_void_p]),
     "sr_radiance_rays_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, ip, ip, dp, C.c_int,
                                        C.c_void_p, C.c_void_p]),
     "sr_radiance_jac_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, ip, ip, dp, dp, C.c_int,

@@ -97,6 +97,13 @@ struct Stager {
     pending = true;
     return SR_OK;
   }
+  // re-record `done` behind the kernels that read (or write) the device mirror, so that the slot is
+  // not refilled while they run
+  int mark(hipStream_t st) {
+    HIPCHK(hipEventRecord(done, st));
+    pending = true;
+    return SR_OK;
+  }
   void release() {
     if (pending && done) (void)hipEventSynchronize(done);
     pending = false;
@@ -1030,6 +1037,208 @@ int sr_radiance_jac_dev(const double *abs_c, const double *emi_c, int n_layers, 
                                 reinterpret_cast<const double *>(base + o_col),
                                 reinterpret_cast<const double *>(base + o_d), n_par, rad, jac, st));
   return SR_OK;
+}
+
+// ------------------------------------------------------------------------
+// Device LOS pipeline
+// ------------------------------------------------------------------------
+} // extern "C"
+
+namespace {
+
+// One staged LOS description on the device (a slot of a small ring, see sr_radiance_rays_dev).
+struct LosDev {
+  const int *seg_off, *seg_layer, *pt_off, *par_gas;
+  const double *x, *nd, *prof, *scale;
+  double *col;  // [n_gas + n_par][n_seg]
+  int n_seg, n_pt, n_prof;
+  Stager *slot;
+};
+
+int check_los(const sr_los_desc *los, int n_layers, int *n_seg_out, int *n_pt_out) {
+  if (!los || los->n_rays <= 0 || los->n_gas <= 0 || !los->seg_off || !los->x || !los->nd || !los->vmr) return SR_ERR_ARG;
+  if (los->n_gas > 4) return SR_ERR_LIMIT;
+  if (los->init_mode < 0 || los->init_mode > 2) return SR_ERR_ARG;
+  if (los->init_mode == 2 && !(los->t_init > 0.0 && los->step > 0.0)) return SR_ERR_ARG;
+  const int n_seg = los->seg_off[los->n_rays];
+  if (los->seg_off[0] != 0 || n_seg <= 0 || !los->seg_layer || !los->pt_off) return SR_ERR_ARG;
+  for (int r = 0; r < los->n_rays; ++r)
+    if (los->seg_off[r + 1] < los->seg_off[r]) return SR_ERR_ARG;
+  if (los->pt_off[0] != 0) return SR_ERR_ARG;
+  for (int s = 0; s < n_seg; ++s) {
+    if (n_layers > 0 && (los->seg_layer[s] < 0 || los->seg_layer[s] >= n_layers)) return SR_ERR_ARG; // out-of-bounds read
+    const int np = los->pt_off[s + 1] - los->pt_off[s];
+    if (np < 2) return SR_ERR_ARG;
+    if (np > 8000) return SR_ERR_LIMIT; // imxstp, parameters.inc:64
+  }
+  *n_seg_out = n_seg;
+  *n_pt_out = los->pt_off[n_seg];
+  return SR_OK;
+}
+
+// Stage the LOS on `st` and evaluate the columns of the gases and of n_par profile parameters.
+int stage_los(const sr_los_desc *los, int n_layers, int n_par, const int32_t *par_gas, const double *par_w,
+              hipStream_t st, LosDev *out) {
+  int n_seg = 0, n_pt = 0;
+  int rc = check_los(los, n_layers, &n_seg, &n_pt);
+  if (rc) return rc;
+  if (n_par < 0 || (n_par > 0 && (!par_gas || !par_w))) return SR_ERR_ARG;
+  for (int p = 0; p < n_par; ++p)
+    if (par_gas[p] < 0 || par_gas[p] >= los->n_gas) return SR_ERR_ARG;
+  static thread_local Stager s_ring[4];
+  static thread_local unsigned s_next = 0;
+  Stager &sg = s_ring[s_next++ & 3];
+  const int n_prof = los->n_gas + n_par, nr = los->n_rays;
+  auto al = [](size_t v) { return (v + 15) / 16 * 16; };
+  const size_t o_x = 0, o_nd = o_x + sizeof(double) * n_pt, o_prof = o_nd + sizeof(double) * n_pt;
+  const size_t o_scale = o_prof + sizeof(double) * (size_t)n_prof * n_pt;
+  const size_t o_soff = al(o_scale + sizeof(double) * n_prof), o_slay = al(o_soff + sizeof(int) * (nr + 1));
+  const size_t o_poff = al(o_slay + sizeof(int) * n_seg), o_pgas = al(o_poff + sizeof(int) * (n_seg + 1));
+  const size_t in_bytes = al(o_pgas + sizeof(int) * (size_t)std::max(n_par, 1));
+  const size_t total = in_bytes + sizeof(double) * (size_t)n_prof * n_seg; // + the column table (device only)
+  rc = sg.prepare(total);
+  if (rc) return rc;
+  char *h = sg.host<char>();
+  std::memcpy(h + o_x, los->x, sizeof(double) * n_pt);
+  std::memcpy(h + o_nd, los->nd, sizeof(double) * n_pt);
+  std::memcpy(h + o_prof, los->vmr, sizeof(double) * (size_t)los->n_gas * n_pt);
+  if (n_par) std::memcpy(h + o_prof + sizeof(double) * (size_t)los->n_gas * n_pt, par_w, sizeof(double) * (size_t)n_par * n_pt);
+  double *sc = reinterpret_cast<double *>(h + o_scale);
+  for (int g = 0; g < los->n_gas; ++g) sc[g] = los->col_scale ? los->col_scale[g] : 1.0;
+  for (int p = 0; p < n_par; ++p) sc[los->n_gas + p] = sc[par_gas[p]];
+  int *so = reinterpret_cast<int *>(h + o_soff), *sl = reinterpret_cast<int *>(h + o_slay);
+  std::memcpy(so, los->seg_off, sizeof(int) * (nr + 1));
+  if (los->los_order == 0) {
+    std::memcpy(sl, los->seg_layer, sizeof(int) * n_seg);
+  }
+  // observer order: the recursion walks every ray's segments backwards.  Segment s keeps its index (and
+  // its sample points, whose x must stay increasing); only the walk order changes, through a permutation
+  // applied to seg_layer and to the column table's segment axis alike.
+  std::vector<int> perm(n_seg);
+  for (int r = 0; r < nr; ++r)
+    for (int s = los->seg_off[r]; s < los->seg_off[r + 1]; ++s)
+      perm[s] = los->los_order == 0 ? s : los->seg_off[r] + (los->seg_off[r + 1] - 1 - s);
+  int *po = reinterpret_cast<int *>(h + o_poff);
+  if (los->los_order != 0) {
+    // re-list the segments in photon order: new segment q = old segment perm[q]; sample points re-packed
+    std::vector<double> x2(n_pt), nd2(n_pt), pr2((size_t)n_prof * n_pt);
+    const double *prs = reinterpret_cast<const double *>(h + o_prof);
+    int at = 0;
+    for (int q = 0; q < n_seg; ++q) {
+      const int s = perm[q], a = los->pt_off[s], b = los->pt_off[s + 1];
+      sl[q] = los->seg_layer[s];
+      po[q] = at;
+      for (int i = a; i < b; ++i, ++at) {
+        x2[at] = los->x[i];
+        nd2[at] = los->nd[i];
+        for (int f = 0; f < n_prof; ++f) pr2[(size_t)f * n_pt + at] = prs[(size_t)f * n_pt + i];
+      }
+    }
+    po[n_seg] = at;
+    std::memcpy(h + o_x, x2.data(), sizeof(double) * n_pt);
+    std::memcpy(h + o_nd, nd2.data(), sizeof(double) * n_pt);
+    std::memcpy(h + o_prof, pr2.data(), sizeof(double) * (size_t)n_prof * n_pt);
+  } else {
+    std::memcpy(po, los->pt_off, sizeof(int) * (n_seg + 1));
+  }
+  if (n_par) std::memcpy(h + o_pgas, par_gas, sizeof(int) * n_par);
+  rc = sg.push(in_bytes, st);
+  if (rc) return rc;
+  char *d = sg.d.as<char>();
+  out->x = reinterpret_cast<const double *>(d + o_x);
+  out->nd = reinterpret_cast<const double *>(d + o_nd);
+  out->prof = reinterpret_cast<const double *>(d + o_prof);
+  out->scale = reinterpret_cast<const double *>(d + o_scale);
+  out->seg_off = reinterpret_cast<const int *>(d + o_soff);
+  out->seg_layer = reinterpret_cast<const int *>(d + o_slay);
+  out->pt_off = reinterpret_cast<const int *>(d + o_poff);
+  out->par_gas = reinterpret_cast<const int *>(d + o_pgas);
+  out->col = reinterpret_cast<double *>(d + in_bytes);
+  out->n_seg = n_seg;
+  out->n_pt = n_pt;
+  out->n_prof = n_prof;
+  out->slot = &sg;
+  LAUNCHCHK(launch_los_columns(out->nd, out->x, out->prof, out->scale, out->pt_off, n_seg, n_pt, n_prof, out->col, st));
+  return SR_OK;
+}
+
+LimbOpts limb_opts(const sr_los_desc *los, int n_seg) {
+  LimbOpts o;
+  o.n_gas = los->n_gas;
+  o.n_seg_total = n_seg;
+  o.solo_absorption = los->solo_absorption ? 1 : 0;
+  o.init_mode = los->init_mode;
+  o.g_lo = (int)los->g_lo;
+  o.t_init = los->t_init;
+  o.w0 = los->w0;
+  o.gstep = los->step;
+  return o;
+}
+
+} // namespace
+
+extern "C" {
+
+int sr_los_columns(const sr_los_desc *los, double *col_out) {
+  if (!col_out) return SR_ERR_ARG;
+  LosDev D;
+  int rc = stage_los(los, 0, 0, nullptr, nullptr, nullptr, &D);
+  if (rc) return rc;
+  std::vector<double> tmp((size_t)los->n_gas * D.n_seg);
+  HIPCHK(hipMemcpy(tmp.data(), D.col, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+  // back to the caller's segment numbering
+  for (int g = 0; g < los->n_gas; ++g)
+    for (int r = 0; r < los->n_rays; ++r)
+      for (int s = los->seg_off[r]; s < los->seg_off[r + 1]; ++s) {
+        const int q = los->los_order == 0 ? s : los->seg_off[r] + (los->seg_off[r + 1] - 1 - s);
+        col_out[(size_t)g * D.n_seg + s] = tmp[(size_t)g * D.n_seg + q];
+      }
+  return SR_OK;
+}
+
+int sr_limb_rays_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, const sr_los_desc *los,
+                     double *rad, void *stream) {
+  if (!abs_c || !emi_c || !rad || n_layers <= 0 || n_pts <= 0) return SR_ERR_ARG;
+  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LosDev D;
+  int rc = stage_los(los, n_layers, 0, nullptr, nullptr, st, &D);
+  if (rc) return rc;
+  LAUNCHCHK(launch_limb(abs_c, emi_c, (int)n_pts, n_layers, los->n_rays, D.seg_off, D.seg_layer, D.col,
+                        limb_opts(los, D.n_seg), rad, st));
+  return D.slot->mark(st);
+}
+
+int sr_limb_rays_jac_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts,
+                         const sr_los_desc *los, int n_par, const int32_t *par_gas, const double *par_w, double *rad,
+                         double *jac, void *stream) {
+  if (!abs_c || !emi_c || !rad || !jac || n_layers <= 0 || n_pts <= 0 || n_par <= 0) return SR_ERR_ARG;
+  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LosDev D;
+  int rc = stage_los(los, n_layers, n_par, par_gas, par_w, st, &D);
+  if (rc) return rc;
+  LAUNCHCHK(launch_limb_jac(abs_c, emi_c, (int)n_pts, n_layers, los->n_rays, D.seg_off, D.seg_layer, D.col,
+                            D.col + (size_t)los->n_gas * D.n_seg, D.par_gas, n_par, limb_opts(los, D.n_seg), rad, jac,
+                            st));
+  return D.slot->mark(st);
+}
+
+int sr_limb_rays_jac_layer_dev(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
+                               int n_layers, int64_t n_pts, const sr_los_desc *los, double *jac, void *stream) {
+  if (!abs_c || !emi_c || !dabs || !demi || !jac || n_layers <= 0 || n_pts <= 0) return SR_ERR_ARG;
+  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  if (los && los->init_mode == 1) {
+    g_err = "sr_limb_rays_jac_layer_dev: init_mode 1 (intensity read from a buffer) is not supported, use 0 or 2";
+    return SR_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LosDev D;
+  int rc = stage_los(los, n_layers, 0, nullptr, nullptr, st, &D);
+  if (rc) return rc;
+  LAUNCHCHK(launch_limb_jac_layer(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, los->n_rays, D.seg_off, D.seg_layer,
+                                  D.col, limb_opts(los, D.n_seg), jac, st));
+  return D.slot->mark(st);
 }
 
 // ------------------------------------------------------------------------

@@ -1491,6 +1491,247 @@ __global__ __launch_bounds__(256) void sr_radiance_jac_layer_kernel(
     if (p0 + q < n_layers) jac[((size_t)ray * n_layers + p0 + q) * n_pts + j] = J[q];
 }
 
+// ------------------------------------------------------------------------
+// Device LOS pipeline (the build's own definition standing in for the absent sbm
+// LineOfSight.calc_radtran_steps / radtran_fast, call sites spect_main_module.py:2746-2767, 2834-2845).
+//   sr_los_columns_kernel   Curtis-Godson columns of every (gas | profile parameter, segment):
+//                           curgod_fort_2 (curgods.f:24-45) over the segment's LOS sample points
+//   sr_limb_kernel          recursion of a ray batch over n_gas gases with the call-site options
+//                           solo_absorption / initial_intensity (Planck) (radtran_3D_ch4.py:297-315)
+//   sr_limb_jac_kernel      + derivatives w.r.t. VMR-profile parameters (columns linear in them)
+//   sr_limb_jac_layer_kernel  + derivatives w.r.t. one scalar per layer acting through the coefficients
+// Per segment s of a ray, layer k = seg_layer[s], columns u_g = col[g][s]:
+//   tau = sum_g abs_g[k] u_g,  E = sum_g emi_g[k] u_g,  t = e^-tau,  f = (1 - t)/tau
+//   I <- I t + E f          (E f dropped with solo_absorption)
+// ------------------------------------------------------------------------
+__global__ void sr_los_columns_kernel(const double *__restrict__ nd, const double *__restrict__ x,
+                                      const double *__restrict__ prof, // [n_prof][n_pt]: vmr per gas, then weights per parameter
+                                      const double *__restrict__ scale, // [n_prof]
+                                      const int *__restrict__ pt_off, int n_seg, int n_pt,
+                                      double *__restrict__ col) {      // [n_prof][n_seg]
+  const int s = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (s >= n_seg) return;
+  const double *vmr = prof + (size_t)q * n_pt;
+  double acc = 0.0;
+  for (int i = pt_off[s]; i < pt_off[s + 1] - 1; ++i) { // curgods.f:33-43
+    const double dx = x[i + 1] - x[i];
+    const double A = nd[i] * vmr[i];
+    const double B = nd[i] * (vmr[i + 1] - vmr[i]) / dx;
+    const double fu = nd[i + 1] / nd[i];
+    const double D = log(fu) / dx;
+    acc = acc + (A * D * (fu - 1.) + B * fu * (D * dx - 1.) + B) / (D * D);
+  }
+  col[(size_t)q * n_seg + s] = scale[q] * acc;
+}
+
+int launch_los_columns(const double *nd, const double *x, const double *prof, const double *scale, const int *pt_off,
+                       int n_seg, int n_pt, int n_prof, double *col, hipStream_t st) {
+  if (n_seg <= 0 || n_prof <= 0) return 0;
+  hipLaunchKernelGGL(sr_los_columns_kernel, dim3((n_seg + 63) / 64, n_prof), dim3(64), 0, st, nd, x, prof, scale, pt_off,
+                     n_seg, n_pt, col);
+  return (int)hipGetLastError();
+}
+
+__device__ inline double limb_initial(const LimbOpts &o, const double *rad, size_t at, int j) {
+  if (o.init_mode == 1) return rad[at];
+  if (o.init_mode == 2) { // Calc_BB, spect_classes.py:1886
+    const double nu = o.w0 + (double)(o.g_lo + j) * o.gstep;
+    return 2 * kHcgs * (kCcgs * kCcgs) * (nu * nu * nu) / (exp(kC2 * nu / o.t_init) - 1);
+  }
+  return 0.0;
+}
+
+template <int NG>
+__global__ __launch_bounds__(256) void sr_limb_kernel(const double *__restrict__ abs_c, const double *__restrict__ emi_c,
+                                                      int n_pts, int n_layers, const int *__restrict__ seg_off,
+                                                      const int *__restrict__ seg_layer, const double *__restrict__ col,
+                                                      LimbOpts o, double *__restrict__ rad) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, ray = blockIdx.y;
+  if (j >= n_pts) return;
+  double I = limb_initial(o, rad, (size_t)ray * n_pts + j, j);
+  const int s0 = seg_off[ray], s1 = seg_off[ray + 1];
+  constexpr int kB = NG == 1 ? 8 : (NG == 2 ? 4 : 2); // segments whose loads are issued together (see sr_radiance_kernel)
+  const size_t gstride = (size_t)n_layers * n_pts;
+  for (int sb = s0; sb < s1; sb += kB) {
+    double a[kB][NG], e[kB][NG], u[kB][NG];
+#pragma unroll
+    for (int t = 0; t < kB; ++t) {
+      const int s = min(sb + t, s1 - 1);
+      const size_t ofs = (size_t)seg_layer[s] * n_pts + j;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        a[t][g] = abs_c[g * gstride + ofs];
+        e[t][g] = emi_c[g * gstride + ofs];
+        u[t][g] = col[(size_t)g * o.n_seg_total + s];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kB; ++t) {
+      if (sb + t < s1) {
+        double tau = a[t][0] * u[t][0], E = e[t][0] * u[t][0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+          tau = tau + a[t][g] * u[t][g];
+          E = E + e[t][g] * u[t][g];
+        }
+        const double em1 = -expm1(-tau);
+        const double src = o.solo_absorption ? 0.0 : (fabs(tau) > 1e-12 ? E * (em1 / tau) : E);
+        I = I * exp(-tau) + src;
+      }
+    }
+  }
+  rad[(size_t)ray * n_pts + j] = I;
+}
+
+// Derivatives w.r.t. NP parameters per thread; parameter p belongs to gas par_gas[p] and moves its columns
+// linearly, d u_g[s] / d x_p = dcol[p][s] (profile parameters of RetParam / LinearProfile, smm:319-375):
+//   d tau = a_g D,  d(E f) = e_g D f + E f'(tau) a_g D,  f' = (tau t - (1 - t))/tau^2
+//   J_p <- J_p t + (-I t a_g + e_g f + E f' a_g) D      (single gas: t (e - a I) D)
+template <int NG, int NP>
+__global__ __launch_bounds__(256) void sr_limb_jac_kernel(
+    const double *__restrict__ abs_c, const double *__restrict__ emi_c, int n_pts, int n_layers,
+    const int *__restrict__ seg_off, const int *__restrict__ seg_layer, const double *__restrict__ col,
+    const double *__restrict__ dcol, const int *__restrict__ par_gas, int n_par, LimbOpts o,
+    double *__restrict__ rad, double *__restrict__ jac) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, ray = blockIdx.y, p0 = blockIdx.z * NP;
+  if (j >= n_pts) return;
+  double I = limb_initial(o, rad, (size_t)ray * n_pts + j, j), J[NP];
+  int pg[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    J[q] = 0.0;
+    pg[q] = p0 + q < n_par ? par_gas[p0 + q] : 0;
+  }
+  const int s0 = seg_off[ray], s1 = seg_off[ray + 1];
+  const size_t gstride = (size_t)n_layers * n_pts;
+  for (int s = s0; s < s1; ++s) {
+    const size_t ofs = (size_t)seg_layer[s] * n_pts + j;
+    double a[NG], e[NG];
+    double tau = 0.0, E = 0.0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      a[g] = abs_c[g * gstride + ofs];
+      e[g] = emi_c[g * gstride + ofs];
+      const double u = col[(size_t)g * o.n_seg_total + s];
+      tau = g == 0 ? a[g] * u : tau + a[g] * u;
+      E = g == 0 ? e[g] * u : E + e[g] * u;
+    }
+    const double t = exp(-tau), em1 = -expm1(-tau);
+    const bool thin = !(fabs(tau) > 1e-12);
+    const double f = thin ? 1.0 : em1 / tau;
+    const double fp = thin ? -0.5 : (tau * t - em1) / (tau * tau);
+    const double src = o.solo_absorption ? 0.0 : E * f;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      double ag = a[0], eg = e[0];
+#pragma unroll
+      for (int g = 1; g < NG; ++g) {
+        ag = pg[q] == g ? a[g] : ag;
+        eg = pg[q] == g ? e[g] : eg;
+      }
+      const double D = p0 + q < n_par ? dcol[(size_t)(p0 + q) * o.n_seg_total + s] : 0.0;
+      const double dsrc = o.solo_absorption ? 0.0 : fma(E * fp, ag, eg * f);
+      J[q] = fma(J[q], t, (dsrc - I * t * ag) * D);
+    }
+    I = I * t + src;
+  }
+  if (blockIdx.z == 0) rad[(size_t)ray * n_pts + j] = I;
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+    if (p0 + q < n_par) jac[((size_t)ray * n_par + p0 + q) * n_pts + j] = J[q];
+}
+
+// Derivatives w.r.t. ONE scalar per layer acting through the layer's coefficients (temperature, ...):
+// dabs / demi: [NG][n_layers][n_pts].  See sr_radiance_jac_layer_kernel for the recursion.
+template <int NG, int NP>
+__global__ __launch_bounds__(256) void sr_limb_jac_layer_kernel(
+    const double *__restrict__ abs_c, const double *__restrict__ emi_c, const double *__restrict__ dabs,
+    const double *__restrict__ demi, int n_pts, int n_layers, const int *__restrict__ seg_off,
+    const int *__restrict__ seg_layer, const double *__restrict__ col, LimbOpts o, double *__restrict__ jac) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, ray = blockIdx.y, p0 = blockIdx.z * NP;
+  if (j >= n_pts) return;
+  double I = limb_initial(o, jac, 0, j), J[NP]; // init_mode 1 is refused by the host for this kernel
+#pragma unroll
+  for (int q = 0; q < NP; ++q) J[q] = 0.0;
+  const int s0 = seg_off[ray], s1 = seg_off[ray + 1];
+  const size_t gstride = (size_t)n_layers * n_pts;
+  for (int s = s0; s < s1; ++s) {
+    const int k = seg_layer[s];
+    const size_t ofs = (size_t)k * n_pts + j;
+    const bool mine = k >= p0 && k < p0 + NP;
+    double tau = 0.0, E = 0.0, dtau = 0.0, dE = 0.0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const double u = col[(size_t)g * o.n_seg_total + s];
+      const double av = abs_c[g * gstride + ofs], ev = emi_c[g * gstride + ofs];
+      tau = g == 0 ? av * u : tau + av * u;
+      E = g == 0 ? ev * u : E + ev * u;
+      if (mine) {
+        dtau = fma(dabs[g * gstride + ofs], u, dtau);
+        dE = fma(demi[g * gstride + ofs], u, dE);
+      }
+    }
+    const double t = exp(-tau), em1 = -expm1(-tau);
+    const bool thin = !(fabs(tau) > 1e-12);
+    const double f = thin ? 1.0 : em1 / tau;
+    const double src = o.solo_absorption ? 0.0 : E * f;
+    if (mine) {
+      const double fp = thin ? -0.5 : (tau * t - em1) / (tau * tau);
+      const double d = -I * t * dtau + (o.solo_absorption ? 0.0 : dE * f + E * fp * dtau);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) J[q] = fma(J[q], t, (k == p0 + q) ? d : 0.0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) J[q] *= t;
+    }
+    I = I * t + src;
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+    if (p0 + q < n_layers) jac[((size_t)ray * n_layers + p0 + q) * n_pts + j] = J[q];
+}
+
+#define SR_BY_NGAS(NGV, CALL1, CALL2, CALL3, CALL4) \
+  switch (NGV) { case 1: CALL1; break; case 2: CALL2; break; case 3: CALL3; break; default: CALL4; break; }
+
+int launch_limb(const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, const int *seg_off,
+                const int *seg_layer, const double *col, const LimbOpts &o, double *rad, hipStream_t st) {
+  if (n_pts <= 0 || n_rays <= 0) return 0;
+  const dim3 grid((n_pts + 255) / 256, n_rays);
+#define SR_L(NG) hipLaunchKernelGGL(sr_limb_kernel<NG>, grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, seg_off, \
+                                    seg_layer, col, o, rad)
+  SR_BY_NGAS(o.n_gas, SR_L(1), SR_L(2), SR_L(3), SR_L(4))
+#undef SR_L
+  return (int)hipGetLastError();
+}
+
+int launch_limb_jac(const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, const int *seg_off,
+                    const int *seg_layer, const double *col, const double *dcol, const int *par_gas, int n_par,
+                    const LimbOpts &o, double *rad, double *jac, hipStream_t st) {
+  if (n_pts <= 0 || n_rays <= 0 || n_par <= 0) return 0;
+  constexpr int NP = 4;
+  const dim3 grid((n_pts + 255) / 256, n_rays, (n_par + NP - 1) / NP);
+#define SR_L(NG) hipLaunchKernelGGL((sr_limb_jac_kernel<NG, NP>), grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, \
+                                    seg_off, seg_layer, col, dcol, par_gas, n_par, o, rad, jac)
+  SR_BY_NGAS(o.n_gas, SR_L(1), SR_L(2), SR_L(3), SR_L(4))
+#undef SR_L
+  return (int)hipGetLastError();
+}
+
+int launch_limb_jac_layer(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
+                          int n_layers, int n_rays, const int *seg_off, const int *seg_layer, const double *col,
+                          const LimbOpts &o, double *jac, hipStream_t st) {
+  if (n_pts <= 0 || n_rays <= 0 || n_layers <= 0) return 0;
+  constexpr int NP = 4;
+  const dim3 grid((n_pts + 255) / 256, n_rays, (n_layers + NP - 1) / NP);
+#define SR_L(NG) hipLaunchKernelGGL((sr_limb_jac_layer_kernel<NG, NP>), grid, dim3(256), 0, st, abs_c, emi_c, dabs, demi, \
+                                    n_pts, n_layers, seg_off, seg_layer, col, o, jac)
+  SR_BY_NGAS(o.n_gas, SR_L(1), SR_L(2), SR_L(3), SR_L(4))
+#undef SR_L
+  return (int)hipGetLastError();
+}
+#undef SR_BY_NGAS
+
 int launch_radiance_jac_layer(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
                               int n_pts, int n_layers, int n_rays, const int *seg_off, const int *seg_layer,
                               const double *seg_col, double *jac, hipStream_t st) {

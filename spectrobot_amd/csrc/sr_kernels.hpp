@@ -99,6 +99,21 @@ int abscoeff_tile_points(int variant);
 int launch_abscoeff(int variant, int which, const FastRec *fast, const ColdRec *cold, const IcIndex &ix,
                     const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp,
                     double *abs_out, double *emi_out, hipStream_t st);
+// Options of the device LOS pipeline (include/spectrobot_hip.h: sr_los_desc)
+struct LimbOpts {
+  int n_gas, n_seg_total, solo_absorption, init_mode, g_lo;
+  double t_init, w0, gstep;
+};
+int launch_los_columns(const double *nd, const double *x, const double *prof, const double *scale, const int *pt_off,
+                       int n_seg, int n_pt, int n_prof, double *col, hipStream_t st);
+int launch_limb(const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, const int *seg_off,
+                const int *seg_layer, const double *col, const LimbOpts &o, double *rad, hipStream_t st);
+int launch_limb_jac(const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, const int *seg_off,
+                    const int *seg_layer, const double *col, const double *dcol, const int *par_gas, int n_par,
+                    const LimbOpts &o, double *rad, double *jac, hipStream_t st);
+int launch_limb_jac_layer(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
+                          int n_layers, int n_rays, const int *seg_off, const int *seg_layer, const double *col,
+                          const LimbOpts &o, double *jac, hipStream_t st);
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                     const int *seg_layer, const double *seg_col, int init_from_rad, double *rad,
                     hipStream_t st);

@@ -237,6 +237,117 @@ def radiance_rays(abs_c, emi_c, seg_off, seg_layer, seg_col, rad0=None):
     return rad
 
 
+class LimbLOS(object):
+    """A batch of lines of sight for the device LOS pipeline (sr_los_desc): per ray the segments it crosses,
+    per segment the layer whose coefficients apply and the LOS sample points (path coordinate x [cm], number
+    density nd [cm^-3], VMR of every gas) over which the Curtis-Godson column is integrated on the device.
+
+    seg_off [n_rays+1], seg_layer [n_seg], pt_off [n_seg+1], x / nd [n_pt], vmr [n_gas, n_pt].
+    Options as at the reference's call sites: LOS_order ('photon' | 'observer'), solo_absorption,
+    initial_intensity: None, a temperature (Planck source, Calc_BB) or 'rad0' (given per call)."""
+
+    def __init__(self, seg_off, seg_layer, pt_off, x, nd, vmr, col_scale=None, LOS_order='photon',
+                 solo_absorption=False, initial_temperature=None):
+        self.seg_off, self._so = _i(seg_off)
+        self.seg_layer, self._sl = _i(seg_layer)
+        self.pt_off, self._po = _i(pt_off)
+        self.x, self._x = _d(x)
+        self.nd, self._nd = _d(nd)
+        self.vmr, self._v = _d(np.atleast_2d(vmr))
+        self.n_rays, self.n_gas = self.seg_off.size - 1, self.vmr.shape[0]
+        self.n_seg, self.n_pt = self.seg_layer.size, self.x.size
+        if self.vmr.shape[1] != self.n_pt or self.nd.size != self.n_pt or self.pt_off.size != self.n_seg + 1:
+            raise ValueError("inconsistent LOS arrays")
+        self.col_scale, self._cs = (None, None) if col_scale is None else _d(col_scale)
+        if LOS_order not in ('photon', 'observer'):
+            raise ValueError("LOS_order must be 'photon' or 'observer'")
+        self.LOS_order, self.solo_absorption, self.initial_temperature = LOS_order, bool(solo_absorption), initial_temperature
+
+    def desc(self, grid=None, g_lo=0, rad0=False):
+        d = _lib.LosDesc()
+        d.n_rays, d.n_gas = self.n_rays, self.n_gas
+        d.seg_off, d.seg_layer, d.pt_off, d.x, d.nd, d.vmr = self._so, self._sl, self._po, self._x, self._nd, self._v
+        d.col_scale = self._cs
+        d.los_order = 0 if self.LOS_order == 'photon' else 1
+        d.solo_absorption = int(self.solo_absorption)
+        d.init_mode, d.t_init, d.w0, d.step, d.g_lo = 0, 0.0, 0.0, 0.0, int(g_lo)
+        if rad0:
+            d.init_mode = 1
+        elif self.initial_temperature is not None:
+            if grid is None:
+                raise ValueError("a Planck initial intensity needs the spectral grid")
+            w0, step, _ = grid_params(grid)
+            d.init_mode, d.t_init, d.w0, d.step = 2, float(self.initial_temperature), w0, step
+        return d
+
+    def columns(self):
+        """[n_gas, n_seg] Curtis-Godson columns (curgod_fort_2 per segment, on the device)."""
+        out = np.zeros((self.n_gas, self.n_seg))
+        d = self.desc()
+        check(lib.sr_los_columns(C.byref(d), out.ctypes.data_as(dp)), "sr_los_columns")
+        return out
+
+
+def _gas_stack(coeffs):
+    """[(abs, emi)] per gas or one (abs, emi) pair -> contiguous CUDA [n_gas, n_layers, n_pts] x 2."""
+    if isinstance(coeffs[0], torch.Tensor):
+        coeffs = [coeffs]
+    a = torch.stack([c[0] for c in coeffs]).contiguous() if len(coeffs) > 1 else coeffs[0][0].contiguous()[None]
+    e = torch.stack([c[1] for c in coeffs]).contiguous() if len(coeffs) > 1 else coeffs[0][1].contiguous()[None]
+    assert a.is_cuda and a.dtype == torch.float64 and e.shape == a.shape
+    return a, e
+
+
+def limb_rays(coeffs, los, grid=None, g_lo=0, rad0=None):
+    """Radiances [n_rays, n_pts] of a LimbLOS batch through the gases' coefficients (sr_limb_rays_dev):
+    columns per segment on the device, then the recursion.  coeffs: (abs, emi) or [(abs, emi)] per gas,
+    CUDA [n_layers, n_pts] each.  rad0: CUDA [n_rays, n_pts] initial intensity (overwritten)."""
+    a, e = _gas_stack(coeffs)
+    n_gas, n_layers, n_pts = a.shape
+    if n_gas != los.n_gas:
+        raise ValueError("%d coefficient sets for %d gases" % (n_gas, los.n_gas))
+    rad = rad0 if rad0 is not None else torch.empty((los.n_rays, n_pts), dtype=torch.float64, device="cuda")
+    assert rad.shape == (los.n_rays, n_pts) and rad.is_contiguous()
+    d = los.desc(grid, g_lo, rad0=rad0 is not None)
+    check(lib.sr_limb_rays_dev(C.c_void_p(a.data_ptr()), C.c_void_p(e.data_ptr()), n_layers, n_pts, C.byref(d),
+                               C.c_void_p(rad.data_ptr()), _stream_ptr()), "sr_limb_rays_dev")
+    return rad
+
+
+def limb_rays_jacobian(coeffs, los, par_gas, par_w, grid=None, g_lo=0, rad0=None):
+    """Radiances and d rad / d x_p [n_rays, n_par, n_pts] for VMR-profile parameters: the VMR of gas
+    par_gas[p] at LOS sample point i is sum_p par_w[p, i] x_p (sr_limb_rays_jac_dev)."""
+    a, e = _gas_stack(coeffs)
+    n_gas, n_layers, n_pts = a.shape
+    par_gas, pg = _i(par_gas)
+    par_w, pw = _d(par_w)
+    n_par = par_gas.size
+    if par_w.shape != (n_par, los.n_pt):
+        raise ValueError("par_w must be [n_par, n_pt]")
+    rad = rad0 if rad0 is not None else torch.empty((los.n_rays, n_pts), dtype=torch.float64, device="cuda")
+    jac = torch.empty((los.n_rays, n_par, n_pts), dtype=torch.float64, device="cuda")
+    d = los.desc(grid, g_lo, rad0=rad0 is not None)
+    check(lib.sr_limb_rays_jac_dev(C.c_void_p(a.data_ptr()), C.c_void_p(e.data_ptr()), n_layers, n_pts, C.byref(d),
+                                   n_par, pg, pw, C.c_void_p(rad.data_ptr()), C.c_void_p(jac.data_ptr()),
+                                   _stream_ptr()), "sr_limb_rays_jac_dev")
+    return rad, jac
+
+
+def limb_rays_layer_jacobian(coeffs, dcoeffs, los, grid=None, g_lo=0):
+    """d rad / d (one scalar per layer) [n_rays, n_layers, n_pts]; dcoeffs like coeffs: d(abs, emi of layer k) /
+    d(parameter of layer k) per gas (sr_limb_rays_jac_layer_dev)."""
+    a, e = _gas_stack(coeffs)
+    da, de = _gas_stack(dcoeffs)
+    n_gas, n_layers, n_pts = a.shape
+    assert da.shape == a.shape
+    jac = torch.empty((los.n_rays, n_layers, n_pts), dtype=torch.float64, device="cuda")
+    d = los.desc(grid, g_lo)
+    check(lib.sr_limb_rays_jac_layer_dev(C.c_void_p(a.data_ptr()), C.c_void_p(e.data_ptr()), C.c_void_p(da.data_ptr()),
+                                         C.c_void_p(de.data_ptr()), n_layers, n_pts, C.byref(d),
+                                         C.c_void_p(jac.data_ptr()), _stream_ptr()), "sr_limb_rays_jac_layer_dev")
+    return jac
+
+
 def radiance_jacobian(abs_c, emi_c, seg_off, seg_layer, seg_col, dcol_dpar):
     """Radiances [n_rays, n_pts] and d rad / d x_p [n_rays, n_par, n_pts] for parameters on which the
     segment columns depend linearly: dcol_dpar[s, p] = d col_s / d x_p (sr_radiance_jac_dev)."""

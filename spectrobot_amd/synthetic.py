@@ -98,3 +98,48 @@ def limb_path(z, z_tan, R=2575.0):
 def number_density(P_hpa, T):
     """n = P/(kb*T) with the reference's kb for hPa / cm^-3 (spect_classes.py:34)."""
     return P_hpa / (1.38065e-19 * T)
+
+
+def limb_los(z, nd_levels, vmr_levels, z_tans, R=2575.0, n_sub=3):
+    """Lines of sight of limb rays through spherical shells for the device LOS pipeline
+    (engine.LimbLOS): per ray the shell crossings in photon order (far side -> tangent point ->
+    observer), per crossing n_sub + 1 sample points along the path with the number density
+    interpolated exponentially and every VMR linearly in altitude between the levels z (the
+    profiles curgods.f assumes).  vmr_levels: [n_gas, n_levels].  Returns the LimbLOS arguments
+    dict(seg_off, seg_layer, pt_off, x [cm], nd, vmr [n_gas, n_pt]) plus `alt` [n_pt] (km)."""
+    z = np.asarray(z, float)
+    nd_levels = np.asarray(nd_levels, float)
+    vmr_levels = np.atleast_2d(np.asarray(vmr_levels, float))
+    dz = np.diff(z)
+    top = z[-1] + (dz[-1] if len(dz) else 10.0)
+    bounds = np.concatenate([z, [top]])
+    # profiles continued to the top boundary with the last scale height / last VMR
+    lognd = np.log(nd_levels)
+    lognd_top = lognd[-1] + (lognd[-1] - lognd[-2]) / dz[-1] * (top - z[-1]) if len(dz) else lognd[-1]
+    zz = np.concatenate([z, [top]])
+    ln = np.concatenate([lognd, [lognd_top]])
+    vv = np.concatenate([vmr_levels, vmr_levels[:, -1:]], axis=1)
+    seg_off, seg_layer, pt_off, xs, alts = [0], [], [0], [], []
+    for zt in np.atleast_1d(z_tans):
+        rt = R + zt
+        shells = []
+        for k in range(len(z)):
+            lo, hi = R + bounds[k], R + bounds[k + 1]
+            if hi <= rt:
+                continue
+            s_lo = np.sqrt(lo * lo - rt * rt) if lo > rt else 0.0
+            shells.append((k, s_lo, np.sqrt(hi * hi - rt * rt)))
+        # far side: s from -s_hi(top) up to the tangent point (s = 0), near side: 0 .. +s_hi(top)
+        crossings = [(k, -s_hi, -s_lo) for k, s_lo, s_hi in shells[::-1]] + [(k, s_lo, s_hi) for k, s_lo, s_hi in shells]
+        for k, a, b in crossings:
+            s = np.linspace(a, b, n_sub + 1)
+            seg_layer.append(k)
+            xs += list(s)
+            alts += list(np.sqrt(s * s + rt * rt) - R)
+            pt_off.append(len(xs))
+        seg_off.append(len(seg_layer))
+    alts = np.clip(np.array(alts), z[0], top)
+    nd = np.exp(np.interp(alts, zz, ln))
+    vmr = np.array([np.interp(alts, zz, v) for v in vv])
+    return dict(seg_off=np.array(seg_off, np.int32), seg_layer=np.array(seg_layer, np.int32),
+                pt_off=np.array(pt_off, np.int32), x=np.array(xs) * 1e5, nd=nd, vmr=vmr, alt=alts)
