@@ -56,10 +56,10 @@ def test_analytic_slabs_and_planck_absorption(eng):
     """Homogeneous slab I = S (1 - e^-tau); two slabs I = S1 (1 - e^-tau1) e^-tau2 + S2 (1 - e^-tau2); pure
     absorption of a Planck source I = B(T) e^-tau (radtran_3D_ch4.py:297-315: solo_absorption + initial_intensity)."""
     import torch
-    from spectrobot_amd import spect_classes as spcl
+    from spectrobot_amd import spect_classes as spcl, synthetic as syn
     rng = np.random.default_rng(3)
     n = 4000
-    grid = 2990.0 + 5e-4 * np.arange(n)
+    grid = syn.make_grid(2990.0, 5e-4, n)
     a = np.stack([10.0 ** rng.uniform(-21, -17, n), 10.0 ** rng.uniform(-21, -17, n)])
     e = np.stack([a[0] * rng.uniform(1e-7, 1e-6, n), a[1] * rng.uniform(1e-7, 1e-6, n)])
     ad, ed = torch.tensor(a, device="cuda"), torch.tensor(e, device="cuda")
@@ -156,7 +156,9 @@ def test_limb_jacobians_finite_differences(eng):
     nodes = [z[0] + 50.0, z[nl // 2], z[-1] - 40.0]
     x = [np.array([1.5e-2, 1.2e-2, 0.9e-2]), np.array([1.0e-3, 2.0e-3, 0.7e-3])]
     profs = [smm.LinearProfile_1D_new("g%d" % g, z, nodes, x[g], 0.5 * x[g]) for g in range(2)]
-    L = syn.limb_los(z, atm["nd"], [profs[0].profile(), profs[1].profile()], [z[0] + 5.0, z[6] + 3.0])
+    # densities scaled so that segment optical depths are O(1): both terms of the sensitivities matter and
+    # nothing is saturated away (at tau ~ 1e3 a difference quotient is exactly 0)
+    L = syn.limb_los(z, atm["nd"] * 1e-6, [profs[0].profile(), profs[1].profile()], [z[0] + 5.0, z[6] + 3.0])
     # parameter weights at the LOS sample points: the masks are piecewise linear in altitude, like the VMR
     top = z[-1] + (z[-1] - z[-2])
     W = np.array([np.interp(L["alt"], np.append(z, top), np.append(p.maskgrid.mask, p.maskgrid.mask[-1]))
@@ -171,20 +173,23 @@ def test_limb_jacobians_finite_differences(eng):
     rad, jac = eng.limb_rays_jacobian(coeffs, los_for(xs), par_gas, W)
     assert relerr(rad.cpu().numpy(), eng.limb_rays(coeffs, los_for(xs)).cpu().numpy()) < 1e-14
     for p in range(6):
-        h = 1e-4 * xs[p]
+        # gas 1 is a minor contributor: its derivative is ~1e-5 I / x, so the difference quotient carries
+        # rounding noise ~1e-15 I / h next to its O((h/x)^2 tau^2) truncation; h/x = 1e-3 balances the two at ~1e-7
+        h = 1e-3 * xs[p]
         xp, xm = xs.copy(), xs.copy()
         xp[p] += h
         xm[p] -= h
         fd = (eng.limb_rays(coeffs, los_for(xp)) - eng.limb_rays(coeffs, los_for(xm))) / (2 * h)
         scale = fd.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
-        assert float(((jac[:, p] - fd).abs() / scale).max()) < 1e-6, p
+        assert float(((jac[:, p] - fd).abs() / scale).max()) < 3e-6, p
     # per-layer scalar acting through the coefficients: abs_g[k] -> abs_g[k] + h dabs_g[k]
     da = [rng.uniform(-1, 1, (nl, n)) * a[g] for g in range(2)]
     de = [rng.uniform(-1, 1, (nl, n)) * e[g] for g in range(2)]
     los = los_for(xs)
     jl = eng.limb_rays_layer_jacobian(coeffs, [(t(da[0]), t(de[0])), (t(da[1]), t(de[1]))], los)
-    for k in (0, 7, 19):
-        h = 1e-5
+    # the top layer contributes ~1e-8 of the radiance: a relative step of 1e-5 there drowns in rounding; it is
+    # optically thin (linear response), so a large step is exact enough
+    for k, h, tol in ((0, 1e-5, 1e-6), (7, 1e-5, 1e-6), (19, 1e-1, 1e-5)):
         def run(sign):
             aa = [a[g].copy() for g in range(2)]
             ee = [e[g].copy() for g in range(2)]
@@ -194,7 +199,7 @@ def test_limb_jacobians_finite_differences(eng):
             return eng.limb_rays([(t(aa[0]), t(ee[0])), (t(aa[1]), t(ee[1]))], los)
         fd = (run(+1) - run(-1)) / (2 * h)
         scale = fd.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
-        assert float(((jl[:, k] - fd).abs() / scale).max()) < 1e-6, k
+        assert float(((jl[:, k] - fd).abs() / scale).max()) < tol, k
     assert float(jl[1, :6].abs().max()) == 0.0    # layers below the second ray's tangent height
 
 
