@@ -134,17 +134,20 @@ def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total, 
     return out
 
 
-def build_rays(syn, atm, n_rays, vmr=0.0148):
-    """Tangent heights z_t = 100 + 12.5 r km; per segment the layer and the column
-    n * vmr * iso_ratio * ds (cm^-2)."""
-    offs, lays, cols = [0], [], []
+def build_rays(syn, engine, atm, n_rays, vmr=0.0148):
+    """Tangent heights z_t = 100 + 12.5 r km: the LOS batch of the device pipeline -- per
+    segment the layer and the LOS sample points (x, n, vmr) over which curgod_fort_2 gives the column."""
     nd = syn.number_density(atm["press"], atm["temps"])
-    for r in range(n_rays):
-        sl, ln = syn.limb_path(atm["z"], 100.0 + 12.5 * r + 1e-3)
-        lays += list(sl)
-        cols += list(ln * 1e5 * nd[sl] * vmr * syn.CH4_ISO_RATIO)
-        offs.append(len(lays))
-    return np.array(offs, np.int32), np.array(lays, np.int32), np.array(cols, np.float64)
+    L = syn.limb_los(atm["z"], nd, [np.full(len(atm["z"]), vmr)], 100.0 + 12.5 * np.arange(n_rays) + 1e-3)
+    los = engine.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[syn.CH4_ISO_RATIO])
+    return los, L
+
+
+def cpu_columns(L, scale):
+    """The same columns on the host for the CPU leg (oracle's curgod_fort_2)."""
+    from oracle import oracle as O
+    return np.array([scale * O.curgod(2, L["nd"][a:b], L["x"][a:b], vmr=L["vmr"][0][a:b])
+                     for a, b in zip(L["pt_off"][:-1], L["pt_off"][1:])])
 
 
 def main():
@@ -190,7 +193,7 @@ def main():
     q_part = np.zeros(args.layers)
     tt = np.ascontiguousarray(atm["temps"])
     assert lib.sr_calc_partition_sum(6, 1, tt.ctypes.data_as(dp), args.layers, q_part.ctypes.data_as(dp)) == 0
-    offs, lays, cols = build_rays(syn, atm, args.rays)
+    los, Lr = build_rays(syn, engine, atm, args.rays)
 
     ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)     # lines -> HBM (outside the timed region)
     g_lo, g_hi = sd.shard_bounds(args.grid, world, rank)
@@ -205,7 +208,7 @@ def main():
     def step():
         ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"], q_part=q_part, g_lo=g_lo, g_hi=g_hi,
                            out=(ab, em))
-        rad = engine.radiance_rays(ab, em, offs, lays, cols)
+        rad = engine.limb_rays((ab, em), los)      # columns (curgod_fort_2) + recursion on the device
         if args.shard:
             return rad
         return sd.all_gather_spectrum(rad, args.grid, world, rank, out=full)
@@ -359,8 +362,9 @@ def main():
                 step()
                 torch.cuda.synchronize()
                 gpu = (ab, em)
-            out["cpu_baseline"] = cpu_baseline(L, atm, grid, syn.CH4_MM, e_lev, q_part, args.cpu_seconds,
-                                               args.layers, (offs, lays, cols), gpu=gpu)
+            out["cpu_baseline"] = cpu_baseline(L, atm, grid, syn.CH4_MM, e_lev, q_part, args.cpu_seconds, args.layers,
+                                               (Lr["seg_off"], Lr["seg_layer"], cpu_columns(Lr, syn.CH4_ISO_RATIO)),
+                                               gpu=gpu)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             # the shipped Python path, quoted separately.  2.3 ms per (line, layer)
             # per core was measured in the survey container, not on this box; ideal

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Workloads of BASELINE.json configs[2..4] (synthetic inputs of SURVEY 8-d) -- shared by
+tests/test_gpu_configs.py and `bench.py --config N`, which prints ONE extra JSON line per config (not the
+headline: that is configs[1], bench.py's default).
+
+  config 2  CH4 Titan limb, 1e5 lines x 1e5 grid x 80 layers, 64 tangent-height rays (z_t = 100 + 12.5 r km)
+            batched on one coefficient op, spectral window sharded over the ranks, one all-gather
+  config 3  radtran_3Dvs2D_sza30-80 shape: 8 solar zenith angles = 8 independent atmospheres (vibrational
+            temperatures follow the illumination) x a set of 8 rays, 2e5-point grid, 2e5 lines, per-layer
+            Jacobians w.r.t. T (central differences of the coefficient op + forward sensitivity) and w.r.t.
+            the VMR of every layer (analytic)
+  config 4  retrieval loop: HCN (mol 23) + CH4 on one grid, VIMS-like bands, Gauss-Newton /
+            Levenberg-Marquardt over up to 20 iterations with the reference's stopping rule; a step is one
+            iteration (forward model + Jacobians of all LOS + algebra)
+"""
+import json
+import os
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HCN_MM = 27.010899          # molparam.txt HCN 124
+HCN_ISO_RATIO = 0.985114
+HCN_LEVEL_ENERGIES = np.array([0., 711.98, 1411.41, 2096.85, 3311.48, 4004.17])   # HCN-like level ladder, cm^-1
+
+
+def ch4_case(n_lines, n_grid, n_layers=80, n_levels=12, config_id=2, w0=2975.0):
+    """SURVEY 8-d CH4 case: grid, lines, atmosphere, level energies."""
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(w0, 5e-4, n_grid)
+    L = syn.make_lines(n_lines, grid, config_id=config_id, n_levels=n_levels)
+    atm = syn.make_atmosphere(n_layers, n_levels)
+    atm["nd"] = syn.number_density(atm["press"], atm["temps"])
+    return grid, L, atm, syn.CH4_LEVEL_ENERGIES[:n_levels]
+
+
+def tangent_heights(n_rays):
+    return 100.0 + 12.5 * np.arange(n_rays) + 1e-3      # z_t = 100 + 12.5 r km
+
+
+def sza_atmosphere(atm, sza_deg, n_levels=12):
+    """Atmosphere of one solar zenith angle: the excess of the vibrational temperatures over the kinetic one
+    scales with the illumination cos(SZA); the kinetic profile is warmer on the day side by a few K."""
+    mu = np.cos(np.deg2rad(sza_deg))
+    out = dict(atm)
+    out["temps"] = atm["temps"] + 4.0 * (mu - 0.5)
+    exc = atm["tvib"] - atm["temps"][None, :]
+    out["tvib"] = out["temps"][None, :] + exc * (0.4 + 1.2 * mu)
+    return out
+
+
+def layer_vmr_weights(z, alt):
+    """par_w [n_layers, n_pt]: triangular weight of every altitude level at the LOS sample altitudes (the VMR
+    profile is piecewise linear on the levels: vmr(alt) = sum_k w_k(alt) vmr_k)."""
+    top = z[-1] + (z[-1] - z[-2])
+    zz = np.append(z, top)
+    W = np.zeros((len(z), len(alt)))
+    for k in range(len(z)):
+        m = np.zeros(len(zz))
+        m[k] = 1.0
+        if k == len(z) - 1:
+            m[-1] = 1.0          # the profile is continued with its last value above the top level
+        W[k] = np.interp(alt, zz, m)
+    return W
+
+
+def two_gas_scene(n_lines_ch4, n_lines_hcn, n_grid, n_layers, n_bands=14, seed=0, w0=3290.0):
+    """HCN + CH4 on one grid around the HCN nu3 / CH4 band overlap, VIMS-like Gaussian bands."""
+    from spectrobot_amd import engine, synthetic as syn, retrieval
+    grid = syn.make_grid(w0, 5e-4, n_grid)
+    Lc = syn.make_lines(n_lines_ch4, grid, config_id=4, n_levels=12)
+    Lh = syn.make_lines(n_lines_hcn, grid, config_id=5, n_levels=6)
+    Lh["a_coeff"] = Lh["a_coeff"] * 30.0
+    atm = syn.make_atmosphere(n_layers, 12)
+    z = atm["z"]
+    tv_h = np.array([atm["temps"] + (0.0 if L == 0 else 25.0 * (1.0 - np.exp(-(z - 100.0) / 250.0))) for L in range(6)])
+    ch4 = retrieval.Gas("CH4", engine.LineSet(Lc, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES),
+                        np.full(n_layers, 1.48e-4), syn.CH4_ISO_RATIO, tvib=atm["tvib"])
+    hcn = retrieval.Gas("HCN", engine.LineSet(Lh, grid, 23, 1, HCN_MM, HCN_LEVEL_ENERGIES),
+                        np.full(n_layers, 2e-6), HCN_ISO_RATIO, tvib=tv_h)
+    lam = np.linspace(1e7 / grid[-1] + 1.2, 1e7 / grid[0] - 1.2, n_bands)
+    scene = retrieval.LimbScene(grid, z, atm["temps"], atm["press"], [ch4, hcn], lam, np.full(n_bands, 1.1))
+    return scene
+
+
+def retrieval_problem(scene, n_pix=6, seed=1, noise_frac=0.004):
+    """Truth, a priori, BayesSet and noisy synthetic observations of `scene` (two gases, 4 + 3 altitude nodes)."""
+    from spectrobot_amd import spect_main_module as smm, retrieval
+    rng = np.random.default_rng(seed)
+    z = scene.z
+    span = z[-1] - z[0]
+    nodes = {"CH4": [z[0] + f * span for f in (0.06, 0.3, 0.55, 0.85)], "HCN": [z[0] + f * span for f in (0.1, 0.45, 0.8)]}
+    truth = {"CH4": np.array([1.7e-4, 1.5e-4, 1.25e-4, 1.0e-4]), "HCN": np.array([1.2e-6, 2.6e-6, 4.0e-6])}
+    apr = {"CH4": np.full(4, 1.3e-4), "HCN": np.full(3, 2.2e-6)}
+    pixels = [retrieval.LimbPixel(z[0] + (0.08 + 0.13 * i) * span, fov_half=0.02 * span, pixel_rot=10.0 * (i % 3))
+              for i in range(n_pix)]
+
+    def bayes(values):
+        bs = smm.BayesSet(tag="HCN+CH4 limb")
+        for name in ("CH4", "HCN"):
+            bs.add_set(smm.LinearProfile_1D_new(name, z, nodes[name], apr[name], 0.5 * apr[name], first_guess_prof=values[name]))
+        return bs
+
+    bs_true = bayes(truth)
+    for name in ("CH4", "HCN"):
+        scene.gas(name).add_clim(bs_true.sets[name].profile())
+    y_true = retrieval.radtrans(scene, pixels)
+    for pix, y in zip(pixels, y_true):
+        sig = noise_frac * np.abs(y.spectrum).max() * np.ones_like(y.spectrum)
+        pix.observation = retrieval.Spectrum(y.spectrum + sig * rng.standard_normal(sig.size), scene.bands_nm)
+        pix.noise = retrieval.Spectrum(sig, scene.bands_nm)
+    x_true = np.concatenate([truth["CH4"], truth["HCN"]])
+    return bayes(apr), pixels, x_true
+
+
+def _sync_time(fn, steps, warmup):
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def main(args):
+    import torch
+    from spectrobot_amd import engine, synthetic as syn, distributed as sd, retrieval
+    rank, local, world = sd.init_from_env()
+    assert world == args.gpus
+    engine.set_device(local % max(torch.cuda.device_count(), 1))
+    info = engine.device_info()
+    base = {"unit": "spectra/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "headline": False}
+    if args.config == 2:
+        n_rays = 64 if args.rays == 1 else args.rays
+        grid, L, atm, e_lev = ch4_case(args.lines, args.grid, args.layers)
+        ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)
+        g_lo, g_hi = sd.shard_bounds(args.grid, world, rank)
+        Lr = syn.limb_los(atm["z"], atm["nd"], [np.full(args.layers, 0.0148)], tangent_heights(n_rays))
+        los = engine.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"],
+                             col_scale=[syn.CH4_ISO_RATIO])
+        ab = torch.empty((args.layers, g_hi - g_lo), dtype=torch.float64, device="cuda")
+        em = torch.empty_like(ab)
+        full = torch.empty((n_rays, args.grid), dtype=torch.float64, device="cuda") if world > 1 else None
+
+        def step():
+            ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"], g_lo=g_lo, g_hi=g_hi, out=(ab, em))
+            rad = engine.limb_rays((ab, em), los)
+            return sd.all_gather_spectrum(rad, args.grid, world, rank, out=full)
+
+        dt, spec = _sync_time(step, args.steps, args.warmup)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        out = dict(base, metric="limb spectra/sec, 64 rays batched (BASELINE configs[2])", value=n_rays / dt,
+                   ms_per_step=dt * 1e3, scaling="strong",
+                   config={"workload": "CH4 Titan limb (BASELINE configs[2]): %d lines x %d-pt grid x %d layers, %d rays on one "
+                                       "coefficient op, device LOS pipeline, spectral window / %d + one all-gather"
+                                       % (args.lines, args.grid, args.layers, n_rays, world), "device": info["name"]},
+                   checksum=float(spec.sum().item()))
+    elif args.config == 3:
+        n_grid, n_lines, n_rays, szas = 200000, 200000, 8, [30.0, 37.0, 44.0, 51.0, 58.0, 65.0, 72.0, 80.0]
+        grid, L, atm, e_lev = ch4_case(n_lines, n_grid, args.layers, config_id=3, w0=2950.0)
+        ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)
+        vm = np.full(args.layers, 0.0148)
+        Lr = syn.limb_los(atm["z"], atm["nd"], [vm], 120.0 + 60.0 * np.arange(n_rays))
+        los = engine.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"], col_scale=[syn.CH4_ISO_RATIO])
+        W = layer_vmr_weights(atm["z"], Lr["alt"])
+        my = szas[rank::world]                       # independent ray batches: one SZA set per rank, no collective
+
+        def step():
+            res = None
+            for sza in my:
+                a = sza_atmosphere(atm, sza)
+                co = ls.abscoeff_layers(a["temps"], a["press"], tvib=a["tvib"])
+                ap = ls.abscoeff_layers(a["temps"] + 0.05, a["press"], tvib=a["tvib"])
+                am = ls.abscoeff_layers(a["temps"] - 0.05, a["press"], tvib=a["tvib"])
+                dco = ((ap[0] - am[0]) / 0.1, (ap[1] - am[1]) / 0.1)
+                jt = engine.limb_rays_layer_jacobian(co, dco, los)
+                rad, jv = engine.limb_rays_jacobian(co, los, np.zeros(args.layers, np.int32), W)
+                res = (rad, jt, jv)
+            return res
+
+        dt, res = _sync_time(step, max(1, args.steps // 4), min(args.warmup, 1))
+        out = dict(base, metric="limb spectra/sec with per-layer T and VMR Jacobians (BASELINE configs[3])",
+                   value=len(szas) * n_rays / dt if world == len(szas) or world == 1 else len(my) * n_rays * world / dt,
+                   ms_per_step=dt * 1e3, scaling="weak" if world > 1 else "n/a",
+                   config={"workload": "3D-atmosphere ray sets (BASELINE configs[3]): %d SZA x %d rays, %d lines x %d-pt grid x %d "
+                                       "layers, d/dT_k (central differences of the coefficient op) and d/dVMR_k (analytic) for "
+                                       "every layer; SZA sets are independent batches (split over ranks, no collective)"
+                                       % (len(szas), n_rays, n_lines, n_grid, args.layers), "device": info["name"]},
+                   checksum=float(res[0].sum().item()), jacobian_gb_per_sza=2 * res[1].numel() * 8 / 1e9)
+    elif args.config == 4:
+        scene = two_gas_scene(40000, 8000, 60000, 60)
+        bs, pixels, x_true = retrieval_problem(scene)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        chi, obs, sims, bs = retrieval.inversion_fast_limb(scene, bs, pixels, max_it=20)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_it = len(bs.history)
+        out = dict(base, metric="retrieval iterations/sec, HCN + CH4 (BASELINE configs[4])", unit="iterations/s",
+                   value=n_it / dt, ms_per_step=dt / n_it * 1e3, steps=n_it, scaling="n/a",
+                   config={"workload": "Gauss-Newton / LM retrieval loop (BASELINE configs[4]): HCN + CH4, 40000 + 8000 lines x "
+                                       "60000-pt grid x 60 layers, 6 pixels x 3 LOS, 7 profile parameters, %d VIMS-like bands, "
+                                       "max 20 iterations, reference stopping rule" % len(scene.bands_nm),
+                           "device": info["name"]},
+                   chi_history=[float(c) for c in bs.history], stop=bs.stop,
+                   max_rel_dev_from_truth=float(np.max(np.abs(bs.param_vector() - x_true) / x_true)))
+    else:
+        raise SystemExit("--config must be 1..4")
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()

@@ -1,0 +1,183 @@
+"""Forward model + retrieval loop around the hot path: the structure of the reference's
+`inversion_fast_limb` / `radtrans` (spect_main_module.py:2598-2987, 2990-3287) on the GPU engine.
+
+The reference's loop is, per iteration: LOS stepping and coefficients per LOS (`calc_radtran_steps`),
+radiances + derivatives per spectral split (`radtran_fast`), `hires_to_lowres`, `FOV_integr_1D` over the
+three LOS of every pixel, `chicalc`, the stopping rule (|dchi2|/chi2 < chi_threshold, or chi2 raised),
+`inversion_algebra`, `add_clim(profile)`.  Planet / atmosphere / LineOfSight / VIMSPixel are classes of the
+absent spect_base_module; `LimbScene` is the minimal stand-in the loop needs (a 1-D atmosphere on altitude
+levels, gases with VMR profiles, limb pixels with three lines of sight each).  What runs where:
+
+  per scene      engine.LineSet per gas (lines -> HBM once)
+  per iteration  coefficients of every gas whose temperature / vibrational temperatures changed (once if
+                 only VMRs are retrieved, as in the reference's drivers: radtran_3D_ch4.py:127-170),
+                 engine.limb_rays_jacobian: columns on the device, radiances and d rad / d x_p for ALL LOS
+                 of ALL pixels in one launch, engine.hires_to_lowres for radiances and derivatives
+  host           FOV integration, chi square, the n_par x n_par algebra (smm mirror), bookkeeping
+"""
+import numpy as np
+
+from . import engine
+from . import spect_main_module as smm
+from . import synthetic as syn
+
+
+class Spectrum(object):
+    """Low-resolution spectrum holder with the attributes the smm algebra reads (.spectrum, .spectral_grid)."""
+
+    def __init__(self, spectrum, grid=None):
+        self.spectrum = np.asarray(spectrum, dtype=float)
+        self.spectral_grid = None if grid is None else _Grid(grid)
+
+
+class _Grid(object):
+    def __init__(self, g):
+        self.grid = np.asarray(g, dtype=float)
+
+
+class Gas(object):
+    """One absorber: its line set on the scene's grid, isotopic abundance, VMR profile on the altitude levels
+    and (non-LTE) vibrational temperatures [n_levels, n_layers]."""
+
+    def __init__(self, name, lineset, vmr, iso_ratio=1.0, tvib=None):
+        self.name, self.lineset, self.iso_ratio = name, lineset, float(iso_ratio)
+        self.vmr = np.asarray(vmr, dtype=float)
+        self.tvib = tvib
+        self.coeffs = None      # (abs, emi) CUDA [n_layers, n_grid], computed on demand
+
+    def add_clim(self, profile):
+        """New VMR profile (planet.gases[gas].add_clim, spect_main_module.py:2625, 2985)."""
+        self.vmr = np.asarray(profile, dtype=float)
+
+
+class LimbPixel(object):
+    """A limb pixel: tangent altitude of its centre LOS, half extent of the FOV in altitude (the lower /
+    upper LOS are at alt -+ fov_half: pix.low_LOS() / LOS() / up_LOS(), spect_main_module.py:2704-2706),
+    rotation of the square pixel, observation / noise / mask on the low-resolution bands."""
+
+    def __init__(self, limb_tg_alt, fov_half=0.0, pixel_rot=0.0, observation=None, noise=None, mask=None):
+        self.limb_tg_alt, self.fov_half, self.pixel_rot = float(limb_tg_alt), float(fov_half), float(pixel_rot)
+        self.observation, self.noise, self.mask = observation, noise, mask
+
+    def los_alts(self):
+        return [self.limb_tg_alt - self.fov_half, self.limb_tg_alt, self.limb_tg_alt + self.fov_half]
+
+
+class LimbScene(object):
+    """1-D atmosphere on altitude levels z [km] (temps [K], press [hPa]), gases, spectral grid, instrument bands
+    (centres / Gaussian sigmas in nm)."""
+
+    def __init__(self, grid, z, temps, press, gases, bands_nm, widths_nm, R=2575.0, n_sub=3, out_units="Wm2"):
+        self.grid = np.asarray(grid, dtype=float)
+        self.z, self.temps, self.press = (np.asarray(v, dtype=float) for v in (z, temps, press))
+        self.nd = syn.number_density(self.press, self.temps)
+        self.gases = list(gases)
+        self.bands_nm, self.widths_nm = np.asarray(bands_nm, float), np.asarray(widths_nm, float)
+        self.R, self.n_sub, self.out_units = R, n_sub, out_units
+
+    def gas(self, name):
+        return [g for g in self.gases if g.name == name][0]
+
+    def coefficients(self, refresh=False):
+        """(abs, emi) of every gas at the layer stack; cached: only VMRs change between iterations."""
+        for g in self.gases:
+            if g.coeffs is None or refresh:
+                g.coeffs = g.lineset.abscoeff_layers(self.temps, self.press, tvib=g.tvib)
+        return [g.coeffs for g in self.gases]
+
+    def los(self, tangent_alts, **opts):
+        """engine.LimbLOS of rays with the given tangent altitudes (photon order) + the sample altitudes."""
+        L = syn.limb_los(self.z, self.nd, [g.vmr for g in self.gases], tangent_alts, R=self.R, n_sub=self.n_sub)
+        los = engine.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"],
+                             col_scale=[g.iso_ratio for g in self.gases], **opts)
+        return los, L["alt"]
+
+    def profile_weights(self, bayes_set, alt):
+        """par_gas [n_par], par_w [n_par, n_pt]: the masks of every retrieved parameter at the LOS sample
+        altitudes (masks are piecewise linear on the altitude levels, like the VMR between them)."""
+        names = [g.name for g in self.gases]
+        top = self.z[-1] + (self.z[-1] - self.z[-2])
+        zz = np.append(self.z, top)
+        par_gas, par_w = [], []
+        for par in bayes_set.params():
+            par_gas.append(names.index(par.nameset))
+            m = np.asarray(par.maskgrid.mask, dtype=float)
+            par_w.append(np.interp(alt, zz, np.append(m, m[-1])))
+        return np.array(par_gas, np.int32), np.array(par_w)
+
+
+def simulate(scene, pixels, bayes_set=None, fov_closed_form=True):
+    """One forward-model pass for all pixels (the body of the reference's iteration,
+    spect_main_module.py:2736-2940): returns (sims, derivs) with sims[i] the FOV-integrated low-resolution
+    spectrum of pixel i (Spectrum) and derivs[i][p] its derivative w.r.t. parameter p of bayes_set."""
+    alts = [a for pix in pixels for a in pix.los_alts()]
+    los, alt = scene.los(alts)
+    coeffs = scene.coefficients()
+    n_los = len(alts)
+    if bayes_set is None:
+        rad = engine.limb_rays(coeffs, los)
+        low = engine.hires_to_lowres(rad, scene.grid, scene.bands_nm, scene.widths_nm, out_units=scene.out_units)
+        dlow = None
+    else:
+        par_gas, par_w = scene.profile_weights(bayes_set, alt)
+        rad, jac = engine.limb_rays_jacobian(coeffs, los, par_gas, par_w)
+        low = engine.hires_to_lowres(rad, scene.grid, scene.bands_nm, scene.widths_nm, out_units=scene.out_units)
+        n_par = len(par_gas)
+        dlow = engine.hires_to_lowres(jac.reshape(n_los * n_par, -1), scene.grid, scene.bands_nm, scene.widths_nm,
+                                      out_units=scene.out_units).reshape(n_los, n_par, -1)
+    sims, derivs = [], []
+    for i, pix in enumerate(pixels):
+        three = [Spectrum(low[3 * i + q], scene.bands_nm) for q in range(3)]
+        if pix.fov_half > 0:
+            sims.append(smm.FOV_integr_1D(three, pix.pixel_rot, closed_form=fov_closed_form))
+        else:
+            sims.append(three[1])
+        if dlow is not None:
+            row = []
+            for p in range(dlow.shape[1]):
+                d3 = [Spectrum(dlow[3 * i + q, p], scene.bands_nm) for q in range(3)]
+                row.append(smm.FOV_integr_1D(d3, pix.pixel_rot, closed_form=fov_closed_form) if pix.fov_half > 0 else d3[1])
+            derivs.append(row)
+    return sims, derivs
+
+
+def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10, lambda_LM=0.1, L1_reg=False,
+                        solo_simulation=False, check_log=None, fov_closed_form=True):
+    """The retrieval loop of spect_main_module.inversion_fast_limb (:2725-2987): Levenberg-Marquardt
+    optimal estimation of the VMR-profile parameters in bayes_set from the pixels' observations.
+    Returns (chi, obs, sims, bayes_set) like the reference, plus .history on bayes_set (chi per iteration)
+    and .stop ('converged' | 'raised' | 'max_it')."""
+    pixels = sorted(pixels, key=lambda x: x.limb_tg_alt)                       # :2607
+    for name in bayes_set.sets.keys():                                         # :2624-2625
+        scene.gas(name).add_clim(bayes_set.sets[name].profile())
+    obs = [pix.observation for pix in pixels]
+    masks = None if all(pix.mask is None for pix in pixels) else [pix.mask for pix in pixels]
+    noise = [pix.noise for pix in pixels]
+    bayes_set.history, bayes_set.stop = [], 'max_it'
+    chi_old, chi, sims = None, None, []
+    for num_it in range(max_it):
+        sims, derivs = simulate(scene, pixels, bayes_set, fov_closed_form=fov_closed_form)
+        if solo_simulation:
+            return None
+        for num, row in enumerate(derivs):
+            for par, der in zip(bayes_set.params(), row):
+                par.store_deriv(der, num=num)                                  # :2929, 2940
+                par.set_used()
+        chi = smm.chicalc(obs, sims, noise, masks, bayes_set.n_used_par())      # :2949
+        bayes_set.history.append(chi)
+        if check_log is not None:
+            check_log.write('Iteration {:2d}: chi is {:8.3f}\n'.format(num_it, chi))
+        why = smm.retrieval_converged(chi, chi_old, chi_threshold)             # :2963-2973
+        if why:
+            bayes_set.stop = why
+            return chi, obs, sims, bayes_set
+        chi_old = chi
+        smm.inversion_algebra(obs, sims, noise, bayes_set, lambda_LM=lambda_LM, L1_reg=L1_reg, masks=masks)  # :2977
+        for name in bayes_set.sets.keys():                                     # :2984-2985
+            scene.gas(name).add_clim(bayes_set.sets[name].profile())
+    return chi, obs, sims, bayes_set
+
+
+def radtrans(scene, pixels, fov_closed_form=True):
+    """Simulation only (spect_main_module.radtrans, :2990-3287): the FOV-integrated low-resolution spectra."""
+    return simulate(scene, pixels, None, fov_closed_form=fov_closed_form)[0]

@@ -1,0 +1,183 @@
+"""BASELINE.json configs[1..4] AT THEIR WORKLOAD on the GPU (bench_configs.py builds the synthetic inputs of
+SURVEY 8-d): coefficient parity against the oracle on sampled layers at full lines x grid, radiances against the
+oracle's recursion, shard-vs-whole, Jacobians against finite differences, the 20-iteration two-gas retrieval.
+Needs a real MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from spectrobot_amd import engine
+    engine.set_device(0)
+    return engine
+
+
+def _q(temps):
+    from spectrobot_amd import spect_classes as spcl
+    return np.atleast_1d(spcl.CalcPartitionSum(6, 1, np.asarray(temps, float)))
+
+
+@pytest.fixture(scope="module")
+def cfg1(eng, oracle):
+    """configs[1] / [2] inputs, the GPU coefficients of all 80 layers and the oracle's on 8 of them."""
+    import bench_configs as bc
+    from spectrobot_amd import synthetic as syn
+    grid, L, atm, e_lev = bc.ch4_case(100000, 100000, 80)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)
+    ab, em = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
+    sel = np.array([0, 9, 21, 33, 44, 56, 68, 79])
+    abo, emo = oracle.abscoeff_layers(L, syn.CH4_MM, e_lev, atm["temps"][sel], atm["press"][sel], _q(atm["temps"][sel]),
+                                      atm["tvib"][:, sel], grid, mode=1, n_threads=min(8, os.cpu_count() or 1))
+    return dict(grid=grid, L=L, atm=atm, e_lev=e_lev, ls=ls, ab=ab, em=em, sel=sel, abo=abo, emo=emo)
+
+
+def test_config1_full_size_vs_oracle(eng, cfg1):
+    """configs[1]: 1e5 lines x 1e5 grid x 80 layers -- 8 layers from the Lorentz- to the Doppler-dominated end
+    against the oracle at full lines x grid (north_star bound 1e-6; observed ~4e-12), both evaluation modes."""
+    ab, em = cfg1["ab"][cfg1["sel"]].cpu().numpy(), cfg1["em"][cfg1["sel"]].cpu().numpy()
+    assert relerr(ab, cfg1["abo"]) < 1e-10 and relerr(em, cfg1["emo"]) < 1e-10
+    atm, sel = cfg1["atm"], cfg1["sel"][[0, 4, 7]]
+    eng.set_far_field(0)
+    try:
+        a0, e0 = cfg1["ls"].abscoeff_layers(atm["temps"][sel], atm["press"][sel], tvib=atm["tvib"][:, sel])
+    finally:
+        eng.set_far_field(1)
+    assert relerr(a0.cpu().numpy(), cfg1["abo"][[0, 4, 7]]) < 1e-10 and relerr(e0.cpu().numpy(), cfg1["emo"][[0, 4, 7]]) < 1e-10
+
+
+def test_config2_64_rays_and_eight_shards(eng, oracle, cfg1):
+    """configs[2]: 64 tangent-height rays (z_t = 100 + 12.5 r km) batched on the coefficients of configs[1]:
+    radiances through the device LOS pipeline against the oracle's recursion (all rays, a 1e4-point window of the
+    grid); the 8 spectral shards of shard_bounds(1e5, 8, r) computed one after the other and concatenated equal
+    the unsharded coefficients and radiances."""
+    import torch
+    import bench_configs as bc
+    from spectrobot_amd import synthetic as syn, distributed as sd
+    atm, ls, grid = cfg1["atm"], cfg1["ls"], cfg1["grid"]
+    Lr = syn.limb_los(atm["z"], atm["nd"], [np.full(80, 0.0148)], bc.tangent_heights(64))
+    los = eng.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"], col_scale=[syn.CH4_ISO_RATIO])
+    rad = eng.limb_rays((cfg1["ab"], cfg1["em"]), los)
+    assert tuple(rad.shape) == (64, 100000) and bool(torch.isfinite(rad).all()) and float(rad.min()) >= 0.0
+    col = los.columns()[0]
+    lo, hi = 45000, 55000
+    a_h, e_h = cfg1["ab"][:, lo:hi].cpu().numpy(), cfg1["em"][:, lo:hi].cpu().numpy()
+    rad_h = rad[:, lo:hi].cpu().numpy()
+    for r in range(64):
+        s = slice(Lr["seg_off"][r], Lr["seg_off"][r + 1])
+        want = oracle.radiance_ray(a_h, e_h, Lr["seg_layer"][s], col[s])
+        assert relerr(rad_h[r], want) < 1e-12, r
+    # higher tangent heights see less gas: the band-integrated radiance falls monotonically above the peak
+    tot = rad.sum(dim=1).cpu().numpy()
+    assert np.all(np.diff(tot[8:]) < 0)
+    parts_a, parts_r = [], []
+    for r in range(8):
+        g_lo, g_hi = sd.shard_bounds(100000, 8, r)
+        a_s, e_s = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"], g_lo=g_lo, g_hi=g_hi)
+        parts_a.append(a_s)
+        parts_r.append(eng.limb_rays((a_s, e_s), los))
+    a_cat, r_cat = torch.cat(parts_a, dim=1), torch.cat(parts_r, dim=1)
+    assert float(((a_cat - cfg1["ab"]).abs() / cfg1["ab"].abs()).max()) < 1e-12
+    assert float(((r_cat - rad).abs() / rad.abs().clamp_min(1e-300)).max()) < 1e-12
+
+
+def test_config3_2e5_grid_T_and_vmr_jacobians(eng, oracle):
+    """configs[3]: 2e5-point grid, 2e5 lines, 80 layers, a set of 8 rays at one of the 8 SZA atmospheres (the
+    bench loops over all 8): coefficients against the oracle on sampled layers; per-layer temperature Jacobian
+    and per-layer VMR Jacobian against finite differences of the whole chain at sampled layers."""
+    import torch
+    import bench_configs as bc
+    from spectrobot_amd import synthetic as syn
+    n = 200000
+    grid, L, atm0, e_lev = bc.ch4_case(n, n, 80, config_id=3, w0=2950.0)
+    atm = bc.sza_atmosphere(atm0, 51.0)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)
+    T, P, tv = atm["temps"], atm["press"], atm["tvib"]
+    ab, em = ls.abscoeff_layers(T, P, tvib=tv)
+    sel = np.array([2, 30, 61])
+    abo, emo = oracle.abscoeff_layers(L, syn.CH4_MM, e_lev, T[sel], P[sel], _q(T[sel]), tv[:, sel], grid, mode=1, n_threads=3)
+    assert relerr(ab[sel].cpu().numpy(), abo) < 1e-10 and relerr(em[sel].cpu().numpy(), emo) < 1e-10
+    vmr = np.full(80, 0.0148)
+    tz = 120.0 + 60.0 * np.arange(8)
+    Lr = syn.limb_los(atm["z"], atm["nd"], [vmr], tz)
+    W = bc.layer_vmr_weights(atm["z"], Lr["alt"])
+    assert np.allclose(W.sum(axis=0), 1.0)
+
+    def los_for(v):
+        return eng.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], (W.T @ v)[None, :],
+                           col_scale=[syn.CH4_ISO_RATIO])
+
+    los = los_for(vmr)
+    dT = 0.05
+    ap = ls.abscoeff_layers(T + dT, P, tvib=tv)
+    am = ls.abscoeff_layers(T - dT, P, tvib=tv)
+    dco = ((ap[0] - am[0]) / (2 * dT), (ap[1] - am[1]) / (2 * dT))
+    del ap, am
+    jt = eng.limb_rays_layer_jacobian((ab, em), dco, los)
+    rad, jv = eng.limb_rays_jacobian((ab, em), los, np.zeros(80, np.int32), W)
+    assert tuple(jt.shape) == (8, 80, n) and tuple(jv.shape) == (8, 80, n)
+    assert relerr(rad.cpu().numpy(), eng.limb_rays((ab, em), los).cpu().numpy()) < 1e-13
+    # finite differences of the chain: only the perturbed layer's coefficients change
+    for k in (1, 25, 60):
+        def run(sign):
+            a2, e2 = ab.clone(), em.clone()
+            Tk = T[k:k + 1] + sign * dT
+            ak, ek = ls.abscoeff_layers(Tk, P[k:k + 1], tvib=tv[:, k:k + 1])
+            a2[k], e2[k] = ak[0], ek[0]
+            return eng.limb_rays((a2, e2), los)
+        fd = (run(+1) - run(-1)) / (2 * dT)
+        scale = fd.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+        assert float(((jt[:, k] - fd).abs() / scale).max()) < 1e-5, k
+        h = 1e-3 * vmr[k]
+        vp, vm_ = vmr.copy(), vmr.copy()
+        vp[k] += h
+        vm_[k] -= h
+        fdv = (eng.limb_rays((ab, em), los_for(vp)) - eng.limb_rays((ab, em), los_for(vm_))) / (2 * h)
+        scale = fdv.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+        assert float(((jv[:, k] - fdv).abs() / scale).max()) < 1e-5, k
+    # a ray does not see the layers wholly below its tangent height
+    assert float(jt[7, :40].abs().max()) == 0.0 and float(jv[7, :40].abs().max()) == 0.0
+
+
+def test_config4_two_gas_retrieval_20_iterations(eng):
+    """configs[4]: HCN (mol 23) + CH4 on one grid, forward model + analytic Jacobians of both gases' profile
+    parameters for all LOS in one launch, Gauss-Newton / LM loop with the reference's stopping rule and at most
+    20 iterations (spect_main_module.py:2725-2987).  The Jacobian inside the loop is checked against finite
+    differences of the low-resolution forward model first."""
+    import bench_configs as bc
+    from spectrobot_amd import retrieval
+    scene = bc.two_gas_scene(12000, 2500, 24000, 40)
+    bs, pixels, x_true = bc.retrieval_problem(scene)
+    x0 = bs.param_vector().copy()
+    sims, derivs = retrieval.simulate(scene, pixels, bs)
+    for p in (1, 5):
+        h = 1e-3 * x0[p]
+        outs = []
+        for sign in (+1, -1):
+            par = bs.params()[p]
+            par.value = x0[p] + sign * h
+            for name in bs.sets:
+                scene.gas(name).add_clim(bs.sets[name].profile())
+            outs.append(np.array([s.spectrum for s in retrieval.simulate(scene, pixels, None)[0]]))
+            par.value = x0[p]
+        fd = (outs[0] - outs[1]) / (2 * h)
+        an = np.array([row[p].spectrum for row in derivs])
+        assert np.max(np.abs(an - fd)) < 2e-5 * np.max(np.abs(fd)), p
+    chi, obs, sims, bs = retrieval.inversion_fast_limb(scene, bs, pixels, max_it=20)
+    h = bs.history
+    assert bs.stop in ("converged", "raised") and 3 <= len(h) <= 20
+    assert h[-1] < 0.2 * h[0] and h[-1] < 2.0               # reduced chi square from >> 1 down to ~1
+    bs.update_parerror()
+    x, err = bs.param_vector(), np.array([p.ret_error for p in bs.params()])
+    well = err < 0.1 * 0.5 * bs.apriori_vector()
+    assert well.sum() >= 4
+    assert (np.abs(x - x_true)[well] < 5.0 * err[well]).all()
+    assert (np.abs(x - x_true)[well] < np.abs(x0 - x_true)[well]).all()
