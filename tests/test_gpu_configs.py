@@ -75,9 +75,11 @@ def test_config2_64_rays_and_eight_shards(eng, oracle, cfg1):
         s = slice(Lr["seg_off"][r], Lr["seg_off"][r + 1])
         want = oracle.radiance_ray(a_h, e_h, Lr["seg_layer"][s], col[s])
         assert relerr(rad_h[r], want) < 1e-12, r
-    # higher tangent heights see less gas: the band-integrated radiance falls monotonically above the peak
+    # the band-integrated limb radiance rises with tangent height while the lower atmosphere is opaque
+    # (non-LTE emission from above), peaks, and falls monotonically above the peak
     tot = rad.sum(dim=1).cpu().numpy()
-    assert np.all(np.diff(tot[8:]) < 0)
+    pk = int(np.argmax(tot))
+    assert 0 < pk < 60 and np.all(np.diff(tot[pk:]) < 0)
     parts_a, parts_r = [], []
     for r in range(8):
         g_lo, g_hi = sd.shard_bounds(100000, 8, r)
@@ -157,6 +159,8 @@ def test_config4_two_gas_retrieval_20_iterations(eng):
     scene = bc.two_gas_scene(12000, 2500, 24000, 40)
     bs, pixels, x_true = bc.retrieval_problem(scene)
     x0 = bs.param_vector().copy()
+    for name in bs.sets:                       # the scene still holds the truth the observations were made from
+        scene.gas(name).add_clim(bs.sets[name].profile())
     sims, derivs = retrieval.simulate(scene, pixels, bs)
     for p in (1, 5):
         h = 1e-3 * x0[p]
@@ -177,7 +181,7 @@ def test_config4_two_gas_retrieval_20_iterations(eng):
     assert h[-1] < 0.2 * h[0] and h[-1] < 2.0               # reduced chi square from >> 1 down to ~1
     bs.update_parerror()
     x, err = bs.param_vector(), np.array([p.ret_error for p in bs.params()])
-    well = err < 0.1 * 0.5 * bs.apriori_vector()
+    well = np.diag(bs.av_kernel) > 0.5        # the nodes the measurement constrains (the lowest ones sit under an opaque path)
     assert well.sum() >= 4
-    assert (np.abs(x - x_true)[well] < 5.0 * err[well]).all()
+    assert (np.abs(x - x_true)[well] < 4.0 * err[well]).all()
     assert (np.abs(x - x_true)[well] < np.abs(x0 - x_true)[well]).all()
