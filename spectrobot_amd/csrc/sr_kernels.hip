@@ -589,9 +589,35 @@ __global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restri
     for (int lv = 0; lv <= level; ++lv) per_layer += fp.box_count[lv];
     layer = l_first + idx / per_layer;
     idx -= (layer - l_first) * per_layer;
-    while (level > 0 && idx >= fp.box_count[level]) {
-      idx -= fp.box_count[level];
-      --level;
+    if (fp.top_first) {
+      while (level > 0 && idx >= fp.box_count[level]) {
+        idx -= fp.box_count[level];
+        --level;
+      }
+    } else {
+      // Full grids: inside a layer the boxes of ALL levels are taken super-tile by super-tile (kFarSuper
+      // points = 16 top-level boxes).  A level-major sweep over the whole grid touches the layer's whole
+      // record row (8 MB for 1e5 lines) once per level -- more than an XCD's 4 MB L2 holds, so every level
+      // re-read it from HBM (4.7 GB per step); the records of one super-tile and its window halo
+      // ((16384 + 13010) lines x 80 B = 2.3 MB) stay in L2 across the five levels.
+      const int top_lv = fp.n_levels - 1;
+      const int per_super = (kFarSuper >> 6) * 2 - (kFarSuper >> (6 + top_lv)); // sum over levels of kFarSuper / W
+      const int n_full = fp.box_count[top_lv] > 0 ? (fp.box_count[0] * 64) / kFarSuper : 0; // complete super-tiles
+      int st = idx / per_super;
+      if (st >= n_full) st = n_full; // the last, partial super-tile holds the rest
+      idx -= st * per_super;
+      level = top_lv;
+      for (;;) {
+        const int per = kFarSuper >> (6 + level);                  // boxes of this level per super-tile
+        const int first = st * per;
+        const int cnt = min(per, max(fp.box_count[level] - first, 0));
+        if (idx < cnt || level == 0) {
+          idx += first;
+          break;
+        }
+        idx -= cnt;
+        --level;
+      }
     }
   }
   const int b = idx;

@@ -21,6 +21,31 @@ def shard_bounds(n_grid, world_size, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def shard_bounds_balanced(line_freq, grid, world_size, zone_weight=1.5, align=64):
+    """Contiguous shards of (about) equal WORK instead of equal width (balance by line-window
+    work): the cost of a grid point is the number of lines whose 13010-point window covers it (far-field and
+    near-wings kernels) plus zone_weight x 13010 x the number of line centres on it (the zones kernel's
+    ~240 region-2/3/4 evaluations per line and layer cost about zone_weight times the line's whole
+    region-1 share).  Real HITRAN line lists bunch in band centres: equal-width shards then differ several-fold.
+    Returns [(lo, hi)] for all ranks; boundaries are multiples of `align` grid points."""
+    import numpy as np
+    grid = np.asarray(grid, dtype=float)
+    n, half = grid.size, 6505
+    ic = np.clip(np.rint((np.asarray(line_freq, dtype=float) - grid[0]) / (grid[1] - grid[0])).astype(np.int64), 0, n - 1)
+    centres = np.bincount(ic, minlength=n).astype(float)
+    cum = np.concatenate([[0.0], np.cumsum(centres)])
+    cover = cum[np.minimum(np.arange(n) + half, n)] - cum[np.maximum(np.arange(n) - half + 1, 0)]   # lines covering j
+    cost = cover + zone_weight * 13010.0 * centres + 1e-9        # + epsilon: empty stretches still split somewhere
+    c = np.concatenate([[0.0], np.cumsum(cost)])
+    cuts = [0]
+    for r in range(1, int(world_size)):
+        j = int(np.searchsorted(c, c[-1] * r / world_size))
+        j = int(round(j / align)) * align
+        cuts.append(min(max(j, cuts[-1] + align), n - (world_size - r) * align))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(int(world_size))]
+
+
 def init_from_env(backend=None):
     """torch.distributed rendezvous from RANK / WORLD_SIZE / MASTER_* (torchrun)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -40,18 +65,21 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
-def all_gather_spectrum(shard, n_grid, world_size, rank, out=None):
+def all_gather_spectrum(shard, n_grid, world_size, rank, out=None, bounds=None):
     """Reassemble [n_rays, n_grid] from per-rank shards [n_rays, hi-lo] with a single
-    all-gather.  Shards may differ by one point, so each rank contributes a buffer
-    padded to the largest shard."""
+    all-gather.  Shards may differ in size (by one point with shard_bounds, freely with
+    bounds = shard_bounds_balanced(...)), so each rank contributes a buffer padded to the
+    largest shard."""
     if world_size == 1:
         return shard
     n_rays = shard.shape[0]
-    q = -(-int(n_grid) // int(world_size))
+    if bounds is None:
+        bounds = [shard_bounds(n_grid, world_size, r) for r in range(world_size)]
+    q = max(hi - lo for lo, hi in bounds)
     staged = shard.is_cuda and dist.get_backend() == "gloo"  # rehearsal only: stage through the host
     if out is None:
         out = torch.empty((n_rays, n_grid), dtype=shard.dtype, device=shard.device)
-    if n_grid % world_size == 0 and not staged and shard.is_contiguous():
+    if all(hi - lo == q for lo, hi in bounds) and not staged and shard.is_contiguous():
         # equal shards (the bench: 1e5 points over 1, 2, 4, 8 ranks): no padding, no per-rank copies
         if n_rays == 1:
             dist.all_gather_into_tensor(out.view(world_size, q), shard.view(1, q))  # lands in place
@@ -70,7 +98,6 @@ def all_gather_spectrum(shard, n_grid, world_size, rank, out=None):
         flat = torch.empty((world_size * n_rays, q), dtype=shard.dtype, device=shard.device)
         dist.all_gather_into_tensor(flat, pad)  # concatenation along dim 0, rank-major
     gathered = flat.view(world_size, n_rays, q)
-    for r in range(world_size):
-        lo, hi = shard_bounds(n_grid, world_size, r)
+    for r, (lo, hi) in enumerate(bounds):
         out[:, lo:hi] = gathered[r, :, :hi - lo]
     return out

@@ -185,3 +185,56 @@ def test_config4_two_gas_retrieval_20_iterations(eng):
     assert well.sum() >= 4
     assert (np.abs(x - x_true)[well] < 4.0 * err[well]).all()
     assert (np.abs(x - x_true)[well] < np.abs(x0 - x_true)[well]).all()
+
+
+def test_two_ranks_on_one_gpu_gathered_spectrum(eng, tmp_path):
+    """The sharded path end to end with TWO fresh processes sharing the one GPU (SR_DIST_BACKEND=gloo: RCCL needs
+    one device per rank): each rank computes its spectral shard (halo lines replicated, far-field hierarchy
+    anchored at the shard start) and the shards are gathered; rank 0 compares with the shards computed one after
+    the other in a single process (bit for bit: the path is deterministic) and with the unsharded run (to
+    rounding: a shard's tiles start at its own g_lo).  Equal-width and work-balanced bounds."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text("""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from spectrobot_amd import engine, synthetic as syn, distributed as sd
+rank, local, world = sd.init_from_env()
+engine.set_device(0)
+n = 60000
+grid = syn.make_grid(2980.0, 5e-4, n)
+rng = np.random.default_rng(1)
+L = syn.make_lines(12000, grid, seed=44, n_levels=12)
+L["freq"] = np.sort(np.concatenate([rng.uniform(grid[9000], grid[20000], 8000), rng.uniform(grid[0], grid[-1], 4000)]))
+atm = syn.make_atmosphere(20, 12)
+nd = syn.number_density(atm["press"], atm["temps"])
+Lr = syn.limb_los(atm["z"], nd, [np.full(20, 0.0148)], [atm["z"][0] + 3.0, atm["z"][7] + 2.0, atm["z"][15] + 1.0])
+los = engine.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"], col_scale=[syn.CH4_ISO_RATIO])
+ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+def shard(lo, hi):
+    co = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"], g_lo=lo, g_hi=hi)
+    return engine.limb_rays(co, los)
+for bounds in ([sd.shard_bounds(n, world, r) for r in range(world)], sd.shard_bounds_balanced(L["freq"], grid, world)):
+    lo, hi = bounds[rank]
+    full = sd.all_gather_spectrum(shard(lo, hi), n, world, rank, bounds=bounds)
+    if rank == 0:
+        seq = torch.cat([shard(a, b) for a, b in bounds], dim=1)
+        assert torch.equal(full, seq), "gathered != shards computed one after the other"
+        whole = shard(0, n)
+        rel = float(((full - whole).abs() / whole.abs().clamp_min(1e-300)).max())
+        assert rel < 1e-12, rel
+        assert bounds[0][1] != n // 2 or bounds is not None
+torch.distributed.barrier()
+print("rank", rank, "ok")
+""" % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2", SR_DIST_BACKEND="gloo",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)

@@ -112,6 +112,53 @@ def test_all_gather_spectrum_gloo_world2(tmp_path):
     assert all("ok" in o for o in outs)
 
 
+def test_shard_bounds_balanced_on_skewed_line_density(tmp_path):
+    """Equal-work shards: a band head holding 70 % of the lines in 15 % of the grid.  The
+    work model's per-shard cost spread drops from several-fold (equal width) to a few per cent; the
+    gather with unequal shards reassembles the spectrum (gloo, two ranks)."""
+    from spectrobot_amd import distributed as sd, synthetic as syn
+    rng = np.random.default_rng(3)
+    n = 100000
+    grid = syn.make_grid(2975.0, 5e-4, n)
+    freq = np.sort(np.concatenate([rng.uniform(grid[20000], grid[35000], 70000), rng.uniform(grid[0], grid[-1], 30000)]))
+
+    def costs(bounds):
+        ic = np.clip(np.rint((freq - grid[0]) / (grid[1] - grid[0])).astype(int), 0, n - 1)
+        out = []
+        for lo, hi in bounds:
+            cover = np.clip(np.minimum(ic + 6504, hi - 1) - np.maximum(ic - 6505, lo) + 1, 0, None).sum()   # (line, point) pairs
+            out.append(cover + 1.5 * 13010.0 * np.count_nonzero((ic >= lo) & (ic < hi)))
+        return np.array(out)
+
+    for w in (2, 4, 8):
+        bal = sd.shard_bounds_balanced(freq, grid, w)
+        assert bal[0][0] == 0 and bal[-1][1] == n and all(bal[i][1] == bal[i + 1][0] for i in range(w - 1))
+        assert all((hi - lo) > 0 and lo % 64 == 0 for lo, hi in bal)
+        c_eq = costs([sd.shard_bounds(n, w, r) for r in range(w)])
+        c_bal = costs(bal)
+        assert c_bal.max() / c_bal.mean() < 1.05, (w, c_bal / c_bal.mean())
+        if w == 8:
+            assert c_eq.max() / c_eq.mean() > 2.0
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from spectrobot_amd import distributed as sd\n"
+        "rank, local, world = sd.init_from_env(backend='gloo')\n"
+        "bounds = [(0, 640), (640, 1000)]\n"
+        "full = torch.arange(3 * 1000, dtype=torch.float64).reshape(3, 1000)\n"
+        "lo, hi = bounds[rank]\n"
+        "out = sd.all_gather_spectrum(full[:, lo:hi].contiguous(), 1000, world, rank, bounds=bounds)\n"
+        "assert torch.equal(out, full), rank\n"
+        "torch.distributed.barrier()\n"
+        "print('rank', rank, 'ok')\n" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+
+
 def test_lines_to_soa_matches_linktomolec(golden):
     """Level resolution incl. the reference's quirks (unidentified and same-level lines)."""
     from spectrobot_amd import spect_classes as spcl, spect_base_module as sbm

@@ -26,6 +26,7 @@ run tcc --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum
 python3 tools/rocprof_summary.py "$out"/kt/kt_results.db > "$out/${tag}_kernel_trace_stats.txt"
 python3 tools/rocprof_summary.py "$out"/pmc1/pmc1_results.db "$out"/pmc2/pmc2_results.db > "$out/${tag}_pmc_summary.txt"
 python3 tools/rocprof_summary.py "$out"/fetch/fetch_results.db "$out"/write/write_results.db "$out"/tcc/tcc_results.db > "$out/${tag}_pmc_hbm.txt"
+python3 tools/pmc_hbm_json.py "$tag" "$out"/fetch/fetch_results.db "$out"/write/write_results.db > "$out/${tag}_pmc_hbm.json"
 timeout -k 10 300 python3 bench.py > "$out/${tag}_bench.json" 2> "$out/bench.err"
 echo "bench exit=$?"
 tail -c 600 "$out/${tag}_bench.json"
