@@ -305,9 +305,12 @@ int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double 
  * line's own contribution), near field exact.  0: every (line, point) evaluated
  * exactly (sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel). */
 int sr_set_far_field(int on);
-/* Far-field mode only.  1 (default): sr_abscoeff_near_zones_kernel runs on a second, internal
- * stream beside sr_farfield_kernel (it needs the record tables only) and the wings kernel joins
- * both; the caller's stream sees the op complete in order as before.  0: the four kernels one
+/* Far-field mode only.  1, 2: sr_abscoeff_near_zones_kernel runs on a second, internal stream beside
+ * sr_farfield_kernel (it needs the record tables only) and the wings kernel joins both; the NEXT call's
+ * record tables are prepared on a third internal stream while this call computes -- with 1 (default) as soon
+ * as the tables of the call before are free, with 2 only beside this call's wings kernel (keeps the
+ * HBM-write-bound prep kernel away from the two VALU-bound kernels; measured equal on config 2: 8.63 vs
+ * 8.60 ms per step).  The caller's stream sees the op complete in order as before.  0: the four kernels one
  * after the other on the caller's stream (per-kernel times for sr_last_kernel_ms). */
 int sr_set_overlap(int on);
 /* Memory knob: the per-(line, layer) record tables (208 B each) of one launch are kept

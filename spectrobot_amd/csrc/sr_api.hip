@@ -97,6 +97,20 @@ struct Stager {
     pending = true;
     return SR_OK;
   }
+  // The copy on a dedicated copy stream, `st` only waits for it.  Host-to-device copies of all streams
+  // share the DMA queues in issue order: a small staging copy enqueued on `st` BEHIND 8 ms of kernels
+  // held back the next call's layer-scalar copy (on the prep stream) and with it the pipelined
+  // preparation of the next call's tables (+0.9 ms per step).  prepare() has already waited for the
+  // slot's last consumers, so the copy may run at once.
+  int push_early(size_t bytes, hipStream_t st) {
+    static thread_local hipStream_t copy_st = nullptr;
+    if (!copy_st) HIPCHK(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking));
+    if (bytes) HIPCHK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, copy_st));
+    HIPCHK(hipEventRecord(done, copy_st));
+    HIPCHK(hipStreamWaitEvent(st, done, 0));
+    pending = true;
+    return SR_OK;
+  }
   // re-record `done` behind the kernels that read (or write) the device mirror, so that the slot is
   // not refilled while they run
   int mark(hipStream_t st) {
@@ -172,7 +186,7 @@ struct HostLines {
 // snapshot, so flipping a switch from another thread never changes a call half way.
 std::atomic<int> g_variant{8};   // points per lane in the exact wings kernel
 std::atomic<int> g_far_field{1}; // 1: far wings by local expansions (default), 0: every evaluation exact
-std::atomic<int> g_overlap{1};   // 1: zones kernel on a second stream beside the far-field kernel (default)
+std::atomic<int> g_overlap{1};   // 1 (default), 2: zones kernel on a second stream beside the far-field kernel, next call's prep pipelined (2: gated behind FF+zones; measured equal)
 std::atomic<int> g_counting{0};  // 1: counting instantiations of the far-field-mode kernels (sr_set_counting)
 std::atomic<size_t> g_table_budget{(size_t)48 << 30}; // bytes of FastRec + ColdRec tables per layer batch
 
@@ -209,6 +223,10 @@ struct sr_lineset {
   bool overlapped = false;       // last call ran that way (timing hook)
   bool pipelined = false;        // last call prepared its tables on prep_st
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // overlap mode 2: the NEXT call's table preparation may start only when this call's far-field and zones
+  // kernels are done, i.e. beside the wings kernel (see sr_set_overlap)
+  hipEvent_t ev_tail = nullptr;
+  bool tail_recorded = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int n_timed = 0; // kernels timed in the last call
   bool timed = false;
@@ -274,7 +292,7 @@ int sr_set_far_field(int on) {
 }
 
 int sr_set_overlap(int on) {
-  g_overlap.store(on ? 1 : 0);
+  g_overlap.store(on < 0 ? 0 : (on > 2 ? 2 : on));
   return SR_OK;
 }
 
@@ -532,6 +550,7 @@ int sr_lineset_destroy(sr_lineset *ls) {
   ls->d_zone.release();
   if (ls->ev_fork) (void)hipEventDestroy(ls->ev_fork);
   if (ls->ev_join) (void)hipEventDestroy(ls->ev_join);
+  if (ls->ev_tail) (void)hipEventDestroy(ls->ev_tail);
   if (ls->aux) (void)hipStreamDestroy(ls->aux);
   for (auto &ev : ls->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -643,6 +662,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   }
   // set b was last read by the kernels of the call before the previous one
   if (overlap && ls->free_recorded[b]) HIPCHK(hipStreamWaitEvent(pst, ls->ev_tables_free[b], 0));
+  if (overlap == 2 && ls->tail_recorded) HIPCHK(hipStreamWaitEvent(pst, ls->ev_tail, 0));
   rc = SL.push(hl_bytes, pst);
   if (rc) return rc;
   LayersDev A;
@@ -767,6 +787,9 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
                                 (int)g_lo, (int)g_hi, fp, d_cnt, st));
       HIPCHK(hipEventRecord(ls->ev[2], st));
       if (!small) HIPCHK(hipStreamWaitEvent(st, ls->ev_join, 0));
+      if (!ls->ev_tail) HIPCHK(hipEventCreateWithFlags(&ls->ev_tail, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(ls->ev_tail, st));
+      ls->tail_recorded = true;
       LAUNCHCHK(launch_near(1, small ? 0 : 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, d_zmax.as<int>(), n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st));
       HIPCHK(hipEventRecord(ls->ev[3], st));
@@ -955,13 +978,13 @@ int sr_radiance_rays_dev(const double *abs_c, const double *emi_c, int n_layers,
     std::memcpy(s_seg.host<char>() + o_lay, seg_layer, sizeof(int) * (size_t)n_seg);
     std::memcpy(s_seg.host<char>() + o_col, seg_col, sizeof(double) * (size_t)n_seg);
   }
-  rc = s_seg.push(total, st);
+  rc = s_seg.push_early(total, st);
   if (rc) return rc;
   char *base = s_seg.d.as<char>();
   LAUNCHCHK(launch_radiance(abs_c, emi_c, (int)n_pts, n_rays, reinterpret_cast<const int *>(base),
                             reinterpret_cast<const int *>(base + o_lay),
                             reinterpret_cast<const double *>(base + o_col), init_from_rad, rad, st));
-  return SR_OK;
+  return s_seg.mark(st); // the slot is refilled only after this kernel (the copy no longer rides on `st`)
 }
 
 // ------------------------------------------------------------------------
@@ -990,14 +1013,14 @@ int sr_radiance_jac_layer_dev(const double *abs_c, const double *emi_c, const do
   std::memcpy(h, seg_off, b_off);
   std::memcpy(h + o_lay, seg_layer, b_lay);
   std::memcpy(h + o_col, seg_col, sizeof(double) * (size_t)n_seg);
-  rc = s_seg.push(total, st);
+  rc = s_seg.push_early(total, st);
   if (rc) return rc;
   char *base = s_seg.d.as<char>();
   LAUNCHCHK(launch_radiance_jac_layer(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, n_rays,
                                       reinterpret_cast<const int *>(base),
                                       reinterpret_cast<const int *>(base + o_lay),
                                       reinterpret_cast<const double *>(base + o_col), jac, st));
-  return SR_OK;
+  return s_seg.mark(st);
 }
 
 // ------------------------------------------------------------------------
@@ -1029,14 +1052,14 @@ int sr_radiance_jac_dev(const double *abs_c, const double *emi_c, int n_layers, 
   std::memcpy(h + o_lay, seg_layer, b_lay);
   std::memcpy(h + o_col, seg_col, sizeof(double) * (size_t)n_seg);
   std::memcpy(h + o_d, dcol_dpar, sizeof(double) * (size_t)n_seg * n_par);
-  rc = s_seg.push(total, st);
+  rc = s_seg.push_early(total, st);
   if (rc) return rc;
   char *base = s_seg.d.as<char>();
   LAUNCHCHK(launch_radiance_jac(abs_c, emi_c, (int)n_pts, n_rays, reinterpret_cast<const int *>(base),
                                 reinterpret_cast<const int *>(base + o_lay),
                                 reinterpret_cast<const double *>(base + o_col),
                                 reinterpret_cast<const double *>(base + o_d), n_par, rad, jac, st));
-  return SR_OK;
+  return s_seg.mark(st);
 }
 
 // ------------------------------------------------------------------------
@@ -1142,7 +1165,7 @@ int stage_los(const sr_los_desc *los, int n_layers, int n_par, const int32_t *pa
     std::memcpy(po, los->pt_off, sizeof(int) * (n_seg + 1));
   }
   if (n_par) std::memcpy(h + o_pgas, par_gas, sizeof(int) * n_par);
-  rc = sg.push(in_bytes, st);
+  rc = sg.push_early(in_bytes, st);
   if (rc) return rc;
   char *d = sg.d.as<char>();
   out->x = reinterpret_cast<const double *>(d + o_x);
@@ -1268,13 +1291,13 @@ int sr_lut_interp_dev(const double *g_tab, int n_pt, int64_t n_pts, int n_steps,
   std::memcpy(h, wgt4, b_w);
   if (pop) std::memcpy(h + b_w, pop, b_p); else std::memset(h + b_w, 0, b_p);
   std::memcpy(h + b_w + b_p, idx4, b_i);
-  rc = sg.push(b_w + b_p + b_i, st);
+  rc = sg.push_early(b_w + b_p + b_i, st);
   if (rc) return rc;
   char *d = sg.d.as<char>();
   LAUNCHCHK(launch_lut(combine, g_tab, n_pt, (int)n_pts, n_steps, reinterpret_cast<const int *>(d + b_w + b_p),
                        reinterpret_cast<const double *>(d), reinterpret_cast<const double *>(d + b_w), out_a, out_e,
                        st));
-  return SR_OK;
+  return sg.mark(st);
 }
 
 // ------------------------------------------------------------------------

@@ -435,7 +435,7 @@ def set_points_per_lane(p):
 def set_overlap(on):
     """1 (default): the zones kernel runs beside the far-field kernel on an internal stream;
     0: kernels one after the other (per-kernel times in last_kernel_ms)."""
-    check(lib.sr_set_overlap(int(bool(on))), "sr_set_overlap")
+    check(lib.sr_set_overlap(int(on)), "sr_set_overlap")
 
 
 def set_far_field(on):
