@@ -48,7 +48,7 @@ KERNEL_COUNTERS = {
 def kernel_sources_sha256():
     """Hash of the kernel sources: a PMC traffic figure is only reported for the build it was measured on."""
     h = hashlib.sha256()
-    for f in ("sr_kernels.hip", "sr_api.hip", "sr_device.hpp", "sr_kernels.hpp"):
+    for f in ("sr_kernels.hip", "sr_device.hpp", "sr_kernels.hpp"):     # the kernels; the host API does not change their traffic
         h.update(open(os.path.join(ROOT, "spectrobot_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 

@@ -553,8 +553,13 @@ __device__ inline int lane_reduce_index(int lane, bool &primary) {
 // COUNT: the instantiation sr_set_counting(1) selects; it adds the number of (line, box) expansions
 // this launch performs to cnt[kCntExpansions] (bench.py's executed-work accounting).  The timed
 // instantiation carries no counting code.
+#ifndef SR_FAR_WAVES_PER_EU
+#define SR_FAR_ATTR
+#else
+#define SR_FAR_ATTR __attribute__((amdgpu_waves_per_eu(SR_FAR_WAVES_PER_EU)))
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(64) void sr_farfield_kernel(const FastRec *__restrict__ fast,
+__global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastRec *__restrict__ fast,
                                                          IcIndex ix,
                                                          const int *__restrict__ zmax, int n_sub, int g_lo,
                                                          int /*g_hi*/, FarParams fp,
@@ -1113,8 +1118,13 @@ __device__ inline void core_push(CorePend &P, int &fill, int lane, int a0, int n
 
 // WT points per wave (a multiple of 64): the wider the image, the fewer zones are cut in two by
 // its ends (a zone is ~280 points), i.e. the fewer partially filled lane runs.
+#ifndef SR_ZONES_WAVES_PER_EU
+#define SR_ZONES_ATTR
+#else
+#define SR_ZONES_ATTR __attribute__((amdgpu_waves_per_eu(SR_ZONES_WAVES_PER_EU)))
+#endif
 template <int WT, int NW, bool COUNT>
-__global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
+__global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_kernel(
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, IcIndex ix,
     const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp, int add,
     double *__restrict__ abs_out, double *__restrict__ emi_out, unsigned long long *__restrict__ cnt) {
@@ -1141,7 +1151,13 @@ __global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
   const int l0 = lower_bound_ic(ix, wlo - zm), l1 = lower_bound_ic(ix, whi + zm + 1);
   const FastRec *frow = fast + (size_t)layer * n_sub;
   const ColdRec *crow = cold + (size_t)layer * n_sub;
-  for (int base = l0 + 64 * wave; base < l1; base += 64 * NW) {
+  // Serpentine sweep: even groups take their 64-line chunks left to right, odd groups right to left.  Neighbouring
+  // groups (consecutive work ids, same XCD, started together) share the lines within the zone width of their common
+  // edge -- 45 % more record bytes than the tables hold; swept in opposite directions both reach the shared lines at
+  // the same time (start or end of their sweep) and the second one finds them in L2 instead of HBM.
+  const int n_chunks = (l1 - l0 + 63) >> 6;
+  for (int ci = wave; ci < n_chunks; ci += NW) {
+    const int base = l0 + 64 * ((grp & 1) ? n_chunks - 1 - ci : ci);
     const int lv = min(base + lane, l1 - 1);
     bool act;
     // runs of the lane's line inside this group, start | count << 16 (window indices <= 13010):
@@ -1227,8 +1243,15 @@ __global__ __launch_bounds__(64 * NW) void sr_abscoeff_near_zones_kernel(
             const double y = region2_val(z.q2, fma((double)t, r.xstep, lf ? c_left : c_right));
             if (COUNT) ++n_r2;
             const int idx = t + (lf ? i_left : i_right);
+#ifdef SR_ZONES_R2_RMW
             s_a[idx] = fma(wa, y, s_a[idx]);
             s_e[idx] = fma(we, y, s_e[idx]);
+#else
+            // return-less LDS adds instead of read - fma - write: no wait for the read, and consecutive lines of
+            // the walk, whose runs overlap, no longer serialise on it (one wave per image: the order stays fixed)
+            atomicAdd(&s_a[idx], wa * y);
+            atomicAdd(&s_e[idx], we * y);
+#endif
           }
         }
       }
@@ -1295,11 +1318,15 @@ int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int
   return (int)hipGetLastError();
 }
 
+#ifndef SR_ZONES_WT
+#define SR_ZONES_WT 512
+#endif
+constexpr int kZoneImage = SR_ZONES_WT; // grid points per LDS image of sr_abscoeff_near_zones_kernel (a multiple of 64)
 template <int NW, bool COUNT>
 static void launch_zones(dim3 gz, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
                          int n_sub, int n_t, int g_lo, int g_hi, const GridParams &gp, int add, double *abs_out,
                          double *emi_out, unsigned long long *cnt, hipStream_t st) {
-  hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<512, NW, COUNT>), gz, dim3(64 * NW), 0, st, fast, cold, ix, zmax,
+  hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<kZoneImage, NW, COUNT>), gz, dim3(64 * NW), 0, st, fast, cold, ix, zmax,
                      n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt);
 }
 
@@ -1322,8 +1349,8 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
     // Image width: wider images cut fewer zones in two (fewer (line, group) pairs: 7.1 -> 6.7 ms on
     // 1e5 points x 80 layers with 512 instead of 256) as long as the waves still fill the chip
     // several times over (1024: 9.3 ms, too few waves and 16 KB LDS each).
-    const long waves512 = (long)((g_hi - g_lo + 511) / 512) * n_layers;
-    const int n_t = (g_hi - g_lo + 511) / 512;
+    const long waves512 = (long)((g_hi - g_lo + kZoneImage - 1) / kZoneImage) * n_layers;
+    const int n_t = (g_hi - g_lo + kZoneImage - 1) / kZoneImage;
     const dim3 gz((unsigned)(n_t * n_layers));
 #define SR_ZONES(NW)                                                                                         \
   (cnt ? launch_zones<NW, true>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st) \

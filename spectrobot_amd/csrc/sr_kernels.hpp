@@ -61,7 +61,10 @@ constexpr int kTheta = SR_KTHETA; // admissible distance, in box half-widths
 constexpr int kFD = SR_KFD;       // expansion degree
 constexpr int kFC = kFD + 1;   // coefficients per box and output
 constexpr int kMaxFarLevels = 5;
-constexpr int kFarSuper = 16384; // points per super-tile of sr_farfield_kernel's block order (a multiple of the widest box)
+#ifndef SR_FAR_SUPER
+#define SR_FAR_SUPER 16384
+#endif
+constexpr int kFarSuper = SR_FAR_SUPER; // points per super-tile of sr_farfield_kernel's block order (a multiple of the widest box)
 struct FarParams {
   int n_levels, n_layers, n_boxes_total;
   int top_first; // block order of sr_farfield_kernel: widest two levels of a layer group first

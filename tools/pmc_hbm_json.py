@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def sources_sha256():
     h = hashlib.sha256()
-    for f in ("sr_kernels.hip", "sr_api.hip", "sr_device.hpp", "sr_kernels.hpp"):
+    for f in ("sr_kernels.hip", "sr_device.hpp", "sr_kernels.hpp"):     # the kernels; the host API does not change their traffic
         h.update(open(os.path.join(ROOT, "spectrobot_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
