@@ -314,7 +314,7 @@ def main():
     print("e2e_co_all: abs max %.3e" % abc.max())
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--lowres", "--hitran", "--inversion", "--retrieval", "--gcoeff", "--outer")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--lowres", "--hitran", "--inversion", "--retrieval", "--gcoeff", "--outer", "--containers")):
     main()
 
 
@@ -724,3 +724,82 @@ def golden_outer():
 
 if __name__ == "__main__" and "--outer" in sys.argv:
     golden_outer()
+
+
+def golden_containers():
+    """A11 remainder + the LUT planner, with the reference's own classes: SpectralGrid / SpectralObject unit
+    conversions (spect_classes.py:395-432, 757-807), __getitem__ / __div__ (Python-2 name) / interp_to_grid
+    (:451-507), SpectralIntensity.convertto (:1200-1235), Calc_BB (:1881-1892), SpectralGcoeff.interpolate
+    (:1349-1375, linear sbm.weight) and calc_PT_couples_atmosphere (spect_main_module.py:1746-1844)."""
+    spcl, RF = import_reference_spcl()
+    m_mp = types.ModuleType("memory_profiler")
+    m_mp.profile = lambda f: f
+    sys.modules["memory_profiler"] = m_mp
+    sbm = sys.modules["spect_base_module"]
+    sbm.weight = lambda x, x1, x2, itype="lin": (1.0 - (x - x1) / (x2 - x1), (x - x1) / (x2 - x1))
+
+    class Molec(object):
+        pass
+
+    class IsoMolecS(object):
+        def __init__(self, MM):
+            self.MM = MM
+
+    sbm.Molec, sbm.IsoMolec = Molec, IsoMolecS
+    import spect_main_module as smm
+    rng = np.random.default_rng(20260006)
+    out = {}
+    g0 = np.arange(2000.0, 2003.0, 0.01)
+    sp0 = np.abs(rng.standard_normal(len(g0))) + 0.1
+    out["grid_cm"], out["spec_cm"] = g0, sp0
+    for units in ("nm", "mum", "hz", "cm_1"):
+        o = spcl.SpectralObject(sp0.copy(), spcl.SpectralGrid(g0, units="cm_1"), units="cm_1")
+        o.convert_grid_to(units)
+        out["conv_%s_grid" % units], out["conv_%s_spec" % units] = np.array(o.spectral_grid.grid), np.array(o.spectrum)
+        if units != "cm_1":      # and back
+            o.convertto_cm_1()
+            out["back_%s_grid" % units], out["back_%s_spec" % units] = np.array(o.spectral_grid.grid), np.array(o.spectrum)
+    o = spcl.SpectralObject(sp0.copy(), spcl.SpectralGrid(g0, units="cm_1"), units="cm_1")
+    sub = o[(2000.5, 2001.25)]
+    out["getitem_grid"], out["getitem_spec"] = np.array(sub.spectral_grid.grid), np.array(sub.spectrum)
+    out["getitem_none"] = np.array([o[(3000.0, 3001.0)] is None])
+    out["div_scalar"] = o.__div__(2.5).spectrum
+    out["div_obj"] = o.__div__(spcl.SpectralObject(sp0[::-1].copy(), o.spectral_grid)).spectrum
+    ng = spcl.SpectralGrid(np.linspace(1999.5, 2003.5, 97), units="cm_1")
+    out["interp_grid"], out["interp_spec"] = ng.grid, o.interp_to_grid(ng).spectrum
+    for u in ("Wm2", "nWcm2"):
+        si = spcl.SpectralIntensity(sp0.copy(), spcl.SpectralGrid(g0, units="cm_1"), units="ergscm2")
+        out["intens_" + u] = np.array(si.convertto(u))
+    out["bb_T"] = np.array([150.0, 5777.0])
+    out["bb"] = np.array([spcl.Calc_BB(spcl.SpectralGrid(g0, units="cm_1"), T).spectrum for T in out["bb_T"]])
+    out["bb_Wm2"] = spcl.Calc_BB(spcl.SpectralGrid(g0, units="cm_1"), 150.0, units="Wm2").spectrum
+    sg = spcl.SpectralGrid(g0, units="cm_1")
+    a = spcl.SpectralGcoeff("absorption", sg, 6, 1, 16.0, "L01", spectrum=sp0.copy(), Pres=1.0, Temp=150.0)
+    b = spcl.SpectralGcoeff("absorption", sg, 6, 1, 16.0, "L01", spectrum=sp0[::-1].copy(), Pres=4.0, Temp=150.0)
+    c = spcl.SpectralGcoeff("absorption", sg, 6, 1, 16.0, "L01", spectrum=sp0[::-1].copy(), Pres=1.0, Temp=160.0)
+    out["gint_P"] = a.interpolate(b, Pres=2.2).spectrum
+    out["gint_T"] = a.interpolate(c, Temp=153.0).spectrum
+    # LUT planner on a Titan-like profile
+    from spectrobot_amd import synthetic as syn
+
+    class Atm(object):
+        pass
+    atm = syn.make_atmosphere(80, 0)
+    A = Atm()
+    A.pres, A.temp = atm["press"], atm["temps"]
+    g = syn.make_grid(2990.0, 5e-4, 4000)
+    L = syn.make_lines(40, g, config_id=104, n_levels=0)
+    lines = ref_lines(spcl, 6, 1, L, labels=False)
+    for l in lines:
+        l.P_shift = 0.0
+    for key, kw in (("a", dict()), ("b", dict(pres_step_log=1.0, temp_step=10.0, max_pres=2.0)),
+                    ("c", dict(thres=0.5, add_lowpres=False))):
+        pt = smm.calc_PT_couples_atmosphere(lines, IsoMolecS(syn.CH4_MM), A, **kw)
+        out["pt_" + key] = np.array(pt)
+    out["pt_press"], out["pt_temps"] = atm["press"], atm["temps"]
+    np.savez_compressed(os.path.join(HERE, "containers.npz"), **out, **{"line_" + k: v for k, v in L.items()})
+    print("containers: PT couples", [len(out["pt_" + k]) for k in "abc"], "bb", out["bb"][:, 0])
+
+
+if __name__ == "__main__" and "--containers" in sys.argv:
+    golden_containers()

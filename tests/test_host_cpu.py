@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import relerr
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -372,3 +374,62 @@ def test_molparam_and_key_input_readers(tmp_path, monkeypatch):
     bad.write_text("[n_threads]\n[test]\nTrue\n")
     with pytest.raises(ValueError):
         sbm.read_inputs(str(bad), ["n_threads"], itype=[int])
+
+
+def test_containers_and_lut_planner_vs_reference(golden):
+    """A11 remainder and the LUT planner against the reference's own classes (make_golden.py --containers): unit
+    conversions of grid + spectral density, __getitem__, __truediv__, interp_to_grid, intensity units, Calc_BB,
+    SpectralGcoeff.interpolate, calc_PT_couples_atmosphere."""
+    from spectrobot_amd import spect_classes as spcl, spect_main_module as smm, spect_base_module as sbm
+    g = golden("containers")
+    g0, sp0 = g["grid_cm"], g["spec_cm"]
+    for units in ("nm", "mum", "hz", "cm_1"):
+        o = spcl.SpectralObject(sp0.copy(), spcl.SpectralGrid(g0, units="cm_1"), units="cm_1")
+        grid, spec = o.convert_grid_to(units)
+        assert o.spectral_grid.units == units
+        assert np.array_equal(grid, g["conv_%s_grid" % units]) and np.array_equal(spec, g["conv_%s_spec" % units]), units
+        if units != "cm_1":
+            o.convertto_cm_1()
+            assert np.array_equal(o.spectral_grid.grid, g["back_%s_grid" % units]), units
+            assert np.array_equal(o.spectrum, g["back_%s_spec" % units]), units
+    with pytest.raises(ValueError):
+        o.convert_grid_to("furlongs")
+    o = spcl.SpectralObject(sp0.copy(), spcl.SpectralGrid(g0, units="cm_1"), units="cm_1")
+    sub = o[(2000.5, 2001.25)]
+    assert np.array_equal(sub.spectral_grid.grid, g["getitem_grid"]) and np.array_equal(sub.spectrum, g["getitem_spec"])
+    assert o[(3000.0, 3001.0)] is None and bool(g["getitem_none"][0])
+    assert np.array_equal((o / 2.5).spectrum, g["div_scalar"])
+    assert np.array_equal((o / spcl.SpectralObject(sp0[::-1].copy(), o.spectral_grid)).spectrum, g["div_obj"])
+    ng = spcl.SpectralGrid(g["interp_grid"], units="cm_1")
+    assert np.array_equal(o.interp_to_grid(ng).spectrum, g["interp_spec"])
+    for u in ("Wm2", "nWcm2"):
+        si = spcl.SpectralIntensity(sp0.copy(), spcl.SpectralGrid(g0, units="cm_1"), units="ergscm2")
+        assert np.array_equal(si.convertto(u), g["intens_" + u]) and si.units == u
+    with pytest.raises(ValueError):
+        si.convertto("lumens")
+    sgr = spcl.SpectralGrid(g0, units="cm_1")
+    for T, want in zip(g["bb_T"], g["bb"]):
+        assert relerr(spcl.Calc_BB(sgr, float(T)).spectrum, want) < 1e-15
+    assert relerr(spcl.Calc_BB(sgr, 150.0, units="Wm2").spectrum, g["bb_Wm2"]) < 1e-15
+    a = spcl.SpectralGcoeff("absorption", sgr, 6, 1, 16.0, "L01", spectrum=sp0.copy(), Pres=1.0, Temp=150.0)
+    b = spcl.SpectralGcoeff("absorption", sgr, 6, 1, 16.0, "L01", spectrum=sp0[::-1].copy(), Pres=4.0, Temp=150.0)
+    c = spcl.SpectralGcoeff("absorption", sgr, 6, 1, 16.0, "L01", spectrum=sp0[::-1].copy(), Pres=1.0, Temp=160.0)
+    gp, gt = a.interpolate(b, Pres=2.2), a.interpolate(c, Temp=153.0)
+    assert np.array_equal(gp.spectrum, g["gint_P"]) and np.array_equal(gt.spectrum, g["gint_T"])
+    assert (gp.pres, gp.temp, gt.pres, gt.temp) == (2.2, 150.0, 1.0, 153.0) and gp.lev_string == "L01"
+    with pytest.raises(ValueError):
+        b.interpolate(c, Temp=155.0)          # both P and T differ
+    assert a.interpolate(None, Pres=2.0) is None
+
+    class Atm(object):
+        pass
+    A = Atm()
+    A.pres, A.temp = g["pt_press"], g["pt_temps"]
+    lines = [spcl.SpectLine([6, 1, g["line_freq"][i], 0.0, g["line_a_coeff"][i], g["line_air_broad"][i], 0.0,
+                             g["line_e_lower"][i], g["line_t_dep_broad"][i], 0.0, "??", "??", "", "", "",
+                             g["line_g_up"][i], g["line_g_lo"][i]], nomi=spcl.cose_hit) for i in range(len(g["line_freq"]))]
+    iso = sbm.IsoMolec(6, 1, 16.0313)
+    for key, kw in (("a", dict()), ("b", dict(pres_step_log=1.0, temp_step=10.0, max_pres=2.0)),
+                    ("c", dict(thres=0.5, add_lowpres=False))):
+        pt = np.array(smm.calc_PT_couples_atmosphere(lines, iso, A, **kw))
+        assert pt.shape == g["pt_" + key].shape and np.array_equal(pt, g["pt_" + key]), key
