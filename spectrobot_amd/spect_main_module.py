@@ -703,6 +703,75 @@ class LinearProfile_1D_new(RetSet):
         return i == len(self.alts) - 1 or not coord_range['alt'][0] > self.alts[i + 1]
 
 
+class LinearProfile_1D(LinearProfile_1D_new):
+    """The older constructor (spect_main_module.py:543-585): takes the atmosphere (its altitude grid is
+    atmosphere.grid.grid[0]) and -- sic -- gives the MIDDLE nodes the a priori / first guess / error of the node
+    before them (the zip at :560 runs over the unsliced profiles)."""
+
+    def __init__(self, name, atmosphere, alt_nodes, apriori_prof, apriori_prof_err, first_guess_prof=None):
+        z = np.asarray(atmosphere.grid.grid[0], dtype=float)
+        nodes = list(alt_nodes)
+        fg = apriori_prof if first_guess_prof is None else first_guess_prof
+        self.name, self.alts, self.n_par, self.set = name, nodes, len(nodes), []
+        self.set.append(RetParam(name, nodes[0], alt_triangle(z, nodes[0], node_up=nodes[1], first=True),
+                                 apriori_prof[0], apriori_prof_err[0], first_guess=fg[0]))
+        for j in range(1, len(nodes) - 1):
+            self.set.append(RetParam(name, nodes[j], alt_triangle(z, nodes[j], node_lo=nodes[j - 1], node_up=nodes[j + 1]),
+                                     apriori_prof[j - 1], apriori_prof_err[j - 1], first_guess=fg[j - 1]))
+        self.set.append(RetParam(name, nodes[-1], alt_triangle(z, nodes[-1], node_lo=nodes[-2], last=True),
+                                 apriori_prof[-1], apriori_prof_err[-1], first_guess=fg[-1]))
+        self.orig_atmosphere = atmosphere
+
+
+class GridMask2D(object):
+    """Mask over (latitude box, altitude): what cos.maskgrid.merge(latbox) builds at spect_main_module.py:412
+    (AtmGridMask.merge is in the absent module): the outer product of the latitude-box mask and the altitude mask."""
+
+    def __init__(self, lat_mask, alt_mask):
+        self.grid = (lat_mask.grid, alt_mask.grid)
+        self.mask = np.outer(lat_mask.mask, alt_mask.mask)
+        self.interp = {'lat': lat_mask.interp, 'alt': alt_mask.interp}
+
+    def __mul__(self, value):
+        return self.mask * value
+
+    __rmul__ = __mul__
+
+
+class LinearProfile_2D(RetSet):
+    """Altitude nodes x latitude boxes (spect_main_module.py:389-447): one LinearProfile_1D_new per box, every
+    node's altitude mask merged with the box mask; keys are (lat, alt_node)."""
+
+    def __init__(self, name, atmosphere, alt_nodes, lat_limits, apriori_profs, apriori_prof_errs, first_guess_profs=None):
+        self.name, self.set = name, []
+        self.n_par = len(alt_nodes) * len(lat_limits)
+        self.alts, self.lats = list(alt_nodes), list(lat_limits)
+        z = np.asarray(atmosphere.grid.coords['alt'], dtype=float)
+        for apriori_prof, apriori_prof_err, lat in zip(apriori_profs, apriori_prof_errs, lat_limits):
+            one_d = LinearProfile_1D_new(name, z, alt_nodes, apriori_prof, apriori_prof_err)   # sic: the first guess
+            latbox = lat_box(lat_limits, lat)                                                   # is not passed on (:409)
+            for cos in one_d.set:
+                self.set.append(RetParam(name, (lat, cos.key), GridMask2D(latbox, cos.maskgrid), cos.apriori, cos.apriori_err))
+
+    def profile(self):
+        """[n_lat, n_alt]: sum of mask x value."""
+        return sum(p.maskgrid * p.value for p in self.set)
+
+    def check_involved(self, parkey, coord_range):
+        """spect_main_module.py:430-447: not involved when the path starts above the next altitude node or lies
+        outside the parameter's latitude box."""
+        i = self.alts.index(parkey[1])
+        involved = i == len(self.alts) - 1 or not coord_range['alt'][0] > self.alts[i + 1]
+        latz = coord_range['lat']
+        j = self.lats.index(parkey[0])
+        if j == len(self.lats) - 1:
+            if latz[1] < parkey[0]:
+                involved = False
+        elif latz[1] < parkey[0] or latz[0] > self.lats[j + 1]:
+            involved = False
+        return involved
+
+
 class BayesSet(object):
     """The full parameter space of a retrieval: ordered RetSets (spect_main_module.py:169-253)."""
 

@@ -537,6 +537,35 @@ def golden_retrieval():
     out["fov_wl"], out["fov_spe"], out["fov_rot"] = wl, spe, np.array([0.0, 20.0, -45.0])
     out["fov_out"] = np.array([smm.FOV_integr_1D([Rad(wl, v) for v in spe], pixel_rot=r).spectrum
                                for r in out["fov_rot"]])
+    # LinearProfile_1D (older constructor, with its unsliced zip) and LinearProfile_2D (alt nodes x lat boxes).
+    # AtmGridMask.merge is in the absent module: the stub below merges as the outer product lat x alt.
+    class Atmo(object):
+        pass
+    atmo = Atmo()
+    atmo.grid = alt_grid
+
+    def merge(self, other):
+        m = AtmGridMask((other.grid, self.grid), np.outer(other.mask, self.mask), {"lat": other.interp, "alt": self.interp})
+        return m
+    AtmGridMask.merge = merge
+    p1 = smm.LinearProfile_1D("CH4", atmo, nodes_a, ap_a, er_a, first_guess_prof=fg_a)
+    out["lp1d_masks"] = np.array([p.maskgrid.mask for p in p1.set])
+    out["lp1d_apriori"] = np.array([p.apriori for p in p1.set])
+    out["lp1d_err"] = np.array([p.apriori_err for p in p1.set])
+    out["lp1d_value"] = np.array([p.value for p in p1.set])
+    lat_lim2 = [-90.0, -30.0, 30.0]
+    aps = [np.array(ap_a) * f for f in (1.0, 1.5, 0.5)]
+    ers = [np.array(er_a) * f for f in (1.0, 1.2, 0.8)]
+    p2 = smm.LinearProfile_2D("CH4", atmo, nodes_a, lat_lim2, aps, ers, first_guess_profs=[np.array(fg_a)] * 3)
+    out["lp2d_lat_limits"] = np.array(lat_lim2)
+    out["lp2d_aps"], out["lp2d_ers"] = np.array(aps), np.array(ers)
+    out["lp2d_masks"] = np.array([p.maskgrid.mask for p in p2.set])
+    out["lp2d_keys"] = np.array([list(p.key) for p in p2.set])
+    out["lp2d_apriori"] = np.array([p.apriori for p in p2.set])
+    out["lp2d_value"] = np.array([p.value for p in p2.set])
+    out["lp2d_involved"] = np.array([[p2.check_involved(p.key, {"alt": (lo, lo + 50.0), "lat": la}) for p in p2.set]
+                                     for lo, la in ((100.0, (-80.0, -70.0)), (320.0, (-40.0, -20.0)), (650.0, (40.0, 50.0)),
+                                                    (850.0, (-10.0, 10.0)))], dtype=bool)
     np.savez_compressed(os.path.join(HERE, "retrieval_classes.npz"), **out)
     print("retrieval: x_after_pos", out["x_after_pos"][:3], "fov", out["fov_out"][:, 0])
 

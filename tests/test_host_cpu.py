@@ -433,3 +433,38 @@ def test_containers_and_lut_planner_vs_reference(golden):
                     ("c", dict(thres=0.5, add_lowpres=False))):
         pt = np.array(smm.calc_PT_couples_atmosphere(lines, iso, A, **kw))
         assert pt.shape == g["pt_" + key].shape and np.array_equal(pt, g["pt_" + key]), key
+
+
+def test_linear_profile_1d_and_2d_vs_reference(golden):
+    """LinearProfile_1D (older constructor: middle nodes take the a priori of the node before them, sic) and
+    LinearProfile_2D (altitude nodes x latitude boxes; masks merged as lat x alt) against the reference's classes."""
+    from spectrobot_amd import spect_main_module as smm
+    g = golden("retrieval_classes")
+
+    class Grid(object):
+        pass
+
+    class Atmo(object):
+        pass
+    atmo = Atmo()
+    atmo.grid = Grid()
+    atmo.grid.grid = [g["alts"]]
+    atmo.grid.coords = {"alt": g["alts"]}
+    p1 = smm.LinearProfile_1D("CH4", atmo, list(g["nodes_a"]), list(g["ap_a"]), list(g["er_a"]), first_guess_prof=list(g["fg_a"]))
+    assert np.array_equal(np.array([p.maskgrid.mask for p in p1.set]), g["lp1d_masks"])
+    assert np.array_equal(np.array([p.apriori for p in p1.set]), g["lp1d_apriori"])
+    assert np.array_equal(np.array([p.apriori_err for p in p1.set]), g["lp1d_err"])
+    assert np.array_equal(np.array([p.value for p in p1.set]), g["lp1d_value"])
+    assert p1.set[2].apriori == g["ap_a"][1]          # the reference's unsliced zip
+    p2 = smm.LinearProfile_2D("CH4", atmo, list(g["nodes_a"]), list(g["lp2d_lat_limits"]), list(g["lp2d_aps"]),
+                              list(g["lp2d_ers"]), first_guess_profs=[g["fg_a"]] * 3)
+    assert p2.n_par == 15 and len(p2.set) == 15
+    assert np.array_equal(np.array([p.maskgrid.mask for p in p2.set]), g["lp2d_masks"])
+    assert np.array_equal(np.array([list(p.key) for p in p2.set]), g["lp2d_keys"])
+    assert np.array_equal(np.array([p.apriori for p in p2.set]), g["lp2d_apriori"])
+    assert np.array_equal(np.array([p.value for p in p2.set]), g["lp2d_value"])
+    inv = np.array([[p2.check_involved(p.key, {"alt": (lo, lo + 50.0), "lat": la}) for p in p2.set]
+                    for lo, la in ((100.0, (-80.0, -70.0)), (320.0, (-40.0, -20.0)), (650.0, (40.0, 50.0)), (850.0, (-10.0, 10.0)))])
+    assert np.array_equal(inv, g["lp2d_involved"])
+    prof = p2.profile()
+    assert prof.shape == (3, len(g["alts"])) and np.allclose(prof[1], sum(m * v for m, v in zip(g["masks_a"], g["lp2d_aps"][1])))
