@@ -12,6 +12,8 @@
 //   sr_radiance_kernel / sr_radiance_jac_kernel   limb recursion (+ Jacobian) per (point, ray)
 //   sr_lowres_kernel    Gaussian ILS onto low-resolution bands (hires_to_lowres)
 //   shims               humliv_bb / sum_all_lines / curgod_fort_N call shapes.
+#include <cstdlib>
+
 #include "sr_device.hpp"
 #include "sr_kernels.hpp"
 
@@ -1355,7 +1357,11 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
 #define SR_ZONES(NW)                                                                                         \
   (cnt ? launch_zones<NW, true>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st) \
        : launch_zones<NW, false>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st))
-    if (waves512 >= 3 * 4096)
+    // SR_ZONES_NW=1|2|4|8 (environment, read once): tuning override of the waves per image
+    static const int nw_env = [] { const char *e = getenv("SR_ZONES_NW"); return e ? atoi(e) : 0; }();
+    if (nw_env == 1 || nw_env == 2 || nw_env == 4 || nw_env == 8) {
+      switch (nw_env) { case 1: SR_ZONES(1); break; case 2: SR_ZONES(2); break; case 4: SR_ZONES(4); break; default: SR_ZONES(8); }
+    } else if (waves512 >= 3 * 4096)
       SR_ZONES(1);
     else if (waves512 >= 3 * 2048)
       SR_ZONES(2);

@@ -23,7 +23,7 @@ def prepare_spe_grid(wn_range, sp_step=5.e-4, units='cm_1'):
     """spect_main_module.py:1262-1272"""
     spoffo = np.arange(wn_range[0], wn_range[1] + sp_step / 2, sp_step, dtype=float)
     spect_grid = spcl.SpectralGrid(spoffo, units=units)
-    return spcl.SpectralObject(np.zeros(len(spect_grid.grid), dtype=float), spect_grid)
+    return spcl.SpectralObject(np.zeros(len(spect_grid.grid), dtype=float), spect_grid, units=units)
 
 
 class AbsSetLOS(object):
@@ -475,7 +475,7 @@ def make_abscoeff_isomolec(wn_range_tot, isomolec, Temps, Press, LTE=True, allLU
         if store_in_memory:
             aset.prepare_export()
         for row in host:
-            obj = spcl.SpectralObject(row, spectral_grid, link_grid=True)
+            obj = spcl.SpectralObject(row, spectral_grid, units='cm_1', link_grid=True)   # as prepare_spe_grid, :2039
             aset.add_dump(obj) if store_in_memory else aset.add_set(obj)
         if store_in_memory:
             aset.finalize_IO()
