@@ -44,7 +44,14 @@ def main():
     # 1. the (P, T) couples the atmosphere needs, and the table
     class Atm(object):
         pres, temp = atm["press"], atm["temps"]
-    PT = smm.calc_PT_couples_atmosphere(lines, iso, Atm, pres_step_log=1.0, temp_step=5.0)
+    planned = smm.calc_PT_couples_atmosphere(lines, iso, Atm, pres_step_log=1.0, temp_step=5.0)
+    print("calc_PT_couples_atmosphere: %d couples for this atmosphere" % len(planned))
+    # a rectangular table here: LutSet.calculate takes the two nearest temperatures of the WHOLE table at the two
+    # nearest pressures (nearest in P, not log P) and raises when such a couple is not tabulated
+    # (spect_main_module.py:985-995) -- as the reference does on a ragged table
+    Ps = np.exp(np.arange(np.floor(np.log(atm["press"].min())), np.log(atm["press"].max()) + 1.0, 1.0))
+    Ts = np.arange(5.0 * np.floor(atm["temps"].min() / 5.0) - 5.0, atm["temps"].max() + 10.0, 5.0)
+    PT = [[float(P), float(T)] for P in Ps for T in Ts]
     t0 = time.time()
     lut = smm.LookUpTable(iso, [grid[0], grid[-1]], LTE=False)
     lut.make(sg, lines, PT)
