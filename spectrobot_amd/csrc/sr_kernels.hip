@@ -1768,11 +1768,17 @@ int launch_limb_jac(const double *abs_c, const double *emi_c, int n_pts, int n_l
                     const int *seg_layer, const double *col, const double *dcol, const int *par_gas, int n_par,
                     const LimbOpts &o, double *rad, double *jac, hipStream_t st) {
   if (n_pts <= 0 || n_rays <= 0 || n_par <= 0) return 0;
-  constexpr int NP = 4;
-  const dim3 grid((n_pts + 255) / 256, n_rays, (n_par + NP - 1) / NP);
-#define SR_L(NG) hipLaunchKernelGGL((sr_limb_jac_kernel<NG, NP>), grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, \
-                                    seg_off, seg_layer, col, dcol, par_gas, n_par, o, rad, jac)
-  SR_BY_NGAS(o.n_gas, SR_L(1), SR_L(2), SR_L(3), SR_L(4))
+  // Every block of NP parameters repeats the recursion (exp, expm1, the coefficient loads): with many parameters
+  // (configs[3]: one per layer) 16 per thread instead of 4 cut the kernel's instructions 3.4x (160 segments x
+  // (60 + NP) per block of NP).
+#define SR_L(NG, NP) hipLaunchKernelGGL((sr_limb_jac_kernel<NG, NP>), dim3((n_pts + 255) / 256, n_rays, (n_par + NP - 1) / NP), \
+                                        dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, seg_off, seg_layer, col, dcol,      \
+                                        par_gas, n_par, o, rad, jac)
+  if (n_par > 8) {
+    SR_BY_NGAS(o.n_gas, SR_L(1, 16), SR_L(2, 16), SR_L(3, 16), SR_L(4, 16))
+  } else {
+    SR_BY_NGAS(o.n_gas, SR_L(1, 4), SR_L(2, 4), SR_L(3, 4), SR_L(4, 4))
+  }
 #undef SR_L
   return (int)hipGetLastError();
 }
@@ -1781,11 +1787,13 @@ int launch_limb_jac_layer(const double *abs_c, const double *emi_c, const double
                           int n_layers, int n_rays, const int *seg_off, const int *seg_layer, const double *col,
                           const LimbOpts &o, double *jac, hipStream_t st) {
   if (n_pts <= 0 || n_rays <= 0 || n_layers <= 0) return 0;
-  constexpr int NP = 4;
-  const dim3 grid((n_pts + 255) / 256, n_rays, (n_layers + NP - 1) / NP);
-#define SR_L(NG) hipLaunchKernelGGL((sr_limb_jac_layer_kernel<NG, NP>), grid, dim3(256), 0, st, abs_c, emi_c, dabs, demi, \
-                                    n_pts, n_layers, seg_off, seg_layer, col, o, jac)
-  SR_BY_NGAS(o.n_gas, SR_L(1), SR_L(2), SR_L(3), SR_L(4))
+#define SR_L(NG, NP) hipLaunchKernelGGL((sr_limb_jac_layer_kernel<NG, NP>), dim3((n_pts + 255) / 256, n_rays, (n_layers + NP - 1) / NP), \
+                                        dim3(256), 0, st, abs_c, emi_c, dabs, demi, n_pts, n_layers, seg_off, seg_layer, col, o, jac)
+  if (n_layers > 8) { // see launch_limb_jac
+    SR_BY_NGAS(o.n_gas, SR_L(1, 16), SR_L(2, 16), SR_L(3, 16), SR_L(4, 16))
+  } else {
+    SR_BY_NGAS(o.n_gas, SR_L(1, 4), SR_L(2, 4), SR_L(3, 4), SR_L(4, 4))
+  }
 #undef SR_L
   return (int)hipGetLastError();
 }
