@@ -1067,10 +1067,9 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   }
 }
 
-// Region-3/4 points waiting for evaluation, one per lane.  The core runs of consecutive lines are
-// packed into full 64-lane chunks (a line's own runs would leave the last chunk of each partly
-// empty: 57 % lane use before); a chunk can hold points of several lines at the same grid index,
-// hence the LDS atomics (same wave, program order: the sums stay deterministic).
+// One region-3/4 point of a line: the point's window index and the line's data, per lane.  Several lines can
+// hit the same grid point in one step, hence LDS atomics (one wave per image, program order: the sums stay
+// deterministic).
 struct CorePend {
   int k, base; // window index; idx in the image = k + base
   double gc, x0, dwp, inv_dwp, ryf, wa, we;
@@ -1089,37 +1088,11 @@ __device__ inline void core_eval(const CorePend &P, bool on, const GridParams &g
     atomicAdd(&s_e[idx], P.we * y);
   }
 }
-// append the points [a0, a0+na) and [b0, b0+nb) of one line; fill is wave-uniform
-template <int REGION>
-__device__ inline void core_push(CorePend &P, int &fill, int lane, int a0, int na, int b0, int nb, int base,
-                                 double gc, const ColdRec &z, double wa, double we, const GridParams &gp,
-                                 double *s_a, double *s_e) {
-  const int n = na + nb;
-  for (int done = 0; done < n;) {
-    const int m = min(64 - fill, n - done);
-    const int t = done + lane - fill;
-    if (lane >= fill && lane < fill + m) {
-      P.k = t < na ? a0 + t : b0 + (t - na);
-      P.base = base;
-      P.gc = gc;
-      P.x0 = z.x0;
-      P.dwp = z.dwp;
-      P.inv_dwp = z.inv_dwp;
-      P.ryf = z.ryf;
-      P.wa = wa;
-      P.we = we;
-    }
-    fill += m;
-    done += m;
-    if (fill == 64) {
-      core_eval<REGION>(P, true, gp, s_a, s_e);
-      fill = 0;
-    }
-  }
-}
-
 // WT points per wave (a multiple of 64): the wider the image, the fewer zones are cut in two by
 // its ends (a zone is ~280 points), i.e. the fewer partially filled lane runs.
+#ifndef SR_ZONES_ROW
+#define SR_ZONES_ROW 8 // lanes per row of the region-2 / region-4 walk: eight lines at a time (16: 4.35, 8: 4.1, 4: 4.87, 32: 5.09 ms)
+#endif
 #ifndef SR_ZONES_WAVES_PER_EU
 #define SR_ZONES_ATTR
 #else
@@ -1143,11 +1116,6 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
   const int zm = min(zmax[layer], kHalf - 1);
 #pragma unroll
   for (int p = 0; p < WT / 64; ++p) s_a[lane + 64 * p] = s_e[lane + 64 * p] = 0.;
-  CorePend p4;
-  p4.k = 1;
-  p4.base = 0;
-  p4.gc = p4.x0 = p4.dwp = p4.inv_dwp = p4.ryf = p4.wa = p4.we = 0.;
-  int fill4 = 0;
   unsigned n_r2 = 0, n_r3 = 0, n_r4 = 0; // COUNT: evaluations of this lane per region
   // lines whose zone [ic - zm, ic + zm] can meet the group
   const int l0 = lower_bound_ic(ix, wlo - zm), l1 = lower_bound_ic(ix, whi + zm + 1);
@@ -1217,56 +1185,83 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         }
       }
     }
-    unsigned long long todo = __ballot(act);
-    while (todo) {
-      const int i = __builtin_ctzll(todo);
-      todo &= todo - 1;
-      const FastRec r = frow[base + i];
-      const ColdRec z = crow[base + i];
-      const int j1 = r.j1, il = r.il(), ir2 = z.ir2();
-      const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
-      const double wa = r.wabs, we = r.wemi;
-      const int base_idx = j1 - 1 - wlo;
-      // ---- region 2: the left then the right run as one run of consecutive lanes (lanes = lines was
-      // tried for it too: 300 ds_add_f64 per 64 lines at scattered addresses cost more than the
-      // chunks' idle lanes)
-      {
-        const unsigned ul = __builtin_amdgcn_readlane(run2l, i), ur = __builtin_amdgcn_readlane(run2r, i);
+    // ---- regions 2 and 4, kRows lines at a time: each row of kRowLanes lanes walks the points of ONE line,
+    // kRowLanes per step, with the line's data in its own registers (per-lane loads of the record fields: the four
+    // rows read four records).  History: one line at a time with 64 points per step left the last chunk of each
+    // run mostly empty (a line has ~150 region-2 and ~72 region-4 points: 64 + 64 + 22 lanes, 71-78 % lane use)
+    // and cost a scalar record fetch + ~40 scalar / vector instructions per line; packing region-4 points of
+    // consecutive lines into full chunks fixed its lane use but not the per-line walk.  Rows: lane use 90-94 %, no
+    // scalar walk, no pending state: sr_abscoeff_near_zones_kernel 4.9 -> 4.2 ms on config 2.
+    {
+      constexpr int kRowLanes = SR_ZONES_ROW, kRows = 64 / kRowLanes;
+      const int row = lane / kRowLanes, col = lane % kRowLanes;
+      // this lane's line of the next kRows lines in `todo` (index into the chunk), -1 when there is none left
+      auto take = [&](unsigned long long &todo) {
+        int li = -1;
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+          if (todo) {
+            const int i = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            li = row == q ? i : li;
+          }
+        }
+        return li;
+      };
+      // region 2 (lineshape.f:503-522): item t of a line: left k = a0 + t, x = xs2l - (k - il) xstep; right
+      // k = b0 + (t - na), x = xs2r + (k - ir2) xstep.  Only x^2 enters, so both are t xstep + c with a per-line c.
+      for (unsigned long long todo = __ballot(act && ((run2l >> 16) + (run2r >> 16)) > 0); todo;) {
+        const int li = take(todo), ls_ = max(li, 0);
+        const FastRec &r = frow[base + ls_];
+        const ColdRec &z = crow[base + ls_];
+        const unsigned ul = (unsigned)__shfl((int)run2l, ls_), ur = (unsigned)__shfl((int)run2r, ls_);
         const int a0 = (int)(ul & 0xffffu), na = (int)(ul >> 16), b0 = (int)(ur & 0xffffu), nb = (int)(ur >> 16);
-        // item t of the run: left k = a0 + t, x = xs2l - (k - il) xstep; right k = b0 + (t - na),
-        // x = xs2r + (k - ir2) xstep.  Only x^2 enters, so both are t xstep + c with a per-line c
-        const double c_left = fma((double)(a0 - il), r.xstep, -z.xs2l);
-        const double c_right = fma((double)(b0 - na - ir2), r.xstep, z.xs2r);
+        const int n = li >= 0 ? na + nb : 0;
+        const double xstep = r.xstep, wa = r.wabs, we = r.wemi;
+        double q2[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) q2[q] = z.q2[q];
+        const int base_idx = r.j1 - 1 - wlo;
+        const double c_left = fma((double)(a0 - r.il()), xstep, -z.xs2l);
+        const double c_right = fma((double)(b0 - na - z.ir2()), xstep, z.xs2r);
         const int i_left = a0 + base_idx, i_right = b0 - na + base_idx;
-        for (int t0 = 0; t0 < na + nb; t0 += 64) {
-          const int t = t0 + lane;
-          if (t < na + nb) {
+        for (int t = col; __any(t < n); t += kRowLanes) {
+          if (t < n) {
             const bool lf = t < na;
-            const double y = region2_val(z.q2, fma((double)t, r.xstep, lf ? c_left : c_right));
+            const double y = region2_val(q2, fma((double)t, xstep, lf ? c_left : c_right));
             if (COUNT) ++n_r2;
             const int idx = t + (lf ? i_left : i_right);
-#ifdef SR_ZONES_R2_RMW
-            s_a[idx] = fma(wa, y, s_a[idx]);
-            s_e[idx] = fma(we, y, s_e[idx]);
-#else
-            // return-less LDS adds instead of read - fma - write: no wait for the read, and consecutive lines of
-            // the walk, whose runs overlap, no longer serialise on it (one wave per image: the order stays fixed)
-            atomicAdd(&s_a[idx], wa * y);
+            atomicAdd(&s_a[idx], wa * y); // return-less LDS adds: no wait for a read, runs of different lines overlap
             atomicAdd(&s_e[idx], we * y);
-#endif
           }
         }
       }
-      // ---- region 4: its points join the pending chunk (evaluated whenever 64 are waiting)
-      {
-        const unsigned ul = __builtin_amdgcn_readlane(run4l, i), ur = __builtin_amdgcn_readlane(run4r, i);
-        if (COUNT && lane == 0) n_r4 += (ul >> 16) + (ur >> 16);
-        core_push<4>(p4, fill4, lane, (int)(ul & 0xffffu), (int)(ul >> 16), (int)(ur & 0xffffu), (int)(ur >> 16),
-                     base_idx, xf.gc, z, wa, we, gp, s_a, s_e);
+      // region 4 (lineshape.f:530-546), on both sides of the region-3 interval
+      for (unsigned long long todo = __ballot(act && ((run4l >> 16) + (run4r >> 16)) > 0); todo;) {
+        const int li = take(todo), ls_ = max(li, 0);
+        const FastRec &r = frow[base + ls_];
+        const ColdRec &z = crow[base + ls_];
+        const unsigned ul = (unsigned)__shfl((int)run4l, ls_), ur = (unsigned)__shfl((int)run4r, ls_);
+        const int a0 = (int)(ul & 0xffffu), na = (int)(ul >> 16), b0 = (int)(ur & 0xffffu), nb = (int)(ur >> 16);
+        const int n = li >= 0 ? na + nb : 0;
+        const int j1 = r.j1;
+        CorePend P;
+        P.base = j1 - 1 - wlo;
+        P.gc = grid_at(gp, j1 + kHalf);
+        P.x0 = z.x0;
+        P.dwp = z.dwp;
+        P.inv_dwp = z.inv_dwp;
+        P.ryf = z.ryf;
+        P.wa = r.wabs;
+        P.we = r.wemi;
+        for (int t = col; __any(t < n); t += kRowLanes) {
+          P.k = t < na ? a0 + t : b0 + (t - na);
+          if (COUNT) n_r4 += t < n;
+          core_eval<4>(P, t < n, gp, s_a, s_e);
+        }
       }
     }
   }
-  core_eval<4>(p4, lane < fill4, gp, s_a, s_e); // what is still waiting
   if (COUNT) {
     count_add(cnt, kCntRegion2, n_r2, lane);
     count_add(cnt, kCntRegion3, n_r3, lane);
