@@ -856,213 +856,165 @@ __device__ inline void window_end_sum(bool ends, int pos, double c[2 * kWE], int
   out_e += pe;
 }
 
-// NS slots of 64 points per wave: 4 (two groups of 4 per wave measured slower: occupancy, SGPR
-// spills), or 2 for small shards, where 4 leave wave slots empty and a wave's own latency is the
-// kernel time.  The walk is per SLOT: a ballot per slot and kind, and a loop body without flag tests --
-// the shared scalar unit is what bounds this kernel (walking the lines once with per-slot flag
-// tests and a record prefetch cost 117 scalar instructions per line against 100 vector ones).
-template <int NS, bool COUNT>
+// One 64-point slot per wave (4 or 2 slots per wave measured slower: 2.53 / 2.31 ms on config 2 at the time).
+// Per chunk of 64 candidate lines (lane = line): which lines have region-1 points in the slot that no far-field
+// level owns; window ends / starts by expansion and scan; the rest in ROWS: eight lines at a time, each row of 8
+// lanes evaluates ONE line at 8 points per step (8 steps cover the slot), the line's record in the row's registers
+// by per-lane loads.  Before, every such line cost a scalar record fetch, a ballot walk and four specialised masked
+// loops: the walk took 0.87 of the kernel's 1.34 ms for 0.27 ms worth of vector work.
+template <bool COUNT>
 __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
     const FastRec *__restrict__ fast, IcIndex ix, const int *__restrict__ zmax, int n_sub,
     int n_tiles, int g_lo, int g_hi, FarParams fp, int add, double *__restrict__ abs_out,
     double *__restrict__ emi_out, unsigned long long *__restrict__ cnt) {
-  constexpr int WT = 64 * NS;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
-  const int wlo = g_lo + tile * WT;
-  const int whi = min(wlo + WT, g_hi) - 1;
+  const int wlo = g_lo + tile * 64;
+  const int whi = min(wlo + 64, g_hi) - 1;
   const int lane = threadIdx.x;
   const int pm = fp.pm[layer];
   const int thr0 = ff_thr2(0, pm);
   int rs[3], re[3];
-  near_ranges(ix, wlo, WT, min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1), rs, re);
+  near_ranges(ix, wlo, 64, min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1), rs, re);
 
-  double acc_a[NS], acc_e[NS], fl[4];
+  constexpr int kRowLanes = 8, kRows = 8;
+  const int row = lane / kRowLanes, col = lane % kRowLanes;
+  double sum_a = 0., sum_e = 0.; // this lane's point wlo + lane: window ends, polynomials, and the rows' total
+  double ra[kRows], rb[kRows];    // rows: partial sums (abs, emi) of point wlo + col + 8 s over the lines of this lane's row
 #pragma unroll
-  for (int p = 0; p < NS; ++p) acc_a[p] = acc_e[p] = 0.;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) fl[p] = (double)(lane + 64 * p);
-  int lp[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) lp[p] = lane + 64 * p;
+  for (int q = 0; q < kRows; ++q) ra[q] = rb[q] = 0.;
   const FastRec *frow = fast + (size_t)layer * n_sub;
   unsigned n_r1 = 0, n_we = 0; // COUNT: region-1 evaluations of this lane, window-end expansions
   for (int rg = 0; rg < 3; ++rg) {
     for (int base = rs[rg]; base < re[rg]; base += 64) {
       const int lv = base + lane;
-      // bits 0-3: slot lies wholly in one wing; bit 4: all four do, same wing.  Slots that also hold
-      // zone points, a window end or the grid end have region-1 points on one side only (bits 5-8
-      // left wing, 9-12 right wing) unless a zone narrower than the slot lies inside it (13-16)
-      int flags = 0;
+      // lane = line: does the line have region-1 points in this slot that no far-field level owns, and are they
+      // cut by the window end / start only (then it can join the expansion + scan below)
+      bool need = false, fastl = false;
+      int pos = 64; // lanes without a line: never selected by the scan
       if (lv < re[rg]) {
         const int j1 = frow[lv].j1;
         const unsigned ilir = frow[lv].ilir;
         const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
-#pragma unroll
-        for (int p = 0; p < NS; ++p) {
-          const int slo = wlo + 64 * p, shi = min(slo + 63, whi);
-          if (slo <= whi && jN >= slo && j1 <= shi && !ff_admissible(j1, il, ir, slo, slo + 63, thr0)) {
-            if (classify(j1, il, ir, slo, shi) != 0) {
-              flags |= 1 << p;
-            } else {
-              const bool has_l = max(slo, j1) <= min(shi, j1 + il - 2); // points with 1 <= k < il
-              const bool has_r = max(slo, j1 + ir) <= min(shi, jN);     // points with ir < k <= 13010
-              flags |= (has_l && has_r ? 8192 : (has_l ? 32 : (has_r ? 512 : 0))) << p;
-            }
-          }
+        // cut-off position of the scan: every line of the range takes part in it (the positions are
+        // non-decreasing over the lanes), lines handled elsewhere with zero coefficients
+        pos = rg == 0 ? min(max(jN - wlo, -1), 64) : min(max(j1 - wlo, 0), 64);
+        if (jN >= wlo && j1 <= whi && !ff_admissible(j1, il, ir, wlo, wlo + 63, thr0)) {
+          const bool has_l = max(wlo, j1) <= min(whi, j1 + il - 2); // points with 1 <= k < il
+          const bool has_r = max(wlo, j1 + ir) <= min(whi, jN);     // points with ir < k <= 13010
+          need = has_l || has_r;
+          if (rg != 1 && classify(j1, il, ir, wlo, whi) == 0)
+            fastl = rg == 0 ? (has_r && !has_l && j1 + ir <= wlo) : (has_l && !has_r && j1 + il - 2 >= wlo + 63);
         }
-        if (NS == 4 && flags == 15 && classify(j1, il, ir, wlo, whi) != 0) flags = 16;
       }
-      if (__ballot(flags != 0) == 0) continue;
-      if constexpr (NS == 1) {
-        // window ends (range 0) / starts (range 2) of this slot, when there are enough of them
-        if (rg != 1) {
-          const bool ends = rg == 0;
-          bool fastl = false;
-          int pos = ends ? 64 : 64; // lanes without a line: never selected
+      if (__ballot(need) == 0) continue;
+      // window ends (range 0) / starts (range 2) of this slot, when there are enough of them
+      if (rg != 1) {
+        const bool ends = rg == 0;
+        const unsigned long long fm = __ballot(fastl);
+        if (__builtin_popcountll(fm) >= 12) {
           double c[2 * kWE];
 #pragma unroll
           for (int n = 0; n < 2 * kWE; ++n) c[n] = 0.;
-          if (lv < re[rg]) {
-            const int j1 = frow[lv].j1;
-            const unsigned ilir = frow[lv].ilir;
-            const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
-            // the slot's region-1 points are cut by the window end (and the grid end) only, not by the zone
-            fastl = ends ? (flags == 512 && j1 + ir <= wlo) : (flags == 32 && j1 + il - 2 >= wlo + 63);
-            pos = ends ? min(max(jN - wlo, -1), 64) : min(max(j1 - wlo, 0), 64);
-          }
-          const unsigned long long fm = __ballot(fastl);
-          if (__builtin_popcountll(fm) >= 12) {
-            if (fastl) {
-              const FastRec r = frow[lv];
-              // -x (starts: left wing) or x (ends: right wing) at the slot centre wlo + 31.5
-              const double xc = ends ? fma(0.5 * (double)(2 * (wlo - (r.j1 + r.ir() - 1)) + 63), r.xstep, r.xr)
-                                     : fma(0.5 * (double)(2 * (wlo - r.j1) + 63), r.xstep, -r.xl);
-              double f[kWE];
-              wing_series6(xc, 32.0 * r.xstep, r, f);
-              if (COUNT) ++n_we;
+          if (fastl) {
+            const FastRec r = frow[lv];
+            // -x (starts: left wing) or x (ends: right wing) at the slot centre wlo + 31.5
+            const double xc = ends ? fma(0.5 * (double)(2 * (wlo - (r.j1 + r.ir() - 1)) + 63), r.xstep, r.xr)
+                                   : fma(0.5 * (double)(2 * (wlo - r.j1) + 63), r.xstep, -r.xl);
+            double f[kWE];
+            wing_series6(xc, 32.0 * r.xstep, r, f);
+            if (COUNT) ++n_we;
 #pragma unroll
-              for (int n = 0; n < kWE; ++n) {
-                c[n] = r.wabs * f[n];
-                c[kWE + n] = r.wemi * f[n];
-              }
-              flags = 0; // done here
+            for (int n = 0; n < kWE; ++n) {
+              c[n] = r.wabs * f[n];
+              c[kWE + n] = r.wemi * f[n];
             }
-            window_end_sum(ends, pos, c, lane, acc_a[0], acc_e[0]);
-            if (__ballot(flags != 0) == 0) continue;
+            need = false; // done here
+          }
+          window_end_sum(ends, pos, c, lane, sum_a, sum_e);
+          if (__ballot(need) == 0) continue;
+        }
+      }
+      // rows: region 1 is k < il (running x from k = 1: x = (k - 1) xstep - xl, i.e. -x) or k > ir
+      // (x = (k - ir) xstep + xr), inside the window and the grid (lineshape.f:461-477, last writer wins)
+      for (unsigned long long todo = __ballot(need); todo;) {
+        int li = -1;
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+          if (todo) {
+            const int i = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            li = row == q ? i : li;
           }
         }
-      }
-      // four whole slots in one wing: shared reciprocal
-      if constexpr (NS == 4) {
-        for (unsigned long long todo = __ballot(flags == 16); todo; todo &= todo - 1) {
-          const FastRec r = frow[base + __builtin_ctzll(todo)];
-          const int cls = wlo < r.j1 + kHalf ? 1 : 2; // the group lies before / after the line centre
-          wing_eval4(wing_x_at(r, cls, r.j1, wlo), r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl, acc_a, acc_e);
-          if (COUNT) n_r1 += 4;
-        }
-      }
+        const FastRec &r = frow[base + max(li, 0)];
+        const double xl = r.xl, xr = r.xr, xstep = r.xstep, a = r.a, b = r.b, c = r.c, d = r.d;
+        const double wa = li >= 0 ? r.wabs : 0.0, we = li >= 0 ? r.wemi : 0.0;
+        const int j1 = r.j1, il = r.il(), ir = r.ir();
+        const int k0 = wlo + col - j1 + 1; // window index of this lane's first point
+        const int k_last = min(kImxsig, whi - j1 + 1);
 #pragma unroll
-      for (int p = 0; p < NS; ++p) {
-        const int slo = wlo + 64 * p;
-        // whole slot in one wing
-        for (unsigned long long todo = __ballot((flags & (1 << p)) != 0); todo; todo &= todo - 1) {
-          const FastRec r = frow[base + __builtin_ctzll(todo)];
-          const double xb = wing_x_at(r, slo < r.j1 + kHalf ? 1 : 2, r.j1, slo);
-          const double x = fma(fl[0], r.xstep, xb);
+        for (int q = 0; q < kRows; ++q) {
+          const int k = k0 + kRowLanes * q;
+          const bool left = k < il;
+          const double x = fma((double)(k - (left ? 1 : ir)), xstep, left ? -xl : xr);
           const double x2 = x * x;
-          const double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
-          acc_a[p] = fma(r.wabs, y, acc_a[p]);
-          acc_e[p] = fma(r.wemi, y, acc_e[p]);
-          if (COUNT) ++n_r1;
-        }
-        // left-wing points only, k in [1, min(il - 1, end of the group)]: x = (k - 1) xstep - xl (= -x)
-        for (unsigned long long todo = __ballot((flags & (32 << p)) != 0); todo; todo &= todo - 1) {
-          const FastRec r = frow[base + __builtin_ctzll(todo)];
-          const int km1 = lp[p] + (wlo - r.j1); // k - 1
-          const double x = fma((double)km1, r.xstep, -r.xl);
-          const double x2 = x * x;
-          double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma3s(x2, fma3s(x2, 4.0, r.d), r.c));
-          const bool on = (unsigned)km1 <= (unsigned)(min(r.il() - 1, whi - r.j1 + 1) - 1);
-          y = on ? y : 0.0;
-          if (COUNT) n_r1 += on;
-          acc_a[p] = fma(r.wabs, y, acc_a[p]);
-          acc_e[p] = fma(r.wemi, y, acc_e[p]);
-        }
-        // right-wing points only, k in [ir + 1, min(13010, end of the group)]: x = (k - ir) xstep + xr
-        for (unsigned long long todo = __ballot((flags & (512 << p)) != 0); todo; todo &= todo - 1) {
-          const FastRec r = frow[base + __builtin_ctzll(todo)];
-          const int ir = r.ir();
-          const int kmr = lp[p] + (wlo - r.j1 + 1 - ir); // k - ir
-          const double x = fma((double)kmr, r.xstep, r.xr);
-          const double x2 = x * x;
-          double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma3s(x2, fma3s(x2, 4.0, r.d), r.c));
-          const bool on = (unsigned)(kmr - 1) <= (unsigned)(min(kImxsig, whi - r.j1 + 1) - ir - 1);
-          y = on ? y : 0.0;
-          if (COUNT) n_r1 += on;
-          acc_a[p] = fma(r.wabs, y, acc_a[p]);
-          acc_e[p] = fma(r.wemi, y, acc_e[p]);
-        }
-        // both wings in one slot (a zone narrower than the slot): per-lane side
-        for (unsigned long long todo = __ballot((flags & (8192 << p)) != 0); todo; todo &= todo - 1) {
-          const FastRec r = frow[base + __builtin_ctzll(todo)];
-          const int j1 = r.j1, il = r.il(), ir = r.ir();
-          const int klo = max(1, wlo - j1 + 1), khi = min(kImxsig, whi - j1 + 1); // window and group, as k
-          const int k = lp[p] + (wlo - j1 + 1);                                   // 1-based window index
-          const bool left = k < il; // region 1: k < il or k > ir (lineshape.f:461-477, last writer wins)
-          const double x = fma((double)(k - (left ? 1 : ir)), r.xstep, left ? -r.xl : r.xr);
-          const double x2 = x * x;
-          double y = fma(x2, r.b, r.a) * fast_rcp<1>(fma3s(x2, fma3s(x2, 4.0, r.d), r.c));
-          const bool on = ((unsigned)(k - klo) <= (unsigned)(khi - klo)) & ((unsigned)(k - il) > (unsigned)(ir - il));
-          y = on ? y : 0.0;
-          if (COUNT) n_r1 += on;
-          acc_a[p] = fma(r.wabs, y, acc_a[p]);
-          acc_e[p] = fma(r.wemi, y, acc_e[p]);
+          // the select compiles to a branch per step, which skips the steps no lane of the wave needs;
+          // evaluating all eight and selecting afterwards measured 13% slower (1.41 vs 1.25 ms)
+          const bool on = ((unsigned)(k - 1) < (unsigned)k_last) & ((unsigned)(k - il) > (unsigned)(ir - il));
+          const double y = on ? fma(x2, b, a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, d), c)) : 0.0;
+          if (COUNT) n_r1 += on && li >= 0;
+          ra[q] = fma(wa, y, ra[q]);
+          rb[q] = fma(we, y, rb[q]);
         }
       }
+    }
+  }
+  // totals of the rows: point wlo + lane is (col, step) = (lane % 8, lane / 8): sum over the eight rows of that step
+#pragma unroll
+  for (int q = 0; q < kRows; ++q) {
+    double ta = ra[q], te = rb[q];
+#pragma unroll
+    for (int m = kRowLanes; m < 64; m <<= 1) {
+      ta += __shfl_xor(ta, m);
+      te += __shfl_xor(te, m);
+    }
+    if (row == q) {
+      sum_a += ta;
+      sum_e += te;
     }
   }
   if (COUNT) {
     count_add(cnt, kCntRegion1, n_r1, lane);
     count_add(cnt, kCntWindowEnds, n_we, lane);
-    unsigned n_poly = 0;
-    for (int p = 0; p < NS; ++p) n_poly += (wlo + 64 * p + lane <= whi) ? (unsigned)fp.n_levels : 0u;
-    count_add(cnt, kCntPolyPoints, n_poly, lane);
+    count_add(cnt, kCntPolyPoints, (wlo + lane <= whi) ? (unsigned)fp.n_levels : 0u, lane);
   }
-  // far field: one polynomial per level and slot
+  // far field: one polynomial per level
   const double *cl = fp.coef + (size_t)layer * fp.n_boxes_total * (2 * kFC);
+  for (int lv = 0; lv < fp.n_levels; ++lv) {
+    const int W = 64 << lv;
+    const int b = (wlo - g_lo) >> (6 + lv);
+    const int blo = g_lo + b * W;
+    const double t = (double)(2 * (wlo + lane - blo) - (W - 1)) * (1.0 / 64 / (double)(1 << lv)); // exact: W = 2^(6+lv)
+    const double *c = cl + (size_t)(fp.box_off[lv] + b) * (2 * kFC);
+    double pa = c[kFC - 1], pe = c[2 * kFC - 1];
 #pragma unroll
-  for (int p = 0; p < NS; ++p) {
-    const int slo = wlo + 64 * p;
-    if (slo > whi) continue;
-    for (int lv = 0; lv < fp.n_levels; ++lv) {
-      const int W = 64 << lv;
-      const int b = (slo - g_lo) >> (6 + lv);
-      const int blo = g_lo + b * W;
-      const double t = (double)(2 * (slo + lane - blo) - (W - 1)) * (1.0 / 64 / (double)(1 << lv)); // exact: W = 2^(6+lv)
-      const double *c = cl + (size_t)(fp.box_off[lv] + b) * (2 * kFC);
-      double pa = c[kFC - 1], pe = c[2 * kFC - 1];
-#pragma unroll
-      for (int n = kFC - 2; n >= 0; --n) {
-        pa = fma3s(pa, t, c[n]);
-        pe = fma3s(pe, t, c[kFC + n]);
-      }
-      acc_a[p] += pa;
-      acc_e[p] += pe;
+    for (int n = kFC - 2; n >= 0; --n) {
+      pa = fma3s(pa, t, c[n]);
+      pe = fma3s(pe, t, c[kFC + n]);
     }
+    sum_a += pa;
+    sum_e += pe;
   }
-  const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
-#pragma unroll
-  for (int p = 0; p < NS; ++p) {
-    const int j = wlo + lane + 64 * p;
-    if (j <= whi) {
-      if (add) { // the zones kernel ran first (overlapped with the far-field kernel) and stored its sums
-        abs_out[row + (j - g_lo)] += acc_a[p];
-        emi_out[row + (j - g_lo)] += acc_e[p];
-      } else {
-        abs_out[row + (j - g_lo)] = acc_a[p];
-        emi_out[row + (j - g_lo)] = acc_e[p];
-      }
+  const size_t orow = (size_t)layer * (size_t)(g_hi - g_lo);
+  const int j = wlo + lane;
+  if (j <= whi) {
+    if (add) { // the zones kernel ran first (overlapped with the far-field kernel) and stored its sums
+      abs_out[orow + (j - g_lo)] += sum_a;
+      emi_out[orow + (j - g_lo)] += sum_e;
+    } else {
+      abs_out[orow + (j - g_lo)] = sum_a;
+      emi_out[orow + (j - g_lo)] = sum_e;
     }
   }
 }
@@ -1337,10 +1289,10 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
     // slots per wave: 4 (256-point groups) measured 2.53 ms on config 2, 2: 2.31 ms, 1: see DESIGN.md
     const int n_g1 = (g_hi - g_lo + 63) / 64;
     if (cnt)
-      hipLaunchKernelGGL((sr_abscoeff_near_wings_kernel<1, true>), dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
+      hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<true>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
                          fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, abs_out, emi_out, cnt);
     else
-      hipLaunchKernelGGL((sr_abscoeff_near_wings_kernel<1, false>), dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
+      hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<false>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
                          fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, abs_out, emi_out, cnt);
   } else {
     // Image width: wider images cut fewer zones in two (fewer (line, group) pairs: 7.1 -> 6.7 ms on
