@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -185,7 +187,7 @@ struct HostLines {
 // Process-wide mode switches (sr_set_*).  Atomic: a call reads each ONCE at entry and works with that
 // snapshot, so flipping a switch from another thread never changes a call half way.
 std::atomic<int> g_variant{8};   // points per lane in the exact wings kernel
-std::atomic<int> g_far_field{1}; // 1: far wings by local expansions (default), 0: every evaluation exact
+std::atomic<int> g_far_field{1}; // 1: far wings by per-line local expansions, 2: by box pairs (multipole -> local), 0: every evaluation exact
 std::atomic<int> g_overlap{1};   // 1 (default), 2: zones kernel on a second stream beside the far-field kernel, next call's prep pipelined (2: gated behind FF+zones; measured equal)
 std::atomic<int> g_counting{0};  // 1: counting instantiations of the far-field-mode kernels (sr_set_counting)
 std::atomic<size_t> g_table_budget{(size_t)48 << 30}; // bytes of FastRec + ColdRec tables per layer batch
@@ -208,12 +210,13 @@ struct sr_lineset {
   std::vector<double> e_lev;
   std::vector<int> ic; // host copy, sorted
   double freq_max = 0.0;
+  double gamma_max = 0.0, ndep_min = 0.0, ndep_max = 0.0; // air broadening / its temperature exponent over the lines
   DevBuf d_lines;      // one allocation, carved below
   LinesDev L{};
   // [2]: with sr_set_overlap(1) the tables of call c+1 are prepared (on prep_st) while the kernels
   // of call c still read theirs
   Stager s_layers[2];
-  DevBuf d_fast[2], d_cold[2], d_zmax[2], d_coef, d_first, d_zone;
+  DevBuf d_fast[2], d_cold[2], d_zmax[2], d_coef, d_first, d_zone, d_mom;
   int first_x0 = 0, first_n = 0; // IcIndex table domain
   hipStream_t aux = nullptr;     // second stream: zones kernel beside the far-field kernel
   hipStream_t prep_st = nullptr; // third stream: staging copy + sr_prep_kernel of the NEXT call
@@ -287,7 +290,7 @@ int sr_set_table_budget(int64_t bytes) {
 }
 
 int sr_set_far_field(int on) {
-  g_far_field.store(on ? 1 : 0);
+  g_far_field.store(on < 0 ? 0 : (on > 2 ? 2 : on));
   return SR_OK;
 }
 
@@ -372,6 +375,13 @@ static int lineset_upload(sr_lineset *ls) {
   ls->freq_max = 0.0;
   for (int64_t q = 0; q < H.m; ++q) ls->freq_max = std::max(ls->freq_max, H.d[q]);
   for (int64_t q = 0; q < ls->host_outer.m; ++q) ls->freq_max = std::max(ls->freq_max, ls->host_outer.d[q]);
+  ls->gamma_max = 0.0;
+  ls->ndep_min = ls->ndep_max = H.m > 0 ? H.d[9 * H.md] : 0.0;
+  for (int64_t q = 0; q < H.m; ++q) {
+    ls->gamma_max = std::max(ls->gamma_max, H.d[8 * H.md + q]);
+    ls->ndep_min = std::min(ls->ndep_min, H.d[9 * H.md + q]);
+    ls->ndep_max = std::max(ls->ndep_max, H.d[9 * H.md + q]);
+  }
   int rc = upload_soa(H, ls->d_lines, ls->L);
   if (rc) return rc;
   ls->n_outer = (int)ls->host_outer.m;
@@ -546,6 +556,7 @@ int sr_lineset_destroy(sr_lineset *ls) {
   ls->d_counts.release();
   if (ls->prep_st) (void)hipStreamDestroy(ls->prep_st);
   ls->d_coef.release();
+  ls->d_mom.release();
   ls->d_first.release();
   ls->d_zone.release();
   if (ls->ev_fork) (void)hipEventDestroy(ls->ev_fork);
@@ -559,6 +570,27 @@ int sr_lineset_destroy(sr_lineset *ls) {
 }
 
 } // extern "C"
+
+// Translation operator of the box-pair far field: built once per process and device (0.8 MB).
+static int m2l_table_dev(const double **out) {
+  static std::mutex mu;
+  static std::map<int, double *> tabs;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = tabs.find(dev);
+  if (it == tabs.end()) {
+    const size_t n = (size_t)2 * kM2LOffsets * kM2LQ * kM2LRow;
+    std::vector<double> h(n);
+    m2l_table_host(h.data());
+    double *d = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), sizeof(double) * n));
+    HIPCHK(hipMemcpy(d, h.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    it = tabs.emplace(dev, d).first;
+  }
+  *out = it->second;
+  return SR_OK;
+}
 
 // The coefficient op with the output weights of `W` (sr_kernels.hpp); the public entry points below
 // choose W.  abs_out / emi_out: DEVICE [n_layers][g_hi - g_lo].
@@ -607,7 +639,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
 
   // per-layer scalars (host, fp64)
   const size_t hl_doubles = (size_t)nl * (4 + npop);
-  const size_t hl_bytes = sizeof(double) * hl_doubles + sizeof(int) * (size_t)nl;
+  const size_t hl_bytes = sizeof(double) * hl_doubles + sizeof(int) * 2 * (size_t)nl; // + pole margins pm, pm_src
   // Table set of this call and the stream its preparation runs on.  With overlap, call c + 1
   // prepares set (c + 1) % 2 on prep_st while the kernels of call c (which the caller's stream is
   // still running) read set c % 2: the HBM-write-bound prep kernel hides behind the VALU-bound ones.
@@ -650,6 +682,11 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       const double dwp_max = ls->freq_max / kCcgs * sq[k] / std::sqrt(kLn2);
       int *pmh = reinterpret_cast<int *>(T + hl_doubles);
       pmh[k] = (int)std::ceil(0.71 * dwp_max / ls->gp.gstep) + 1;
+      // box-pair mode: the multipole series of a source box converges outside the largest |pole| =
+      // sqrt(1/2 + ry^2) dw' = sqrt(dw'^2 / 2 + lw^2) of its lines (bound over the lines of the layer)
+      const double lw_max = ls->gamma_max * pa[k] * std::max(std::pow(tr[k], ls->ndep_min), std::pow(tr[k], ls->ndep_max));
+      const double pole = std::sqrt(0.5 * dwp_max * dwp_max + lw_max * lw_max) / ls->gp.gstep;
+      pmh[nl + k] = (int)std::ceil(std::min(pole, 1e6)) + 1;
     }
     if (nlev > 0) {
       for (int lv = 0; lv < nlev; ++lv) {
@@ -757,6 +794,35 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     if (rc) return rc;
     fp.pm = d_pm;
     fp.coef = ls->d_coef.as<double>();
+    fp.m2l = far_field == 2 ? 1 : 0;
+    fp.pm_src = d_pm + nl;
+    fp.mom = nullptr;
+    fp.tab = nullptr;
+    for (int lv = 0; lv < kMaxFarLevels; ++lv) fp.n_src[lv] = fp.src_off[lv] = 0;
+    if (fp.m2l) {
+      // level-0 source boxes: kSrcPad left of the shard, the shard, the window half-width right of it; a whole
+      // number of widest boxes, so that every level halves exactly
+      const int top_boxes = (int)(((size_t)kSrcPad * 64 + n_pts + kHalf + 64) >> (6 + kMaxFarLevels - 1)) + 1;
+      int total = 0;
+      for (int lv = 0; lv < kMaxFarLevels; ++lv) {
+        fp.n_src[lv] = top_boxes << (kMaxFarLevels - 1 - lv);
+        fp.src_off[lv] = total;
+        total += fp.n_src[lv];
+      }
+      rc = ls->d_mom.ensure(sizeof(double) * (size_t)total * nl * kMomPerBox);
+      if (rc) return rc;
+      fp.mom = ls->d_mom.as<double>();
+      rc = m2l_table_dev(&fp.tab);
+      if (rc) return rc;
+    }
+    // far-field pass(es): per-line expansions (all levels, or level 0 of the box-pair mode), then the box pairs
+    auto far_pass = [&]() -> int {
+      LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, fp,
+                                d_cnt, st));
+      if (fp.m2l)
+        LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, st));
+      return SR_OK;
+    };
     if (overlap) {
       // The zones kernel needs only the record tables, the wings kernel needs the far-field
       // coefficients: zones runs on a second stream beside the far-field kernel and STORES its sums,
@@ -783,8 +849,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, d_zmax.as<int>(), n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, ls->aux));
       HIPCHK(hipEventRecord(ls->ev_join, ls->aux));
-      LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, d_zmax.as<int>(), n_sub, nl,
-                                (int)g_lo, (int)g_hi, fp, d_cnt, st));
+      rc = far_pass();
+      if (rc) return rc;
       HIPCHK(hipEventRecord(ls->ev[2], st));
       if (!small) HIPCHK(hipStreamWaitEvent(st, ls->ev_join, 0));
       if (!ls->ev_tail) HIPCHK(hipEventCreateWithFlags(&ls->ev_tail, hipEventDisableTiming));
@@ -801,8 +867,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       ls->overlapped = true;
     } else {
       ls->overlapped = false;
-      LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, d_zmax.as<int>(), n_sub, nl,
-                                (int)g_lo, (int)g_hi, fp, d_cnt, st));
+      rc = far_pass();
+      if (rc) return rc;
       HIPCHK(hipEventRecord(ls->ev[2], st));
       for (int part = 1; part <= 2; ++part) {
         LAUNCHCHK(launch_near(part, part == 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix,

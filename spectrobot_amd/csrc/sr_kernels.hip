@@ -519,6 +519,21 @@ __device__ inline bool ff_admissible(int j1, int il, int ir, int blo, int bhi, i
 }
 __device__ inline int ff_thr2(int level, int pm) { return kTheta * (64 << level) + 2 * pm; }
 
+// Box-pair mode (FarParams::m2l).  Source box s and target box t of level l, both counted in boxes of 64 << l
+// points from g_lo, o = t - s: the pair is VALID when every line centred in s sees all of t in one region-1 wing
+// inside its window, far enough for the multipole / local pair of expansions: gap between the boxes >= the widest
+// zone of the layer (zreq) and >= 2 box widths + 5 pole radii (truncation ratio <= 1/5: (1/5)^(kFD+1) ~ 1e-16).
+// Validity is monotone down the hierarchy (children of a valid pair are valid), so a pair is TRANSLATED at level
+// l iff it is valid there and its parent pair is not, and a level-0 pair is covered by some level iff it is valid
+// at level 0.  Valid pairs are admissible for every line of s (ff_admissible at level 0), so the near kernels
+// need not know about box pairs at all.
+__device__ inline bool m2l_valid(int level, int o, int zreq, int pms) {
+  const int W = 64 << level, a = o < 0 ? -o : o;
+  if (a < 3 || (a - 1) * W < max(zreq, 2 * W + 5 * pms)) return false;
+  // window [ic - kHalf, ic + kHalf - 1] of every centre ic of s holds all of t
+  return (a + 1) * W <= (o > 0 ? kHalf : kHalf + 1);
+}
+
 // Sum N per-lane values over the 64 lanes: at step M the pairs (i, i + N/2) are split
 // between the lanes with bit M clear / set, an unpaired last value takes a plain butterfly.
 // Afterwards v[0] of each lane is the total of value lane_reduce_index(lane) (several lanes
@@ -560,7 +575,7 @@ __device__ inline int lane_reduce_index(int lane, bool &primary) {
 #else
 #define SR_FAR_ATTR __attribute__((amdgpu_waves_per_eu(SR_FAR_WAVES_PER_EU)))
 #endif
-template <bool COUNT>
+template <bool COUNT, bool M2L>
 __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastRec *__restrict__ fast,
                                                          IcIndex ix,
                                                          const int *__restrict__ zmax, int n_sub, int g_lo,
@@ -581,6 +596,11 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
   int idx = wid - grp * lg * fp.n_boxes_total;                // within the group
   const int n_top = fp.top_first ? min(2, fp.n_levels - 1) : 0; // levels taken first (small shards only)
   int level = fp.n_levels - 1, layer = -1;
+  if (M2L) { // box-pair mode: level 0 only (grid = box_count[0] * n_layers), layer-major
+    layer = wid / fp.box_count[0];
+    idx = wid - layer * fp.box_count[0];
+    level = 0;
+  }
   for (int t = 0; t < n_top && layer < 0; ++t, --level) {
     const int cnt = l_cnt * fp.box_count[level];
     if (idx < cnt) {
@@ -634,13 +654,23 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
   const int pm = fp.pm[layer];
   const int zm = min(zmax[layer], kHalf - 1);
   const int thr2 = ff_thr2(level, pm);
-  const bool top = level == fp.n_levels - 1;
+  const bool top = level == fp.n_levels - 1 && !M2L;
   const int W2 = 2 * W, plo = g_lo + (b >> 1) * W2, phi = plo + W2 - 1, thr2p = ff_thr2(level + 1, pm);
+  const int zreq = zm + 2, pms = M2L ? fp.pm_src[layer] : 0; // box-pair mode: see m2l_valid
 
   // candidate centre intervals [lo, hi] (inclusive), see DESIGN.md
   int clo[4], chi[4], nr;
   const int mid = blo + h, near_in = kTheta * h + pm;
-  if (top) {
+  if (M2L) {
+    // the (line, box) pairs no box pair covers: source boxes closer than the first valid offset, and the two
+    // source boxes on either side whose lines' windows end inside or just beyond this box (|o| = 101, 102)
+    const int a_min = max(3, (max(zreq, 128 + 5 * pms) + 63) / 64 + 1);
+    clo[0] = blo - kHalf - 1; chi[0] = blo - 100 * 64;
+    clo[1] = blo - (a_min - 1) * 64 - 1; chi[1] = mid - near_in + 1;
+    clo[2] = mid + near_in - 2; chi[2] = bhi + (a_min - 1) * 64 + 1;
+    clo[3] = blo + 101 * 64 - 1; chi[3] = bhi + kHalf + 1;
+    nr = 4;
+  } else if (top) {
     clo[0] = blo - kHalf - 1; chi[0] = mid - near_in + 1;
     clo[1] = mid + near_in - 2; chi[1] = bhi + kHalf + 1;
     nr = 2;
@@ -682,7 +712,11 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
       const FastRec r = frow[l];
       const int j1 = r.j1, il = r.il(), ir = r.ir();
       if (!ff_admissible(j1, il, ir, blo, bhi, thr2)) continue;
-      if (!top && ff_admissible(j1, il, ir, plo, phi, thr2p)) continue; // owned by a wider box
+      if (M2L) {
+        if (m2l_valid(0, b - ((j1 + kHalf - g_lo) >> 6), zreq, pms)) continue; // covered by a box pair
+      } else if (!top && ff_admissible(j1, il, ir, plo, phi, thr2p)) {
+        continue; // owned by a wider box
+      }
       const int cls = classify(j1, il, ir, blo, bhi);
       if (COUNT) ++n_exp;
       // x (or -x) at the box centre blo + h - 1/2, and the half-width in x units
@@ -706,6 +740,21 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
       v[1] = fma(r.wabs, f1, v[1]); v[kFC + 1] = fma(r.wemi, f1, v[kFC + 1]);
       v[2] = fma(r.wabs, f2, v[2]); v[kFC + 2] = fma(r.wemi, f2, v[kFC + 2]);
       v[3] = fma(r.wabs, f3, v[3]); v[kFC + 3] = fma(r.wemi, f3, v[kFC + 3]);
+      // Box-pair mode: the lines of the window bands are > 6000 points away -- the series converges like
+      // (32/6000)^n, eight terms carry it to 1e-18 of the leading one.  The bands are disjoint runs of the sorted
+      // list, so whole chunks take the short path.
+      constexpr int kShort = kFC < 8 ? kFC : 8;
+      const int d_abs = blo - (j1 + kHalf);
+      if (M2L && __all((d_abs < 0 ? -d_abs : d_abs) > 4096)) {
+#pragma unroll
+        for (int n = 4; n < kShort; ++n) {
+          const double fn = -fma(D1, f3, fma(D2, f2, fma(D3, f1, D4 * f0)));
+          v[n] = fma(r.wabs, fn, v[n]);
+          v[kFC + n] = fma(r.wemi, fn, v[kFC + n]);
+          f0 = f1; f1 = f2; f2 = f3; f3 = fn;
+        }
+        continue;
+      }
 #pragma unroll
       for (int n = 4; n < kFC; ++n) {
         const double fn = -fma(D1, f3, fma(D2, f2, fma(D3, f1, D4 * f0)));
@@ -725,6 +774,214 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
   if (primary)
     fp.coef[((size_t)layer * fp.n_boxes_total + fp.box_off[level] + b) * (2 * kFC) + n_out] = v[0];
   if (COUNT) count_add(cnt, kCntExpansions, n_exp, lane);
+}
+
+// ------------------------------------------------------------------------
+// Box-pair far field (FarParams::m2l): multipole moments, upward pass, translations.
+//
+// Region 1 of a line is w g(x), g(x) = (a + b x^2)/(c + d x^2 + 4 x^4), x = xstep (j - j0) with j0 the (real)
+// grid position where the reference's running x of that wing passes through zero.  At infinity
+// g = sum_n e_(n-1) x^(-2n), e_0 = b/4, e_1 = (a - d e_0)/4, e_k = -(d e_(k-1) + c e_(k-2))/4, and about the
+// centre C of a source box of half-width h (delta = j0 - C, J = j - C):
+//   (J - delta)^(-2n) = sum_m binom(2n + m - 1, m) delta^m J^(-2n-m)
+//   =>  g = sum_q M_q J^(-q),  M_q / (h^q (q-1)!) = sum_(2n+m=q) [e_(n-1) (xstep h)^(-2n)/(2n-1)!] [(delta/h)^m/m!]
+// -- a convolution of two short series per line, summed over the lines of the box with lanes = lines.  The
+// scaled moments mh_q of a parent box follow from its children (centres -+ h/2 from its own) by
+//   mh_q = 2^-q sum_(m=0..q-2) (mhL_(q-m) (-1)^m + mhR_(q-m))/m!
+// and the local coefficients (in t = (j - centre)/h, the polynomial each point evaluates) of a target box
+// o boxes away by  L_n = sum_q T_o[n][q] mh_q,  T_o[n][q] = (-1)^n (q+n-1)!/n! (1/2o)^(q+n)  (host table).
+// The two wings of a line use different anchors (xl from x(1), xr from x(ir): lineshape.f:462, 471; they differ
+// by the rounding of the grid, ~1e-9 points), hence two sets of moments: side 0 serves targets right of the
+// source box, side 1 targets left of it.
+// ------------------------------------------------------------------------
+__device__ constexpr double inv_factorial(int n) {
+  double f = 1.0;
+  for (int i = 2; i <= n; ++i) f *= (double)i;
+  return 1.0 / f;
+}
+template <bool COUNT>
+__global__ __launch_bounds__(64) void sr_s2m_kernel(const FastRec *__restrict__ fast, IcIndex ix, int n_sub, int g_lo,
+                                                    FarParams fp, unsigned long long *__restrict__ cnt) {
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int side = wid & 1, rest = wid >> 1;
+  const int layer = rest / fp.n_src[0], sb = rest - layer * fp.n_src[0];
+  const int lane = threadIdx.x;
+  const int s_lo = g_lo + (sb - kSrcPad) * 64; // first centre position of the box
+  const int l0 = lower_bound_ic(ix, s_lo), l1 = lower_bound_ic(ix, s_lo + 64);
+  constexpr int NE = kFD / 2; // terms of the Laurent series
+  double v[2 * kMQ];          // [0, kMQ): abs, [kMQ, 2 kMQ): emi
+#pragma unroll
+  for (int n = 0; n < 2 * kMQ; ++n) v[n] = 0.;
+  const FastRec *frow = fast + (size_t)layer * n_sub;
+  unsigned n_lines = 0;
+  for (int base = l0; base < l1; base += 64) {
+    const int l = base + lane;
+    if (l >= l1) continue;
+    const FastRec r = frow[l];
+    if (COUNT) ++n_lines;
+    constexpr double h = 32.0;
+    const double sh = r.xstep * h;
+    const double V = fast_rcp<2>(sh * sh);
+    double E[NE]; // e_(n-1) (xstep h)^(-2n) / (2n-1)!
+    {
+      const double dV = 0.25 * r.d * V, cV = 0.25 * r.c * (V * V);
+      E[0] = 0.25 * r.b * V;
+      E[1] = fma(0.25 * r.a * V, V, -dV * E[0]);
+#pragma unroll
+      for (int k = 2; k < NE; ++k) E[k] = -fma(dV, E[k - 1], cV * E[k - 2]);
+#pragma unroll
+      for (int k = 1; k < NE; ++k) E[k] *= inv_factorial(2 * k + 1);
+    }
+    // delta / h: zero of the running x of this wing, relative to the box centre s_lo + 31.5
+    const double off = side == 0 ? (double)(r.j1 + r.ir() - 1 - s_lo - 32) + (0.5 - r.xr / r.xstep)
+                                 : (double)(r.j1 - s_lo - 32) + (0.5 + r.xl / r.xstep);
+    const double dt = off * (1.0 / h);
+    double D[kMQ]; // (delta/h)^m / m!, m = 0..kFD-2
+    D[0] = 1.0;
+#pragma unroll
+    for (int m = 1; m < kMQ; ++m) D[m] = D[m - 1] * (dt * (1.0 / (double)m));
+#pragma unroll
+    for (int q = 2; q <= kFD; ++q) {
+      double mq = 0.;
+#pragma unroll
+      for (int n = 1; 2 * n <= q; ++n) mq = fma(E[n - 1], D[q - 2 * n], mq);
+      v[q - 2] = fma(r.wabs, mq, v[q - 2]);
+      v[kMQ + q - 2] = fma(r.wemi, mq, v[kMQ + q - 2]);
+    }
+  }
+  lane_reduce<2 * kMQ, 32>(v, lane);
+  bool primary = true;
+  const int n_out = lane_reduce_index<2 * kMQ, 32>(lane, primary);
+  if (primary)
+    fp.mom[((size_t)(fp.src_off[0] + sb) * fp.n_layers + layer) * kMomPerBox + side * (2 * kMQ) + n_out] = v[0];
+  if (COUNT) count_add(cnt, kCntS2M, n_lines, lane);
+}
+
+// Upward pass: one thread per (widest-level source box, layer, side, weight) builds every wider level of its
+// subtree (15 boxes at 5 levels), children before parents.  n_src[l - 1] = 2 n_src[l] (host).
+__global__ __launch_bounds__(64) void sr_m2m_kernel(FarParams fp) {
+  const int top = fp.n_levels - 1;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= fp.n_src[top] * fp.n_layers * 4) return;
+  const int sw = tid & 3, rest = tid >> 2;
+  const int layer = rest % fp.n_layers, tb = rest / fp.n_layers;
+  for (int l = 1; l <= top; ++l) {
+    const int per = 1 << (top - l);
+    for (int i = 0; i < per; ++i) {
+      const int p = tb * per + i;
+      const double *cl = fp.mom + ((size_t)(fp.src_off[l - 1] + 2 * p) * fp.n_layers + layer) * kMomPerBox + sw * kMQ;
+      const double *cr = cl + (size_t)fp.n_layers * kMomPerBox;
+      double *par = fp.mom + ((size_t)(fp.src_off[l] + p) * fp.n_layers + layer) * kMomPerBox + sw * kMQ;
+      double a[kMQ], b[kMQ];
+#pragma unroll
+      for (int q = 0; q < kMQ; ++q) {
+        a[q] = cl[q];
+        b[q] = cr[q];
+      }
+      double scale = 0.25; // 2^-q
+#pragma unroll
+      for (int q = 2; q <= kFD; ++q) {
+        double s = 0.;
+#pragma unroll
+        for (int m = 0; m <= q - 2; ++m) {
+          const double pair = (m & 1) ? b[q - m - 2] - a[q - m - 2] : b[q - m - 2] + a[q - m - 2];
+          s = fma(pair, inv_factorial(m), s);
+        }
+        par[q - 2] = s * scale;
+        scale *= 0.5;
+      }
+    }
+  }
+}
+
+// Translations: L[pair][n] += sum_q mh[pair][q] T_o[q][n] is a small dense product per box offset o, the one
+// place of this path with the shape of a matrix multiplication: v_mfma_f64_16x16x4_f64 with A = the moments of 16
+// (target box, layer) pairs (rows) and B = the operator (16 of the kFC columns).  The matrix unit is no faster than
+// the vector unit in fp64, but one lane-load of A and of B feeds 2 x 256 fma: the vector formulations were bound by
+// their loads (lanes = pairs, operator by scalar loads: 0.9-1.6 ms on config 2; lane = (pair, n) with two
+// accumulators: 63 loads per 42 fma, 1.0 ms).  Layout (cdna_hip_programming.md): A[row = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][col = lane & 15], D[row = (lane >> 4) + 4 r][col = lane & 15], r = 0..3.
+// A pair that does not take part in an offset (its own validity, or it lies outside the level) enters with zeros.
+// Stores the local coefficients of levels >= 1, adds to those the level-0 pass of sr_farfield_kernel stored.
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kM2LSlices = kM2LRow / 16; // column tiles: all in one wave (the A loads are the cost, shared by them)
+__global__ __launch_bounds__(64) void sr_m2l_kernel(const int *__restrict__ zmax, FarParams fp) {
+  int chunk = blockIdx.x, level = 0;
+  for (;;) {
+    const int c = (fp.box_count[level] * fp.n_layers + 15) >> 4;
+    if (chunk < c || level + 1 >= fp.n_levels) break;
+    chunk -= c;
+    ++level;
+  }
+  const int lane = threadIdx.x, lo = lane & 15, kq = lane >> 4;
+  const int n_pairs = fp.box_count[level] * fp.n_layers;
+  // the pair of this lane's A row
+  const int idx = chunk * 16 + lo;
+  const bool live = idx < n_pairs;
+  const int t = live ? idx / fp.n_layers : 0, layer = live ? idx - t * fp.n_layers : 0;
+  const int zreq = min(zmax[layer], kHalf - 1) + 2, pms = fp.pm_src[layer];
+  const int W = 64 << level;
+  const bool has_parent = level + 1 < fp.n_levels;
+  const int a_max = (kHalf + 1) / W - 1;
+  // offsets whose parent pair can be invalid: close ones (parent closer than its first valid offset, taken over
+  // the wave's layers) and the ones at the window ends
+  int near_hi = a_max, win_lo = a_max + 1;
+  if (has_parent) {
+    const int W2 = 2 * W;
+    int a_min_p = max(3, (max(zreq, 2 * W2 + 5 * pms) + W2 - 1) / W2 + 1);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) a_min_p = max(a_min_p, __shfl_xor(a_min_p, m));
+    near_hi = __builtin_amdgcn_readfirstlane(min(a_max, 2 * a_min_p + 1));
+    win_lo = max(near_hi + 1, 2 * (kHalf / W2 - 1));
+  }
+  v4d acc_a[kM2LSlices], acc_e[kM2LSlices];
+#pragma unroll
+  for (int sl = 0; sl < kM2LSlices; ++sl) acc_a[sl] = acc_e[sl] = v4d{0., 0., 0., 0.};
+  const int pad = kSrcPad >> level;
+  for (int a = 3; a <= a_max; a = (a == near_hi ? win_lo : a + 1)) {
+    for (int sg = 0; sg < 2; ++sg) {
+      const int o = sg ? -a : a, s = t - o;
+      const int sidx = s + pad;
+      const bool on = live && sidx >= 0 && sidx < fp.n_src[level] && m2l_valid(level, o, zreq, pms) &&
+                      !(has_parent && m2l_valid(level + 1, (t >> 1) - (s >> 1), zreq, pms));
+      if (!__any(on)) continue;
+      const double *m = fp.mom + ((size_t)(fp.src_off[level] + (on ? sidx : 0)) * fp.n_layers + layer) * kMomPerBox + sg * (2 * kMQ);
+      const double *T = fp.tab + ((size_t)sg * kM2LOffsets + a) * (kM2LQ * kM2LRow) + lo;
+#pragma unroll
+      for (int ks = 0; ks < kM2LQ / 4; ++ks) {
+        const int q = 4 * ks + kq;
+        const bool use = on && q < kMQ;
+        const double A_a = use ? m[q] : 0.0;
+        const double A_e = use ? m[kMQ + q] : 0.0;
+#pragma unroll
+        for (int sl = 0; sl < kM2LSlices; ++sl) {
+          const double B = T[q * kM2LRow + 16 * sl];
+          acc_a[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_a, B, acc_a[sl], 0, 0, 0);
+          acc_e[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_e, B, acc_e[sl], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int io = chunk * 16 + kq + 4 * r; // the pair of D's row
+    if (io >= n_pairs) continue;
+    const int to = io / fp.n_layers, lyo = io - to * fp.n_layers;
+    double *c = fp.coef + ((size_t)lyo * fp.n_boxes_total + fp.box_off[level] + to) * (2 * kFC);
+#pragma unroll
+    for (int sl = 0; sl < kM2LSlices; ++sl) {
+      const int n = 16 * sl + lo; // this lane's column of D
+      if (n < kFC) {
+        if (level == 0) {
+          c[n] += acc_a[sl][r];
+          c[kFC + n] += acc_e[sl][r];
+        } else {
+          c[n] = acc_a[sl][r];
+          c[kFC + n] = acc_e[sl][r];
+        }
+      }
+    }
+  }
 }
 
 // Exact near field + evaluation of the far-field polynomials.  The scalar unit is shared by
@@ -1259,12 +1516,52 @@ int launch_add2(double *a, const double *za, double *e, const double *ze, size_t
 int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo,
                     int g_hi, const FarParams &fp, unsigned long long *cnt, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
-  const dim3 grid((unsigned)(fp.n_boxes_total * n_layers));
-  if (cnt)
-    hipLaunchKernelGGL(sr_farfield_kernel<true>, grid, dim3(64), 0, st, fast, ix, zmax, n_sub, g_lo, g_hi, fp, cnt);
-  else
-    hipLaunchKernelGGL(sr_farfield_kernel<false>, grid, dim3(64), 0, st, fast, ix, zmax, n_sub, g_lo, g_hi, fp, cnt);
+  const dim3 grid((unsigned)((fp.m2l ? fp.box_count[0] : fp.n_boxes_total) * n_layers));
+#define SR_FAR(C, M) hipLaunchKernelGGL((sr_farfield_kernel<C, M>), grid, dim3(64), 0, st, fast, ix, zmax, n_sub, g_lo, g_hi, fp, cnt)
+  if (fp.m2l) {
+    if (cnt) SR_FAR(true, true); else SR_FAR(false, true);
+  } else {
+    if (cnt) SR_FAR(true, false); else SR_FAR(false, false);
+  }
+#undef SR_FAR
   return (int)hipGetLastError();
+}
+
+int launch_m2l(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi,
+               const FarParams &fp, unsigned long long *cnt, hipStream_t st) {
+  if (g_hi <= g_lo || n_layers <= 0) return 0;
+  const dim3 g1((unsigned)(fp.n_src[0] * n_layers * 2));
+  if (cnt)
+    hipLaunchKernelGGL(sr_s2m_kernel<true>, g1, dim3(64), 0, st, fast, ix, n_sub, g_lo, fp, cnt);
+  else
+    hipLaunchKernelGGL(sr_s2m_kernel<false>, g1, dim3(64), 0, st, fast, ix, n_sub, g_lo, fp, cnt);
+  const int n2 = fp.n_src[fp.n_levels - 1] * n_layers * 4;
+  hipLaunchKernelGGL(sr_m2m_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, st, fp);
+  int chunks = 0;
+  for (int lv = 0; lv < fp.n_levels; ++lv) chunks += (fp.box_count[lv] * n_layers + 15) / 16;
+  hipLaunchKernelGGL(sr_m2l_kernel, dim3((unsigned)chunks), dim3(64), 0, st, zmax, fp);
+  return (int)hipGetLastError();
+}
+
+// Translation operator of the box-pair far field, [o > 0 | o < 0][|o|][q - 2 < kM2LQ][n < kM2LRow]:
+// (-1)^n (q + n - 1)!/n! r^(q+n), r = 1/(2o) (see sr_m2l_kernel); long double, rounded once.
+void m2l_table_host(double *tab) {
+  for (size_t i = 0; i < (size_t)2 * kM2LOffsets * kM2LQ * kM2LRow; ++i) tab[i] = 0.0; // padding rows / columns
+  for (int sg = 0; sg < 2; ++sg)
+    for (int a = 0; a < kM2LOffsets; ++a)
+      for (int q = 2; q <= kFD; ++q) {
+        double *row = tab + (((size_t)sg * kM2LOffsets + a) * kM2LQ + (q - 2)) * kM2LRow;
+        if (a == 0) continue;
+        const long double r = (sg ? -1.0L : 1.0L) / (2.0L * a);
+        long double v = 1.0L;
+        for (int k = 2; k < q; ++k) v *= k;        // (q-1)!
+        for (int k = 0; k < q; ++k) v *= r;        // r^q
+        row[0] = (double)v;
+        for (int n = 1; n < kFC; ++n) {
+          v *= -r * (long double)(q + n - 1) / (long double)n;
+          row[n] = (double)v;
+        }
+      }
 }
 
 #ifndef SR_ZONES_WT

@@ -65,12 +65,31 @@ constexpr int kMaxFarLevels = 5;
 #define SR_FAR_SUPER 16384
 #endif
 constexpr int kFarSuper = SR_FAR_SUPER; // points per super-tile of sr_farfield_kernel's block order (a multiple of the widest box)
+// Far field by box pairs (sr_set_far_field(2)): the lines of a SOURCE box (64 << l line centres wide, same frame
+// as the target boxes) are summed into multipole moments about the box centre (sr_s2m_kernel, sr_m2m_kernel) and
+// translated to the local expansion of every target box of the level that is well separated from it
+// (sr_m2l_kernel); only the (line, box) pairs no box pair covers keep their own expansion (level 0 of
+// sr_farfield_kernel).  Moments: orders q = 2..kFD of the Laurent series at infinity, scaled by the box
+// half-width and by 1/(q-1)!, for the two running-x anchors of the reference (right / left wing) and the two
+// output weights.
+constexpr int kMQ = kFD - 1;         // multipole orders per (side, weight)
+constexpr int kMomPerBox = 4 * kMQ;  // [side: 0 right-going, 1 left-going][abs, emi][q - 2]
+constexpr int kSrcPad = 112;         // level-0 source boxes left of the shard start: 7168 points >= kHalf, a multiple of the widest box
+constexpr int kM2LOffsets = 104;     // |box offset| < this (level 0: (|o| + 1) 64 <= kHalf)
+constexpr int kM2LRow = (kFC + 15) / 16 * 16; // columns of the translation operator (kFC, padded with zeros to MFMA tiles)
+constexpr int kM2LQ = (kMQ + 3) / 4 * 4;      // rows (kMQ, padded with zeros)
 struct FarParams {
   int n_levels, n_layers, n_boxes_total;
   int top_first; // block order of sr_farfield_kernel: widest two levels of a layer group first
   int box_count[kMaxFarLevels], box_off[kMaxFarLevels];
   const int *pm; // [n_layers] pole margin in grid points
   double *coef;  // [n_layers][n_boxes_total][2][kFC]
+  // box-pair mode (m2l != 0)
+  int m2l;
+  int n_src[kMaxFarLevels], src_off[kMaxFarLevels]; // source boxes per level (storage index = box + (kSrcPad >> level))
+  const int *pm_src; // [n_layers] largest pole radius |sqrt(1/2 + ry^2)| dw' of the layer's lines, in grid points
+  double *mom;       // [sum n_src][n_layers][kMomPerBox]
+  const double *tab; // [2: o > 0, o < 0][kM2LOffsets][kM2LQ][kM2LRow] translation operator (host, long double)
 };
 int launch_add2(double *a, const double *za, double *e, const double *ze, size_t n, hipStream_t st);
 // Executed-work counters of the counting instantiations (sr_set_counting): index into cnt[kCntN].
@@ -82,11 +101,17 @@ enum {
   kCntRegion2 = 4,    // region-2 evaluations                      sr_abscoeff_near_zones_kernel
   kCntRegion3 = 5,    // region-3 evaluations
   kCntRegion4 = 6,    // region-4 evaluations
+  kCntS2M = 7,        // (line, side) multipole expansions (box-pair mode)  sr_s2m_kernel
   kCntN = 8
 };
 // cnt: device counters [kCntN] or nullptr (the timed instantiations: no counting code)
 int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo,
                     int g_hi, const FarParams &fp, unsigned long long *cnt, hipStream_t st);
+// box-pair mode: moments of the level-0 source boxes, the wider levels, the translations (after the level-0 pass
+// of launch_farfield, which stores; the translations add at level 0 and store above)
+int launch_m2l(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi,
+               const FarParams &fp, unsigned long long *cnt, hipStream_t st);
+void m2l_table_host(double *tab); // [2][kM2LOffsets][kM2LQ][kM2LRow]
 // part 1: wing-only pairs + far-field polynomials (writes); part 2: general pairs (adds)
 int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
                 int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp,

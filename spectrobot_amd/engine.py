@@ -439,8 +439,9 @@ def set_overlap(on):
 
 
 def set_far_field(on):
-    """1 (default): far wings by local expansions; 0: every evaluation exact."""
-    check(lib.sr_set_far_field(int(bool(on))), "sr_set_far_field")
+    """1: far wings by per-line local expansions; 2: by box pairs (multipole moments of the lines of a source
+    box, translated to the local expansions of the well-separated target boxes); 0: every evaluation exact."""
+    check(lib.sr_set_far_field(int(on)), "sr_set_far_field")
 
 
 _UNITS = {"Wm2": 0, "ergscm2": 1, "nWcm2": 2}
