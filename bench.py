@@ -36,10 +36,15 @@ FLOP_PER_EVAL = 16             # SURVEY 8-d flop model per (line, layer, grid po
 # sr_farfield_kernel's source (setup 42, reciprocal 9, f0..f3 14, 23 coefficients x 2 outputs).  Per
 # (point, level) polynomial: 2 outputs x degree 22 Horner.  Per window-end expansion: series + its share
 # of the lane scan.
+# Box-pair far field (default): per (line, side) multipole expansion 430 (Laurent series 52, anchor 14, powers 40,
+# convolution 121 fma, two weighted accumulations 42 fma); per (source box, target box, layer) translation
+# 21 x 23 x 2 outputs fma = 1932 (the MFMA tiles execute 24 x 32: padding not counted); the short series of the
+# window-band lines in the level-0 pass are not counted at all.
 FLOP = {"region1_evals": 15, "region2_evals": 23, "region3_evals": 146, "region4_evals": 146,
-        "farfield_expansions": 281, "poly_point_levels": 93, "window_end_expansions": 187}
+        "farfield_expansions": 281, "poly_point_levels": 93, "window_end_expansions": 187,
+        "multipole_line_sides": 430, "box_pair_translations": 1932}
 KERNEL_COUNTERS = {
-    "sr_farfield_kernel": ("farfield_expansions",),
+    "sr_farfield_kernel": ("farfield_expansions", "multipole_line_sides", "box_pair_translations"),
     "sr_abscoeff_near_wings_kernel": ("region1_evals", "window_end_expansions", "poly_point_levels"),
     "sr_abscoeff_near_zones_kernel": ("region2_evals", "region3_evals", "region4_evals"),
 }
@@ -166,6 +171,8 @@ def main():
     ap.add_argument("--shard", default="", help="R/W: time only the spectral shard of rank R of W on this GPU "
                     "(tuning aid for the multi-GPU shard size; not a bench line of the metric)")
     ap.add_argument("--exact", action="store_true", help="evaluate every (line, point) exactly (no far-field expansions)")
+    ap.add_argument("--far-field", type=int, default=2, choices=(1, 2), help="2 (default): far-field expansions from box "
+                    "pairs (multipole -> local); 1: per line and box")
     args = ap.parse_args()
 
     import __graft_entry__
@@ -181,7 +188,7 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     engine.set_device(local % max(torch.cuda.device_count(), 1))
     engine.set_points_per_lane(args.ppl)
-    engine.set_far_field(0 if args.exact else 1)
+    engine.set_far_field(0 if args.exact else args.far_field)
     info = engine.device_info()
 
     # ---- synthetic workload, identical on every rank ----
@@ -266,7 +273,7 @@ def main():
             spec_x = step()
             exact_kms += np.array(ls.last_kernel_ms()) / 2
         exact_checksum = float(spec_x.sum().item())
-        engine.set_far_field(1)
+        engine.set_far_field(args.far_field)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -299,10 +306,13 @@ def main():
                                                 "sr_abscoeff_cores_kernel"], [float(v) for v in kms[:3]])),
                         "flops_per_launch": flops_bf, "mode": "exact"}
         else:
-            names = ["sr_farfield_kernel", "sr_abscoeff_near_wings_kernel", "sr_abscoeff_near_zones_kernel"]
+            # box-pair mode: the far-field part is four kernels between two timing events
+            far_name = ("sr_farfield_kernel" if args.far_field == 1 else
+                        "sr_farfield_kernel (level 0) + sr_s2m_kernel + sr_m2m_kernel + sr_m2l_kernel")
+            names = [far_name, "sr_abscoeff_near_wings_kernel", "sr_abscoeff_near_zones_kernel"]
             per_kernel = {}
             for nm, ms in zip(names, serial_kms[1:4]):
-                fl = float(sum(FLOP[c] * counts[c] for c in KERNEL_COUNTERS[nm]))
+                fl = float(sum(FLOP[c] * counts[c] for c in KERNEL_COUNTERS[nm.split(" ")[0]]))
                 per_kernel[nm] = {"ms": float(ms), "executed_flops": fl,
                                   "achieved_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
                                   "frac": fl / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if ms > 0 else None}
@@ -314,7 +324,8 @@ def main():
                 "kernel": dom, "kernel_ms": d["ms"], "flops_per_launch": d["executed_flops"],
                 "executed_counts": counts, "flop_model": FLOP, "kernels": per_kernel,
                 "sr_prep_kernel_ms": float(serial_kms[0]),
-                "coefficient_op_ms_in_timed_steps": main_ms, "mode": "far-field",
+                "coefficient_op_ms_in_timed_steps": main_ms,
+                "mode": "far-field (box pairs)" if args.far_field == 2 else "far-field (per line)",
                 "note": "dominant kernel of the step; achieved = flops it EXECUTES (evaluations counted on the device "
                         "by the counting instantiations of the same kernels x the per-region flops of SURVEY 8-d) / "
                         "its average HIP-event duration over 5 launches with the kernels one after the other on the "
@@ -331,7 +342,7 @@ def main():
                        "n_lines": args.lines, "n_grid": args.grid, "n_layers": args.layers, "n_rays": args.rays,
                        "sharding": ("spectral window / %d, one RCCL all-gather" % world if world > 1 else
                                     ("ONLY shard %s timed (tuning aid)" % args.shard if args.shard else "none")),
-                       "mode": "exact" if args.exact else "far-field", "device": info["name"],
+                       "mode": "exact" if args.exact else ("far-field, box pairs" if args.far_field == 2 else "far-field, per line"), "device": info["name"],
                        "cu_count": info["cu_count"]},
             "roofline": roofline,
             "roofline_hbm": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

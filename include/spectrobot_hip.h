@@ -300,10 +300,13 @@ int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double 
                            const double *centers_nm, const double *widths_nm, int n_bands, double n_sigma,
                            int out_units, double *out_host, void *stream);
 
-/* Evaluation mode of the coefficient op.  1 (default): far region-1 wings by
- * local Taylor expansions per box of grid points (truncation <= 2.6e-13 of a
- * line's own contribution), near field exact.  0: every (line, point) evaluated
- * exactly (sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel). */
+/* Evaluation mode of the coefficient op.  Far region-1 wings by local Taylor expansions per box of grid
+ * points (truncation <= 2.6e-13 of a line's own contribution), near field exact, with the expansions built
+ * 2 (default): from box pairs -- multipole moments of the lines of a source box (sr_s2m_kernel, sr_m2m_kernel)
+ *    translated to every well-separated target box of the level (sr_m2l_kernel), per-line expansions only for
+ *    the (line, box) pairs no box pair covers;
+ * 1: per line and box at every level (sr_farfield_kernel).
+ * 0: every (line, point) evaluated exactly (sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel). */
 int sr_set_far_field(int on);
 /* Far-field mode only.  1, 2: sr_abscoeff_near_zones_kernel runs on a second, internal stream beside
  * sr_farfield_kernel (it needs the record tables only) and the wings kernel joins both; the NEXT call's
@@ -323,12 +326,13 @@ int sr_set_points_per_lane(int p);
 /* Executed-work accounting for bench.py's roofline (far-field mode only).  sr_set_counting(1): the
  * following sr_abscoeff_layers* calls run the counting instantiations of the three coefficient kernels
  * (same results; one atomic per wave and counter) -- not for timed runs.  sr_last_eval_counts: the
- * counters of the most recent such call on this lineset, counts8[0] (line, box) far-field expansions,
+ * counters of the most recent such call on this lineset, counts10[0] (line, box) far-field expansions,
  * [1] region-1 evaluations done point by point, [2] window-end expansions, [3] (point, level)
- * far-field polynomial evaluations, [4] region-2, [5] region-3, [6] region-4 evaluations, [7] 0.
- * Synchronises. */
+ * far-field polynomial evaluations, [4] region-2, [5] region-3, [6] region-4 evaluations, [7] (line, side)
+ * multipole expansions and [8] (source box, target box, layer) translations of the box-pair far field
+ * (sr_set_far_field(2)), [9] 0.  Synchronises. */
 int sr_set_counting(int on);
-int sr_last_eval_counts(sr_lineset *ls, uint64_t *counts8);
+int sr_last_eval_counts(sr_lineset *ls, uint64_t *counts10);
 
 /* Timing hook for bench.py: HIP-event times (ms) of the kernels of the most
  * recent sr_abscoeff_layers* call on this lineset, measured on the stream they

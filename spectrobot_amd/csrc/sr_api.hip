@@ -187,7 +187,7 @@ struct HostLines {
 // Process-wide mode switches (sr_set_*).  Atomic: a call reads each ONCE at entry and works with that
 // snapshot, so flipping a switch from another thread never changes a call half way.
 std::atomic<int> g_variant{8};   // points per lane in the exact wings kernel
-std::atomic<int> g_far_field{1}; // 1: far wings by per-line local expansions, 2: by box pairs (multipole -> local), 0: every evaluation exact
+std::atomic<int> g_far_field{2}; // 1: far wings by per-line local expansions, 2: by box pairs (multipole -> local), 0: every evaluation exact
 std::atomic<int> g_overlap{1};   // 1 (default), 2: zones kernel on a second stream beside the far-field kernel, next call's prep pipelined (2: gated behind FF+zones; measured equal)
 std::atomic<int> g_counting{0};  // 1: counting instantiations of the far-field-mode kernels (sr_set_counting)
 std::atomic<size_t> g_table_budget{(size_t)48 << 30}; // bytes of FastRec + ColdRec tables per layer batch
@@ -211,6 +211,7 @@ struct sr_lineset {
   std::vector<int> ic; // host copy, sorted
   double freq_max = 0.0;
   double gamma_max = 0.0, ndep_min = 0.0, ndep_max = 0.0; // air broadening / its temperature exponent over the lines
+  int64_t n_disp_lo = 0, n_disp_hi = 0; // leading / trailing lines centred beyond the grid ends (window clamped to the end point)
   DevBuf d_lines;      // one allocation, carved below
   LinesDev L{};
   // [2]: with sr_set_overlap(1) the tables of call c+1 are prepared (on prep_st) while the kernels
@@ -381,6 +382,14 @@ static int lineset_upload(sr_lineset *ls) {
     ls->gamma_max = std::max(ls->gamma_max, H.d[8 * H.md + q]);
     ls->ndep_min = std::min(ls->ndep_min, H.d[9 * H.md + q]);
     ls->ndep_max = std::max(ls->ndep_max, H.d[9 * H.md + q]);
+  }
+  ls->n_disp_lo = ls->n_disp_hi = 0;
+  if (H.m > 0) {
+    const double g0 = grid_at(ls->gp, 0), g1 = grid_at(ls->gp, (int)ls->gp.n_grid - 1), tol = 0.75 * ls->gp.gstep;
+    while (ls->n_disp_lo < H.m && H.i[ls->n_disp_lo] == 0 && H.d[ls->n_disp_lo] < g0 - tol) ++ls->n_disp_lo;
+    while (ls->n_disp_hi < H.m - ls->n_disp_lo && H.i[H.m - 1 - ls->n_disp_hi] == (int)ls->gp.n_grid - 1 &&
+           H.d[H.m - 1 - ls->n_disp_hi] > g1 + tol)
+      ++ls->n_disp_hi;
   }
   int rc = upload_soa(H, ls->d_lines, ls->L);
   if (rc) return rc;
@@ -686,7 +695,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       // sqrt(1/2 + ry^2) dw' = sqrt(dw'^2 / 2 + lw^2) of its lines (bound over the lines of the layer)
       const double lw_max = ls->gamma_max * pa[k] * std::max(std::pow(tr[k], ls->ndep_min), std::pow(tr[k], ls->ndep_max));
       const double pole = std::sqrt(0.5 * dwp_max * dwp_max + lw_max * lw_max) / ls->gp.gstep;
-      pmh[nl + k] = (int)std::ceil(std::min(pole, 1e6)) + 1;
+      pmh[nl + k] = (int)std::ceil(std::min(pole, 1e6));
     }
     if (nlev > 0) {
       for (int lv = 0; lv < nlev; ++lv) {
@@ -796,6 +805,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     fp.coef = ls->d_coef.as<double>();
     fp.m2l = far_field == 2 ? 1 : 0;
     fp.pm_src = d_pm + nl;
+    fp.disp_lo_end = (int)std::min<int64_t>(std::max<int64_t>(ls->n_disp_lo - line_lo, 0), n_sub);
+    fp.disp_hi_begin = (int)std::min<int64_t>(std::max<int64_t>(ls->n_lines - ls->n_disp_hi - line_lo, 0), n_sub);
     fp.mom = nullptr;
     fp.tab = nullptr;
     for (int lv = 0; lv < kMaxFarLevels; ++lv) fp.n_src[lv] = fp.src_off[lv] = 0;
@@ -990,7 +1001,9 @@ int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, 
   return rc;
 }
 
-int sr_last_eval_counts(sr_lineset *ls, uint64_t *counts8) {
+int sr_last_eval_counts(sr_lineset *ls, uint64_t *counts10) {
+  uint64_t *counts8 = counts10;
+  static_assert(kCntN == 10, "sr_last_eval_counts: the header documents ten counters");
   if (!ls || !counts8 || !ls->counted) return SR_ERR_ARG;
   HIPCHK(hipEventSynchronize(ls->ev_last_done));
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");

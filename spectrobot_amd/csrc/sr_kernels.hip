@@ -522,16 +522,28 @@ __device__ inline int ff_thr2(int level, int pm) { return kTheta * (64 << level)
 // Box-pair mode (FarParams::m2l).  Source box s and target box t of level l, both counted in boxes of 64 << l
 // points from g_lo, o = t - s: the pair is VALID when every line centred in s sees all of t in one region-1 wing
 // inside its window, far enough for the multipole / local pair of expansions: gap between the boxes >= the widest
-// zone of the layer (zreq) and >= 2 box widths + 5 pole radii (truncation ratio <= 1/5: (1/5)^(kFD+1) ~ 1e-16).
+// zone of the layer (zreq) and >= 2 box widths (truncation ratio 1/5: (1/5)^(kFD+1) ~ 1e-16), more where the poles
+// of the layer's lines (pms grid points from their centres) are not small against the box (m2l_separated).
 // Validity is monotone down the hierarchy (children of a valid pair are valid), so a pair is TRANSLATED at level
 // l iff it is valid there and its parent pair is not, and a level-0 pair is covered by some level iff it is valid
 // at level 0.  Valid pairs are admissible for every line of s (ff_admissible at level 0), so the near kernels
 // need not know about box pairs at all.
+__device__ inline bool m2l_separated(int level, int a, int zreq, int pms) { // a = |o|
+  const int W = 64 << level;
+  // gap >= zone and >= two boxes; (h + pole) <= 0.27 (distance of the centres - h), h = W / 2: 0.27^(kFD+1) = 8e-14
+  return a >= 3 && (a - 1) * W >= zreq && 100 * (W + 2 * pms) <= 27 * (2 * a - 1) * W;
+}
 __device__ inline bool m2l_valid(int level, int o, int zreq, int pms) {
   const int W = 64 << level, a = o < 0 ? -o : o;
-  if (a < 3 || (a - 1) * W < max(zreq, 2 * W + 5 * pms)) return false;
+  if (!m2l_separated(level, a, zreq, pms)) return false;
   // window [ic - kHalf, ic + kHalf - 1] of every centre ic of s holds all of t
   return (a + 1) * W <= (o > 0 ? kHalf : kHalf + 1);
+}
+// smallest separated |o| of the level (capped: beyond the window nothing is valid anyway)
+__device__ inline int m2l_first_offset(int level, int zreq, int pms) {
+  int a = 3;
+  while (a < 128 && !m2l_separated(level, a, zreq, pms)) ++a;
+  return a;
 }
 
 // Sum N per-lane values over the 64 lanes: at step M the pairs (i, i + N/2) are split
@@ -659,17 +671,19 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
   const int zreq = zm + 2, pms = M2L ? fp.pm_src[layer] : 0; // box-pair mode: see m2l_valid
 
   // candidate centre intervals [lo, hi] (inclusive), see DESIGN.md
-  int clo[4], chi[4], nr;
+  int clo[4], chi[4], nr, n_extra = 0;
   const int mid = blo + h, near_in = kTheta * h + pm;
   if (M2L) {
     // the (line, box) pairs no box pair covers: source boxes closer than the first valid offset, and the two
     // source boxes on either side whose lines' windows end inside or just beyond this box (|o| = 101, 102)
-    const int a_min = max(3, (max(zreq, 128 + 5 * pms) + 63) / 64 + 1);
-    clo[0] = blo - kHalf - 1; chi[0] = blo - 100 * 64;
+    const int a_min = m2l_first_offset(0, zreq, pms);
+    // (of those only the lines whose window holds the whole box: centre in [bhi - kHalf + 1, blo + kHalf])
+    clo[0] = bhi - kHalf; chi[0] = blo - 100 * 64;
     clo[1] = blo - (a_min - 1) * 64 - 1; chi[1] = mid - near_in + 1;
     clo[2] = mid + near_in - 2; chi[2] = bhi + (a_min - 1) * 64 + 1;
-    clo[3] = blo + 101 * 64 - 1; chi[3] = bhi + kHalf + 1;
+    clo[3] = blo + 101 * 64 - 1; chi[3] = blo + kHalf + 1;
     nr = 4;
+    n_extra = 2; // + the lines beyond the grid ends (FarParams::disp_lo_end)
   } else if (top) {
     clo[0] = blo - kHalf - 1; chi[0] = mid - near_in + 1;
     clo[1] = mid + near_in - 2; chi[1] = bhi + kHalf + 1;
@@ -682,12 +696,17 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
     clo[3] = plo + kHalf - 1; chi[3] = phi + kHalf + 1;          // window start inside the parent
     nr = 4;
   }
-  int rs[4], re[4];
+  int rs[6], re[6];
   for (int i = 0; i < nr; ++i) {
     rs[i] = lower_bound_ic(ix, clo[i]);
     re[i] = lower_bound_ic(ix, chi[i] + 1);
   }
-  for (int i = 1; i < nr; ++i) // sort by start (4 elements)
+  if (n_extra) {
+    rs[nr] = 0; re[nr] = fp.disp_lo_end;
+    rs[nr + 1] = fp.disp_hi_begin; re[nr + 1] = n_sub;
+    nr += 2;
+  }
+  for (int i = 1; i < nr; ++i) // sort by start
     for (int k = i; k > 0 && rs[k] < rs[k - 1]; --k) {
       int t0 = rs[k]; rs[k] = rs[k - 1]; rs[k - 1] = t0;
       t0 = re[k]; re[k] = re[k - 1]; re[k - 1] = t0;
@@ -713,7 +732,8 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
       const int j1 = r.j1, il = r.il(), ir = r.ir();
       if (!ff_admissible(j1, il, ir, blo, bhi, thr2)) continue;
       if (M2L) {
-        if (m2l_valid(0, b - ((j1 + kHalf - g_lo) >> 6), zreq, pms)) continue; // covered by a box pair
+        const bool displaced = l < fp.disp_lo_end || l >= fp.disp_hi_begin;
+        if (!displaced && m2l_valid(0, b - ((j1 + kHalf - g_lo) >> 6), zreq, pms)) continue; // covered by a box pair
       } else if (!top && ff_admissible(j1, il, ir, plo, phi, thr2p)) {
         continue; // owned by a wider box
       }
@@ -799,13 +819,16 @@ __device__ constexpr double inv_factorial(int n) {
   for (int i = 2; i <= n; ++i) f *= (double)i;
   return 1.0 / f;
 }
+// One wave per (source box, layer); lane = (line % 32, side): the lower half-wave builds the right-going moments
+// of 32 lines at a time, the upper half the left-going ones of the same lines, and each half sums its 2 kMQ values
+// over its own 32 lanes.  (A box holds 64 +- 8 lines on config 2: with 64 lines per step and one wave per side the
+// second step of most boxes ran nearly empty.)
 template <bool COUNT>
 __global__ __launch_bounds__(64) void sr_s2m_kernel(const FastRec *__restrict__ fast, IcIndex ix, int n_sub, int g_lo,
                                                     FarParams fp, unsigned long long *__restrict__ cnt) {
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
-  const int side = wid & 1, rest = wid >> 1;
-  const int layer = rest / fp.n_src[0], sb = rest - layer * fp.n_src[0];
-  const int lane = threadIdx.x;
+  const int layer = wid / fp.n_src[0], sb = wid - layer * fp.n_src[0];
+  const int lane = threadIdx.x, side = lane >> 5, sub = lane & 31;
   const int s_lo = g_lo + (sb - kSrcPad) * 64; // first centre position of the box
   const int l0 = lower_bound_ic(ix, s_lo), l1 = lower_bound_ic(ix, s_lo + 64);
   constexpr int NE = kFD / 2; // terms of the Laurent series
@@ -814,9 +837,9 @@ __global__ __launch_bounds__(64) void sr_s2m_kernel(const FastRec *__restrict__ 
   for (int n = 0; n < 2 * kMQ; ++n) v[n] = 0.;
   const FastRec *frow = fast + (size_t)layer * n_sub;
   unsigned n_lines = 0;
-  for (int base = l0; base < l1; base += 64) {
-    const int l = base + lane;
-    if (l >= l1) continue;
+  for (int base = l0; base < l1; base += 32) {
+    const int l = base + sub;
+    if (l >= l1 || l < fp.disp_lo_end || l >= fp.disp_hi_begin) continue;
     const FastRec r = frow[l];
     if (COUNT) ++n_lines;
     constexpr double h = 32.0;
@@ -849,16 +872,23 @@ __global__ __launch_bounds__(64) void sr_s2m_kernel(const FastRec *__restrict__ 
       v[kMQ + q - 2] = fma(r.wemi, mq, v[kMQ + q - 2]);
     }
   }
-  lane_reduce<2 * kMQ, 32>(v, lane);
+  // sums within each half-wave, one weight at a time (kMQ values over 32 lanes leave one per lane)
+  lane_reduce<kMQ, 16>(v, lane);
+  lane_reduce<kMQ, 16>(v + kMQ, lane);
   bool primary = true;
-  const int n_out = lane_reduce_index<2 * kMQ, 32>(lane, primary);
-  if (primary)
-    fp.mom[((size_t)(fp.src_off[0] + sb) * fp.n_layers + layer) * kMomPerBox + side * (2 * kMQ) + n_out] = v[0];
+  const int n_out = lane_reduce_index<kMQ, 16>(sub, primary);
+  if (primary) {
+    double *mo = fp.mom + ((size_t)(fp.src_off[0] + sb) * fp.n_layers + layer) * kMomPerBox + side * (2 * kMQ) + n_out;
+    mo[0] = v[0];
+    mo[kMQ] = v[kMQ];
+  }
   if (COUNT) count_add(cnt, kCntS2M, n_lines, lane);
 }
 
 // Upward pass: one thread per (widest-level source box, layer, side, weight) builds every wider level of its
-// subtree (15 boxes at 5 levels), children before parents.  n_src[l - 1] = 2 n_src[l] (host).
+// subtree (15 boxes at 5 levels), children before parents, the two children's moments in registers.  70 us on
+// config 2; a block per subtree with a thread per order, reading the children from memory inside the sums, took
+// 440 us.  n_src[l - 1] = 2 n_src[l] (host).
 __global__ __launch_bounds__(64) void sr_m2m_kernel(FarParams fp) {
   const int top = fp.n_levels - 1;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -905,7 +935,9 @@ __global__ __launch_bounds__(64) void sr_m2m_kernel(FarParams fp) {
 // Stores the local coefficients of levels >= 1, adds to those the level-0 pass of sr_farfield_kernel stored.
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kM2LSlices = kM2LRow / 16; // column tiles: all in one wave (the A loads are the cost, shared by them)
-__global__ __launch_bounds__(64) void sr_m2l_kernel(const int *__restrict__ zmax, FarParams fp) {
+template <bool COUNT>
+__global__ __launch_bounds__(64) void sr_m2l_kernel(const int *__restrict__ zmax, FarParams fp,
+                                                    unsigned long long *__restrict__ cnt) {
   int chunk = blockIdx.x, level = 0;
   for (;;) {
     const int c = (fp.box_count[level] * fp.n_layers + 15) >> 4;
@@ -928,12 +960,13 @@ __global__ __launch_bounds__(64) void sr_m2l_kernel(const int *__restrict__ zmax
   int near_hi = a_max, win_lo = a_max + 1;
   if (has_parent) {
     const int W2 = 2 * W;
-    int a_min_p = max(3, (max(zreq, 2 * W2 + 5 * pms) + W2 - 1) / W2 + 1);
+    int a_min_p = m2l_first_offset(level + 1, zreq, pms);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) a_min_p = max(a_min_p, __shfl_xor(a_min_p, m));
     near_hi = __builtin_amdgcn_readfirstlane(min(a_max, 2 * a_min_p + 1));
     win_lo = max(near_hi + 1, 2 * (kHalf / W2 - 1));
   }
+  unsigned n_pairs_on = 0; // COUNT: translations of this lane's pair (counted once per pair: kq == 0)
   v4d acc_a[kM2LSlices], acc_e[kM2LSlices];
 #pragma unroll
   for (int sl = 0; sl < kM2LSlices; ++sl) acc_a[sl] = acc_e[sl] = v4d{0., 0., 0., 0.};
@@ -945,6 +978,7 @@ __global__ __launch_bounds__(64) void sr_m2l_kernel(const int *__restrict__ zmax
       const bool on = live && sidx >= 0 && sidx < fp.n_src[level] && m2l_valid(level, o, zreq, pms) &&
                       !(has_parent && m2l_valid(level + 1, (t >> 1) - (s >> 1), zreq, pms));
       if (!__any(on)) continue;
+      if (COUNT) n_pairs_on += on && kq == 0;
       const double *m = fp.mom + ((size_t)(fp.src_off[level] + (on ? sidx : 0)) * fp.n_layers + layer) * kMomPerBox + sg * (2 * kMQ);
       const double *T = fp.tab + ((size_t)sg * kM2LOffsets + a) * (kM2LQ * kM2LRow) + lo;
 #pragma unroll
@@ -962,6 +996,7 @@ __global__ __launch_bounds__(64) void sr_m2l_kernel(const int *__restrict__ zmax
       }
     }
   }
+  if (COUNT) count_add(cnt, kCntM2L, n_pairs_on, lane);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int io = chunk * 16 + kq + 4 * r; // the pair of D's row
@@ -1530,7 +1565,7 @@ int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int
 int launch_m2l(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi,
                const FarParams &fp, unsigned long long *cnt, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
-  const dim3 g1((unsigned)(fp.n_src[0] * n_layers * 2));
+  const dim3 g1((unsigned)(fp.n_src[0] * n_layers));
   if (cnt)
     hipLaunchKernelGGL(sr_s2m_kernel<true>, g1, dim3(64), 0, st, fast, ix, n_sub, g_lo, fp, cnt);
   else
@@ -1539,7 +1574,10 @@ int launch_m2l(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_su
   hipLaunchKernelGGL(sr_m2m_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, st, fp);
   int chunks = 0;
   for (int lv = 0; lv < fp.n_levels; ++lv) chunks += (fp.box_count[lv] * n_layers + 15) / 16;
-  hipLaunchKernelGGL(sr_m2l_kernel, dim3((unsigned)chunks), dim3(64), 0, st, zmax, fp);
+  if (cnt)
+    hipLaunchKernelGGL(sr_m2l_kernel<true>, dim3((unsigned)chunks), dim3(64), 0, st, zmax, fp, cnt);
+  else
+    hipLaunchKernelGGL(sr_m2l_kernel<false>, dim3((unsigned)chunks), dim3(64), 0, st, zmax, fp, cnt);
   return (int)hipGetLastError();
 }
 

@@ -87,6 +87,10 @@ struct FarParams {
   // box-pair mode (m2l != 0)
   int m2l;
   int n_src[kMaxFarLevels], src_off[kMaxFarLevels]; // source boxes per level (storage index = box + (kSrcPad >> level))
+  // Lines beyond the grid ends have their window on the first / last grid point (closest_grid, spect_classes.py:1941)
+  // and their centre up to kHalf points outside it: they are sorted first / last (indices of the shard's line
+  // table), take no part in the box moments and keep per-line expansions (level 0) over their whole window.
+  int disp_lo_end, disp_hi_begin;
   const int *pm_src; // [n_layers] largest pole radius |sqrt(1/2 + ry^2)| dw' of the layer's lines, in grid points
   double *mom;       // [sum n_src][n_layers][kMomPerBox]
   const double *tab; // [2: o > 0, o < 0][kM2LOffsets][kM2LQ][kM2LRow] translation operator (host, long double)
@@ -102,7 +106,8 @@ enum {
   kCntRegion3 = 5,    // region-3 evaluations
   kCntRegion4 = 6,    // region-4 evaluations
   kCntS2M = 7,        // (line, side) multipole expansions (box-pair mode)  sr_s2m_kernel
-  kCntN = 8
+  kCntM2L = 8,        // (source box, target box, layer) translations      sr_m2l_kernel
+  kCntN = 10
 };
 // cnt: device counters [kCntN] or nullptr (the timed instantiations: no counting code)
 int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo,

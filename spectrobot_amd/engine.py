@@ -178,10 +178,10 @@ class LineSet(object):
     def last_eval_counts(self):
         """Executed-work counters of the last abscoeff_layers call made under set_counting(1)
         (sr_last_eval_counts): dict name -> count."""
-        c = (C.c_uint64 * 8)()
+        c = (C.c_uint64 * 10)()
         check(lib.sr_last_eval_counts(self._h, c), "sr_last_eval_counts")
         names = ("farfield_expansions", "region1_evals", "window_end_expansions", "poly_point_levels",
-                 "region2_evals", "region3_evals", "region4_evals")
+                 "region2_evals", "region3_evals", "region4_evals", "multipole_line_sides", "box_pair_translations")
         return dict(zip(names, (int(v) for v in c)))
 
 
@@ -436,6 +436,9 @@ def set_overlap(on):
     """1 (default): the zones kernel runs beside the far-field kernel on an internal stream;
     0: kernels one after the other (per-kernel times in last_kernel_ms)."""
     check(lib.sr_set_overlap(int(on)), "sr_set_overlap")
+
+
+FAR_FIELD_DEFAULT = 2  # the library's default far-field mode (sr_set_far_field)
 
 
 def set_far_field(on):

@@ -50,7 +50,7 @@ def test_config1_full_size_vs_oracle(eng, cfg1):
     try:
         a0, e0 = cfg1["ls"].abscoeff_layers(atm["temps"][sel], atm["press"][sel], tvib=atm["tvib"][:, sel])
     finally:
-        eng.set_far_field(1)
+        eng.set_far_field(eng.FAR_FIELD_DEFAULT)
     assert relerr(a0.cpu().numpy(), cfg1["abo"][[0, 4, 7]]) < 1e-10 and relerr(e0.cpu().numpy(), cfg1["emo"][[0, 4, 7]]) < 1e-10
 
 

@@ -58,11 +58,11 @@ def test_humliv_shim_golden(eng, golden):
         assert relerr(out, y) < 1e-13
 
 
-@pytest.mark.parametrize("ppl,far", [(8, 1), (8, 0), (4, 0)])
+@pytest.mark.parametrize("ppl,far", [(8, 2), (8, 1), (8, 0), (4, 0)])
 def test_e2e_ch4_levels_golden(eng, golden, ppl, far):
     """A2-A8 against the reference Python run: non-LTE levels, clipped windows,
-    dropped (unidentified / same-level) lines, an A=0 line.  far=1: far wings by
-    local expansions (default mode); far=0: every evaluation exact."""
+    dropped (unidentified / same-level) lines, an A=0 line.  far=2: far wings by local expansions built
+    from box pairs (default mode); far=1: built per line; far=0: every evaluation exact."""
     g = golden("e2e_ch4_levels")
     eng.set_points_per_lane(ppl)
     eng.set_far_field(far)
@@ -75,7 +75,7 @@ def test_e2e_ch4_levels_golden(eng, golden, ppl, far):
     assert relerr(ab0.cpu().numpy(), g["abs_lte0"]) < TOL
     assert relerr(em0.cpu().numpy(), g["emi_lte0"]) < TOL
     eng.set_points_per_lane(8)
-    eng.set_far_field(1)
+    eng.set_far_field(eng.FAR_FIELD_DEFAULT)
 
 
 def test_e2e_co_all_golden(eng, golden):
@@ -259,13 +259,14 @@ def test_full_size_linearity_property(eng):
     # the two evaluation modes at full size (far-field expansions vs every evaluation exact)
     eng.set_far_field(0)
     ab0, em0 = full.abscoeff_layers(T, P, tvib=tv)
-    eng.set_far_field(1)
+    eng.set_far_field(eng.FAR_FIELD_DEFAULT)
     assert float(((ab0 - ab).abs() / ab0.abs()).max()) < 2e-11
     assert float(((em0 - em).abs() / em0.abs()).max()) < 2e-11
 
 
-def test_far_field_vs_exact_mode(eng, oracle):
-    """The two evaluation modes of the coefficient op against each other and the oracle on a
+@pytest.mark.parametrize("far", [2, 1])
+def test_far_field_vs_exact_mode(eng, oracle, far):
+    """The far-field modes of the coefficient op against the exact mode and the oracle on a
     case where every far-field level is populated (3e4-point grid, dense lines, 4 layers from
     Doppler- to Lorentz-dominated, shard not aligned to the box hierarchy)."""
     from spectrobot_amd import synthetic as syn
@@ -278,8 +279,9 @@ def test_far_field_vs_exact_mode(eng, oracle):
     lo, hi = 777, 29001
     eng.set_far_field(0)
     a0, e0 = ls.abscoeff_layers(T, P, tvib=tv, g_lo=lo, g_hi=hi)
-    eng.set_far_field(1)
+    eng.set_far_field(far)
     a1, e1 = ls.abscoeff_layers(T, P, tvib=tv, g_lo=lo, g_hi=hi)
+    eng.set_far_field(eng.FAR_FIELD_DEFAULT)
     assert relerr(a1.cpu().numpy(), a0.cpu().numpy()) < 2e-11
     assert relerr(e1.cpu().numpy(), e0.cpu().numpy()) < 2e-11
     q = np.array([oracle.calc_partition_sum(*_tips(6, 1), t) for t in T])
@@ -312,8 +314,9 @@ def test_hires_to_lowres_golden(eng, golden):
         hi.hires_to_lowres(obs, spectral_widths=[1.0, 2.0])
 
 
+@pytest.mark.parametrize("far", [2, 1])
 @pytest.mark.parametrize("seed", range(16))
-def test_randomized_configs_far_vs_exact_vs_oracle(eng, oracle, seed):
+def test_randomized_configs_far_vs_exact_vs_oracle(eng, oracle, seed, far):
     """Random grids (step, length not a multiple of 64, shard offsets), molar masses, pressures from
     Doppler- to Lorentz-dominated (zones wider than the far-field near band), line densities: the
     far-field mode, the exact mode and the oracle must agree."""
@@ -342,8 +345,9 @@ def test_randomized_configs_far_vs_exact_vs_oracle(eng, oracle, seed):
     hi = int(rng.integers(2 * n_grid // 3, n_grid + 1))
     eng.set_far_field(0)
     a0, e0 = ls.abscoeff_layers(T, P, tvib=tv, q_part=q, g_lo=lo, g_hi=hi)
-    eng.set_far_field(1)
+    eng.set_far_field(far)
     a1, e1 = ls.abscoeff_layers(T, P, tvib=tv, q_part=q, g_lo=lo, g_hi=hi)
+    eng.set_far_field(eng.FAR_FIELD_DEFAULT)
     abo, emo = oracle.abscoeff_layers(L, mm, e_lev, T, P, q, tv, grid, mode=1, n_threads=3)
     a0, e0, a1, e1 = (x.cpu().numpy() for x in (a0, e0, a1, e1))
     ref_a, ref_e = abo[:, lo:hi], emo[:, lo:hi]
@@ -374,7 +378,7 @@ def test_maximum_grid_size(eng):
     for lo, hi in ((0, 30000), (590000, 625000), (n - 20000, n)):
         eng.set_far_field(0)
         a0, e0 = ls.abscoeff_layers(T, P, g_lo=lo, g_hi=hi)
-        eng.set_far_field(1)
+        eng.set_far_field(eng.FAR_FIELD_DEFAULT)
         a1, e1 = ls.abscoeff_layers(T, P, g_lo=lo, g_hi=hi)
         nz = (a0 != 0)
         assert bool(((a1 != 0) == nz).all())
@@ -482,7 +486,7 @@ def test_zones_kernel_wave_sharing_paths(eng, n_grid, n_layers):
     ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
     eng.set_far_field(0)
     a0, e0 = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
-    eng.set_far_field(1)
+    eng.set_far_field(eng.FAR_FIELD_DEFAULT)
     a1, e1 = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
     a2, e2 = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
     assert bool((a1 == a2).all()) and bool((e1 == e2).all())
@@ -694,7 +698,7 @@ def test_executed_work_counters(eng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("far", [1, 0])
+@pytest.mark.parametrize("far", [2, 1, 0])
 def test_outer_lines_golden_and_oracle(eng, oracle, golden, far):
     """Lines whose centre lies outside their own window (3.3 - 25 cm-1 outside the grid): the coarse op
     adds their far wings like the reference (humliv_bb's outer branches), in both evaluation modes;
@@ -719,7 +723,7 @@ def test_outer_lines_golden_and_oracle(eng, oracle, golden, far):
         # running sums of up to 13010 steps vs one fma: the drift of test_randomized_configs
         assert relerr(abo[nz], g["abs_outer_only"][nz]) < 1e-9 and relerr(emo[nz], g["emi_outer_only"][nz]) < 1e-9
     finally:
-        eng.set_far_field(1)
+        eng.set_far_field(eng.FAR_FIELD_DEFAULT)
     # a line close to the window: the sequential branches' core / region-2 segments (x0 within 5.5 dw')
     grid2 = syn_grid = None
     from spectrobot_amd import synthetic as syn

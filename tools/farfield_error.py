@@ -26,7 +26,7 @@ def main():
     T, P, tv = atm["temps"][sel], atm["press"][sel], atm["tvib"][:, sel]
     eng.set_far_field(0)
     a0, e0 = ls.abscoeff_layers(T, P, tvib=tv)
-    eng.set_far_field(1)
+    eng.set_far_field(eng.FAR_FIELD_DEFAULT)
     a1, e1 = ls.abscoeff_layers(T, P, tvib=tv)
     ra = ((a1 - a0).abs() / a0.abs()).amax(dim=1).cpu().numpy()
     re = ((e1 - e0).abs() / e0.abs()).amax(dim=1).cpu().numpy()

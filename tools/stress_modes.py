@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spectrobot_amd import engine as eng, synthetic as syn  # noqa: E402
 
 
+FAR = eng.FAR_FIELD_DEFAULT  # --far1: the per-line far field (sr_set_far_field(1)) instead of the default box pairs
 LARGE = False   # --large: grids up to 1.2e5 points, up to 70 layers, up to one line per point (all kernel paths)
 
 
@@ -41,7 +42,7 @@ def one(seed):
     hi = int(rng.integers(2 * n_grid // 3, n_grid + 1))
     eng.set_far_field(0)
     a0, e0 = ls.abscoeff_layers(T, P, tvib=tv, q_part=q, g_lo=lo, g_hi=hi)
-    eng.set_far_field(1)
+    eng.set_far_field(FAR)
     a1, e1 = ls.abscoeff_layers(T, P, tvib=tv, q_part=q, g_lo=lo, g_hi=hi)
     a0, e0, a1, e1 = (x.cpu().numpy() for x in (a0, e0, a1, e1))
     nz = a0 != 0
@@ -53,6 +54,9 @@ def one(seed):
 
 
 if __name__ == "__main__":
+    if "--far1" in sys.argv:
+        FAR = 1
+        sys.argv.remove("--far1")
     if "--large" in sys.argv:
         LARGE = True
         sys.argv.remove("--large")
