@@ -35,7 +35,7 @@ def main():
     kernels = {k: {"fetch_bytes": f.get(k, 0.0), "write_bytes": w.get(k, 0.0)} for k in sorted(set(f) | set(w))}
     coef = [k for k in kernels if any(s in k for s in ("sr_farfield_kernel<false", "near_wings_kernel<false>",
                                                         "near_zones_kernel<512, 1, false>", "sr_s2m_kernel<false>",
-                                                        "sr_m2m_kernel", "sr_m2l_kernel"))]
+                                                        "sr_m2m_kernel", "sr_m2l_kernel<false>"))]
     step = [k for k in kernels if k in coef or "sr_prep_kernel" in k or "sr_limb_kernel" in k or "sr_los_columns" in k]
     out = {
         "profile_tag": tag,
