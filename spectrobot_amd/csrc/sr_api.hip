@@ -217,7 +217,7 @@ struct sr_lineset {
   // [2]: with sr_set_overlap(1) the tables of call c+1 are prepared (on prep_st) while the kernels
   // of call c still read theirs
   Stager s_layers[2];
-  DevBuf d_fast[2], d_cold[2], d_zmax[2], d_coef, d_first, d_zone, d_mom;
+  DevBuf d_fast[2], d_cold[2], d_coef, d_first, d_zone, d_mom;
   int first_x0 = 0, first_n = 0; // IcIndex table domain
   hipStream_t aux = nullptr;     // second stream: zones kernel beside the far-field kernel
   hipStream_t prep_st = nullptr; // third stream: staging copy + sr_prep_kernel of the NEXT call
@@ -556,7 +556,6 @@ int sr_lineset_destroy(sr_lineset *ls) {
     ls->s_layers[b].release();
     ls->d_fast[b].release();
     ls->d_cold[b].release();
-    ls->d_zmax[b].release();
     if (ls->ev_prep_done[b]) (void)hipEventDestroy(ls->ev_prep_done[b]);
     if (ls->ev_tables_free[b]) (void)hipEventDestroy(ls->ev_tables_free[b]);
   }
@@ -647,8 +646,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   }
 
   // per-layer scalars (host, fp64)
-  const size_t hl_doubles = (size_t)nl * (4 + npop);
-  const size_t hl_bytes = sizeof(double) * hl_doubles + sizeof(int) * 2 * (size_t)nl; // + pole margins pm, pm_src
+  const size_t hl_doubles = (size_t)nl * (5 + npop);
+  const size_t hl_bytes = sizeof(double) * hl_doubles + sizeof(int) * 3 * (size_t)nl; // + pole margins pm, pm_src, widest zone
   // Table set of this call and the stream its preparation runs on.  With overlap, call c + 1
   // prepares set (c + 1) % 2 on prep_st while the kernels of call c (which the caller's stream is
   // still running) read set c % 2: the HBM-write-bound prep kernel hides behind the VALU-bound ones.
@@ -669,10 +668,10 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     pst = ls->prep_st;
   }
   Stager &SL = ls->s_layers[b];
-  DevBuf &d_fast = ls->d_fast[b], &d_cold = ls->d_cold[b], &d_zmax = ls->d_zmax[b];
+  DevBuf &d_fast = ls->d_fast[b], &d_cold = ls->d_cold[b];
   int rc = SL.prepare(hl_bytes);
   if (rc) return rc;
-  double *T = SL.host<double>(), *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *pop = sq + nl;
+  double *T = SL.host<double>(), *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *ltr = sq + nl, *pop = ltr + nl;
   std::vector<double> q(nl);
   if (atm->q_part) {
     std::copy(atm->q_part, atm->q_part + nl, q.begin());
@@ -685,6 +684,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     pa[k] = atm->press[k] * kHpaToAtm;                                        // spect_classes.py:2034
     tr[k] = kTref / T[k];                                                     // :1972
     sq[k] = std::sqrt(2 * kAvogadro * kKcgs * T[k] * kLn2 / ls->mm);          // :1984
+    ltr[k] = std::log(tr[k]);
     {
       // pole margin of the far-field expansions: the region-1 rational has its poles at
       // |x| = sqrt(1/2 + ry^2), i.e. within 0.71 dw' of the line centre on the real axis
@@ -696,6 +696,11 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       const double lw_max = ls->gamma_max * pa[k] * std::max(std::pow(tr[k], ls->ndep_min), std::pow(tr[k], ls->ndep_max));
       const double pole = std::sqrt(0.5 * dwp_max * dwp_max + lw_max * lw_max) / ls->gp.gstep;
       pmh[nl + k] = (int)std::ceil(std::min(pole, 1e6));
+      // widest region-2/3/4 zone of the layer, in grid points from the line centre: region 1 starts where
+      // |x| - ry >= 15 (lineshape.f:447-454), i.e. (lw + 15 dw') / step points out, +-1 for the nint and the
+      // centre's offset inside its grid cell.  A bound over the lines (every kernel reads this one value, so they
+      // agree on who evaluates what); kernels clamp it to the window half-width.
+      pmh[2 * nl + k] = (int)std::min(std::ceil((lw_max + 15.0 * dwp_max) / ls->gp.gstep) + 2.0, (double)kHalf);
     }
     if (nlev > 0) {
       for (int lv = 0; lv < nlev; ++lv) {
@@ -713,9 +718,10 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   if (rc) return rc;
   LayersDev A;
   const double *dl = SL.d.as<double>();
-  A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.pop = dl + 4 * nl;
+  A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.ltrat = dl + 4 * nl; A.pop = dl + 5 * nl;
   A.n_layers = nl; A.n_pop = npop;
   const int *d_pm = reinterpret_cast<const int *>(dl + hl_doubles);
+  const int *zmax_dev = d_pm + 2 * nl; // [n_layers] widest zone (host bound, see above)
   A.sqrt_ln2 = std::sqrt(kLn2);            // spect_classes.py:1999
   A.sqrt_pi_ln2 = std::sqrt(kPi / kLn2);   // :1997
 
@@ -772,15 +778,11 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   rc = d_cold.ensure(sizeof(ColdRec) * ((size_t)n_sub * nl + 1));
   if (rc) return rc;
 
-  rc = d_zmax.ensure(sizeof(int) * (size_t)nl);
-  if (rc) return rc;
-  HIPCHK(hipMemsetAsync(d_zmax.p, 0, sizeof(int) * (size_t)nl, pst));
 
   HIPCHK(hipEventRecord(ls->ev[0], pst));
   // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
   LAUNCHCHK(launch_prep(ls->L, A, ls->gp, W, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
-                        far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(),
-                        d_zmax.as<int>(), pst));
+                        far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), pst));
   HIPCHK(hipEventRecord(ls->ev[1], pst));
   if (overlap) { // the caller's stream takes over once the tables are ready
     HIPCHK(hipEventRecord(ls->ev_prep_done[b], pst));
@@ -828,10 +830,10 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     }
     // far-field pass(es): per-line expansions (all levels, or level 0 of the box-pair mode), then the box pairs
     auto far_pass = [&]() -> int {
-      LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, fp,
+      LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp,
                                 d_cnt, st));
       if (fp.m2l)
-        LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, st));
+        LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, st));
       return SR_OK;
     };
     if (overlap) {
@@ -857,7 +859,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         z_abs = ls->d_zone.as<double>();
         z_emi = z_abs + n_pts * nl;
       }
-      LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, d_zmax.as<int>(), n_sub,
+      LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, ls->aux));
       HIPCHK(hipEventRecord(ls->ev_join, ls->aux));
       rc = far_pass();
@@ -867,7 +869,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       if (!ls->ev_tail) HIPCHK(hipEventCreateWithFlags(&ls->ev_tail, hipEventDisableTiming));
       HIPCHK(hipEventRecord(ls->ev_tail, st));
       ls->tail_recorded = true;
-      LAUNCHCHK(launch_near(1, small ? 0 : 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, d_zmax.as<int>(), n_sub,
+      LAUNCHCHK(launch_near(1, small ? 0 : 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st));
       HIPCHK(hipEventRecord(ls->ev[3], st));
       if (small) {
@@ -883,7 +885,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       HIPCHK(hipEventRecord(ls->ev[2], st));
       for (int part = 1; part <= 2; ++part) {
         LAUNCHCHK(launch_near(part, part == 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix,
-                              d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out,
+                              zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out,
                               d_cnt, st));
         HIPCHK(hipEventRecord(ls->ev[2 + part], st));
       }
@@ -893,7 +895,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     ls->n_timed = 3;
     for (int which = 0; which < 2; ++which) {
       LAUNCHCHK(launch_abscoeff(variant, which, d_fast.as<FastRec>(), d_cold.as<ColdRec>(),
-                                ix, d_zmax.as<int>(), n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
+                                ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
                                 abs_out, emi_out, st));
       HIPCHK(hipEventRecord(ls->ev[2 + which], st));
     }

@@ -11,6 +11,7 @@
 //   spect_classes.py:1967-2008  widths and MakeShape normalisation.
 //   spect_classes.py:1736-1853  Einstein / G coefficients.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -324,27 +325,56 @@ __device__ inline ColdRec make_cold(const Bounds &B, double dwp, double x0, cons
     int k3lo = 1, k3hi = 0; // empty
     if (clo <= chi) {
       auto is3 = [&](int k) { return !core_is_region4(fabs(xf(k) - x0) / dwp, B.ry); };
-      // the point closest to the centre: |x(k) - x0| is V-shaped in k
-      int a = clo, b = chi;
-      while (a < b) {
-        const int m = (a + b) >> 1;
-        if (xf(m) < x0) a = m + 1; else b = m;
-      }
-      int kc = a; // first k with x(k) >= x0 (or chi)
-      if (kc > clo && fabs(xf(kc - 1) - x0) < fabs(xf(kc) - x0)) --kc;
-      if (is3(kc)) {
-        int lo = clo, hi = kc; // smallest k in [clo, kc] with is3 (true ... true towards kc)
-        while (lo < hi) {
-          const int m = (lo + hi) >> 1;
-          if (is3(m)) hi = m; else lo = m + 1;
+      if constexpr (std::is_same<XF, WinX>::value) {
+        // The window grid is affine in k up to rounding, and region 3 is |x(k) - x0| <= (ry + 0.176)/0.195 dw up
+        // to rounding: start each search at the index that formula gives and let the reference's own tests move it
+        // (zero or one step).  Same results as the binary searches below -- both rely only on monotonicity -- for
+        // 5 instead of ~16 evaluations of the test with its IEEE division (a quarter of sr_prep_kernel's
+        // instructions).
+        const double inv_delta = 1.0 / xf.lin_delta, base = xf.lin_start + xf.gc; // x(k) ~ base + (k - 1) delta
+        auto near_index = [&](double x, int lo_, int hi_) {
+          const double kf = fma(x - base, inv_delta, 1.0);
+          const int k = (int)fmin(fmax(kf, (double)lo_ - 1.0), (double)hi_ + 1.0);
+          return min(max(k, lo_), hi_);
+        };
+        int kc = near_index(x0, clo, chi); // first k in [clo, chi] with x(k) >= x0 (or chi)
+        while (kc > clo && xf(kc - 1) >= x0) --kc;
+        while (kc < chi && xf(kc) < x0) ++kc;
+        if (kc > clo && fabs(xf(kc - 1) - x0) < fabs(xf(kc) - x0)) --kc;
+        if (is3(kc)) {
+          const double reach = (B.ry + 0.176) / 0.195 * dwp;
+          int lo = near_index(x0 - reach, clo, kc); // smallest k in [clo, kc] with is3
+          while (lo > clo && is3(lo - 1)) --lo;
+          while (lo < kc && !is3(lo)) ++lo;
+          k3lo = lo;
+          int hi = near_index(x0 + reach, kc, chi); // largest k in [kc, chi] with is3
+          while (hi < chi && is3(hi + 1)) ++hi;
+          while (hi > kc && !is3(hi)) --hi;
+          k3hi = hi;
         }
-        k3lo = lo;
-        lo = kc; hi = chi;     // largest k in [kc, chi] with is3
-        while (lo < hi) {
-          const int m = (lo + hi + 1) >> 1;
-          if (is3(m)) lo = m; else hi = m - 1;
+      } else {
+        // the point closest to the centre: |x(k) - x0| is V-shaped in k
+        int a = clo, b = chi;
+        while (a < b) {
+          const int m = (a + b) >> 1;
+          if (xf(m) < x0) a = m + 1; else b = m;
         }
-        k3hi = lo;
+        int kc = a; // first k with x(k) >= x0 (or chi)
+        if (kc > clo && fabs(xf(kc - 1) - x0) < fabs(xf(kc) - x0)) --kc;
+        if (is3(kc)) {
+          int lo = clo, hi = kc; // smallest k in [clo, kc] with is3 (true ... true towards kc)
+          while (lo < hi) {
+            const int m = (lo + hi) >> 1;
+            if (is3(m)) hi = m; else lo = m + 1;
+          }
+          k3lo = lo;
+          lo = kc; hi = chi;     // largest k in [kc, chi] with is3
+          while (lo < hi) {
+            const int m = (lo + hi + 1) >> 1;
+            if (is3(m)) lo = m; else hi = m - 1;
+          }
+          k3hi = lo;
+        }
       }
     }
     c.k3 = (uint32_t)k3lo | ((uint32_t)k3hi << 16);

@@ -34,7 +34,7 @@ __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, c
   LinePhys P;
   const double T = A.temps[k];
   const double x0 = L.freq[ln];
-  P.lw = pow(A.trat[k], L.t_dep[ln]) * (L.air_broad[ln] * A.p_atm[k]);
+  P.lw = exp(L.t_dep[ln] * A.ltrat[k]) * (L.air_broad[ln] * A.p_atm[k]); // (296/T)^n gamma P  (spcl:1972)
   const double dw = x0 / kCcgs * A.sqk[k];
   P.dwp = dw / A.sqrt_ln2;
   const double fac = dw * A.sqrt_pi_ln2;
@@ -76,8 +76,7 @@ __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, c
 __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, GridParams gp, WeightMode W,
                                                       int line_lo, int n_sub, int cold_lo, int cold_hi,
                                                       FastRec *__restrict__ fast,
-                                                      ColdRec *__restrict__ cold,
-                                                      int *__restrict__ zmax) {
+                                                      ColdRec *__restrict__ cold) {
   // records leave through LDS: a lane's 80 / 128 B record is written in 16-byte pieces at a
   // 80 / 128 B stride across the lanes, which the memory side handles badly (1.8 TB/s); the
   // wave's 64 records are contiguous in the table, so they are transposed and stored 1 KB per
@@ -131,29 +130,29 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
       const ColdRec c = make_cold(B, dwp, x0, xf);
       const uint4 *cp = reinterpret_cast<const uint4 *>(&c);
       uint4 *gc = reinterpret_cast<uint4 *>(cold + o);
-      constexpr int NH = NC / 2; // 16-byte pieces per half record
+      // 32 records at a time, whole: every store instruction writes 1 KB of consecutive bytes (two half-record
+      // passes wrote 64-byte pieces at a 128-byte stride: 2.0 instead of 3.9 TB/s for the tables)
+      static_assert(32 * (NC + 1) * 16 <= sizeof(s_rec[0]), "staging buffer holds 32 padded cold records");
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int part = 0; part < 2; ++part) {
         __builtin_amdgcn_wave_barrier();
+        if ((lane >> 5) == part) {
 #pragma unroll
-        for (int q = 0; q < NH; ++q) buf[lane * NH + q] = cp[half * NH + q];
+          for (int q = 0; q < NC; ++q) buf[(lane & 31) * (NC + 1) + q] = cp[q]; // padded: 144-byte stride, fewer bank conflicts
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // piece m of the half-record table: record m / NH, piece m % NH of this half
 #pragma unroll
-        for (int q = 0; q < NH; ++q) {
-          const int m = q * 64 + lane;
-          if (m < n_valid * NH) gc[(m / NH) * NC + half * NH + (m % NH)] = buf[m];
+        for (int q = 0; q < NC / 2; ++q) {
+          const int m = q * 64 + lane; // piece m of the 32 records
+          if (32 * part + m / NC < n_valid) gc[32 * part * NC + m] = buf[(m / NC) * (NC + 1) + (m % NC)];
         }
       }
     }
   }
-  // widest region-2/3/4 zone of the layer, in grid points from the window centre
-  // (k = 6506): tells sr_abscoeff_cores_kernel how far to look for candidates
-  int hw = valid ? max(kHalf + 1 - B.il, B.ir - (kHalf + 1)) : 0;
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) hw = max(hw, __shfl_xor(hw, m));
-  if ((threadIdx.x & 63) == 0) atomicMax(&zmax[k], hw);
+  // (The widest zone of the layer, which the other kernels use to bound their candidate ranges, comes from the host
+  // as a bound -- (lw_max + 15 dw'_max) / step: the wave maxima + one atomicMax per wave on the layer's single counter
+  // serialised in L2 and WERE this kernel's 0.8 ms: it took as long with its stores or its arithmetic compiled out.)
 }
 
 // ------------------------------------------------------------------------
@@ -1657,11 +1656,11 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
 }
 
 int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, const WeightMode &W, int line_lo,
-                int n_sub, int cold_lo, int cold_hi, FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st) {
+                int n_sub, int cold_lo, int cold_hi, FastRec *fast, ColdRec *cold, hipStream_t st) {
   if (n_sub <= 0 || A.n_layers <= 0) return 0;
   dim3 grid((n_sub + 255) / 256, A.n_layers);
   hipLaunchKernelGGL(sr_prep_kernel, grid, dim3(256), 0, st, L, A, gp, W, line_lo, n_sub, cold_lo, cold_hi, fast,
-                     cold, zmax);
+                     cold);
   return (int)hipGetLastError();
 }
 

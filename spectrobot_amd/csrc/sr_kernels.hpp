@@ -17,6 +17,7 @@ struct LinesDev {
 // fp64 with correctly rounded sqrt (80 values) and uploaded.
 struct LayersDev {
   const double *temps, *p_atm, *trat, *sqk; // T, P[atm], 296/T, sqrt(2 N_A k T ln2 / MM)
+  const double *ltrat;                      // log(296/T): (296/T)^n = exp(n log(296/T)), a third of pow()'s instructions
   const double *pop;                        // [n_layers][n_pop] level populations / Q
   int n_layers, n_pop;
   double sqrt_ln2, sqrt_pi_ln2;
@@ -123,7 +124,7 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
                 double *abs_out, double *emi_out, unsigned long long *cnt, hipStream_t st);
 
 int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, const WeightMode &W, int line_lo,
-                int n_sub, int cold_lo, int cold_hi, FastRec *fast, ColdRec *cold, int *zmax, hipStream_t st);
+                int n_sub, int cold_lo, int cold_hi, FastRec *fast, ColdRec *cold, hipStream_t st);
 // Lines whose centre lies outside their own window (humliv_bb's outer branches, lineshape.f:272-442):
 // records per (line, layer), then one thread per (grid point, layer) adds them in line order.
 int launch_outer(const LinesDev &Lo, int n_out, const LayersDev &A, const GridParams &gp, const WeightMode &W,
