@@ -242,6 +242,41 @@ __device__ inline double exp_bounded(double u) {
   return ldexp(p, (int)n);
 }
 
+// One segment of the radiance recursion: t = exp(-tau), em1 = 1 - exp(-tau) and f = em1 / tau (1 where
+// |tau| <= 1e-12) from ONE range reduction and polynomial: -tau = n ln2 + r, e^r - 1 = r (1 + r P(r)) =: pm1 with
+// exp_bounded's polynomial, s = 2^n, t = s + s pm1, em1 = (1 - s) - s pm1 (n = 0: -pm1, exact for thin segments; no
+// cancellation otherwise: |r| <= 0.35), the quotient by reciprocal + two Newton steps.  ~30 instructions for what
+// exp() + expm1() + an IEEE division spent ~95 on: the recursion kernels are VALU-bound (64 rays x 160 segments
+// x 1e5 points), sr_limb_kernel 1.5 -> see DESIGN.md.  tau may be negative (stimulated emission).
+struct Atten {
+  double t, em1, f, rtau; // rtau = 1 / tau (unspecified where |tau| <= 1e-12)
+  bool thin;
+};
+__device__ inline Atten attenuation(double tau) {
+  const double x = -tau;
+  const double n = rint(x * 0x1.71547652b82fep+0);  // log2(e)
+  double r = fma(-n, 0x1.62e42fefa39efp-1, x);      // ln2 hi
+  r = fma(-n, 0x1.abc9e3b39803fp-56, r);            // ln2 lo
+  double p = fma3(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+  p = fma3(r, p, 0x1.71dee623fde64p-19);
+  p = fma3(r, p, 0x1.a01997c89e6b0p-16);
+  p = fma3(r, p, 0x1.a01a014761f6ep-13);
+  p = fma3(r, p, 0x1.6c16c1852b7b0p-10);
+  p = fma3(r, p, 0x1.1111111122322p-7);
+  p = fma3(r, p, 0x1.55555555502a1p-5);
+  p = fma3(r, p, 0x1.5555555555511p-3);
+  p = fma3(r, p, 0x1.000000000000bp-1);
+  const double pm1 = r * fma(r, p, 1.0);
+  const double s = ldexp(1.0, (int)fmin(fmax(n, -1100.0), 1100.0));
+  Atten A;
+  A.t = fma(s, pm1, s);
+  A.em1 = fma(-s, pm1, 1.0 - s);
+  A.thin = !(fabs(tau) > 1e-12);
+  A.rtau = fast_rcp<2>(tau);
+  A.f = A.thin ? 1.0 : A.em1 * A.rtau;
+  return A;
+}
+
 // Regions 3 and 4 at c2 = (a, b) = ((double)(float)ry, (double)(float)(-rx)): cmplx() is
 // default kind, both parts are rounded to single (lineshape.f:529).
 __device__ inline double core_region4(double a, double b) { // :530-546

@@ -1721,10 +1721,8 @@ __global__ __launch_bounds__(256) void sr_radiance_kernel(const double *__restri
 #pragma unroll
     for (int t = 0; t < kB; ++t) {
       if (sb + t < s1) {
-        const double tau = a[t] * u[t];
-        const double em1 = -expm1(-tau);
-        const double src = fabs(tau) > 1e-12 ? (e[t] * u[t]) * (em1 / tau) : e[t] * u[t];
-        I = I * exp(-tau) + src;
+        const Atten A = attenuation(a[t] * u[t]);
+        I = I * A.t + (e[t] * u[t]) * A.f;
       }
     }
   }
@@ -1766,10 +1764,8 @@ __global__ __launch_bounds__(256) void sr_radiance_jac_kernel(const double *__re
       const int s = sb + k;
       if (s < s1) {
         const double u = seg_col[s], a = av[k], e = ev[k];
-        const double tau = a * u;
-        const double t = exp(-tau);
-        const double em1 = -expm1(-tau);
-        const double src = fabs(tau) > 1e-12 ? (e * u) * (em1 / tau) : e * u;
+        const Atten A = attenuation(a * u);
+        const double t = A.t, src = (e * u) * A.f;
         const double g = t * (e - a * I);
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -1809,13 +1805,12 @@ __global__ __launch_bounds__(256) void sr_radiance_jac_layer_kernel(
     const size_t o = (size_t)k * n_pts + j;
     const double u = seg_col[s], a = abs_c[o], e = emi_c[o];
     const double tau = a * u;
-    const double t = exp(-tau);
-    const double em1 = -expm1(-tau);
-    const bool thin = !(fabs(tau) > 1e-12);
-    const double f = thin ? 1.0 : em1 / tau;
+    const Atten A = attenuation(tau);
+    const double t = A.t, em1 = A.em1, f = A.f;
+    const bool thin = A.thin;
     const double src = (e * u) * f;
     if (k >= p0 && k < p0 + NP) { // this segment's layer is one of this thread's parameters
-      const double fp = thin ? -0.5 : (tau * t - em1) / (tau * tau);
+      const double fp = thin ? -0.5 : (tau * t - em1) * (A.rtau * A.rtau);
       const double da = dabs[o], de = demi[o];
       const double d = I * (-u * t * da) + u * f * de + e * u * u * fp * da;
 #pragma unroll
@@ -1914,9 +1909,8 @@ __global__ __launch_bounds__(256) void sr_limb_kernel(const double *__restrict__
           tau = tau + a[t][g] * u[t][g];
           E = E + e[t][g] * u[t][g];
         }
-        const double em1 = -expm1(-tau);
-        const double src = o.solo_absorption ? 0.0 : (fabs(tau) > 1e-12 ? E * (em1 / tau) : E);
-        I = I * exp(-tau) + src;
+        const Atten A = attenuation(tau);
+        I = I * A.t + (o.solo_absorption ? 0.0 : E * A.f);
       }
     }
   }
@@ -1956,10 +1950,10 @@ __global__ __launch_bounds__(256) void sr_limb_jac_kernel(
       tau = g == 0 ? a[g] * u : tau + a[g] * u;
       E = g == 0 ? e[g] * u : E + e[g] * u;
     }
-    const double t = exp(-tau), em1 = -expm1(-tau);
-    const bool thin = !(fabs(tau) > 1e-12);
-    const double f = thin ? 1.0 : em1 / tau;
-    const double fp = thin ? -0.5 : (tau * t - em1) / (tau * tau);
+    const Atten A = attenuation(tau);
+    const double t = A.t, em1 = A.em1, f = A.f;
+    const bool thin = A.thin;
+    const double fp = thin ? -0.5 : (tau * t - em1) * (A.rtau * A.rtau);
     const double src = o.solo_absorption ? 0.0 : E * f;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
@@ -2011,12 +2005,12 @@ __global__ __launch_bounds__(256) void sr_limb_jac_layer_kernel(
         dE = fma(demi[g * gstride + ofs], u, dE);
       }
     }
-    const double t = exp(-tau), em1 = -expm1(-tau);
-    const bool thin = !(fabs(tau) > 1e-12);
-    const double f = thin ? 1.0 : em1 / tau;
+    const Atten A = attenuation(tau);
+    const double t = A.t, em1 = A.em1, f = A.f;
+    const bool thin = A.thin;
     const double src = o.solo_absorption ? 0.0 : E * f;
     if (mine) {
-      const double fp = thin ? -0.5 : (tau * t - em1) / (tau * tau);
+      const double fp = thin ? -0.5 : (tau * t - em1) * (A.rtau * A.rtau);
       const double d = -I * t * dtau + (o.solo_absorption ? 0.0 : dE * f + E * fp * dtau);
 #pragma unroll
       for (int q = 0; q < NP; ++q) J[q] = fma(J[q], t, (k == p0 + q) ? d : 0.0);
