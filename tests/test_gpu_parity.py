@@ -698,6 +698,50 @@ def test_executed_work_counters(eng):
 
 
 @pytest.mark.gpu
+def test_box_pair_far_field_work_and_dense_boxes(eng, oracle):
+    """The box-pair far field (default): its counters -- one moment set per (line of the shard's table, layer, side),
+    translations at every level, an order of magnitude fewer per-line expansions than the per-line scheme -- and a
+    case with 4 lines per grid point (every 64-point source box needs several passes of 32 lines; zones of
+    neighbouring lines overlap many times) against the exact mode and the oracle."""
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2990.0, 5e-4, 40000)
+    L = syn.make_lines(9000, grid, seed=23, n_levels=0)
+    T = np.array([170.0, 130.0, 110.0])
+    P = np.array([8.0, 0.05, 1e-6])
+    q = np.array([220.0, 160.0, 140.0])
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM)
+    counts = {}
+    eng.set_counting(1)
+    try:
+        for far in (2, 1):
+            eng.set_far_field(far)
+            ls.abscoeff_layers(T, P, q_part=q)
+            counts[far] = ls.last_eval_counts()
+    finally:
+        eng.set_counting(0)
+        eng.set_far_field(eng.FAR_FIELD_DEFAULT)
+    c2, c1 = counts[2], counts[1]
+    assert c2["multipole_line_sides"] == 2 * 9000 * 3 and c1["multipole_line_sides"] == 0
+    assert c2["box_pair_translations"] > 0 and c1["box_pair_translations"] == 0
+    assert 0 < c2["farfield_expansions"] < 0.25 * c1["farfield_expansions"]
+    for k in ("region1_evals", "region2_evals", "region3_evals", "region4_evals", "window_end_expansions"):
+        assert c2[k] == c1[k], k          # the near field does not depend on how the far field is built
+    # dense: 4 lines per point
+    grid = syn.make_grid(2990.0, 5e-4, 3000)
+    L = syn.make_lines(12000, grid, seed=29, n_levels=3)
+    tv = np.array([T + 2.0 * i for i in range(3)])
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES[:3])
+    eng.set_far_field(0)
+    a0, e0 = ls.abscoeff_layers(T, P, tvib=tv, q_part=q)
+    eng.set_far_field(2)
+    a2, e2 = ls.abscoeff_layers(T, P, tvib=tv, q_part=q)
+    eng.set_far_field(eng.FAR_FIELD_DEFAULT)
+    assert relerr(a2.cpu().numpy(), a0.cpu().numpy()) < 2e-11 and relerr(e2.cpu().numpy(), e0.cpu().numpy()) < 2e-11
+    abo, emo = oracle.abscoeff_layers(L, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES[:3], T, P, q, tv, grid, mode=1, n_threads=4)
+    assert relerr(a2.cpu().numpy(), abo) < TOL and relerr(e2.cpu().numpy(), emo) < TOL
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("far", [2, 1, 0])
 def test_outer_lines_golden_and_oracle(eng, oracle, golden, far):
     """Lines whose centre lies outside their own window (3.3 - 25 cm-1 outside the grid): the coarse op

@@ -1,3 +1,5 @@
+"""HBM fill / copy / read bandwidth of the box with plain torch ops on a 1.67 GB buffer (the size of the record
+tables): the yardstick for sr_prep_kernel's stores (fill 6.2, copy 5.0, read 6.0 TB/s)."""
 import torch, time
 x = torch.empty(1670000000 // 8, dtype=torch.float64, device="cuda")
 y = torch.empty_like(x)

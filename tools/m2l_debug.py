@@ -1,3 +1,6 @@
+"""Far-field modes 1 and 2 against the exact mode on the random configurations of
+tests/test_gpu_parity.py::test_randomized_configs_far_vs_exact_vs_oracle: where the largest difference sits.
+usage: python tools/m2l_debug.py FIRST_SEED END_SEED"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
