@@ -3,13 +3,18 @@
 //   sr_prep_kernel      one thread per (line, layer): widths, G coefficients,
 //                       level-population weights, Humlicek region boundaries
 //                       -> FastRec / ColdRec tables in HBM.
-//   coefficient spectra, gather formulation (no atomics, no [n_lines x 13010]
-//   matrix, coalesced fp64 stores; fp64 VALU bound, no MFMA: not a contraction):
-//     default  sr_farfield_kernel            far region-1 wings as per-box Taylor sums
-//              sr_abscoeff_near_wings_kernel  exact region 1 of the near lines + polynomials
+//   coefficient spectra, gather formulation (no global atomics, no [n_lines x 13010]
+//   matrix, coalesced fp64 stores; fp64 VALU bound):
+//     default  far region-1 wings as per-box Taylor sums (local expansions), built from box pairs:
+//                sr_s2m_kernel / sr_m2m_kernel   multipole moments of the lines of each source box, all levels
+//                sr_m2l_kernel                   moments -> local coefficients (fp64 MFMA: the one matrix product here)
+//                sr_farfield_kernel<., true>     per-line expansions of the (line, box) pairs no box pair covers
+//              (sr_set_far_field(1): sr_farfield_kernel<., false>, one expansion per (line, box) at every level)
+//              sr_abscoeff_near_wings_kernel  exact region 1 of the near lines + one polynomial per level and point
 //              sr_abscoeff_near_zones_kernel  regions 2/3/4 through an LDS image of the group
 //     exact    sr_abscoeff_wings_kernel / sr_abscoeff_cores_kernel: every evaluation
-//   sr_radiance_kernel / sr_radiance_jac_kernel   limb recursion (+ Jacobian) per (point, ray)
+//   sr_los_columns_kernel / sr_limb_kernel / sr_limb_jac*_kernel   Curtis-Godson columns, limb recursion, Jacobians
+//   sr_radiance_kernel / sr_radiance_jac_kernel   the same recursion on host-built columns
 //   sr_lowres_kernel    Gaussian ILS onto low-resolution bands (hires_to_lowres)
 //   shims               humliv_bb / sum_all_lines / curgod_fort_N call shapes.
 #include <cstdlib>
@@ -1020,18 +1025,17 @@ __global__ __launch_bounds__(64) void sr_m2l_kernel(const int *__restrict__ zmax
 
 // Exact near field + evaluation of the far-field polynomials.  The scalar unit is shared by
 // the CU's four SIMDs, so ownership tests and interval arithmetic run on the VALU, 64 candidate
-// lines at a time (lane = line); ballots mark the lines with work and only those are walked,
-// their records fetched by scalar loads.
+// lines at a time (lane = line); ballots mark the lines with work; those are walked in ROWS: the
+// wave's 64 lanes as 8 rows of 8, a row takes one line (its record by per-lane loads) and steps
+// through that line's points 8 at a time.
 //
 // sr_abscoeff_near_wings_kernel (one 64-point slot per wave): every REGION-1 point of the
-//   lines that no far-field level owns for the slot -- whole slots; slots that also hold zone
-//   points or the grid end with a one-sided per-lane mask; the slots holding a window end or
+//   lines that no far-field level owns for the slot, in rows; the slots holding a window end or
 //   start by per-line expansions and a lane scan (window_end_sum) -- plus one far-field
 //   polynomial per level; writes abs/emi (or adds, when the zones kernel stored first).
-// sr_abscoeff_near_zones_kernel (one 256/512-point LDS image per wave; adds to abs/emi):
-//   region 3 (~15 points per line) with lanes = lines in the chunk phase; region 2 as one run
-//   of consecutive lanes per line; region 4 packed ACROSS lines into full 64-lane chunks
-//   (pending points carry their line's parameters; LDS atomics).
+// sr_abscoeff_near_zones_kernel (one 512-point LDS image per wave; stores or adds to abs/emi):
+//   region 3 (~15 points per line) with lanes = lines in the chunk phase; regions 2 and 4 in
+//   rows, sums by return-less LDS adds (one wave per image, program order: deterministic).
 // ------------------------------------------------------------------------
 __device__ inline void near_ranges(const IcIndex &ix, int wlo, int width, int zm,
                                    int rs[3], int re[3]) {
