@@ -72,14 +72,15 @@ struct __attribute__((aligned(16))) FastRec {
 };
 static_assert(sizeof(FastRec) == 80, "FastRec must be 80 bytes");
 
-// Everything regions 2-4 of one (line, layer) need, read (two scalar loads) only
-// where a wave's points meet the line's region-2/3/4 zone.  128 bytes.
+// What regions 2-4 of one (line, layer) need beyond the FastRec, as stored: 48 bytes.  The eight region-2
+// coefficients, (double)(float)ry and 1/dw' are functions of ry and dw' alone and are rebuilt where a line's
+// record is taken into registers (ColdFull, expand_cold: ~35 flops per line) -- stored, they were 80 of the
+// record's 128 bytes, 0.64 GB of config 2's tables written and 0.9 GB read per call.
 struct __attribute__((aligned(16))) ColdRec {
-  double ry, ryf;        // lw/dw' and (double)(float)ry: cmplx() is default kind (lineshape.f:529)
-  double dwp, inv_dwp;   // dw' = dw/sqrt(ln2) and ~1/dw'
+  double ry;             // lw/dw'
+  double dwp;            // dw' = dw/sqrt(ln2)
   double x0;             // line centre
   double xs2l, xs2r;     // region-2 running-x starts (lineshape.f:504, 514)
-  double q2[8];          // region-2 coefficients a..h (lineshape.f:492-502)
   uint32_t il2ir2;       // il2 | ir2 << 16
   uint32_t k3;           // region-3 interval of the core, k3lo | k3hi << 16 (k3lo > k3hi: empty)
   __host__ __device__ inline int il2() const { return (int)(il2ir2 & 0xffffu); }
@@ -87,7 +88,19 @@ struct __attribute__((aligned(16))) ColdRec {
   __host__ __device__ inline int k3lo() const { return (int)(k3 & 0xffffu); }
   __host__ __device__ inline int k3hi() const { return (int)(k3 >> 16); }
 };
-static_assert(sizeof(ColdRec) == 128, "ColdRec must be 128 bytes");
+static_assert(sizeof(ColdRec) == 48, "ColdRec must be 48 bytes");
+// The record in registers, with the derived values.
+struct ColdFull {
+  double ry, ryf;        // lw/dw' and (double)(float)ry: cmplx() is default kind (lineshape.f:529)
+  double dwp, inv_dwp;   // dw' and ~1/dw'
+  double x0, xs2l, xs2r;
+  double q2[8];          // region-2 coefficients a..h (lineshape.f:492-502)
+  uint32_t il2ir2, k3;
+  __host__ __device__ inline int il2() const { return (int)(il2ir2 & 0xffffu); }
+  __host__ __device__ inline int ir2() const { return (int)(il2ir2 >> 16); }
+  __host__ __device__ inline int k3lo() const { return (int)(k3 & 0xffffu); }
+  __host__ __device__ inline int k3hi() const { return (int)(k3 >> 16); }
+};
 
 // One (line, layer) of a line whose centre lies outside its own window: humliv_bb's sequential
 // outer branches (lineshape.f:272-357 for x0 <= x(i1), :358-442 for x0 >= x(i2)) reduced to three
@@ -342,13 +355,10 @@ template <class XF>
 __device__ inline ColdRec make_cold(const Bounds &B, double dwp, double x0, const XF &xf) {
   ColdRec c;
   c.ry = B.ry;
-  c.ryf = (double)(float)B.ry;
   c.dwp = dwp;
-  c.inv_dwp = fast_rcp<2>(dwp);
   c.x0 = x0;
   c.xs2l = (x0 - xf(B.il)) / dwp;  // lineshape.f:504
   c.xs2r = (xf(B.ir2) - x0) / dwp; // :514
-  region2_coef(B.ry, c.q2);
   c.il2ir2 = (uint32_t)B.il2 | ((uint32_t)B.ir2 << 16);
   // Region-3 interval inside the core (il2a, ir2a): rx = |x(k)-x0|/dw grows away from the
   // centre and the region test is monotone in rx, so region 3 is one interval around the
@@ -417,10 +427,28 @@ __device__ inline ColdRec make_cold(const Bounds &B, double dwp, double x0, cons
   return c;
 }
 
+// The derived values of a cold record (see ColdRec).
+__device__ inline double cold_ryf(double ry) { return (double)(float)ry; }
+__device__ inline double cold_inv_dwp(double dwp) { return fast_rcp<2>(dwp); }
+__device__ inline ColdFull expand_cold(const ColdRec &c) {
+  ColdFull f;
+  f.ry = c.ry;
+  f.ryf = cold_ryf(c.ry);
+  f.dwp = c.dwp;
+  f.inv_dwp = cold_inv_dwp(c.dwp);
+  f.x0 = c.x0;
+  f.xs2l = c.xs2l;
+  f.xs2r = c.xs2r;
+  region2_coef(c.ry, f.q2);
+  f.il2ir2 = c.il2ir2;
+  f.k3 = c.k3;
+  return f;
+}
+
 // Value of humliv_bb at 1-based index k (1..n) for one (line, layer), any region;
 // follows the write order of lineshape.f:455-562 (last writer wins).
 template <class XF>
-__device__ inline double humliv_point(int k, const FastRec &r, const ColdRec &z, const XF &xf) {
+__device__ inline double humliv_point(int k, const FastRec &r, const ColdFull &z, const XF &xf) {
   const int il = r.il(), ir = r.ir(), il2 = z.il2(), ir2 = z.ir2();
   const int il2a = (il2 == il) ? il - 1 : il2; // lineshape.f:524-525
   const int ir2a = (ir2 == ir) ? ir + 1 : ir2;

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
   // records leave through LDS: stored from the registers, a lane's 80 / 128 B record goes out in 16-byte pieces at
   // a 80 / 128 B stride across the lanes; the wave's 64 records are contiguous in the table, so they are transposed
   // and stored 1 KB of consecutive bytes per instruction instead (the kernel writes its 1.63 GB at 5.2 TB/s).
-  __shared__ uint4 s_rec[4][64 * sizeof(FastRec) / 16]; // per wave: 64 fast records, or 32 padded cold records
+  __shared__ uint4 s_rec[4][64 * sizeof(FastRec) / 16]; // per wave: 64 fast records, then its 64 cold records
+  static_assert(sizeof(ColdRec) <= sizeof(FastRec), "the cold records share the fast records' staging buffer");
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
   const int wave_first = i0 - (threadIdx.x & 63);
@@ -127,30 +128,22 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
     __builtin_amdgcn_wave_barrier();
     // The cold record (regions 2-4) is read only for lines whose zone meets [cold_lo, cold_hi]: in
     // far-field mode that is the shard, so the halo lines of a multi-GPU shard (half of its lines
-    // at 8 GPUs) skip its computation and its 128 B; exact mode reads it for window ends too and
+    // at 8 GPUs) skip its computation and its 48 B; exact mode reads it for window ends too and
     // passes the whole index range.
     const int zl = r.j1 + B.il - 1, zh = r.j1 + B.ir - 1;
     if (__any(valid && zl <= cold_hi && zh >= cold_lo)) {
       const ColdRec c = make_cold(B, dwp, x0, xf);
       const uint4 *cp = reinterpret_cast<const uint4 *>(&c);
       uint4 *gc = reinterpret_cast<uint4 *>(cold + o);
-      // 32 records at a time, whole: every store instruction writes 1 KB of consecutive bytes
-      static_assert(32 * (NC + 1) * 16 <= sizeof(s_rec[0]), "staging buffer holds 32 padded cold records");
+      // staged like the fast records: 64 x 48 bytes, consecutive in the table, 1 KB per store instruction
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int part = 0; part < 2; ++part) {
-        __builtin_amdgcn_wave_barrier();
-        if ((lane >> 5) == part) {
+      for (int q = 0; q < NC; ++q) buf[lane * NC + q] = cp[q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int q = 0; q < NC; ++q) buf[(lane & 31) * (NC + 1) + q] = cp[q]; // padded: 144-byte stride, fewer bank conflicts
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < NC / 2; ++q) {
-          const int m = q * 64 + lane; // piece m of the 32 records
-          if (32 * part + m / NC < n_valid) gc[32 * part * NC + m] = buf[(m / NC) * (NC + 1) + (m % NC)];
-        }
-      }
+      for (int q = 0; q < NC; ++q)
+        if (q * 64 + lane < n_valid * NC) gc[q * 64 + lane] = buf[q * 64 + lane];
     }
   }
   // (The widest zone of the layer, which the other kernels use to bound their candidate ranges, comes from the host
@@ -460,7 +453,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
     ColdRec cnxt = crow[rs[rg]];
     for (int l = rs[rg]; l < re[rg]; ++l) {
       const FastRec r = nxt;
-      const ColdRec cr = cnxt;
+      const ColdFull cr = expand_cold(cnxt);
       nxt = frow[l + 1]; // one record of slack behind both tables
       cnxt = crow[l + 1];
       const int j1 = r.j1, jN = j1 + (kImxsig - 1);
@@ -1414,7 +1407,7 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
       const int n3 = (act && has3) ? max(e1 - e0 + 1, 0) : 0;
       if (__any(n3 > 0)) {
         const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
-        const double x0 = z.x0, dwp = z.dwp, inv_dwp = z.inv_dwp, ryf = z.ryf, wa = r.wabs, we = r.wemi;
+        const double x0 = z.x0, dwp = z.dwp, inv_dwp = cold_inv_dwp(z.dwp), ryf = cold_ryf(z.ry), wa = r.wabs, we = r.wemi;
         const int ibase = j1 - 1 - wlo;
         for (int t = 0; __any(t < n3); ++t) {
           if (t < n3) {
@@ -1464,8 +1457,7 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         const int n = li >= 0 ? na + nb : 0;
         const double xstep = r.xstep, wa = r.wabs, we = r.wemi;
         double q2[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) q2[q] = z.q2[q];
+        region2_coef(z.ry, q2); // rebuilt per line (ColdRec): 25 flops against ~19 steps of 30 instructions
         const int base_idx = r.j1 - 1 - wlo;
         const double c_left = fma((double)(a0 - r.il()), xstep, -z.xs2l);
         const double c_right = fma((double)(b0 - na - z.ir2()), xstep, z.xs2r);
@@ -1495,8 +1487,8 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         P.gc = grid_at(gp, j1 + kHalf);
         P.x0 = z.x0;
         P.dwp = z.dwp;
-        P.inv_dwp = z.inv_dwp;
-        P.ryf = z.ryf;
+        P.inv_dwp = cold_inv_dwp(z.dwp);
+        P.ryf = cold_ryf(z.ry);
         P.wa = r.wabs;
         P.we = r.wemi;
         for (int t = col; __any(t < n); t += kRowLanes) {
@@ -2122,7 +2114,7 @@ __global__ __launch_bounds__(256) void sr_humliv_kernel(const double *__restrict
   region1_coef(B.ry, r.a, r.b, r.c, r.d);
   r.wabs = r.wemi = 1.0; r.j1 = 0;
   r.ilir = (uint32_t)B.il | ((uint32_t)B.ir << 16);
-  const ColdRec c = make_cold(B, dwp, x0, xf);
+  const ColdFull c = expand_cold(make_cold(B, dwp, x0, xf));
   for (int k = blockIdx.x * blockDim.x + threadIdx.x + 1; k <= n; k += gridDim.x * blockDim.x)
     y[i1 - 1 + k - 1] = humliv_point(k, r, c, xf);
 }
