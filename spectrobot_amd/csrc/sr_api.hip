@@ -616,7 +616,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   const bool counting = g_counting.load() != 0 && far_field;
   const size_t table_budget = g_table_budget.load();
 
-  // The per-(line, layer) record tables cost 208 B each; a long LOS (the reference allows
+  // The per-(line, layer) record tables cost 128 B each; a long LOS (the reference allows
   // imxstp = 8000 steps) is processed in layer batches that keep them under g_table_budget.
   {
     const size_t per_layer = (size_t)std::max<int64_t>(ls->n_lines, 1) * (sizeof(FastRec) + sizeof(ColdRec));
