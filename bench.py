@@ -40,6 +40,7 @@ FLOP_PER_EVAL = 16             # SURVEY 8-d flop model per (line, layer, grid po
 # convolution 121 fma, two weighted accumulations 42 fma); per (source box, target box, layer) translation
 # 21 x 23 x 2 outputs fma = 1932 (the MFMA tiles execute 24 x 32: padding not counted); the short series of the
 # window-band lines in the level-0 pass are not counted at all.
+ASYNC_GATHER = os.environ.get("SR_GATHER_ASYNC", "1") != "0"   # SR_GATHER_ASYNC=0: every step waits for its all-gather
 FLOP = {"region1_evals": 15, "region2_evals": 23, "region3_evals": 146, "region4_evals": 146,
         "farfield_expansions": 281, "poly_point_levels": 93, "window_end_expansions": 187,
         "multipole_line_sides": 430, "box_pair_translations": 1932}
@@ -218,9 +219,12 @@ def main():
         rad = engine.limb_rays((ab, em), los)      # columns (curgod_fort_2) + recursion on the device
         if args.shard:
             return rad
-        return sd.all_gather_spectrum(rad, args.grid, world, rank, out=full)
+        # async: the next step's kernels need not wait for this step's (latency-bound) gather; barrier() below
+        # synchronises the device, collectives included, before any time is taken or `full` is read
+        return sd.all_gather_spectrum(rad, args.grid, world, rank, out=full, async_op=ASYNC_GATHER)
 
     def barrier():
+        sd.wait_gathers()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()

@@ -104,6 +104,13 @@ def test_all_gather_spectrum_gloo_world2(tmp_path):
         "    buf = torch.zeros((rays, n), dtype=torch.float64)\n"
         "    assert sd.all_gather_spectrum(full[:, lo:hi].contiguous(), n, world, rank, out=buf) is buf\n"
         "    assert torch.equal(buf, full), (rank, n, rays)\n"
+        "# async_op: several steps in flight into the same buffer, valid after wait_gathers()\n"
+        "n = 1000; lo, hi = sd.shard_bounds(n, world, rank); buf = torch.zeros((1, n), dtype=torch.float64)\n"
+        "for step in range(7):\n"
+        "    full = torch.arange(n, dtype=torch.float64).reshape(1, n) + 1000.0 * step\n"
+        "    assert sd.all_gather_spectrum(full[:, lo:hi].contiguous(), n, world, rank, out=buf, async_op=True) is buf\n"
+        "sd.wait_gathers()\n"
+        "assert torch.equal(buf, full) and not sd._pending, rank\n"
         "torch.distributed.barrier()\n"
         "print('rank', rank, 'ok')\n" % ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
