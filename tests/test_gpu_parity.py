@@ -742,6 +742,27 @@ def test_box_pair_far_field_work_and_dense_boxes(eng, oracle):
 
 
 @pytest.mark.gpu
+def test_many_layers_unaligned_shard(eng):
+    """331 layers (the (box, layer) pairs of a translation wave straddle boxes when the layer count is no multiple
+    of 16; several layer batches in the far-field block order) on a shard that is not aligned to the box hierarchy:
+    both far-field modes against the exact mode."""
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2990.0, 5e-4, 20000)
+    L = syn.make_lines(8000, grid, seed=5, n_levels=3)
+    nl = 331
+    rng = np.random.default_rng(3)
+    T, P, q = rng.uniform(80, 280, nl), 10.0 ** rng.uniform(-6, 2.5, nl), rng.uniform(50, 500, nl)
+    tv = np.array([T + 2.0 * i for i in range(3)])
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES[:3])
+    out = {}
+    for m in (0, 1, 2):
+        eng.set_far_field(m)
+        out[m] = ls.abscoeff_layers(T, P, tvib=tv, q_part=q, g_lo=333, g_hi=19001)[1].cpu().numpy()
+    eng.set_far_field(eng.FAR_FIELD_DEFAULT)
+    assert relerr(out[1], out[0]) < 1e-12 and relerr(out[2], out[0]) < 1e-12
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("far", [2, 1, 0])
 def test_outer_lines_golden_and_oracle(eng, oracle, golden, far):
     """Lines whose centre lies outside their own window (3.3 - 25 cm-1 outside the grid): the coarse op
