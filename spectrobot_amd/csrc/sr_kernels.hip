@@ -1308,6 +1308,15 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
 // One region-3/4 point of a line: the point's window index and the line's data, per lane.  Several lines can
 // hit the same grid point in one step, hence LDS atomics (one wave per image, program order: the sums stay
 // deterministic).
+// Largest of a value that is uniform within each row of 8 lanes, as a scalar: eight v_readlane + scalar max.  The
+// row loops then run on a scalar step counter; "while any lane has a step left" costs three VALU instructions per
+// step however it is written (the ballot's mask goes through v_cndmask + v_cmp_ne).
+__device__ inline int rows_max(int v) {
+  int m = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+  for (int r = 8; r < 64; r += 8) m = max(m, __builtin_amdgcn_readlane(v, r));
+  return m;
+}
 struct CorePend {
   int k, base; // window index; idx in the image = k + base
   double gc, x0, dwp, inv_dwp, ryf, wa, we;
@@ -1462,7 +1471,9 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         const double c_left = fma((double)(a0 - r.il()), xstep, -z.xs2l);
         const double c_right = fma((double)(b0 - na - z.ir2()), xstep, z.xs2r);
         const int i_left = a0 + base_idx, i_right = b0 - na + base_idx;
-        for (int t = col; __any(t < n); t += kRowLanes) {
+        const int n_steps = (rows_max(n) + kRowLanes - 1) / kRowLanes; // wave-uniform: a scalar loop counter
+        for (int st = 0; st < n_steps; ++st) {
+          const int t = col + kRowLanes * st;
           if (t < n) {
             const bool lf = t < na;
             const double y = region2_val(q2, fma((double)t, xstep, lf ? c_left : c_right));
@@ -1491,7 +1502,9 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         P.ryf = cold_ryf(z.ry);
         P.wa = r.wabs;
         P.we = r.wemi;
-        for (int t = col; __any(t < n); t += kRowLanes) {
+        const int n_steps = (rows_max(n) + kRowLanes - 1) / kRowLanes;
+        for (int st = 0; st < n_steps; ++st) {
+          const int t = col + kRowLanes * st;
           P.k = t < na ? a0 + t : b0 + (t - na);
           if (COUNT) n_r4 += t < n;
           core_eval<4>(P, t < n, gp, s_a, s_e);
