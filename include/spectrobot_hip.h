@@ -320,6 +320,11 @@ int sr_set_overlap(int on);
  * under this many bytes (default 48 GiB of the 288 GB); a longer layer stack (the reference
  * allows imxstp = 8000 LOS steps) is processed in batches of layers. */
 int sr_set_table_budget(int64_t bytes);
+/* Per-layer radiance Jacobians (sr_limb_rays_jac_layer_dev).  0 (default): one pass over each ray for all layers,
+ * every segment's sensitivity times the transmission behind it added to its layer's entry (sr_limb_jac_layer_suffix_kernel;
+ * up to 8 layers: the forward-sensitivity kernel).  1: the forward-sensitivity kernel always (it carries 16 layers'
+ * derivatives through the recursion and repeats it per block of 16 layers) -- kept as the check of the other. */
+int sr_set_jac_layer_mode(int forward);
 /* Tuning knob of the exact wings kernel: grid points per lane (4 or 8; default 8). */
 int sr_set_points_per_lane(int p);
 

@@ -189,6 +189,7 @@ struct HostLines {
 std::atomic<int> g_variant{8};   // points per lane in the exact wings kernel
 std::atomic<int> g_far_field{2}; // 1: far wings by per-line local expansions, 2: by box pairs (multipole -> local), 0: every evaluation exact
 std::atomic<int> g_overlap{1};   // 1 (default), 2: zones kernel on a second stream beside the far-field kernel, next call's prep pipelined (2: gated behind FF+zones; measured equal)
+std::atomic<int> g_jac_layer_forward{0}; // 1: per-layer Jacobians by the forward-sensitivity kernel (sr_set_jac_layer_mode)
 std::atomic<int> g_counting{0};  // 1: counting instantiations of the far-field-mode kernels (sr_set_counting)
 std::atomic<size_t> g_table_budget{(size_t)48 << 30}; // bytes of FastRec + ColdRec tables per layer batch
 
@@ -302,6 +303,11 @@ int sr_set_overlap(int on) {
 
 int sr_set_counting(int on) {
   g_counting.store(on ? 1 : 0);
+  return SR_OK;
+}
+
+int sr_set_jac_layer_mode(int forward) {
+  g_jac_layer_forward.store(forward ? 1 : 0);
   return SR_OK;
 }
 
@@ -1340,7 +1346,7 @@ int sr_limb_rays_jac_layer_dev(const double *abs_c, const double *emi_c, const d
   LosDev D;
   int rc = stage_los(los, n_layers, 0, nullptr, nullptr, st, &D);
   if (rc) return rc;
-  LAUNCHCHK(launch_limb_jac_layer(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, los->n_rays, D.seg_off, D.seg_layer,
+  LAUNCHCHK(launch_limb_jac_layer(g_jac_layer_forward.load(), abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, los->n_rays, D.seg_off, D.seg_layer,
                                   D.col, limb_opts(los, D.n_seg), jac, st));
   return D.slot->mark(st);
 }

@@ -146,7 +146,9 @@ int launch_limb(const double *abs_c, const double *emi_c, int n_pts, int n_layer
 int launch_limb_jac(const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, const int *seg_off,
                     const int *seg_layer, const double *col, const double *dcol, const int *par_gas, int n_par,
                     const LimbOpts &o, double *rad, double *jac, hipStream_t st);
-int launch_limb_jac_layer(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
+// forward != 0: the forward-sensitivity kernel for any layer count (default: one pass with suffix transmissions when
+// there are more than 8 layers)
+int launch_limb_jac_layer(int forward, const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
                           int n_layers, int n_rays, const int *seg_off, const int *seg_layer, const double *col,
                           const LimbOpts &o, double *jac, hipStream_t st);
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,

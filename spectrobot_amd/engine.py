@@ -438,6 +438,11 @@ def set_overlap(on):
     check(lib.sr_set_overlap(int(on)), "sr_set_overlap")
 
 
+def set_jac_layer_mode(forward):
+    """0 (default): per-layer Jacobians in one pass per ray; 1: the forward-sensitivity kernel (sr_set_jac_layer_mode)."""
+    check(lib.sr_set_jac_layer_mode(int(forward)), "sr_set_jac_layer_mode")
+
+
 FAR_FIELD_DEFAULT = 2  # the library's default far-field mode (sr_set_far_field)
 
 

@@ -201,6 +201,14 @@ def test_limb_jacobians_finite_differences(eng):
         scale = fd.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
         assert float(((jl[:, k] - fd).abs() / scale).max()) < tol, k
     assert float(jl[1, :6].abs().max()) == 0.0    # layers below the second ray's tangent height
+    # the one-pass kernel (default for > 8 layers) against the forward-sensitivity kernel
+    eng.set_jac_layer_mode(1)
+    try:
+        jf = eng.limb_rays_layer_jacobian(coeffs, [(t(da[0]), t(de[0])), (t(da[1]), t(de[1]))], los)
+    finally:
+        eng.set_jac_layer_mode(0)
+    scale = jf.abs().amax(dim=2, keepdim=True).clamp_min(1e-300)
+    assert float(((jl - jf).abs() / scale).max()) < 1e-11
 
 
 def test_per_level_partial_radiances_sum_to_total(eng):
