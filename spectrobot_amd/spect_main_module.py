@@ -651,9 +651,9 @@ class RetParam(object):
     def store_deriv(self, derivative, num):
         """Derivative spectrum of observation `num` (replaces an existing entry, else appends)."""
         if 0 <= num < len(self.derivatives):
-            self.derivatives[num] = copy.deepcopy(derivative)
+            self.derivatives[num] = _clone_spectrum(derivative)
         else:
-            self.derivatives.append(copy.deepcopy(derivative))
+            self.derivatives.append(_clone_spectrum(derivative))
 
 
 class RetSet(object):
@@ -840,6 +840,15 @@ def retrieval_converged(chi, chi_old, chi_threshold=0.01):
     return 'raised' if chi > chi_old else ''
 
 
+def _clone_spectrum(obj, spectrum=None):
+    """A private copy of a spectrum holder: its own spectrum array, the (immutable) grid shared.  The reference
+    deep-copies here (spect_main_module.py:3372, 640-645); python's deepcopy of these small objects was 2.5 of the 5.5 ms
+    of a retrieval iteration."""
+    out = copy.copy(obj)
+    out.spectrum = np.array(obj.spectrum if spectrum is None else spectrum, dtype=float, copy=True)
+    return out
+
+
 def FOV_integr_1D(radtrans, pixel_rot=0.0, closed_form=False):
     """Field-of-view integration over a square pixel rotated by pixel_rot degrees, from the spectra of
     three lines of sight at -dmax, 0, +dmax across it (spect_main_module.py:3342-3374): the spectrum
@@ -876,6 +885,4 @@ def FOV_integr_1D(radtrans, pixel_rot=0.0, closed_form=False):
             return q * esse if abs(x) <= delta else q * esse * abs(dmax - abs(x)) / edge
 
         spet_fov = np.array([integrate.quad(weighted, -dmax, dmax, args=(j,))[0] for j in range(len(s1))])
-    out = copy.deepcopy(radtrans[0])
-    out.spectrum = spet_fov
-    return out
+    return _clone_spectrum(radtrans[0], spet_fov)

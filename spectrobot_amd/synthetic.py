@@ -100,6 +100,9 @@ def number_density(P_hpa, T):
     return P_hpa / (1.38065e-19 * T)
 
 
+_LOS_GEOMETRY = {}   # (levels, tangent heights, R, n_sub) -> segment / sample-point geometry of limb_los
+
+
 def limb_los(z, nd_levels, vmr_levels, z_tans, R=2575.0, n_sub=3):
     """Lines of sight of limb rays through spherical shells for the device LOS pipeline
     (engine.LimbLOS): per ray the shell crossings in photon order (far side -> tangent point ->
@@ -119,27 +122,37 @@ def limb_los(z, nd_levels, vmr_levels, z_tans, R=2575.0, n_sub=3):
     zz = np.concatenate([z, [top]])
     ln = np.concatenate([lognd, [lognd_top]])
     vv = np.concatenate([vmr_levels, vmr_levels[:, -1:]], axis=1)
-    seg_off, seg_layer, pt_off, xs, alts = [0], [], [0], [], []
-    for zt in np.atleast_1d(z_tans):
-        rt = R + zt
-        shells = []
-        for k in range(len(z)):
-            lo, hi = R + bounds[k], R + bounds[k + 1]
-            if hi <= rt:
-                continue
-            s_lo = np.sqrt(lo * lo - rt * rt) if lo > rt else 0.0
-            shells.append((k, s_lo, np.sqrt(hi * hi - rt * rt)))
-        # far side: s from -s_hi(top) up to the tangent point (s = 0), near side: 0 .. +s_hi(top)
-        crossings = [(k, -s_hi, -s_lo) for k, s_lo, s_hi in shells[::-1]] + [(k, s_lo, s_hi) for k, s_lo, s_hi in shells]
-        for k, a, b in crossings:
-            s = np.linspace(a, b, n_sub + 1)
-            seg_layer.append(k)
-            xs += list(s)
-            alts += list(np.sqrt(s * s + rt * rt) - R)
-            pt_off.append(len(xs))
-        seg_off.append(len(seg_layer))
-    alts = np.clip(np.array(alts), z[0], top)
+    z_tans = np.atleast_1d(np.asarray(z_tans, float))
+    # the geometry depends on the levels and the tangent heights only: a retrieval loop asks for the same rays with
+    # new VMR profiles every iteration (it was 11 of the 15 ms of a configs[4] iteration)
+    key = (z.tobytes(), z_tans.tobytes(), float(R), int(n_sub))
+    geo = _LOS_GEOMETRY.get(key)
+    if geo is None:
+        seg_off, seg_layer, pt_off, xs, alts = [0], [], [0], [], []
+        for zt in z_tans:
+            rt = R + zt
+            shells = []
+            for k in range(len(z)):
+                lo, hi = R + bounds[k], R + bounds[k + 1]
+                if hi <= rt:
+                    continue
+                s_lo = np.sqrt(lo * lo - rt * rt) if lo > rt else 0.0
+                shells.append((k, s_lo, np.sqrt(hi * hi - rt * rt)))
+            # far side: s from -s_hi(top) up to the tangent point (s = 0), near side: 0 .. +s_hi(top)
+            crossings = [(k, -s_hi, -s_lo) for k, s_lo, s_hi in shells[::-1]] + [(k, s_lo, s_hi) for k, s_lo, s_hi in shells]
+            for k, a, b in crossings:
+                s = np.linspace(a, b, n_sub + 1)
+                seg_layer.append(k)
+                xs += list(s)
+                alts += list(np.sqrt(s * s + rt * rt) - R)
+                pt_off.append(len(xs))
+            seg_off.append(len(seg_layer))
+        geo = (np.array(seg_off, np.int32), np.array(seg_layer, np.int32), np.array(pt_off, np.int32),
+               np.array(xs) * 1e5, np.clip(np.array(alts), z[0], top))
+        if len(_LOS_GEOMETRY) >= 8:
+            _LOS_GEOMETRY.pop(next(iter(_LOS_GEOMETRY)))
+        _LOS_GEOMETRY[key] = geo
+    seg_off, seg_layer, pt_off, x_cm, alts = geo
     nd = np.exp(np.interp(alts, zz, ln))
     vmr = np.array([np.interp(alts, zz, v) for v in vv])
-    return dict(seg_off=np.array(seg_off, np.int32), seg_layer=np.array(seg_layer, np.int32),
-                pt_off=np.array(pt_off, np.int32), x=np.array(xs) * 1e5, nd=nd, vmr=vmr, alt=alts)
+    return dict(seg_off=seg_off, seg_layer=seg_layer, pt_off=pt_off, x=x_cm, nd=nd, vmr=vmr, alt=alts)
