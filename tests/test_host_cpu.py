@@ -475,3 +475,26 @@ def test_linear_profile_1d_and_2d_vs_reference(golden):
     assert np.array_equal(inv, g["lp2d_involved"])
     prof = p2.profile()
     assert prof.shape == (3, len(g["alts"])) and np.allclose(prof[1], sum(m * v for m, v in zip(g["masks_a"], g["lp2d_aps"][1])))
+
+
+def test_limb_los_geometry_cache():
+    """synthetic.limb_los keeps the ray geometry between calls (a retrieval loop changes the VMR profiles only):
+    cached and fresh results agree, and other levels / tangent heights are not served from the wrong entry."""
+    from spectrobot_amd import synthetic as syn
+    z = np.linspace(100.0, 400.0, 16)
+    nd = 1e15 * np.exp(-(z - 100.0) / 60.0)
+    v1, v2 = np.full((2, 16), 1e-4), np.vstack([np.linspace(1e-4, 3e-4, 16), np.full(16, 2e-6)])
+    syn._LOS_GEOMETRY.clear()
+    a = syn.limb_los(z, nd, v1, [120.0, 250.0])
+    assert len(syn._LOS_GEOMETRY) == 1
+    b = syn.limb_los(z, nd, v2, [120.0, 250.0])           # same geometry, new profiles
+    assert len(syn._LOS_GEOMETRY) == 1 and b["x"] is a["x"]
+    syn._LOS_GEOMETRY.clear()
+    c = syn.limb_los(z, nd, v2, [120.0, 250.0])           # fresh
+    for k in ("seg_off", "seg_layer", "pt_off", "x", "nd", "vmr", "alt"):
+        assert np.array_equal(b[k], c[k]), k
+    assert not np.array_equal(a["vmr"], b["vmr"])
+    d = syn.limb_los(z, nd, v2, [120.0, 260.0])
+    e = syn.limb_los(z + 1.0, nd, v2, [120.0, 250.0])
+    assert len(syn._LOS_GEOMETRY) == 3
+    assert not np.array_equal(d["x"], c["x"]) and not np.array_equal(e["alt"], c["alt"])
