@@ -316,7 +316,7 @@ int sr_set_far_field(int on);
  * 8.60 ms per step).  The caller's stream sees the op complete in order as before.  0: the four kernels one
  * after the other on the caller's stream (per-kernel times for sr_last_kernel_ms). */
 int sr_set_overlap(int on);
-/* Memory knob: the per-(line, layer) record tables (128 B each) of one launch are kept
+/* Memory knob: the per-(line, layer) record tables (128 B each, plus the far-field scratch of a layer) of one launch are kept
  * under this many bytes (default 48 GiB of the 288 GB); a longer layer stack (the reference
  * allows imxstp = 8000 LOS steps) is processed in batches of layers. */
 int sr_set_table_budget(int64_t bytes);

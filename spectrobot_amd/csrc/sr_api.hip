@@ -622,11 +622,18 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   const bool counting = g_counting.load() != 0 && far_field;
   const size_t table_budget = g_table_budget.load();
 
-  // The per-(line, layer) record tables cost 128 B each; a long LOS (the reference allows
-  // imxstp = 8000 steps) is processed in layer batches that keep them under g_table_budget.
+  // The per-(line, layer) record tables cost 128 B each, the far-field scratch of a layer (local coefficients
+  // of all levels' target boxes, multipole moments of the source boxes) 1 KB per 64 grid points + 1.3 KB per 64
+  // points of grid and window halo; a long LOS (the reference allows imxstp = 8000 steps) is processed in layer
+  // batches that keep them under g_table_budget.
   {
-    const size_t per_layer = (size_t)std::max<int64_t>(ls->n_lines, 1) * (sizeof(FastRec) + sizeof(ColdRec));
-    const int nl_max = (int)std::max<size_t>(1, table_budget / (overlap ? 2 : 1) / per_layer); // two table sets
+    const size_t n_pts_b = (size_t)(g_hi - g_lo);
+    const size_t far_per_layer = !far_field ? 0
+        : (2 * (n_pts_b / 64 + 2)) * (size_t)(2 * kFC) * sizeof(double) +
+          (far_field == 2 ? (2 * ((n_pts_b + 64 * kSrcPad + kHalf) / 64 + 16)) * (size_t)kMomPerBox * sizeof(double) : 0);
+    const size_t per_layer = (size_t)std::max<int64_t>(ls->n_lines, 1) * (sizeof(FastRec) + sizeof(ColdRec)) *
+                                 (overlap ? 2 : 1) + far_per_layer; // two table sets with overlap
+    const int nl_max = (int)std::max<size_t>(1, table_budget / per_layer);
     if (nl > nl_max) {
       const size_t n_pts_all = (size_t)(g_hi - g_lo);
       for (int k0 = 0; k0 < nl; k0 += nl_max) {
