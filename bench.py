@@ -243,11 +243,19 @@ def main():
         step()
         kms += np.array(ls.last_kernel_ms())
     barrier()
+    dist_rec = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what the collective really was, and the asynchronous gather of the last timed step against a blocking one
+        # of the same shard (outside the timed region)
+        dist_rec = dict(sd.dist_info(), async_gather=bool(ASYNC_GATHER), gathers=dict(sd.stats))
+        rad_chk = engine.limb_rays((ab, em), los)
+        blocking = sd.all_gather_spectrum(rad_chk, args.grid, world, rank, async_op=False)
+        torch.cuda.synchronize()
+        dist_rec["async_equals_blocking"] = bool(torch.equal(blocking, spec))
     kms /= args.steps
     prep_ms = float(kms[0])
     main_ms = float(kms[1:].sum())   # far-field mode: the coefficient op as a whole (its kernels overlap)
@@ -361,6 +369,8 @@ def main():
                         "by per-box Taylor expansions, so this exceeds what brute force could reach"},
             "checksum": checksum,
         }
+        if dist_rec is not None:
+            out["dist"] = dist_rec
         if exact_kms is not None:
             xm = float(exact_kms[1] + exact_kms[2])
             out["roofline_exact_mode"] = {

@@ -65,6 +65,20 @@ class IsoMolec(object):
 # input files.  Both readers live in the absent spect_base_module; they are written
 # from their call sites and from the files they read, which ARE in the reference tree.
 # ----------------------------------------------------------------------------
+def trova_spip(ifile, hasha='#', read_past=False):
+    """Advance an open text file past its header: read lines up to and including the first one that starts with
+    `hasha` ('#'); with read_past return the rest of that line.  Call site: read_line_database(n_skip=-1)
+    (spect_classes.py:1558-1559); the function itself is in the absent module (unpinned: restated from the call
+    site and the author's .dat file convention -- free-text header, one '#' line, data).  A file without such a
+    line is an error here, not an endless loop."""
+    while True:
+        linea = ifile.readline()
+        if linea == '':
+            raise ValueError("trova_spip: no line starting with {!r} in the file header".format(hasha))
+        if linea[:1] == hasha:
+            return linea[1:] if read_past else None
+
+
 def read_molparam(filename):
     """HITRAN `molparam.txt` (the file shipped with the reference): blocks `NAME (mol)` followed by one
     row per isotopologue `code abundance Q(296K) gj molar_mass`.  Returns {(mol, iso): dict}, iso =

@@ -689,14 +689,15 @@ def read_line_database(nome_sp, mol=None, iso=None, up_lev=None, down_lev=None, 
         widths, names = _HITRAN_WIDTHS, cose_hit
     else:
         raise ValueError('Allowed values for db_format: {}, {}'.format('gbb', 'HITRAN'))
-    if n_skip == -1:
-        raise NotImplementedError('n_skip=-1 (sbm.trova_spip header search) needs spect_base_module')
     edges = np.concatenate([[0], np.cumsum(widths)])
     kinds = [int, int] + [float] * 8 + [str] * (5 if db_format == 'HITRAN' else 4) + \
         ([float, float] if db_format == 'HITRAN' else [])
     linee_ok = []
     with open(nome_sp, 'r') as infi:
-        for _ in range(n_skip):
+        if n_skip == -1:
+            from . import spect_base_module as sbm
+            sbm.trova_spip(infi)               # :1558-1559: the data start behind the header's '#' line
+        for _ in range(max(n_skip, 0)):
             infi.readline()
         for raw in infi:
             raw = raw.rstrip('\n').rstrip('\r')

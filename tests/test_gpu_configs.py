@@ -238,3 +238,66 @@ print("rank", rank, "ok")
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_rccl_async_gather_branch_one_rank(eng, tmp_path):
+    """The RCCL branch of the bench's step on hardware: backend "nccl" with a ONE-rank process group on the one GPU
+    (RCCL needs a device per rank, so more ranks cannot be rehearsed here).  Nine steps of coefficient op + limb
+    recursion + asynchronous all_gather_spectrum(force_collective=True) into one `out`, the shard tensor freshly
+    allocated each step as in bench.py: RCCL initialisation, the lifetime of the Work handles and of their input
+    shards (four in flight, older ones waited on), the ordering of consecutive gathers into the same buffer, and
+    wait_gathers(); the result equals a blocking gather and the shard itself bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text("""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from spectrobot_amd import engine, synthetic as syn, distributed as sd
+rank, local, world = sd.init_from_env(backend="nccl", single_rank_group=True)
+assert (rank, world) == (0, 1) and sd.dist_info() == {"backend": "nccl", "world_size": 1, "rank": 0}
+engine.set_device(0)
+n = 20000
+grid = syn.make_grid(2980.0, 5e-4, n)
+L = syn.make_lines(3000, grid, seed=45, n_levels=12)
+atm = syn.make_atmosphere(12, 12)
+nd = syn.number_density(atm["press"], atm["temps"])
+Lr = syn.limb_los(atm["z"], nd, [np.full(12, 0.0148)], [atm["z"][0] + 3.0])
+los = engine.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"], col_scale=[syn.CH4_ISO_RATIO])
+ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+full = torch.zeros((1, n), dtype=torch.float64, device="cuda")
+ab = torch.empty((12, n), dtype=torch.float64, device="cuda"); em = torch.empty_like(ab)
+def step(scale, **kw):
+    # the atmosphere changes from step to step, so a gather that read a recycled shard would show
+    ls.abscoeff_layers(atm["temps"] + scale, atm["press"], tvib=atm["tvib"] + scale, out=(ab, em))
+    rad = engine.limb_rays((ab, em), los)
+    return rad, sd.all_gather_spectrum(rad, n, 1, 0, out=full, force_collective=True, **kw)
+for i in range(9):
+    rad, out = step(0.5 * i, async_op=True)
+    assert out is full
+    del rad, out
+    junk = torch.full((1, n), -1.0, dtype=torch.float64, device="cuda")   # would take over a freed shard's block
+    del junk
+assert sd.stats["async_gathers"] == 9 and sd.stats["evicted_waits"] == 5 and len(sd._pending) == 4, sd.stats
+sd.wait_gathers()
+torch.cuda.synchronize()
+assert not sd._pending
+got = full.clone()
+rad, blocking = step(0.5 * 8, async_op=False)
+torch.cuda.synchronize()
+assert sd.stats["blocking_gathers"] == 1
+assert torch.equal(blocking, rad) and torch.equal(got, rad), float((got - rad).abs().max())
+assert float(rad.abs().max()) > 0
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print("rccl one-rank ok", sd.stats)
+""" % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SR_DIST_BACKEND", None)
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "rccl one-rank ok" in out, out

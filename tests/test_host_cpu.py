@@ -121,6 +121,72 @@ def test_all_gather_spectrum_gloo_world2(tmp_path):
     assert all("ok" in o for o in outs)
 
 
+def test_async_gather_branch_bookkeeping(monkeypatch):
+    """The asynchronous branch of all_gather_spectrum (taken for the RCCL backend only) with the collective
+    replaced by a recorder: every Work handle is waited on exactly once -- on eviction (at most 4 in flight) or
+    by wait_gathers() -- and its input shard stays referenced until then."""
+    import gc
+    import weakref
+    import torch
+    from spectrobot_amd import distributed as sd
+
+    class Work(object):
+        def __init__(self, log, i):
+            self.log, self.i = log, i
+
+        def wait(self):
+            self.log.append(self.i)
+
+    waited, issued, refs = [], [], []
+
+    def fake_gather(out, inp, async_op=False):
+        assert async_op
+        out.copy_(inp.expand_as(out))
+        issued.append(len(issued))
+        return Work(waited, issued[-1])
+
+    monkeypatch.setattr(sd.dist, "get_backend", lambda: "nccl")
+    monkeypatch.setattr(sd.dist, "all_gather_into_tensor", fake_gather)
+    monkeypatch.setattr(sd, "_pending", [])
+    before = dict(sd.stats)
+    buf = torch.zeros((1, 64), dtype=torch.float64)
+    for step in range(7):
+        shard = torch.full((1, 32), float(step), dtype=torch.float64)
+        refs.append(weakref.ref(shard))
+        assert sd.all_gather_spectrum(shard, 64, 2, 0, out=buf, async_op=True) is buf
+        del shard
+    gc.collect()
+    assert sd.stats["async_gathers"] - before["async_gathers"] == 7                   # the async branch ran
+    assert sd.stats["blocking_gathers"] == before["blocking_gathers"]
+    assert waited == [0, 1, 2] and len(sd._pending) == 4                                  # evicted handles were waited on
+    assert all(r() is None for r in refs[:3]) and all(r() is not None for r in refs[3:])  # in-flight inputs stay alive
+    sd.wait_gathers()
+    assert waited == list(range(7)) and not sd._pending
+    gc.collect()
+    assert all(r() is None for r in refs)
+    # a one-rank group goes through the collective only when asked to (the hardware test of the RCCL branch)
+    one = torch.ones((1, 8), dtype=torch.float64)
+    assert sd.all_gather_spectrum(one, 8, 1, 0) is one and len(issued) == 7
+    out = sd.all_gather_spectrum(one, 8, 1, 0, async_op=True, force_collective=True)
+    sd.wait_gathers()
+    assert len(issued) == 8 and torch.equal(out, one)
+    with pytest.raises(ValueError):
+        sd.all_gather_spectrum(one, 8, 2, 0, bounds=[(0, -4), (-4, 8)])
+
+
+def test_shard_bounds_balanced_short_grid():
+    """Grids shorter than world_size x align: boundaries get finer instead of negative / overlapping."""
+    from spectrobot_amd import distributed as sd, synthetic as syn
+    grid = syn.make_grid(2975.0, 5e-4, 300)
+    freq = np.sort(np.random.default_rng(0).uniform(grid[0], grid[-1], 50))
+    for w in (2, 8):
+        b = sd.shard_bounds_balanced(freq, grid, w)
+        assert b[0][0] == 0 and b[-1][1] == 300
+        assert all(lo < hi for lo, hi in b) and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+    with pytest.raises(ValueError):
+        sd.shard_bounds_balanced(freq, grid[:4], 8)
+
+
 def test_shard_bounds_balanced_on_skewed_line_density(tmp_path):
     """Equal-work shards: a band head holding 70 % of the lines in 15 % of the grid.  The
     work model's per-shard cost spread drops from several-fold (equal width) to a few per cent; the
@@ -235,7 +301,7 @@ def test_no_product_import_of_the_oracle():
                     assert bad not in txt, (f, bad)
 
 
-def test_read_line_database_hitran(golden):
+def test_read_line_database_hitran(golden, tmp_path):
     """N3: the HITRAN 160-column reader against the reference's read_line_database
     (spect_classes.py:1532-1601) on a file written by the reference's Print_hitran."""
     from spectrobot_amd import spect_classes as spcl
@@ -254,6 +320,15 @@ def test_read_line_database_hitran(golden):
     assert np.array_equal([l.Freq for l in frac], g["frac_freq"])
     with pytest.raises(ValueError):
         spcl.read_line_database(path, db_format="xyz")
+    # n_skip: a fixed number of header lines, or -1 = up to the header's '#' line (sbm.trova_spip, spcl:1558-1559)
+    body = open(path).read()
+    hdr = tmp_path / "with_header.par"
+    hdr.write_text("line list printed for the test\ntwo lines of free text\n#\n" + body)
+    for ns in (3, -1):
+        got = spcl.read_line_database(str(hdr), n_skip=ns)
+        assert np.array_equal([l.Freq for l in got], g["Freq"]), ns
+    with pytest.raises(ValueError):
+        spcl.read_line_database(path, n_skip=-1)      # no '#' line: an error, not an endless loop
     soa = spcl.lines_to_soa(sel)
     assert np.array_equal(soa["freq"], g["sel_freq"]) and soa["lev_up"].min() == -1
 
