@@ -17,6 +17,7 @@ and `cpu_baseline` (the oracle, i.e. the CPU restatement of the reference, on th
 host cores; N = 1 only).
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -233,6 +234,11 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # A full collection of the Python garbage collector walks every object torch / numpy imported (~40 ms here):
+    # one of those inside the timed region of a 1 ms step is a 40-step hiccup (tools/stall_probe.py found it at the
+    # 60th step of every run).  Collect now and move what exists into the permanent generation.
+    gc.collect()
+    gc.freeze()
     kms = np.zeros(5)
     t0 = time.perf_counter()
     for _ in range(args.steps):   # no host synchronisation inside: consecutive steps pipeline on the GPU
