@@ -305,6 +305,79 @@ __device__ inline double core_region4(double a, double b) { // :530-546
   const double ratio = fma(nr, qr, ni * qi) * fast_rcp<1>(fma(qr, qr, qi * qi));
   return exp_bounded(ur) * cos_bounded(ui) - ratio;
 }
+// a*b + c with b forced into a VGPR and c in an SGPR pair: the first Horner step of a polynomial whose two leading
+// coefficients are both wave-uniform constants would otherwise need a v_mov_b64 (one constant-bus operand per VOP3).
+__device__ inline double fma3vs(double a, double b_const, double c_uniform) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b_const), "s"(c_uniform));
+  return r;
+}
+
+__device__ inline double fma3vs_neg(double a, double b_const, double c_uniform) { // -a*b + c
+  double r;
+  asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "v"(b_const), "s"(c_uniform));
+  return r;
+}
+
+// cos(t) with the argument range decided by the caller for the whole wave (tier, a scalar):
+//   2: |t| < 6.5e-3 on every lane: 1 - z/2 + z^2/24, z = t^2 (next term z^3/720 <= 1e-16)
+//   1: |t| < 0.78: the cosine kernel (what cos_bounded returns there, bit for bit)
+//   0: anything (|t| <= ~1e3): cos_bounded
+// In the zones kernel t = 2 ry rx with rx < ~5.6: tier 2 above ~390 km of the Titan-like profile (51 of 80 layers),
+// tier 1 for all but the lowest few.
+__device__ inline double cos_tiered(double t, int tier) {
+  if (tier == 2) {
+    const double z = t * t;
+    return fma(z, fma(z, 4.16666666666666019037e-02, -0.5), 1.0);
+  }
+  if (tier == 1) {
+    const double z = t * t;
+    double pc = fma3(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma3(z, pc, -2.75573143513906633035e-07);
+    pc = fma3(z, pc, 2.48015872894767294178e-05);
+    pc = fma3(z, pc, -1.38888888888741095749e-03);
+    pc = fma3(z, pc, 4.16666666666666019037e-02);
+    return fma(z * z, pc, fma(-0.5, z, 1.0));
+  }
+  return cos_bounded(t);
+}
+
+// Region 4 (:530-546) for the row walks of the zones kernel: a = (double)(float)ry with a2 = a a and two_a = 2 a
+// per line (a is a single: a a is exact), m = (double)(float)rx >= 0.  The value is even in the sign of
+// Im c2 (P, Q have real coefficients: flipping b flips Im P, Im Q and Im(c2 P) together), so m stands in for
+// b = -rx; Re c1 = a^2 - m^2 in one fma (m m is exact too: the same rounding as a a - b b).  cos by tier.
+__device__ inline double core_region4_m(double a, double a2, double two_a, double m, int tier) {
+  const double ur = fma(-m, m, a2), ui = two_a * m;
+  const double r = ur + ur, s = fma(ur, ur, ui * ui);
+  // P4 = sum p_k c1^k, k = 0..6 (quadratic-factor recurrence, see real_poly_at)
+  const double p6 = SR_F32(.56419);
+  double pa = fma3vs(r, p6, -SR_F32(1.320522)), pb = fma3vs_neg(s, p6, SR_F32(35.76683));
+  {
+    const double P4[4] = {SR_F32(36183.31), -SR_F32(3321.9905), SR_F32(1540.787), -SR_F32(219.0313)};
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+      const double t = fma(r, pa, pb);
+      pb = fma(-s, pa, P4[j]);
+      pa = t;
+    }
+  }
+  const double pr = fma(ur, pa, pb), pi = ui * pa;
+  // Q4 = sum q_k c1^k, k = 0..7, q_7 = -1
+  double qa = SR_F32(1.841439) - r, qb = s - SR_F32(61.57037);
+  {
+    const double Q4[5] = {SR_F32(32066.6), -SR_F32(24322.84), SR_F32(9022.228), -SR_F32(2186.181), SR_F32(364.2191)};
+#pragma unroll
+    for (int j = 4; j >= 0; --j) {
+      const double t = fma(r, qa, qb);
+      qb = fma(-s, qa, Q4[j]);
+      qa = t;
+    }
+  }
+  const double qr = fma(ur, qa, qb), qi = ui * qa;
+  const double nr = fma(a, pr, -(m * pi)), ni = fma(a, pi, m * pr); // c2 * P
+  const double ratio = fma(nr, qr, ni * qi) * fast_rcp<1>(fma(qr, qr, qi * qi));
+  return fma(exp_bounded(ur), cos_tiered(ui, tier), -ratio);
+}
 __device__ inline double core_region3(double a, double b) { // :554-560
   const double N3[5] = {SR_F32(16.4955), SR_F32(20.20933), SR_F32(11.96482), SR_F32(3.778987),
                         SR_F32(.5642236)};

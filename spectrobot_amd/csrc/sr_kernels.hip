@@ -1319,17 +1319,16 @@ __device__ inline int rows_max(int v) {
 }
 struct CorePend {
   int k, base; // window index; idx in the image = k + base
-  double gc, x0, dwp, inv_dwp, ryf, wa, we;
+  double gc, x0, dwp, inv_dwp, ryf, ryf2, two_ryf, wa, we;
 };
-template <int REGION>
-__device__ inline void core_eval(const CorePend &P, bool on, const GridParams &gp, double *s_a, double *s_e) {
+// cos_tier: see cos_tiered (wave-uniform, from the largest 2 ry rx of the rows' runs)
+__device__ inline void core_eval4(const CorePend &P, bool on, const GridParams &gp, int cos_tier, double *s_a, double *s_e) {
   if (on) {
     const WinX xf{gp.lin_start, gp.lin_delta, P.gc};
     const double d = fabs(xf(P.k) - P.x0);
     double rx = d * P.inv_dwp; // |x(k)-x0|/dw correctly rounded: one residual correction
     rx = fma(fma(-P.dwp, rx, d), P.inv_dwp, rx);
-    const double b = (double)(float)(-rx);
-    const double y = REGION == 4 ? core_region4(P.ryf, b) : core_region3(P.ryf, b);
+    const double y = core_region4_m(P.ryf, P.ryf2, P.two_ryf, (double)(float)rx, cos_tier);
     const int idx = P.k + P.base;
     atomicAdd(&s_a[idx], P.wa * y);
     atomicAdd(&s_e[idx], P.we * y);
@@ -1500,14 +1499,24 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         P.dwp = z.dwp;
         P.inv_dwp = cold_inv_dwp(z.dwp);
         P.ryf = cold_ryf(z.ry);
+        P.ryf2 = P.ryf * P.ryf;
+        P.two_ryf = P.ryf + P.ryf;
         P.wa = r.wabs;
         P.we = r.wemi;
+        // largest |Im c1| = 2 ry rx of this round's runs (rx is largest at the outer ends of the two runs)
+        int cos_tier;
+        {
+          const WinX xf{gp.lin_start, gp.lin_delta, P.gc};
+          const double rx_max = fmax(fabs(xf(a0) - P.x0), fabs(xf(b0 + nb - 1) - P.x0)) * P.inv_dwp * 1.001;
+          const double ui_max = n > 0 ? P.two_ryf * rx_max : 0.0;
+          cos_tier = __all(ui_max < 6.5e-3) ? 2 : (__all(ui_max < 0.78) ? 1 : 0);
+        }
         const int n_steps = (rows_max(n) + kRowLanes - 1) / kRowLanes;
         for (int st = 0; st < n_steps; ++st) {
           const int t = col + kRowLanes * st;
           P.k = t < na ? a0 + t : b0 + (t - na);
           if (COUNT) n_r4 += t < n;
-          core_eval<4>(P, t < n, gp, s_a, s_e);
+          core_eval4(P, t < n, gp, cos_tier, s_a, s_e);
         }
       }
     }

@@ -23,6 +23,10 @@ for _ in range(3): step()
 k = np.zeros(5)
 for _ in range(8):
     step(); k += np.array(ls.last_kernel_ms()) / 8
+if os.environ.get("SR_SERIAL_ONLY"):   # under rocprofv3 --kernel-trace: stand-alone kernel durations only
+    torch.cuda.synchronize()
+    print("serial: prep %.3f ff %.3f wings %.3f zones %.3f" % tuple(k[:4]))
+    sys.exit(0)
 engine.set_overlap(1)
 for _ in range(4): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
