@@ -33,7 +33,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (= fp64 matrix) dense peak, 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 FLOP_PER_EVAL = 16             # SURVEY 8-d flop model per (line, layer, grid point), brute force
 # Executed-work flop model.  Per evaluation, SURVEY 8-d: region 1 = 9, region 2 = 17,
-# core = 140, + 6 for the weighted accumulations.  Per far-field (line, box) expansion: counted from
+# core = 140, + 6 for the weighted accumulations; region 3 (no exp / cos, degree 4 / 5 instead of 6 / 7: counted from
+# core_region3: rx 8, two polynomials 9 x 2 + 11 x 2, quotient 12, weights 6) = 70, not the core's 146.  Per far-field (line, box) expansion: counted from
 # sr_farfield_kernel's source (setup 42, reciprocal 9, f0..f3 14, 23 coefficients x 2 outputs).  Per
 # (point, level) polynomial: 2 outputs x degree 22 Horner.  Per window-end expansion: series + its share
 # of the lane scan.
@@ -42,7 +43,7 @@ FLOP_PER_EVAL = 16             # SURVEY 8-d flop model per (line, layer, grid po
 # 21 x 23 x 2 outputs fma = 1932 (the MFMA tiles execute 24 x 32: padding not counted); the short series of the
 # window-band lines in the level-0 pass are not counted at all.
 ASYNC_GATHER = os.environ.get("SR_GATHER_ASYNC", "1") != "0"   # SR_GATHER_ASYNC=0: every step waits for its all-gather
-FLOP = {"region1_evals": 15, "region2_evals": 23, "region3_evals": 146, "region4_evals": 146,
+FLOP = {"region1_evals": 15, "region2_evals": 23, "region3_evals": 70, "region4_evals": 146,
         "farfield_expansions": 281, "poly_point_levels": 93, "window_end_expansions": 187,
         "multipole_line_sides": 430, "box_pair_translations": 1932}
 KERNEL_COUNTERS = {
@@ -92,6 +93,45 @@ def reference_kernel_timing():
         return out
     except Exception as e:  # the reference build is optional on the box
         return {"available": False, "note": str(e)[:100]}
+
+
+def serial_kernel_times_and_counts(engine, ls, step, n=5):
+    """Stand-alone HIP-event durations of the coefficient kernels (sr_set_overlap(0): one after the other on the
+    caller's stream, average of n launches of `step`) and the work they execute (one pass of the counting
+    instantiations).  `step` must run exactly one coefficient op on `ls` last."""
+    engine.set_overlap(0)
+    step()
+    serial_kms = np.zeros(5)
+    for _ in range(n):
+        step()
+        serial_kms += np.array(ls.last_kernel_ms()) / n
+    engine.set_counting(1)
+    step()
+    counts = ls.last_eval_counts()
+    engine.set_counting(0)
+    engine.set_overlap(1)
+    return serial_kms, counts
+
+
+def coefficient_roofline(serial_kms, counts, far_field=2):
+    """roofline object of the dominant coefficient kernel from its stand-alone duration and executed work."""
+    far_name = ("sr_farfield_kernel" if far_field == 1 else
+                "sr_farfield_kernel (level 0) + sr_s2m_kernel + sr_m2m_kernel + sr_m2l_kernel")
+    names = [far_name, "sr_abscoeff_near_wings_kernel", "sr_abscoeff_near_zones_kernel"]
+    per_kernel = {}
+    for nm, ms in zip(names, serial_kms[1:4]):
+        fl = float(sum(FLOP[c] * counts[c] for c in KERNEL_COUNTERS[nm.split(" ")[0]]))
+        per_kernel[nm] = {"ms": float(ms), "executed_flops": fl,
+                          "achieved_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                          "frac": fl / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if ms > 0 else None}
+    dom = max(names, key=lambda n: per_kernel[n]["ms"])
+    d = per_kernel[dom]
+    return {"bound": "fp64-valu", "achieved": d["achieved_tflops"], "peak": FP64_VALU_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": d["frac"], "traffic": None,
+            "kernel": dom, "kernel_ms": d["ms"], "flops_per_launch": d["executed_flops"],
+            "executed_counts": counts, "flop_model": FLOP, "kernels": per_kernel,
+            "sr_prep_kernel_ms": float(serial_kms[0]),
+            "mode": "far-field (box pairs)" if far_field == 2 else "far-field (per line)"}
 
 
 def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total, rays, gpu=None):
@@ -270,17 +310,7 @@ def main():
     # stream they run on), and the work each one executes (counting instantiations, device counters)
     serial_kms = counts = None
     if not args.exact:
-        engine.set_overlap(0)
-        step()
-        serial_kms = np.zeros(5)
-        for _ in range(5):
-            step()
-            serial_kms += np.array(ls.last_kernel_ms()) / 5
-        engine.set_counting(1)
-        step()
-        counts = ls.last_eval_counts()
-        engine.set_counting(0)
-        engine.set_overlap(1)
+        serial_kms, counts = serial_kernel_times_and_counts(engine, ls, step)
     # outside the timed region: the brute-force kernels (every evaluation exact) for reference
     exact_kms = None
     if not args.exact and world == 1:
@@ -324,32 +354,16 @@ def main():
                                                 "sr_abscoeff_cores_kernel"], [float(v) for v in kms[:3]])),
                         "flops_per_launch": flops_bf, "mode": "exact"}
         else:
-            # box-pair mode: the far-field part is four kernels between two timing events
-            far_name = ("sr_farfield_kernel" if args.far_field == 1 else
-                        "sr_farfield_kernel (level 0) + sr_s2m_kernel + sr_m2m_kernel + sr_m2l_kernel")
-            names = [far_name, "sr_abscoeff_near_wings_kernel", "sr_abscoeff_near_zones_kernel"]
-            per_kernel = {}
-            for nm, ms in zip(names, serial_kms[1:4]):
-                fl = float(sum(FLOP[c] * counts[c] for c in KERNEL_COUNTERS[nm.split(" ")[0]]))
-                per_kernel[nm] = {"ms": float(ms), "executed_flops": fl,
-                                  "achieved_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else None,
-                                  "frac": fl / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if ms > 0 else None}
-            dom = max(names, key=lambda n: per_kernel[n]["ms"])
-            d = per_kernel[dom]
-            roofline = {
-                "bound": "fp64-valu", "achieved": d["achieved_tflops"], "peak": FP64_VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": dom, "kernel_ms": d["ms"], "flops_per_launch": d["executed_flops"],
-                "executed_counts": counts, "flop_model": FLOP, "kernels": per_kernel,
-                "sr_prep_kernel_ms": float(serial_kms[0]),
+            roofline = coefficient_roofline(serial_kms, counts, args.far_field)
+            roofline.update({
+                "traffic": traffic, "traffic_source": traffic_src,
                 "coefficient_op_ms_in_timed_steps": main_ms,
-                "mode": "far-field (box pairs)" if args.far_field == 2 else "far-field (per line)",
                 "note": "dominant kernel of the step; achieved = flops it EXECUTES (evaluations counted on the device "
-                        "by the counting instantiations of the same kernels x the per-region flops of SURVEY 8-d) / "
-                        "its average HIP-event duration over 5 launches with the kernels one after the other on the "
-                        "caller's stream (in the timed steps the zones kernel overlaps the far-field kernel on a "
-                        "second stream); peak 78.6 TFLOP/s = fp64 vector = fp64 MFMA dense peak of MI355X (no MFMA "
-                        "use: not a contraction).  HBM is not the bound: arithmetic intensity ~1e3 flop/B"}
+                        "by the counting instantiations of the same kernels x the per-region flops of SURVEY 8-d; region 3 "
+                        "at its own 70) / its average HIP-event duration over 5 launches with the kernels one after the "
+                        "other on the caller's stream (in the timed steps the zones kernel overlaps the far-field kernel "
+                        "on a second stream); peak 78.6 TFLOP/s = fp64 vector = fp64 MFMA dense peak of MI355X (no MFMA "
+                        "use: not a contraction).  HBM is not the bound: arithmetic intensity ~1e3 flop/B"})
         out = {
             "metric": "limb spectra/sec (1e5 lines x 1e5 nu-grid, 80 layers)",
             "value": value * args.rays, "unit": "spectra/s", "n_gpus": world, "steps": args.steps,

@@ -126,6 +126,24 @@ def _sync_time(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps, out
 
 
+def _event_time(fn, kernel, bytes_alg, note, n=5):
+    """HIP-event time of `fn` on the stream it launches on (torch's current stream) and the HBM roofline of its
+    algorithmic bytes."""
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    gbs = bytes_alg / (ms * 1e-3) / 1e9
+    return {"kernel": kernel, "ms": ms, "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+            "bytes_per_launch": bytes_alg, "note": note}
+
+
 def main(args):
     import torch
     from spectrobot_amd import engine, synthetic as syn, distributed as sd, retrieval
@@ -157,7 +175,27 @@ def main(args):
             t = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
-        out = dict(base, metric="limb spectra/sec, 64 rays batched (BASELINE configs[2])", value=n_rays / dt,
+        extra = {}
+        if rank == 0:
+            import bench as B
+            kms, counts = B.serial_kernel_times_and_counts(engine, ls, lambda: ls.abscoeff_layers(
+                atm["temps"], atm["press"], tvib=atm["tvib"], g_lo=g_lo, g_hi=g_hi, out=(ab, em)))
+            extra["roofline"] = B.coefficient_roofline(kms, counts)
+            extra["recursion"] = _event_time(lambda: engine.limb_rays((ab, em), los), "sr_los_columns_kernel + sr_limb_kernel<1>",
+                                             bytes_alg=8.0 * (2 * ab.numel() + n_rays * ab.shape[1]),
+                                             note="64 rays x 160 segments x %d points: algorithmic bytes = the two coefficient "
+                                                  "tables once + the radiances; VALU-bound (one fused exp / expm1 per segment "
+                                                  "and point), the 64 rays re-read the tables from L2 / MALL" % ab.shape[1])
+            if world == 1 and args.cpu_seconds > 0:
+                q_part = np.zeros(args.layers)
+                from spectrobot_amd._lib import lib, dp
+                tt = np.ascontiguousarray(atm["temps"])
+                assert lib.sr_calc_partition_sum(6, 1, tt.ctypes.data_as(dp), args.layers, q_part.ctypes.data_as(dp)) == 0
+                extra["cpu_baseline"] = B.cpu_baseline(L, atm, grid, syn.CH4_MM, e_lev, q_part, args.cpu_seconds, args.layers,
+                                                       (Lr["seg_off"], Lr["seg_layer"], B.cpu_columns(Lr, syn.CH4_ISO_RATIO)))
+                extra["speedup_vs_cpu_baseline"] = n_rays / dt / extra["cpu_baseline"]["value"]
+        out = dict(base, **extra)
+        out = dict(out, metric="limb spectra/sec, 64 rays batched (BASELINE configs[2])", value=n_rays / dt,
                    ms_per_step=dt * 1e3, scaling="strong",
                    config={"workload": "CH4 Titan limb (BASELINE configs[2]): %d lines x %d-pt grid x %d layers, %d rays on one "
                                        "coefficient op, device LOS pipeline, spectral window / %d + one all-gather"
@@ -173,28 +211,60 @@ def main(args):
         W = layer_vmr_weights(atm["z"], Lr["alt"])
         my = szas[rank::world]                       # independent ray batches: one SZA set per rank, no collective
 
+        def coef3(a):
+            co = ls.abscoeff_layers(a["temps"], a["press"], tvib=a["tvib"])
+            ap = ls.abscoeff_layers(a["temps"] + 0.05, a["press"], tvib=a["tvib"])
+            am = ls.abscoeff_layers(a["temps"] - 0.05, a["press"], tvib=a["tvib"])
+            return co, ((ap[0] - am[0]) / 0.1, (ap[1] - am[1]) / 0.1)
+
+        pg = np.zeros(args.layers, np.int32)
+
         def step():
             res = None
             for sza in my:
-                a = sza_atmosphere(atm, sza)
-                co = ls.abscoeff_layers(a["temps"], a["press"], tvib=a["tvib"])
-                ap = ls.abscoeff_layers(a["temps"] + 0.05, a["press"], tvib=a["tvib"])
-                am = ls.abscoeff_layers(a["temps"] - 0.05, a["press"], tvib=a["tvib"])
-                dco = ((ap[0] - am[0]) / 0.1, (ap[1] - am[1]) / 0.1)
-                jt = engine.limb_rays_layer_jacobian(co, dco, los)
-                rad, jv = engine.limb_rays_jacobian(co, los, np.zeros(args.layers, np.int32), W)
-                res = (rad, jt, jv)
+                co, dco = coef3(sza_atmosphere(atm, sza))
+                # radiances + d/dT_k + d/dVMR_k of the 8 rays in one pass per ray
+                res = engine.limb_rays_jacobians(co, los, dcoeffs=dco, par_gas=pg, par_w=W)
             return res
 
         dt, res = _sync_time(step, max(1, args.steps // 4), min(args.warmup, 1))
-        out = dict(base, metric="limb spectra/sec with per-layer T and VMR Jacobians (BASELINE configs[3])",
+        extra = {}
+        if rank == 0:
+            import bench as B
+            a0 = sza_atmosphere(atm, my[0])
+            kms, counts = B.serial_kernel_times_and_counts(engine, ls, lambda: ls.abscoeff_layers(a0["temps"], a0["press"], tvib=a0["tvib"]), n=3)
+            extra["roofline"] = B.coefficient_roofline(kms, counts)
+            co, dco = coef3(a0)
+            jac_bytes = 8.0 * (res[1].numel() + res[2].numel())
+            extra["jacobian_kernel"] = _event_time(
+                lambda: engine.limb_rays_jacobians(co, los, dcoeffs=dco, par_gas=pg, par_w=W), "sr_limb_adjoint_kernel<1, true, true>",
+                bytes_alg=jac_bytes + 8.0 * (4 * co[0].numel() + res[0].numel()),
+                note="per set of 8 rays: algorithmic bytes = the two Jacobians written once (%.2f GB) + the four coefficient "
+                     "tables read once + the radiances; the plan stores a row at its first touch and adds at the second "
+                     "(a limb path crosses a layer twice): ~1.5x the Jacobian bytes move" % (jac_bytes / 1e9))
+            del co, dco
+            if world == 1 and args.cpu_seconds > 0:
+                from spectrobot_amd._lib import lib, dp
+                q_part = np.zeros(args.layers)
+                tt = np.ascontiguousarray(a0["temps"])
+                assert lib.sr_calc_partition_sum(6, 1, tt.ctypes.data_as(dp), args.layers, q_part.ctypes.data_as(dp)) == 0
+                cb = B.cpu_baseline(L, a0, grid, syn.CH4_MM, e_lev, q_part, args.cpu_seconds, args.layers,
+                                    (Lr["seg_off"], Lr["seg_layer"], B.cpu_columns(Lr, syn.CH4_ISO_RATIO)))
+                # the oracle leg is ONE coefficient op + the radiances of the set's 8 rays; a set with its temperature
+                # Jacobian costs three ops (T, T +- dT): the Jacobian recursions themselves are not in the CPU figure
+                cb["value"] = cb["value"] / 3.0
+                cb["sample"] += "; /3: a set needs the coefficient op at T, T + dT, T - dT (the CPU leg runs one and no Jacobian recursion)"
+                extra["cpu_baseline"] = cb
+                extra["speedup_vs_cpu_baseline"] = (len(szas) * n_rays / dt) / cb["value"]
+        out = dict(base, **extra)
+        out = dict(out, metric="limb spectra/sec with per-layer T and VMR Jacobians (BASELINE configs[3])",
                    value=len(szas) * n_rays / dt if world == len(szas) or world == 1 else len(my) * n_rays * world / dt,
                    ms_per_step=dt * 1e3, scaling="weak" if world > 1 else "n/a",
                    config={"workload": "3D-atmosphere ray sets (BASELINE configs[3]): %d SZA x %d rays, %d lines x %d-pt grid x %d "
                                        "layers, d/dT_k (central differences of the coefficient op) and d/dVMR_k (analytic) for "
                                        "every layer; SZA sets are independent batches (split over ranks, no collective)"
                                        % (len(szas), n_rays, n_lines, n_grid, args.layers), "device": info["name"]},
-                   checksum=float(res[0].sum().item()), jacobian_gb_per_sza=2 * res[1].numel() * 8 / 1e9)
+                   checksum=float(res[0].sum().item()), jacobian_gb_per_sza=(res[1].numel() + res[2].numel()) * 8 / 1e9)
     elif args.config == 4:
         scene = two_gas_scene(40000, 8000, 60000, 60)
         bs, pixels, x_true = retrieval_problem(scene)

@@ -264,6 +264,18 @@ int sr_limb_rays_jac_dev(const double *abs_c, const double *emi_c, int n_layers,
 int sr_limb_rays_jac_layer_dev(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
                                int n_layers, int64_t n_pts, const sr_los_desc *los, double *jac, void *stream);
 
+/* Radiances and both kinds of Jacobian in ONE pass over each ray (round 3; BASELINE configs[3]: "Jacobians w.r.t. T
+ * and VMR per layer").  Any of the three outputs may be left out: rad NULL; jac_layer NULL (then dabs = demi = NULL);
+ * n_par = 0 (then par_gas = par_w = jac_par = NULL) -- but at least one Jacobian.  Each segment's own sensitivity
+ * times the transmission of everything behind it is added to the rows it acts on; the host plans per ray which
+ * access stores, which adds and which contributions are carried in registers across consecutive segments, so a
+ * Jacobian row is written about once per crossing instead of memset + read-add-store per segment.  Falls back to the
+ * forward-sensitivity kernels (sr_limb_rays_jac_dev / _jac_layer_dev under sr_set_jac_layer_mode(1)) when a segment
+ * touches more than four parameters; same definitions, same layouts. */
+int sr_limb_rays_jacobians_dev(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
+                               int n_layers, int64_t n_pts, const sr_los_desc *los, int n_par, const int32_t *par_gas,
+                               const double *par_w, double *rad, double *jac_layer, double *jac_par, void *stream);
+
 /* Radiances and their Jacobian with respect to n_par retrieval parameters on which the absorber
  * columns depend linearly, col_s = sum_p dcol_dpar[s][p] * x_p (VMR profile parameters of the
  * reference's RetParam / LinearProfile classes, spect_main_module.py:319-375; the reference's own
@@ -320,10 +332,11 @@ int sr_set_overlap(int on);
  * under this many bytes (default 48 GiB of the 288 GB); a longer layer stack (the reference
  * allows imxstp = 8000 LOS steps) is processed in batches of layers. */
 int sr_set_table_budget(int64_t bytes);
-/* Per-layer radiance Jacobians (sr_limb_rays_jac_layer_dev).  0 (default): one pass over each ray for all layers,
- * every segment's sensitivity times the transmission behind it added to its layer's entry (sr_limb_jac_layer_suffix_kernel;
- * up to 8 layers: the forward-sensitivity kernel).  1: the forward-sensitivity kernel always (it carries 16 layers'
- * derivatives through the recursion and repeats it per block of 16 layers) -- kept as the check of the other. */
+/* Radiance Jacobians of the device LOS pipeline (sr_limb_rays_jac_dev with more than 8 parameters,
+ * sr_limb_rays_jac_layer_dev with more than 8 layers, sr_limb_rays_jacobians_dev).  0 (default): one pass over each
+ * ray, every segment's sensitivity times the transmission behind it added to the rows it acts on
+ * (sr_limb_adjoint_kernel).  1: the forward-sensitivity kernels always (they carry 16 derivatives through the
+ * recursion and repeat it per block of 16) -- kept as the check of the other. */
 int sr_set_jac_layer_mode(int forward);
 /* Tuning knob of the exact wings kernel: grid points per lane (4 or 8; default 8). */
 int sr_set_points_per_lane(int p);

@@ -1326,12 +1326,190 @@ int sr_limb_rays_dev(const double *abs_c, const double *emi_c, int n_layers, int
   return D.slot->mark(st);
 }
 
+} // extern "C"
+
+namespace {
+
+// Plan of the one-pass Jacobian kernel (sr_limb_adjoint_kernel): per segment, in the order the recursion walks
+// them, the layer with its first-touch flag and the column parameters the segment touches (d col / d x_p != 0 iff
+// the parameter's weight is non-zero at one of the segment's sample points), runs of consecutive touches carried
+// in one of four registers; per ray the rows it never touches.  Returns false when a segment touches more than
+// kAdjEnt parameters (the forward-sensitivity kernel takes those calls).
+struct AdjPlan {
+  std::vector<int> seg;      // [n_seg][kAdjPlanInts]
+  std::vector<int> zero_off; // [n_rays + 1]
+  std::vector<int> zero_row; // layer rows (< n_layers) and parameter rows (n_layers + p)
+};
+bool build_adj_plan(const sr_los_desc *los, int n_layers, int n_par, const int32_t *par_gas, const double *par_w,
+                    bool want_layer, int n_pt, AdjPlan *out) {
+  const int nr = los->n_rays, n_seg = los->seg_off[nr];
+  out->seg.assign((size_t)n_seg * kAdjPlanInts, 0);
+  out->zero_off.assign(nr + 1, 0);
+  out->zero_row.clear();
+  std::vector<char> lay_seen(n_layers), par_seen(std::max(n_par, 1));
+  std::vector<std::vector<int>> touch(n_par); // walk positions (within the ray) of the segments touching p
+  for (int r = 0; r < nr; ++r) {
+    const int a = los->seg_off[r], b = los->seg_off[r + 1], m = b - a;
+    std::fill(lay_seen.begin(), lay_seen.end(), 0);
+    auto orig = [&](int q) { return los->los_order == 0 ? a + q : a + (m - 1 - q); }; // walk position -> caller's segment
+    for (int q = 0; q < m; ++q) {
+      int *pl = &out->seg[(size_t)(a + q) * kAdjPlanInts];
+      const int k = los->seg_layer[orig(q)];
+      pl[0] = k;
+      pl[1] = lay_seen[k] ? 0 : 1;
+      lay_seen[k] = 1;
+    }
+    for (int p = 0; p < n_par; ++p) {
+      touch[p].clear();
+      const double *w = par_w + (size_t)p * n_pt;
+      for (int q = 0; q < m; ++q) {
+        const int s = orig(q);
+        bool nz = false;
+        for (int i = los->pt_off[s]; i < los->pt_off[s + 1] && !nz; ++i) nz = w[i] != 0.0;
+        if (nz) touch[p].push_back(q);
+      }
+    }
+    // entries per segment; runs of consecutive touches take a register while one is free
+    bool slot_busy[4] = {false, false, false, false};
+    std::vector<int> slot_of(std::max(n_par, 1), -1), run_left(std::max(n_par, 1), 0), pos(std::max(n_par, 1), 0);
+    std::fill(par_seen.begin(), par_seen.end(), 0);
+    for (int q = 0; q < m; ++q) {
+      int *pl = &out->seg[(size_t)(a + q) * kAdjPlanInts];
+      int n_ent = 0;
+      for (int p = 0; p < n_par; ++p) {
+        if (pos[p] >= (int)touch[p].size() || touch[p][pos[p]] != q) continue;
+        if (n_ent == 4) return false;
+        const bool next_too = pos[p] + 1 < (int)touch[p].size() && touch[p][pos[p] + 1] == q + 1;
+        int fl = 0, sl = slot_of[p];
+        if (sl < 0) { // no carry in: a run starts here
+          fl |= 1;
+          if (next_too)
+            for (int c = 0; c < 4; ++c)
+              if (!slot_busy[c]) { sl = c; slot_busy[c] = true; break; }
+        }
+        const bool carry_out = next_too && sl >= 0;
+        if (!carry_out) {
+          fl |= 2;                        // written here
+          if (!par_seen[p]) fl |= 4;      // first write of this parameter in the ray: store
+          par_seen[p] = 1;
+          if (sl >= 0) slot_busy[sl] = false;
+          slot_of[p] = -1;
+        } else {
+          slot_of[p] = sl;
+        }
+        pl[4 + n_ent] = p;
+        pl[4 + 4 + n_ent] = par_gas[p] | (std::max(sl, 0) << 8) | (fl << 16);
+        ++n_ent;
+        ++pos[p];
+      }
+      pl[2] = n_ent;
+    }
+    if (want_layer)
+      for (int k = 0; k < n_layers; ++k)
+        if (!lay_seen[k]) out->zero_row.push_back(k);
+    for (int p = 0; p < n_par; ++p)
+      if (!par_seen[p]) out->zero_row.push_back(n_layers + p);
+    out->zero_off[r + 1] = (int)out->zero_row.size();
+  }
+  return true;
+}
+
+// Radiances (rad may be NULL) + per-layer Jacobian (dabs / demi / jac_layer may be NULL) + column-parameter Jacobian
+// (n_par may be 0) in one pass.  *done = 0 when the plan does not fit the kernel (nothing launched).
+int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_layers,
+                 int64_t n_pts, const sr_los_desc *los, int n_par, const int32_t *par_gas, const double *par_w,
+                 double *rad, double *jac_layer, double *jac_par, hipStream_t st, int *done) {
+  *done = 0;
+  int n_seg = 0, n_pt = 0;
+  int rc = check_los(los, n_layers, &n_seg, &n_pt);
+  if (rc) return rc;
+  AdjPlan plan;
+  if (!build_adj_plan(los, n_layers, n_par, par_gas, par_w, jac_layer != nullptr, n_pt, &plan)) return SR_OK;
+  LosDev D;
+  rc = stage_los(los, n_layers, n_par, par_gas, par_w, st, &D);
+  if (rc) return rc;
+  static thread_local Stager s_ring[4];
+  static thread_local unsigned s_next = 0;
+  Stager &sg = s_ring[s_next++ & 3];
+  auto al = [](size_t v) { return (v + 15) / 16 * 16; };
+  const size_t b_plan = sizeof(int) * plan.seg.size(), o_zo = al(b_plan);
+  const size_t o_zr = al(o_zo + sizeof(int) * plan.zero_off.size());
+  const size_t in_bytes = al(o_zr + sizeof(int) * std::max<size_t>(plan.zero_row.size(), 1));
+  rc = sg.prepare(in_bytes + adj_prog_bytes(n_seg));
+  if (rc) return rc;
+  char *h = sg.host<char>();
+  std::memcpy(h, plan.seg.data(), b_plan);
+  std::memcpy(h + o_zo, plan.zero_off.data(), sizeof(int) * plan.zero_off.size());
+  if (!plan.zero_row.empty()) std::memcpy(h + o_zr, plan.zero_row.data(), sizeof(int) * plan.zero_row.size());
+  rc = sg.push_early(in_bytes, st);
+  if (rc) return rc;
+  char *d = sg.d.as<char>();
+  SegProg *prog = reinterpret_cast<SegProg *>(d + in_bytes);
+  LAUNCHCHK(launch_adj_pack(reinterpret_cast<const int *>(d), D.col, los->n_gas, n_seg, prog, st));
+  LAUNCHCHK(launch_limb_adjoint(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, los->n_rays, D.seg_off, prog,
+                                reinterpret_cast<const int *>(d + o_zo), reinterpret_cast<const int *>(d + o_zr), n_par,
+                                limb_opts(los, D.n_seg), rad, jac_layer, jac_par, st));
+  rc = sg.mark(st);
+  if (rc) return rc;
+  *done = 1;
+  return D.slot->mark(st);
+}
+
+} // namespace
+
+extern "C" {
+
+int sr_limb_rays_jacobians_dev(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
+                               int n_layers, int64_t n_pts, const sr_los_desc *los, int n_par, const int32_t *par_gas,
+                               const double *par_w, double *rad, double *jac_layer, double *jac_par, void *stream) {
+  if (!abs_c || !emi_c || n_layers <= 0 || n_pts <= 0 || n_par < 0) return SR_ERR_ARG;
+  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  const bool want_layer = jac_layer != nullptr, want_par = n_par > 0;
+  if (want_layer != (dabs != nullptr && demi != nullptr) || (want_par && (!jac_par || !par_gas || !par_w))) return SR_ERR_ARG;
+  if (!want_layer && !want_par) return SR_ERR_ARG;
+  if (want_layer && los && los->init_mode == 1) {
+    g_err = "per-layer Jacobians: init_mode 1 (intensity read from a buffer) is not supported, use 0 or 2";
+    return SR_ERR_UNSUPPORTED;
+  }
+  if (want_par && los)
+    for (int p = 0; p < n_par; ++p)
+      if (par_gas[p] < 0 || par_gas[p] >= los->n_gas) return SR_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int done = 0;
+  if (!g_jac_layer_forward.load()) {
+    const int rc = limb_adjoint(abs_c, emi_c, dabs, demi, n_layers, n_pts, los, n_par, par_gas, par_w, rad, jac_layer,
+                                jac_par, st, &done);
+    if (rc || done) return rc;
+  }
+  // forward-sensitivity kernels, one call per kind (a segment touching more than four parameters, or asked for)
+  std::vector<char> keep;
+  if (want_par) {
+    if (!rad) return SR_ERR_ARG; // the forward kernel writes the radiances too
+    const int rc = sr_limb_rays_jac_dev(abs_c, emi_c, n_layers, n_pts, los, n_par, par_gas, par_w, rad, jac_par, stream);
+    if (rc) return rc;
+  }
+  if (want_layer) {
+    const int rc = sr_limb_rays_jac_layer_dev(abs_c, emi_c, dabs, demi, n_layers, n_pts, los, jac_layer, stream);
+    if (rc) return rc;
+    if (rad && !want_par) return sr_limb_rays_dev(abs_c, emi_c, n_layers, n_pts, los, rad, stream);
+  }
+  return SR_OK;
+}
+
 int sr_limb_rays_jac_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts,
                          const sr_los_desc *los, int n_par, const int32_t *par_gas, const double *par_w, double *rad,
                          double *jac, void *stream) {
   if (!abs_c || !emi_c || !rad || !jac || n_layers <= 0 || n_pts <= 0 || n_par <= 0) return SR_ERR_ARG;
   if (n_pts > 2000000) return SR_ERR_LIMIT;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // many parameters: one pass per ray (the forward kernel repeats the recursion per 16 parameters); rad0 given
+  // (init_mode 1) is read by both kernels before they write
+  if (n_par > 8 && !g_jac_layer_forward.load() && par_gas && par_w) {
+    int done = 0;
+    const int rc = limb_adjoint(abs_c, emi_c, nullptr, nullptr, n_layers, n_pts, los, n_par, par_gas, par_w, rad,
+                                nullptr, jac, st, &done);
+    if (rc || done) return rc;
+  }
   LosDev D;
   int rc = stage_los(los, n_layers, n_par, par_gas, par_w, st, &D);
   if (rc) return rc;
@@ -1350,10 +1528,16 @@ int sr_limb_rays_jac_layer_dev(const double *abs_c, const double *emi_c, const d
     return SR_ERR_UNSUPPORTED;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!g_jac_layer_forward.load() && n_layers > 8) {
+    int done = 0;
+    const int rc = limb_adjoint(abs_c, emi_c, dabs, demi, n_layers, n_pts, los, 0, nullptr, nullptr, nullptr, jac,
+                                nullptr, st, &done);
+    if (rc || done) return rc;
+  }
   LosDev D;
   int rc = stage_los(los, n_layers, 0, nullptr, nullptr, st, &D);
   if (rc) return rc;
-  LAUNCHCHK(launch_limb_jac_layer(g_jac_layer_forward.load(), abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, los->n_rays, D.seg_off, D.seg_layer,
+  LAUNCHCHK(launch_limb_jac_layer(1, abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, los->n_rays, D.seg_off, D.seg_layer,
                                   D.col, limb_opts(los, D.n_seg), jac, st));
   return D.slot->mark(st);
 }

@@ -1851,6 +1851,7 @@ __global__ __launch_bounds__(256) void sr_radiance_jac_layer_kernel(
 //                           solo_absorption / initial_intensity (Planck) (radtran_3D_ch4.py:297-315)
 //   sr_limb_jac_kernel      + derivatives w.r.t. VMR-profile parameters (columns linear in them)
 //   sr_limb_jac_layer_kernel  + derivatives w.r.t. one scalar per layer acting through the coefficients
+//   (both: forward sensitivities, NP parameters per thread; many parameters / layers: sr_limb_adjoint_kernel below)
 // Per segment s of a ray, layer k = seg_layer[s], columns u_g = col[g][s]:
 //   tau = sum_g abs_g[k] u_g,  E = sum_g emi_g[k] u_g,  t = e^-tau,  f = (1 - t)/tau
 //   I <- I t + E f          (E f dropped with solo_absorption)
@@ -2041,51 +2042,182 @@ __global__ __launch_bounds__(256) void sr_limb_jac_layer_kernel(
     if (p0 + q < n_layers) jac[((size_t)ray * n_layers + p0 + q) * n_pts + j] = J[q];
 }
 
-// The same derivatives in ONE pass over the ray for all layers.  A layer's derivative is the sum over its
-// segments s of  d_s * T(s+1 .. end),  d_s the segment's own sensitivity (it needs the intensity entering s) and
-// T the transmission of everything behind it = exp(-(tau_total - tau(0..s))): a first sweep adds up tau_total, the
-// second runs the recursion and adds each segment's d_s T to its layer's entry of jac (zeroed before the launch; a
-// limb path crosses a layer twice).  The forward-sensitivity kernel above carries NP accumulators through the whole
-// recursion and repeats it for every block of NP layers: 5 x (recursion + 16 updates per segment) for 80 layers
-// against recursion + one exp here.  tau_total - tau(0..s) is formed by subtraction: absolute error ~1e-16 tau_total,
-// i.e. <= 1e-13 relative in T for optical depths up to 1e3.
-template <int NG>
-__global__ __launch_bounds__(256) void sr_limb_jac_layer_suffix_kernel(
+// ------------------------------------------------------------------------
+// Radiances and BOTH kinds of Jacobian of a ray batch in ONE pass over each ray (round 3).
+//
+// I_final = sum_s src_s T(s+1 .. end) + I_0 T(all), so the derivative with respect to anything that acts through
+// segment s alone is that segment's own sensitivity times the transmission of everything behind it:
+//   w_tau = (-I_prev t + E f') T_after,   w_E = f T_after          (d I_final / d tau_s,  / d E_s)
+//   per-layer scalar (temperature):   J_k += w_tau dtau_k u + w_E dE_k u            over the segments in layer k
+//   column parameter p of gas g:      J_p += (w_tau a_g + w_E e_g) dcol[p][s]       over the segments p touches
+// T_after = exp(-(tau_total - tau(0..s))): a first sweep adds up tau_total (no exp), the second runs the recursion.
+// The forward-sensitivity kernels carry NP accumulators through the whole recursion and repeat it per block of NP
+// parameters: 80 per-layer VMR parameters cost five recursions of 160 x (60 + 16 x 4) instructions; here one of
+// 160 x ~100.  What remains is the traffic of the Jacobian rows (configs[3]: 2 x 1 GB per set of 8 rays), so the
+// host plans the accumulation per ray (SegProg):
+//   * a layer's (parameter's) FIRST touch in the ray stores, later ones add: no memset, no read of zeros;
+//     rows the ray never touches are zero-filled by the kernel;
+//   * a parameter touched by consecutive segments (a level's VMR acts on the shells above and below it) is
+//     carried in one of four registers across them and written once per run: a limb path touches a level on its
+//     way down and again on its way up -- one store, one read-add-store instead of four accesses.
+// Everything in a SegProg is wave-uniform (a block works on one ray): scalar loads and scalar branches.
+// ------------------------------------------------------------------------
+constexpr int kAdjEnt = 4; // column parameters a segment may touch (more: the forward-sensitivity kernel is used)
+struct __attribute__((aligned(16))) SegProg {
+  int layer;
+  int flags;            // bit 0: first touch of the layer in this ray (store), else add
+  int n_ent, pad;
+  int ent_p[kAdjEnt];   // parameter
+  int ent_gf[kAdjEnt];  // gas | slot << 8 | flags << 16: bit 0 run starts here (no carry in), bit 1 run ends here
+                        // (write), bit 2 first write of the parameter in this ray (store)
+  double u[4];          // column of every gas
+  double dc[kAdjEnt];   // d col / d x_p of the entries
+};
+static_assert(sizeof(SegProg) == 112, "SegProg layout");
+
+// The host's plan (layer, flags, entries) + the columns the device computed -> one record per segment.
+__global__ void sr_adj_pack_kernel(const int *__restrict__ plan, // [n_seg][4 + 2 kAdjEnt] ints: layer, flags, n_ent, 0, ent_p, ent_gf
+                                   const double *__restrict__ col, int n_gas, int n_seg, SegProg *__restrict__ out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seg) return;
+  const int *pl = plan + (size_t)s * (4 + 2 * kAdjEnt);
+  SegProg r;
+  r.layer = pl[0]; r.flags = pl[1]; r.n_ent = pl[2]; r.pad = 0;
+#pragma unroll
+  for (int i = 0; i < kAdjEnt; ++i) {
+    r.ent_p[i] = pl[4 + i];
+    r.ent_gf[i] = pl[4 + kAdjEnt + i];
+    r.dc[i] = i < r.n_ent ? col[(size_t)(n_gas + r.ent_p[i]) * n_seg + s] : 0.0;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) r.u[g] = g < n_gas ? col[(size_t)g * n_seg + s] : 0.0;
+  out[s] = r;
+}
+
+template <int NG, bool LAYER, bool PAR>
+__global__ __launch_bounds__(256) void sr_limb_adjoint_kernel(
     const double *__restrict__ abs_c, const double *__restrict__ emi_c, const double *__restrict__ dabs,
     const double *__restrict__ demi, int n_pts, int n_layers, const int *__restrict__ seg_off,
-    const int *__restrict__ seg_layer, const double *__restrict__ col, LimbOpts o, double *__restrict__ jac) {
+    const SegProg *__restrict__ prog, const int *__restrict__ zero_off, const int *__restrict__ zero_row, int n_par,
+    LimbOpts o, double *__restrict__ rad, double *__restrict__ jac_layer, double *__restrict__ jac_par) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, ray = blockIdx.y;
   if (j >= n_pts) return;
   const int s0 = seg_off[ray], s1 = seg_off[ray + 1];
   const size_t gstride = (size_t)n_layers * n_pts;
+  // rows this ray never touches: row < n_layers: layer row, else parameter row - n_layers
+  for (int q = zero_off[ray]; q < zero_off[ray + 1]; ++q) {
+    const int row = zero_row[q];
+    if (row < n_layers) {
+      if (LAYER) jac_layer[((size_t)ray * n_layers + row) * n_pts + j] = 0.0;
+    } else if (PAR) {
+      jac_par[((size_t)ray * n_par + (row - n_layers)) * n_pts + j] = 0.0;
+    }
+  }
   double rem = 0.0; // optical depth of the segments not yet passed
   for (int s = s0; s < s1; ++s) {
-    const size_t ofs = (size_t)seg_layer[s] * n_pts + j;
+    const SegProg &P = prog[s];
+    const size_t ofs = (size_t)P.layer * n_pts + j;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) rem = fma(abs_c[g * gstride + ofs], col[(size_t)g * o.n_seg_total + s], rem);
+    for (int g = 0; g < NG; ++g) rem = fma(abs_c[g * gstride + ofs], P.u[g], rem);
   }
-  double I = limb_initial(o, jac, 0, j); // init_mode 1 is refused by the host for this kernel
-  for (int s = s0; s < s1; ++s) {
-    const int k = seg_layer[s];
-    const size_t ofs = (size_t)k * n_pts + j;
-    double tau = 0.0, E = 0.0, dtau = 0.0, dE = 0.0;
+  double I = limb_initial(o, rad, (size_t)ray * n_pts + j, j);
+  double slot[4] = {0., 0., 0., 0.};
+  constexpr int kB = NG == 1 ? 4 : 2; // segments whose coefficient loads are issued together
+  for (int sb = s0; sb < s1; sb += kB) {
+    double a[kB][NG], e[kB][NG], da[kB][NG], de[kB][NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const double u = col[(size_t)g * o.n_seg_total + s];
-      const double av = abs_c[g * gstride + ofs], ev = emi_c[g * gstride + ofs];
-      tau = g == 0 ? av * u : tau + av * u;
-      E = g == 0 ? ev * u : E + ev * u;
-      dtau = fma(dabs[g * gstride + ofs], u, dtau);
-      dE = fma(demi[g * gstride + ofs], u, dE);
+    for (int t = 0; t < kB; ++t) {
+      const int s = min(sb + t, s1 - 1);
+      const size_t ofs = (size_t)prog[s].layer * n_pts + j;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        a[t][g] = abs_c[g * gstride + ofs];
+        e[t][g] = emi_c[g * gstride + ofs];
+        if (LAYER) {
+          da[t][g] = dabs[g * gstride + ofs];
+          de[t][g] = demi[g * gstride + ofs];
+        }
+      }
     }
-    const Atten A = attenuation(tau);
-    const double fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
-    const double d = -I * A.t * dtau + (o.solo_absorption ? 0.0 : dE * A.f + E * fp * dtau);
-    rem -= tau;
-    double *out = jac + ((size_t)ray * n_layers + k) * n_pts + j;
-    *out += d * attenuation(rem).t;
-    I = I * A.t + (o.solo_absorption ? 0.0 : E * A.f);
+#pragma unroll
+    for (int t = 0; t < kB; ++t) {
+      const int s = sb + t;
+      if (s >= s1) break;
+      const SegProg &P = prog[s];
+      double tau = 0.0, E = 0.0, dtau = 0.0, dE = 0.0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const double u = P.u[g];
+        tau = g == 0 ? a[t][g] * u : tau + a[t][g] * u;
+        E = g == 0 ? e[t][g] * u : E + e[t][g] * u;
+        if (LAYER) {
+          dtau = fma(da[t][g], u, dtau);
+          dE = fma(de[t][g], u, dE);
+        }
+      }
+      const Atten A = attenuation(tau);
+      const double fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
+      rem -= tau;
+      const double Ta = exp_bounded(fmin(fmax(-rem, -700.0), 700.0)); // transmission of everything behind this segment
+      const double w_tau = (o.solo_absorption ? -I * A.t : fma(E, fp, -I * A.t)) * Ta;
+      const double w_E = o.solo_absorption ? 0.0 : A.f * Ta;
+      if (LAYER) {
+        const double d = fma(w_tau, dtau, w_E * dE);
+        double *out = jac_layer + ((size_t)ray * n_layers + P.layer) * n_pts + j;
+        if (P.flags & 1) *out = d; else *out += d;
+      }
+      if (PAR) {
+        for (int i = 0; i < P.n_ent; ++i) {
+          const int gf = P.ent_gf[i], g = gf & 0xff, sl = (gf >> 8) & 0xff, fl = gf >> 16;
+          double ag = a[t][0], eg = e[t][0];
+#pragma unroll
+          for (int q = 1; q < NG; ++q) {
+            ag = g == q ? a[t][q] : ag;
+            eg = g == q ? e[t][q] : eg;
+          }
+          double v = fma(w_tau, ag, w_E * eg) * P.dc[i];
+          if (!(fl & 1)) v += sl == 0 ? slot[0] : (sl == 1 ? slot[1] : (sl == 2 ? slot[2] : slot[3]));
+          if (fl & 2) {
+            double *out = jac_par + ((size_t)ray * n_par + P.ent_p[i]) * n_pts + j;
+            if (fl & 4) *out = v; else *out += v;
+          } else {
+            if (sl == 0) slot[0] = v; else if (sl == 1) slot[1] = v; else if (sl == 2) slot[2] = v; else slot[3] = v;
+          }
+        }
+      }
+      I = I * A.t + (o.solo_absorption ? 0.0 : E * A.f);
+    }
   }
+  if (rad) rad[(size_t)ray * n_pts + j] = I;
+}
+
+size_t adj_prog_bytes(int n_seg) { return sizeof(SegProg) * (size_t)n_seg; }
+static_assert(kAdjPlanInts == 4 + 2 * kAdjEnt, "host plan layout");
+
+int launch_adj_pack(const int *plan, const double *col, int n_gas, int n_seg, SegProg *out, hipStream_t st) {
+  if (n_seg <= 0) return 0;
+  hipLaunchKernelGGL(sr_adj_pack_kernel, dim3((n_seg + 63) / 64), dim3(64), 0, st, plan, col, n_gas, n_seg, out);
+  return (int)hipGetLastError();
+}
+
+int launch_limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
+                        int n_layers, int n_rays, const int *seg_off, const SegProg *prog, const int *zero_off,
+                        const int *zero_row, int n_par, const LimbOpts &o, double *rad, double *jac_layer,
+                        double *jac_par, hipStream_t st) {
+  if (n_pts <= 0 || n_rays <= 0) return 0;
+  const dim3 grid((n_pts + 255) / 256, n_rays);
+#define SR_A(NG, L, P) hipLaunchKernelGGL((sr_limb_adjoint_kernel<NG, L, P>), grid, dim3(256), 0, st, abs_c, emi_c, dabs, demi, \
+                                          n_pts, n_layers, seg_off, prog, zero_off, zero_row, n_par, o, rad, jac_layer, jac_par)
+#define SR_A3(NG)                                                      \
+  do {                                                                 \
+    if (jac_layer && jac_par) SR_A(NG, true, true);                    \
+    else if (jac_layer) SR_A(NG, true, false);                         \
+    else SR_A(NG, false, true);                                        \
+  } while (0)
+  switch (o.n_gas) { case 1: SR_A3(1); break; case 2: SR_A3(2); break; case 3: SR_A3(3); break; default: SR_A3(4); break; }
+#undef SR_A3
+#undef SR_A
+  return (int)hipGetLastError();
 }
 
 #define SR_BY_NGAS(NGV, CALL1, CALL2, CALL3, CALL4) \
@@ -2127,14 +2259,9 @@ int launch_limb_jac_layer(int forward, const double *abs_c, const double *emi_c,
   if (n_pts <= 0 || n_rays <= 0 || n_layers <= 0) return 0;
 #define SR_L(NG, NP) hipLaunchKernelGGL((sr_limb_jac_layer_kernel<NG, NP>), dim3((n_pts + 255) / 256, n_rays, (n_layers + NP - 1) / NP), \
                                         dim3(256), 0, st, abs_c, emi_c, dabs, demi, n_pts, n_layers, seg_off, seg_layer, col, o, jac)
-  if (n_layers > 8 && forward) {
+  (void)forward; // the one-pass formulation is sr_limb_adjoint_kernel (launch_limb_adjoint)
+  if (n_layers > 8) {
     SR_BY_NGAS(o.n_gas, SR_L(1, 16), SR_L(2, 16), SR_L(3, 16), SR_L(4, 16))
-  } else if (n_layers > 8) { // one pass for all layers (the forward-sensitivity kernel repeats the recursion per 16 layers)
-    if (hipMemsetAsync(jac, 0, sizeof(double) * (size_t)n_rays * n_layers * n_pts, st) != hipSuccess) return (int)hipGetLastError();
-#define SR_S(NG) hipLaunchKernelGGL((sr_limb_jac_layer_suffix_kernel<NG>), dim3((n_pts + 255) / 256, n_rays), dim3(256), 0, st, \
-                                    abs_c, emi_c, dabs, demi, n_pts, n_layers, seg_off, seg_layer, col, o, jac)
-    SR_BY_NGAS(o.n_gas, SR_S(1), SR_S(2), SR_S(3), SR_S(4))
-#undef SR_S
   } else {
     SR_BY_NGAS(o.n_gas, SR_L(1, 4), SR_L(2, 4), SR_L(3, 4), SR_L(4, 4))
   }

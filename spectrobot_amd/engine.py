@@ -348,6 +348,36 @@ def limb_rays_layer_jacobian(coeffs, dcoeffs, los, grid=None, g_lo=0):
     return jac
 
 
+def limb_rays_jacobians(coeffs, los, dcoeffs=None, par_gas=None, par_w=None, grid=None, g_lo=0, want_rad=True):
+    """Radiances, per-layer Jacobian (dcoeffs given: d(abs, emi of layer k)/d(scalar of layer k) per gas) and
+    column-parameter Jacobian (par_gas / par_w given, as limb_rays_jacobian) in ONE pass over each ray
+    (sr_limb_rays_jacobians_dev).  Returns (rad | None, jac_layer | None, jac_par | None)."""
+    a, e = _gas_stack(coeffs)
+    n_gas, n_layers, n_pts = a.shape
+    if n_gas != los.n_gas:
+        raise ValueError("%d coefficient sets for %d gases" % (n_gas, los.n_gas))
+    da = de = jl = jp = rad = None
+    if dcoeffs is not None:
+        da, de = _gas_stack(dcoeffs)
+        assert da.shape == a.shape
+        jl = torch.empty((los.n_rays, n_layers, n_pts), dtype=torch.float64, device="cuda")
+    n_par, pg, pw = 0, None, None
+    if par_gas is not None:
+        par_gas, pg = _i(par_gas)
+        par_w, pw = _d(par_w)
+        n_par = par_gas.size
+        if par_w.shape != (n_par, los.n_pt):
+            raise ValueError("par_w must be [n_par, n_pt]")
+        jp = torch.empty((los.n_rays, n_par, n_pts), dtype=torch.float64, device="cuda")
+    if want_rad:
+        rad = torch.empty((los.n_rays, n_pts), dtype=torch.float64, device="cuda")
+    d = los.desc(grid, g_lo)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    check(lib.sr_limb_rays_jacobians_dev(ptr(a), ptr(e), ptr(da), ptr(de), n_layers, n_pts, C.byref(d), n_par, pg, pw,
+                                         ptr(rad), ptr(jl), ptr(jp), _stream_ptr()), "sr_limb_rays_jacobians_dev")
+    return rad, jl, jp
+
+
 def radiance_jacobian(abs_c, emi_c, seg_off, seg_layer, seg_col, dcol_dpar):
     """Radiances [n_rays, n_pts] and d rad / d x_p [n_rays, n_par, n_pts] for parameters on which the
     segment columns depend linearly: dcol_dpar[s, p] = d col_s / d x_p (sr_radiance_jac_dev)."""
@@ -439,7 +469,8 @@ def set_overlap(on):
 
 
 def set_jac_layer_mode(forward):
-    """0 (default): per-layer Jacobians in one pass per ray; 1: the forward-sensitivity kernel (sr_set_jac_layer_mode)."""
+    """0 (default): Jacobians of the device LOS pipeline in one pass per ray; 1: the forward-sensitivity kernels
+    (sr_set_jac_layer_mode)."""
     check(lib.sr_set_jac_layer_mode(int(forward)), "sr_set_jac_layer_mode")
 
 

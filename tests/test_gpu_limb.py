@@ -211,6 +211,77 @@ def test_limb_jacobians_finite_differences(eng):
     assert float(((jl - jf).abs() / scale).max()) < 1e-11
 
 
+def test_one_pass_jacobians_vs_forward_sensitivity(eng):
+    """sr_limb_rays_jacobians_dev (radiances + per-layer + column-parameter Jacobians in one pass per ray, the host's
+    store / add / carry plan) against the forward-sensitivity kernels, which share no code with it beyond the
+    segment's attenuation: two gases, 24 level parameters with triangular weights (two per segment and gas), both
+    LOS orders, solo_absorption, a Planck initial intensity, rays that miss the lower layers (zero-filled rows), and
+    broad weights that make a segment touch more than four parameters (the call then falls back)."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(11)
+    nl, n = 24, 900
+    atm = _atm(nl)
+    z = atm["z"]
+    grid = syn.make_grid(2975.0, 5e-4, n)
+    a = [rng.uniform(0, 4e-18, (nl, n)), rng.uniform(0, 3e-17, (nl, n))]
+    e = [a[0] * rng.uniform(1e-8, 1e-7, (nl, n)), a[1] * rng.uniform(1e-8, 1e-7, (nl, n))]
+    t = lambda v: torch.tensor(np.ascontiguousarray(v), device="cuda")
+    coeffs = [(t(a[0]), t(e[0])), (t(a[1]), t(e[1]))]
+    dco = [(t(rng.uniform(-1, 1, (nl, n)) * a[g]), t(rng.uniform(-1, 1, (nl, n)) * e[g])) for g in range(2)]
+    vm = [np.full(nl, 1.2e-2), np.linspace(2e-3, 5e-4, nl)]
+    L = syn.limb_los(z, atm["nd"] * 1e-6, vm, [z[0] + 5.0, z[6] + 3.0, z[15] + 1.0])
+    top = z[-1] + (z[-1] - z[-2])
+    zz = np.append(z, top)
+    tri = []
+    for k in range(0, nl, 2):                 # 12 level parameters per gas
+        m = np.zeros(nl + 1)
+        m[k] = 1.0
+        if k == nl - 2:
+            m[-2:] = 1.0
+        tri.append(np.interp(L["alt"], zz, m))
+    W = np.array(tri + tri)
+    par_gas = np.array([0] * 12 + [1] * 12, np.int32)
+
+    def cmp(x, y, tol=2e-12):
+        sc = y.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+        return float(((x - y).abs() / sc).max()) < tol
+
+    for opts in (dict(), dict(LOS_order="observer"), dict(solo_absorption=True, initial_temperature=200.0),
+                 dict(initial_temperature=180.0)):
+        los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827, 1.0], **opts)
+        g = grid if "initial_temperature" in opts else None
+        rad, jl, jp = eng.limb_rays_jacobians(coeffs, los, dcoeffs=dco, par_gas=par_gas, par_w=W, grid=g)
+        # each kind alone through the same entry, and the two older entries (which route to the same kernel)
+        r2, jl2, _ = eng.limb_rays_jacobians(coeffs, los, dcoeffs=dco, grid=g)
+        _, _, jp2 = eng.limb_rays_jacobians(coeffs, los, par_gas=par_gas, par_w=W, grid=g, want_rad=False)
+        assert torch.equal(jl, jl2) and torch.equal(jp, jp2) and torch.equal(rad, r2), opts
+        assert torch.equal(jl, eng.limb_rays_layer_jacobian(coeffs, dco, los, grid=g))
+        assert torch.equal(jp, eng.limb_rays_jacobian(coeffs, los, par_gas, W, grid=g)[1])
+        eng.set_jac_layer_mode(1)
+        try:
+            rf, jpf = eng.limb_rays_jacobian(coeffs, los, par_gas, W, grid=g)
+            jlf = eng.limb_rays_layer_jacobian(coeffs, dco, los, grid=g)
+            r3, jl3, jp3 = eng.limb_rays_jacobians(coeffs, los, dcoeffs=dco, par_gas=par_gas, par_w=W, grid=g)
+        finally:
+            eng.set_jac_layer_mode(0)
+        assert torch.equal(jl3, jlf) and torch.equal(jp3, jpf)              # mode 1: the forward kernels
+        assert cmp(rad, rf, 1e-13) and cmp(jl, jlf) and cmp(jp, jpf), opts
+        assert cmp(rad, eng.limb_rays(coeffs, los, grid=g), 1e-13)
+        assert float(jl[2, :15].abs().max()) == 0.0 and float(jp[2, :7].abs().max()) == 0.0   # rows the third ray never touches
+        assert float(jl[0].abs().max()) > 0 and float(jp[0, 3].abs().max()) > 0
+    # broad masks: every parameter touches every segment -> more than four entries per segment: falls back
+    Wb = np.array([np.interp(L["alt"], zz, np.exp(-0.5 * ((zz - z[k]) / 300.0) ** 2)) for k in range(0, nl, 2)])
+    los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827, 1.0])
+    rb, _, jb = eng.limb_rays_jacobians(coeffs, los, par_gas=np.zeros(12, np.int32), par_w=Wb)
+    eng.set_jac_layer_mode(1)
+    try:
+        rbf, jbf = eng.limb_rays_jacobian(coeffs, los, np.zeros(12, np.int32), Wb)
+    finally:
+        eng.set_jac_layer_mode(0)
+    assert torch.equal(jb, jbf) and torch.equal(rb, rbf)
+
+
 def test_per_level_partial_radiances_sum_to_total(eng):
     """single_rad[(gas, iso, lev)] (spect_main_module.py:2883-2887): the radiance emitted by one level and
     absorbed by the whole gas -- the level's emission share (sr_abscoeff_level_dev) with the total
