@@ -268,20 +268,45 @@ def main(args):
     elif args.config == 4:
         scene = two_gas_scene(40000, 8000, 60000, 60)
         bs, pixels, x_true = retrieval_problem(scene)
+        # N > 1: every rank its spectral shard of radiances, Jacobians and partial band integrals, one all-reduce per
+        # iteration, the algebra replicated (retrieval.simulate; spect_main_module.py:2814-2853)
+        shard = sd.shard_bounds(len(scene.grid), world, rank) if world > 1 else None
+        import copy
+        bs0 = copy.deepcopy(bs)
         torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
         t0 = time.perf_counter()
-        chi, obs, sims, bs = retrieval.inversion_fast_limb(scene, bs, pixels, max_it=20)
+        chi, obs, sims, bs = retrieval.inversion_fast_limb(scene, bs, pixels, max_it=20, shard=shard)
         torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
         dt = time.perf_counter() - t0
         n_it = len(bs.history)
+        # the same loop with the coefficient op of both gases inside every iteration (what a retrieval of temperatures
+        # or vibrational temperatures costs; in a VMR retrieval like this one the coefficients do not change)
+        t0 = time.perf_counter()
+        _, _, _, bs_r = retrieval.inversion_fast_limb(scene, bs0, pixels, max_it=20, shard=shard, refresh=True)
+        torch.cuda.synchronize()
+        dt_refresh = (time.perf_counter() - t0) / len(bs_r.history)
         out = dict(base, metric="retrieval iterations/sec, HCN + CH4 (BASELINE configs[4])", unit="iterations/s",
-                   value=n_it / dt, ms_per_step=dt / n_it * 1e3, steps=n_it, scaling="n/a",
+                   value=n_it / dt, ms_per_step=dt / n_it * 1e3, steps=n_it, scaling="strong" if world > 1 else "n/a",
                    config={"workload": "Gauss-Newton / LM retrieval loop (BASELINE configs[4]): HCN + CH4, 40000 + 8000 lines x "
                                        "60000-pt grid x 60 layers, 6 pixels x 3 LOS, 7 profile parameters, %d VIMS-like bands, "
                                        "max 20 iterations, reference stopping rule" % len(scene.bands_nm),
+                           "coefficients": "computed once before the loop and cached: only VMRs are retrieved, the coefficient "
+                                           "spectra do not depend on them (the reference's drivers do the same through their "
+                                           "LUTs); ms_per_iteration_with_coefficient_refresh recomputes both gases' coefficient "
+                                           "op in every iteration",
+                           "sharding": ("spectral window / %d: radiances, Jacobians and partial band integrals per rank, one "
+                                        "all-reduce of [n_los x (1 + n_par) x n_bands] per iteration, algebra replicated" % world
+                                        if world > 1 else "none"),
                            "device": info["name"]},
+                   ms_per_iteration_with_coefficient_refresh=dt_refresh * 1e3,
                    chi_history=[float(c) for c in bs.history], stop=bs.stop,
                    max_rel_dev_from_truth=float(np.max(np.abs(bs.param_vector() - x_true) / x_true)))
+        if world > 1:
+            out["dist"] = sd.dist_info()
     else:
         raise SystemExit("--config must be 1..4")
     if rank == 0:

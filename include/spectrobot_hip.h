@@ -311,6 +311,14 @@ int sr_radiance_jac_layer_dev(const double *abs_c, const double *emi_c, const do
 int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double w0, double step,
                            const double *centers_nm, const double *widths_nm, int n_bands, double n_sigma,
                            int out_units, double *out_host, void *stream);
+/* The same for a spectral shard: rad DEVICE [n_rays][n_pts] holds grid points g_lo .. g_lo + n_pts - 1 of the grid
+ * w0 + j step; out_host receives the PARTIAL band integrals over the trapezoids between those points (bands whose
+ * window misses the shard: 0).  A multi-GPU retrieval gives every rank its shard plus the next rank's first point
+ * and sums the partial integrals over the ranks (one all-reduce of n_rays x n_bands doubles):
+ * spect_main_module.py:2814-2818 splits the forward model spectrally in the same way. */
+int sr_hires_to_lowres_shard_dev(const double *rad, int n_rays, int64_t n_pts, int64_t g_lo, double w0, double step,
+                                 const double *centers_nm, const double *widths_nm, int n_bands, double n_sigma,
+                                 int out_units, double *out_host, void *stream);
 
 /* Evaluation mode of the coefficient op.  Far region-1 wings by local Taylor expansions per box of grid
  * points (truncation <= 2.6e-13 of a line's own contribution), near field exact, with the expansions built

@@ -100,6 +100,8 @@ SYMBOLS = {
                                             C.c_int, ip, ip, dp, C.c_void_p, C.c_void_p]),
     "sr_hires_to_lowres_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_double, dp, dp, C.c_int,
                                          C.c_double, C.c_int, dp, C.c_void_p]),
+    "sr_hires_to_lowres_shard_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_double, C.c_double, dp, dp,
+                                               C.c_int, C.c_double, C.c_int, dp, C.c_void_p]),
     "sr_set_points_per_lane": (C.c_int, [C.c_int]),
     "sr_set_jac_layer_mode": (C.c_int, [C.c_int]),
     "sr_set_far_field": (C.c_int, [C.c_int]),

@@ -1582,8 +1582,15 @@ int sr_lut_interp_dev(const double *g_tab, int n_pt, int64_t n_pts, int n_steps,
 int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double w0, double step,
                            const double *centers_nm, const double *widths_nm, int n_bands, double n_sigma,
                            int out_units, double *out_host, void *stream) {
-  if (!rad || !centers_nm || !widths_nm || !out_host || n_rays <= 0 || n_pts < 2 || n_bands <= 0) return SR_ERR_ARG;
-  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  return sr_hires_to_lowres_shard_dev(rad, n_rays, n_pts, 0, w0, step, centers_nm, widths_nm, n_bands, n_sigma, out_units,
+                                      out_host, stream);
+}
+
+int sr_hires_to_lowres_shard_dev(const double *rad, int n_rays, int64_t n_pts, int64_t g_lo, double w0, double step,
+                                 const double *centers_nm, const double *widths_nm, int n_bands, double n_sigma,
+                                 int out_units, double *out_host, void *stream) {
+  if (!rad || !centers_nm || !widths_nm || !out_host || n_rays <= 0 || n_pts < 2 || n_bands <= 0 || g_lo < 0) return SR_ERR_ARG;
+  if (g_lo + n_pts > 2000000) return SR_ERR_LIMIT;
   if (!(step > 0.0) || !(w0 > 0.0) || !(n_sigma > 0.0) || out_units < 0 || out_units > 2) return SR_ERR_ARG;
   for (int b = 0; b < n_bands; ++b)
     if (!(widths_nm[b] > 0.0)) return SR_ERR_ARG;
@@ -1599,7 +1606,7 @@ int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double 
   if (rc) return rc;
   rc = d_out.ensure(sizeof(double) * nb * n_rays);
   if (rc) return rc;
-  LAUNCHCHK(launch_lowres(rad, (int)n_pts, n_rays, w0, step, s_bands.d.as<double>(), s_bands.d.as<double>() + nb,
+  LAUNCHCHK(launch_lowres(rad, (int)n_pts, (int)g_lo, n_rays, w0, step, s_bands.d.as<double>(), s_bands.d.as<double>() + nb,
                           n_bands, n_sigma, out_units, d_out.as<double>(), st));
   HIPCHK(hipMemcpyAsync(out_host, d_out.p, sizeof(double) * nb * n_rays, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

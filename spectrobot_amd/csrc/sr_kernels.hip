@@ -2534,7 +2534,9 @@ __global__ void sr_curgod_kernel(int which, const double *__restrict__ nd, const
 // spcl:883-918; gaussian, spcl:1926-1934; conv_single = np.trapz, spcl:1162-1164).
 // One block per (band, ray); nm index i <-> cm-1 index n-1-i.
 // ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sr_lowres_kernel(const double *__restrict__ rad, int n_pts, double w0,
+// g_lo: grid index of rad's first point (a spectral shard's PARTIAL band integrals: the trapezoids between the
+// shard's own points, grid values exactly those of the whole grid; the partial sums of the shards add up).
+__global__ __launch_bounds__(256) void sr_lowres_kernel(const double *__restrict__ rad, int n_pts, int g_lo, double w0,
                                                         double gstep, const double *__restrict__ cen,
                                                         const double *__restrict__ wid, int n_bands,
                                                         double n_sigma, int out_units,
@@ -2544,7 +2546,7 @@ __global__ __launch_bounds__(256) void sr_lowres_kernel(const double *__restrict
   const double lo = f - n_sigma * w, hi = f + n_sigma * w;
   const double fac = 1 / (w * sqrt(2. * kPi));
   const double *sp = rad + (size_t)ray * n_pts;
-  auto xnm = [&](int i) { return 1.e7 / (w0 + (double)(n_pts - 1 - i) * gstep); };
+  auto xnm = [&](int i) { return 1.e7 / (w0 + (double)(g_lo + n_pts - 1 - i) * gstep); };
   // first i with x >= lo, first i with x > hi (x ascending in i)
   int i0, i1;
   {
@@ -2558,7 +2560,7 @@ __global__ __launch_bounds__(256) void sr_lowres_kernel(const double *__restrict
   double acc = 0.0;
   for (int i = i0 + threadIdx.x; i + 1 < i1; i += blockDim.x) {
     const int j0 = n_pts - 1 - i, j1 = j0 - 1;
-    const double g0 = w0 + (double)j0 * gstep, g1 = w0 + (double)j1 * gstep;
+    const double g0 = w0 + (double)(g_lo + j0) * gstep, g1 = w0 + (double)(g_lo + j1) * gstep;
     const double x0 = 1.e7 / g0, x1 = 1.e7 / g1;
     const double t0 = (x0 - f) / w, t1 = (x1 - f) / w;
     const double y0 = (sp[j0] * (g0 * g0) * 1.e-7) * (fac * exp(-0.5 * (t0 * t0)));
@@ -2579,10 +2581,10 @@ __global__ __launch_bounds__(256) void sr_lowres_kernel(const double *__restrict
   }
 }
 
-int launch_lowres(const double *rad, int n_pts, int n_rays, double w0, double gstep, const double *cen,
+int launch_lowres(const double *rad, int n_pts, int g_lo, int n_rays, double w0, double gstep, const double *cen,
                   const double *wid, int n_bands, double n_sigma, int out_units, double *out, hipStream_t st) {
   if (n_bands <= 0 || n_rays <= 0) return 0;
-  hipLaunchKernelGGL(sr_lowres_kernel, dim3(n_bands, n_rays), dim3(256), 0, st, rad, n_pts, w0, gstep, cen, wid,
+  hipLaunchKernelGGL(sr_lowres_kernel, dim3(n_bands, n_rays), dim3(256), 0, st, rad, n_pts, g_lo, w0, gstep, cen, wid,
                      n_bands, n_sigma, out_units, out);
   return (int)hipGetLastError();
 }

@@ -174,7 +174,7 @@ int launch_humliv(const double *x, int i1, int i2, double x0, double lw, double 
                   hipStream_t st);
 int launch_sum_lines(double *spe, long n_spe, const double *rows, const int *init, const int *fin,
                      int n_lines, int row_len, hipStream_t st);
-int launch_lowres(const double *rad, int n_pts, int n_rays, double w0, double gstep, const double *cen,
+int launch_lowres(const double *rad, int n_pts, int g_lo, int n_rays, double w0, double gstep, const double *cen,
                   const double *wid, int n_bands, double n_sigma, int out_units, double *out, hipStream_t st);
 int launch_lut(int combine, const double *tab, int n_pt, int n_pts, int n_steps, const int *idx, const double *wgt,
                const double *pop, double *out_a, double *out_e, hipStream_t st);

@@ -486,21 +486,24 @@ def set_far_field(on):
 _UNITS = {"Wm2": 0, "ergscm2": 1, "nWcm2": 2}
 
 
-def hires_to_lowres(rad, grid, centers_nm, widths_nm, out_units="Wm2", n_sigma=5.0):
+def hires_to_lowres(rad, grid, centers_nm, widths_nm, out_units="Wm2", n_sigma=5.0, g_lo=0):
     """Gaussian-ILS degradation of hi-res spectra (CUDA float64 [n_rays, n_grid], 'ergscm2' on the
     cm-1 grid) onto low-resolution bands given in nm: SpectralIntensity.hires_to_lowres
-    (spect_classes.py:1180-1191).  Returns numpy [n_rays, n_bands] in out_units."""
+    (spect_classes.py:1180-1191).  Returns numpy [n_rays, n_bands] in out_units.
+    g_lo > 0: rad holds the grid points g_lo .. g_lo + rad.shape[-1] - 1 only (a spectral shard) and the PARTIAL band
+    integrals over them are returned (sr_hires_to_lowres_shard_dev); `grid` is always the whole grid."""
     w0, step, n = grid_params(grid)
-    assert rad.is_cuda and rad.dtype == torch.float64 and rad.is_contiguous() and rad.shape[-1] == n
-    rad2 = rad.reshape(-1, n)
+    n_sh = rad.shape[-1]
+    assert rad.is_cuda and rad.dtype == torch.float64 and rad.is_contiguous() and 0 <= g_lo and g_lo + n_sh <= n
+    rad2 = rad.reshape(-1, n_sh)
     centers_nm, cp = _d(centers_nm)
     widths_nm, wp = _d(widths_nm)
     if widths_nm.size != centers_nm.size:
         raise ValueError("{} spectral widths for {} grid points".format(widths_nm.size, centers_nm.size))
     out = np.zeros((rad2.shape[0], centers_nm.size))
-    check(lib.sr_hires_to_lowres_dev(C.c_void_p(rad2.data_ptr()), rad2.shape[0], n, w0, step, cp, wp,
-                                     centers_nm.size, float(n_sigma), _UNITS[out_units], out.ctypes.data_as(dp),
-                                     _stream_ptr()), "sr_hires_to_lowres_dev")
+    check(lib.sr_hires_to_lowres_shard_dev(C.c_void_p(rad2.data_ptr()), rad2.shape[0], n_sh, int(g_lo), w0, step, cp, wp,
+                                           centers_nm.size, float(n_sigma), _UNITS[out_units], out.ctypes.data_as(dp),
+                                           _stream_ptr()), "sr_hires_to_lowres_shard_dev")
     return out
 
 

@@ -78,11 +78,14 @@ class LimbScene(object):
     def gas(self, name):
         return [g for g in self.gases if g.name == name][0]
 
-    def coefficients(self, refresh=False):
-        """(abs, emi) of every gas at the layer stack; cached: only VMRs change between iterations."""
+    def coefficients(self, refresh=False, g_lo=0, g_hi=None):
+        """(abs, emi) of every gas at the layer stack over grid points [g_lo, g_hi); cached per shard: only VMRs change
+        between the iterations of a VMR retrieval (refresh=True recomputes, e.g. when temperatures are retrieved)."""
+        g_hi = len(self.grid) if g_hi is None else int(g_hi)
         for g in self.gases:
-            if g.coeffs is None or refresh:
-                g.coeffs = g.lineset.abscoeff_layers(self.temps, self.press, tvib=g.tvib)
+            if g.coeffs is None or refresh or getattr(g, "coeffs_shard", None) != (g_lo, g_hi):
+                g.coeffs = g.lineset.abscoeff_layers(self.temps, self.press, tvib=g.tvib, g_lo=g_lo, g_hi=g_hi)
+                g.coeffs_shard = (g_lo, g_hi)
         return [g.coeffs for g in self.gases]
 
     def los(self, tangent_alts, **opts):
@@ -106,25 +109,52 @@ class LimbScene(object):
         return np.array(par_gas, np.int32), np.array(par_w)
 
 
-def simulate(scene, pixels, bayes_set=None, fov_closed_form=True):
+def shard_with_halo(n_grid, g_lo, g_hi):
+    """Grid range a rank evaluates for its spectral shard [g_lo, g_hi) of an instrument-band integral: one point
+    beyond its upper end, so that the trapezoid between the last own point and the next rank's first is counted
+    exactly once (every interval (j, j + 1) belongs to the shard that owns j)."""
+    return int(g_lo), int(min(g_hi + 1, n_grid))
+
+
+def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, refresh=False):
     """One forward-model pass for all pixels (the body of the reference's iteration,
     spect_main_module.py:2736-2940): returns (sims, derivs) with sims[i] the FOV-integrated low-resolution
-    spectrum of pixel i (Spectrum) and derivs[i][p] its derivative w.r.t. parameter p of bayes_set."""
+    spectrum of pixel i (Spectrum) and derivs[i][p] its derivative w.r.t. parameter p of bayes_set.
+
+    shard = (g_lo, g_hi): this rank's spectral window of a multi-GPU run -- the reference splits the forward model
+    of a retrieval the same way (spect_main_module.py:2814-2818: n_split contiguous chunks of the grid, results
+    put together before the instrument step).  The rank computes radiances and Jacobians on its shard only and its
+    PARTIAL instrument-band integrals; one all-reduce (sum) of [n_los x (1 + n_par) x n_bands] doubles over the
+    ranks completes them (distributed.all_reduce_sum; a no-op without a process group), then every rank holds the
+    same low-resolution spectra and runs the same n_par x n_par algebra."""
+    from . import distributed as sd
     alts = [a for pix in pixels for a in pix.los_alts()]
     los, alt = scene.los(alts)
-    coeffs = scene.coefficients()
+    n_grid = len(scene.grid)
+    g_lo, g_hi = (0, n_grid) if shard is None else shard_with_halo(n_grid, *shard)
+    coeffs = scene.coefficients(refresh=refresh, g_lo=g_lo, g_hi=g_hi)
     n_los = len(alts)
+    lowres = lambda r: engine.hires_to_lowres(r, scene.grid, scene.bands_nm, scene.widths_nm, out_units=scene.out_units, g_lo=g_lo)
     if bayes_set is None:
         rad = engine.limb_rays(coeffs, los)
-        low = engine.hires_to_lowres(rad, scene.grid, scene.bands_nm, scene.widths_nm, out_units=scene.out_units)
-        dlow = None
+        low = lowres(rad)
+        both = low[:, None, :]
     else:
         par_gas, par_w = scene.profile_weights(bayes_set, alt)
         rad, jac = engine.limb_rays_jacobian(coeffs, los, par_gas, par_w)
-        low = engine.hires_to_lowres(rad, scene.grid, scene.bands_nm, scene.widths_nm, out_units=scene.out_units)
+        low = lowres(rad)
         n_par = len(par_gas)
-        dlow = engine.hires_to_lowres(jac.reshape(n_los * n_par, -1), scene.grid, scene.bands_nm, scene.widths_nm,
-                                      out_units=scene.out_units).reshape(n_los, n_par, -1)
+        dlow = lowres(jac.reshape(n_los * n_par, -1)).reshape(n_los, n_par, -1)
+        both = np.concatenate([low[:, None, :], dlow], axis=1)
+    if shard is not None:
+        # the one exchange of a sharded iteration
+        import torch
+        dev = "cuda" if (torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else "cpu"
+        t = torch.from_numpy(np.ascontiguousarray(both)).to(dev)
+        sd.all_reduce_sum(t)
+        both = t.cpu().numpy()
+    low = both[:, 0, :]
+    dlow = None if bayes_set is None else both[:, 1:, :]
     sims, derivs = [], []
     for i, pix in enumerate(pixels):
         three = [Spectrum(low[3 * i + q], scene.bands_nm) for q in range(3)]
@@ -142,11 +172,12 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True):
 
 
 def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10, lambda_LM=0.1, L1_reg=False,
-                        solo_simulation=False, check_log=None, fov_closed_form=True):
+                        solo_simulation=False, check_log=None, fov_closed_form=True, shard=None, refresh=False):
     """The retrieval loop of spect_main_module.inversion_fast_limb (:2725-2987): Levenberg-Marquardt
     optimal estimation of the VMR-profile parameters in bayes_set from the pixels' observations.
     Returns (chi, obs, sims, bayes_set) like the reference, plus .history on bayes_set (chi per iteration)
-    and .stop ('converged' | 'raised' | 'max_it')."""
+    and .stop ('converged' | 'raised' | 'max_it').  shard / refresh: see simulate (every rank of a multi-GPU run
+    calls this with its own spectral shard; all ranks hold the same chi square history and parameters)."""
     pixels = sorted(pixels, key=lambda x: x.limb_tg_alt)                       # :2607
     for name in bayes_set.sets.keys():                                         # :2624-2625
         scene.gas(name).add_clim(bayes_set.sets[name].profile())
@@ -156,7 +187,7 @@ def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10,
     bayes_set.history, bayes_set.stop = [], 'max_it'
     chi_old, chi, sims = None, None, []
     for num_it in range(max_it):
-        sims, derivs = simulate(scene, pixels, bayes_set, fov_closed_form=fov_closed_form)
+        sims, derivs = simulate(scene, pixels, bayes_set, fov_closed_form=fov_closed_form, shard=shard, refresh=refresh)
         if solo_simulation:
             return None
         for num, row in enumerate(derivs):
@@ -178,6 +209,6 @@ def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10,
     return chi, obs, sims, bayes_set
 
 
-def radtrans(scene, pixels, fov_closed_form=True):
+def radtrans(scene, pixels, fov_closed_form=True, shard=None):
     """Simulation only (spect_main_module.radtrans, :2990-3287): the FOV-integrated low-resolution spectra."""
-    return simulate(scene, pixels, None, fov_closed_form=fov_closed_form)[0]
+    return simulate(scene, pixels, None, fov_closed_form=fov_closed_form, shard=shard)[0]

@@ -301,3 +301,56 @@ print("rccl one-rank ok", sd.stats)
     p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0 and "rccl one-rank ok" in out, out
+
+
+def test_config4_retrieval_sharded_over_two_ranks(eng, tmp_path):
+    """configs[4] on N GPUs (Jacobian spectra follow the shard pattern, the algebra stays small): two
+    fresh processes share the one GPU (gloo), each runs retrieval.inversion_fast_limb on its spectral shard --
+    radiances, Jacobians and PARTIAL band integrals, one all-reduce per iteration -- and both must reproduce the
+    chi-square history and the retrieved parameters of the unsharded loop (to rounding: the band integrals are summed
+    in another order), iteration for iteration."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text("""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+import bench_configs as bc
+from spectrobot_amd import engine, retrieval, distributed as sd
+rank, local, world = sd.init_from_env()
+engine.set_device(0)
+scene = bc.two_gas_scene(6000, 1500, 16000, 30)
+bs, pixels, x_true = bc.retrieval_problem(scene)
+shard = sd.shard_bounds(len(scene.grid), world, rank) if world > 1 else None
+# one simulation first: the sharded forward model against ... itself unsharded (same process, whole grid)
+sims_s, der_s = retrieval.simulate(scene, pixels, bs, shard=shard)
+chi, obs, sims, bs = retrieval.inversion_fast_limb(scene, bs, pixels, max_it=20, shard=shard)
+print("RESULT " + json.dumps({"rank": rank, "hist": [float(c) for c in bs.history], "x": bs.param_vector().tolist(),
+                              "stop": bs.stop, "sim0": np.array([s.spectrum for s in sims_s]).tolist(),
+                              "der0": np.array([[d.spectrum for d in row] for row in der_s]).tolist()}))
+if world > 1:
+    torch.distributed.barrier()
+""" % root)
+
+    def run(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", WORLD_SIZE=str(world), SR_DIST_BACKEND="gloo",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+        outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        import json
+        return [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:]) for o in outs]
+
+    whole = run(1)[0]
+    two = run(2)
+    assert len(whole["hist"]) >= 3
+    for r in two:
+        assert r["stop"] == whole["stop"] and len(r["hist"]) == len(whole["hist"])
+        assert np.allclose(r["sim0"], whole["sim0"], rtol=1e-12, atol=0) and np.allclose(r["der0"], whole["der0"], rtol=1e-9, atol=1e-300)
+        assert np.allclose(r["hist"], whole["hist"], rtol=1e-8)
+        assert np.allclose(r["x"], whole["x"], rtol=1e-8)
+    assert two[0]["hist"] == two[1]["hist"] and two[0]["x"] == two[1]["x"]      # the ranks agree bit for bit

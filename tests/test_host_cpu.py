@@ -187,6 +187,48 @@ def test_shard_bounds_balanced_short_grid():
         sd.shard_bounds_balanced(freq, grid[:4], 8)
 
 
+def test_sharded_band_integrals_add_up(oracle):
+    """configs[4] on N GPUs (retrieval.simulate): every rank integrates the instrument bands over its spectral shard
+    plus the next rank's first point; the partial integrals add up to the unsharded ones (each trapezoid belongs to
+    the shard that owns its left point).  Checked with the oracle's hires_to_lowres on the CPU, shard bounds from
+    shard_with_halo; the all-reduce itself under gloo with two ranks."""
+    from spectrobot_amd import distributed as sd, synthetic as syn
+    from spectrobot_amd.retrieval import shard_with_halo
+    n = 6000
+    grid = syn.make_grid(3290.0, 5e-4, n)
+    rng = np.random.default_rng(2)
+    spec_hi = rng.uniform(0.5, 1.5, n) * 1e-3
+    lam = np.linspace(1e7 / grid[-1] + 0.3, 1e7 / grid[0] - 0.3, 9)
+    wid = np.full(9, 0.25)
+    full = oracle.hires_to_lowres(grid, spec_hi, lam, wid)
+    for world in (2, 3, 8):
+        parts = np.zeros_like(full)
+        for r in range(world):
+            lo, hi = shard_with_halo(n, *sd.shard_bounds(n, world, r))
+            assert hi - lo >= 2
+            parts += oracle.hires_to_lowres(grid[lo:hi], spec_hi[lo:hi], lam, wid)
+        assert np.max(np.abs(parts - full)) < 1e-13 * np.max(np.abs(full)), world
+
+
+def test_all_reduce_sum_gloo_world2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from spectrobot_amd import distributed as sd\n"
+        "rank, local, world = sd.init_from_env(backend='gloo')\n"
+        "t = torch.arange(12, dtype=torch.float64).reshape(3, 4) * (rank + 1)\n"
+        "assert sd.all_reduce_sum(t) is t and torch.equal(t, torch.arange(12, dtype=torch.float64).reshape(3, 4) * 3)\n"
+        "assert sd.dist_info() == {'backend': 'gloo', 'world_size': 2, 'rank': rank}\n"
+        "torch.distributed.barrier()\n"
+        "print('rank', rank, 'ok')\n" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29536", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+
+
 def test_shard_bounds_balanced_on_skewed_line_density(tmp_path):
     """Equal-work shards: a band head holding 70 % of the lines in 15 % of the grid.  The
     work model's per-shard cost spread drops from several-fold (equal width) to a few per cent; the
