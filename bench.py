@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--shard", default="", help="R/W: time only the spectral shard of rank R of W on this GPU "
                     "(tuning aid for the multi-GPU shard size; not a bench line of the metric)")
+    ap.add_argument("--3d", dest="three_d", action="store_true", help="--config 3 in its 3-D form: a coefficient row per LOS "
+                    "step (P, T, T_vib at the local SZA along the path), Jacobians per altitude layer")
     ap.add_argument("--exact", action="store_true", help="evaluate every (line, point) exactly (no far-field expansions)")
     ap.add_argument("--far-field", type=int, default=2, choices=(1, 2), help="2 (default): far-field expansions from box "
                     "pairs (multipole -> local); 1: per line and box")

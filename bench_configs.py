@@ -50,6 +50,16 @@ def sza_atmosphere(atm, sza_deg, n_levels=12):
     return out
 
 
+def step_atmosphere(atm, seg_alt_layer, seg_mu):
+    """(T, P, T_vib) of every LOS step of a 3-D path: the altitude shell's profile with the illumination of the step's
+    own position (same law as sza_atmosphere, with the local cos SZA clipped at the terminator)."""
+    k = np.asarray(seg_alt_layer)
+    mu = np.clip(np.asarray(seg_mu, float), 0.0, 1.0)
+    temps = atm["temps"][k] + 4.0 * (mu - 0.5)
+    exc = (atm["tvib"] - atm["temps"][None, :])[:, k]
+    return dict(temps=temps, press=atm["press"][k], tvib=temps[None, :] + exc * (0.4 + 1.2 * mu)[None, :])
+
+
 def layer_vmr_weights(z, alt):
     """par_w [n_layers, n_pt]: triangular weight of every altitude level at the LOS sample altitudes (the VMR
     profile is piecewise linear on the levels: vmr(alt) = sum_k w_k(alt) vmr_k)."""
@@ -124,6 +134,60 @@ def _sync_time(fn, steps, warmup):
         out = fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps, out
+
+
+def config3_3d(args, rank, world, info, base):
+    """configs[3] in its 3-D form (radtran_3Dvs2D_sza30-80_test.py:353-379: use_tangent_sza = False,
+    invert_LOS_direction = True): per ray and per LOS STEP its own (P, T, T_vib(local SZA)) -- the coefficient op
+    runs over the ~900 steps of a set of 8 rays instead of 80 altitude layers (layer batches under the table
+    budget), the temperature Jacobian is still per altitude layer (seg_jac_row), the VMR Jacobian per level."""
+    import torch
+    from spectrobot_amd import engine, synthetic as syn
+    n_grid, n_lines, n_rays, szas = 200000, 200000, 8, [30.0, 37.0, 44.0, 51.0, 58.0, 65.0, 72.0, 80.0]
+    if args.grid != 100000:
+        n_grid = n_lines = args.grid      # reduced sizes for tests
+    grid, L, atm, e_lev = ch4_case(n_lines, n_grid, args.layers, config_id=3, w0=2950.0)
+    ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)
+    vm = np.full(args.layers, 0.0148)
+    tz = 120.0 + 60.0 * np.arange(n_rays)
+    az = 22.5 * np.arange(n_rays)                       # the ray set fans out in azimuth
+    my = szas[rank::world]
+    pg = np.zeros(args.layers, np.int32)
+
+    def one_set(sza):
+        Lr = syn.limb_los_3d(atm["z"], atm["nd"], [vm], tz, sza, az)
+        los = engine.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"], col_scale=[syn.CH4_ISO_RATIO])
+        a = step_atmosphere(atm, Lr["seg_alt_layer"], Lr["seg_mu"])
+        co = ls.abscoeff_layers(a["temps"], a["press"], tvib=a["tvib"])
+        ap = ls.abscoeff_layers(a["temps"] + 0.05, a["press"], tvib=a["tvib"])
+        am = ls.abscoeff_layers(a["temps"] - 0.05, a["press"], tvib=a["tvib"])
+        dco = ((ap[0] - am[0]) / 0.1, (ap[1] - am[1]) / 0.1)
+        del ap, am
+        W = layer_vmr_weights(atm["z"], Lr["alt"])
+        return engine.limb_rays_jacobians(co, los, dcoeffs=dco, par_gas=pg, par_w=W, seg_jac_row=Lr["seg_alt_layer"],
+                                          n_jac_rows=args.layers), len(Lr["seg_layer"])
+
+    def step():
+        res = None
+        for sza in my:
+            res = one_set(sza)
+        return res
+
+    dt, (res, n_steps) = _sync_time(step, max(1, args.steps // 10), min(args.warmup, 1))
+    out = dict(base, metric="limb spectra/sec with per-layer T and VMR Jacobians, 3-D path (BASELINE configs[3])",
+               value=len(szas) * n_rays / dt if world == len(szas) or world == 1 else len(my) * n_rays * world / dt,
+               ms_per_step=dt * 1e3, scaling="weak" if world > 1 else "n/a",
+               config={"workload": "3-D atmosphere (BASELINE configs[3], use_tangent_sza = False): %d tangent SZA x %d rays fanned in "
+                                   "azimuth, %d lines x %d-pt grid, a coefficient row per LOS step (%d steps per set instead of %d "
+                                   "altitude layers), d/dT_k per altitude layer (central differences of the coefficient op over the "
+                                   "steps) and d/dVMR_k per level" % (len(szas), n_rays, n_lines, n_grid, n_steps, args.layers),
+                       "device": info["name"]},
+               checksum=float(res[0].sum().item()), los_steps_per_set=n_steps)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def _event_time(fn, kernel, bytes_alg, note, n=5):
@@ -201,6 +265,8 @@ def main(args):
                                        "coefficient op, device LOS pipeline, spectral window / %d + one all-gather"
                                        % (args.lines, args.grid, args.layers, n_rays, world), "device": info["name"]},
                    checksum=float(spec.sum().item()))
+    elif args.config == 3 and getattr(args, "three_d", False):
+        return config3_3d(args, rank, world, info, base)
     elif args.config == 3:
         n_grid, n_lines, n_rays, szas = 200000, 200000, 8, [30.0, 37.0, 44.0, 51.0, 58.0, 65.0, 72.0, 80.0]
         grid, L, atm, e_lev = ch4_case(n_lines, n_grid, args.layers, config_id=3, w0=2950.0)

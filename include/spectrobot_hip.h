@@ -271,10 +271,15 @@ int sr_limb_rays_jac_layer_dev(const double *abs_c, const double *emi_c, const d
  * access stores, which adds and which contributions are carried in registers across consecutive segments, so a
  * Jacobian row is written about once per crossing instead of memset + read-add-store per segment.  Falls back to the
  * forward-sensitivity kernels (sr_limb_rays_jac_dev / _jac_layer_dev under sr_set_jac_layer_mode(1)) when a segment
- * touches more than four parameters; same definitions, same layouts. */
+ * touches more than four parameters; same definitions, same layouts.
+ * seg_jac_row (HOST [n_seg], or NULL: = seg_layer, n_jac_rows ignored): the row of jac_layer [n_rays][n_jac_rows][n_pts]
+ * a segment's per-layer sensitivity is added to.  A 3-D path (spect_main_module.py:2746-2767 with use_tangent_sza =
+ * False: vibrational temperatures follow the local SZA along the LOS) gives every LOS step its own coefficient row
+ * (seg_layer) while the retrieved scalar still belongs to the step's altitude layer (seg_jac_row). */
 int sr_limb_rays_jacobians_dev(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
-                               int n_layers, int64_t n_pts, const sr_los_desc *los, int n_par, const int32_t *par_gas,
-                               const double *par_w, double *rad, double *jac_layer, double *jac_par, void *stream);
+                               int n_layers, int64_t n_pts, const sr_los_desc *los, const int32_t *seg_jac_row,
+                               int n_jac_rows, int n_par, const int32_t *par_gas, const double *par_w, double *rad,
+                               double *jac_layer, double *jac_par, void *stream);
 
 /* Radiances and their Jacobian with respect to n_par retrieval parameters on which the absorber
  * columns depend linearly, col_s = sum_p dcol_dpar[s][p] * x_p (VMR profile parameters of the

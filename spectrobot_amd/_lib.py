@@ -88,8 +88,8 @@ SYMBOLS = {
     "sr_limb_rays_jac_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(LosDesc), C.c_int, ip, dp,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_limb_rays_jacobians_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
-                                             C.POINTER(LosDesc), C.c_int, ip, dp, C.c_void_p, C.c_void_p, C.c_void_p,
-                                             C.c_void_p]),
+                                             C.POINTER(LosDesc), ip, C.c_int, C.c_int, ip, dp, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
     "sr_limb_rays_jac_layer_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
                                              C.POINTER(LosDesc), C.c_void_p, C.c_void_p]),
     "sr_radiance_rays_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, ip, ip, dp, C.c_int,

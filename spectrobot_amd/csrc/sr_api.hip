@@ -1340,13 +1340,13 @@ struct AdjPlan {
   std::vector<int> zero_off; // [n_rays + 1]
   std::vector<int> zero_row; // layer rows (< n_layers) and parameter rows (n_layers + p)
 };
-bool build_adj_plan(const sr_los_desc *los, int n_layers, int n_par, const int32_t *par_gas, const double *par_w,
-                    bool want_layer, int n_pt, AdjPlan *out) {
+bool build_adj_plan(const sr_los_desc *los, int n_layers, const int32_t *seg_jrow, int n_jrows, int n_par,
+                    const int32_t *par_gas, const double *par_w, bool want_layer, int n_pt, AdjPlan *out) {
   const int nr = los->n_rays, n_seg = los->seg_off[nr];
   out->seg.assign((size_t)n_seg * kAdjPlanInts, 0);
   out->zero_off.assign(nr + 1, 0);
   out->zero_row.clear();
-  std::vector<char> lay_seen(n_layers), par_seen(std::max(n_par, 1));
+  std::vector<char> lay_seen(n_jrows), par_seen(std::max(n_par, 1));
   std::vector<std::vector<int>> touch(n_par); // walk positions (within the ray) of the segments touching p
   for (int r = 0; r < nr; ++r) {
     const int a = los->seg_off[r], b = los->seg_off[r + 1], m = b - a;
@@ -1354,10 +1354,11 @@ bool build_adj_plan(const sr_los_desc *los, int n_layers, int n_par, const int32
     auto orig = [&](int q) { return los->los_order == 0 ? a + q : a + (m - 1 - q); }; // walk position -> caller's segment
     for (int q = 0; q < m; ++q) {
       int *pl = &out->seg[(size_t)(a + q) * kAdjPlanInts];
-      const int k = los->seg_layer[orig(q)];
+      const int k = los->seg_layer[orig(q)], jr = seg_jrow ? seg_jrow[orig(q)] : k;
       pl[0] = k;
-      pl[1] = lay_seen[k] ? 0 : 1;
-      lay_seen[k] = 1;
+      pl[1] = lay_seen[jr] ? 0 : 1;
+      pl[3] = jr;
+      lay_seen[jr] = 1;
     }
     for (int p = 0; p < n_par; ++p) {
       touch[p].clear();
@@ -1405,10 +1406,10 @@ bool build_adj_plan(const sr_los_desc *los, int n_layers, int n_par, const int32
       pl[2] = n_ent;
     }
     if (want_layer)
-      for (int k = 0; k < n_layers; ++k)
+      for (int k = 0; k < n_jrows; ++k)
         if (!lay_seen[k]) out->zero_row.push_back(k);
     for (int p = 0; p < n_par; ++p)
-      if (!par_seen[p]) out->zero_row.push_back(n_layers + p);
+      if (!par_seen[p]) out->zero_row.push_back(n_jrows + p);
     out->zero_off[r + 1] = (int)out->zero_row.size();
   }
   return true;
@@ -1417,14 +1418,19 @@ bool build_adj_plan(const sr_los_desc *los, int n_layers, int n_par, const int32
 // Radiances (rad may be NULL) + per-layer Jacobian (dabs / demi / jac_layer may be NULL) + column-parameter Jacobian
 // (n_par may be 0) in one pass.  *done = 0 when the plan does not fit the kernel (nothing launched).
 int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_layers,
-                 int64_t n_pts, const sr_los_desc *los, int n_par, const int32_t *par_gas, const double *par_w,
-                 double *rad, double *jac_layer, double *jac_par, hipStream_t st, int *done) {
+                 int64_t n_pts, const sr_los_desc *los, const int32_t *seg_jrow, int n_jrows, int n_par,
+                 const int32_t *par_gas, const double *par_w, double *rad, double *jac_layer, double *jac_par,
+                 hipStream_t st, int *done) {
   *done = 0;
   int n_seg = 0, n_pt = 0;
   int rc = check_los(los, n_layers, &n_seg, &n_pt);
   if (rc) return rc;
+  if (!seg_jrow) n_jrows = n_layers;
+  if (seg_jrow)
+    for (int q = 0; q < n_seg; ++q)
+      if (seg_jrow[q] < 0 || seg_jrow[q] >= n_jrows) return SR_ERR_ARG; // would write out of the Jacobian
   AdjPlan plan;
-  if (!build_adj_plan(los, n_layers, n_par, par_gas, par_w, jac_layer != nullptr, n_pt, &plan)) return SR_OK;
+  if (!build_adj_plan(los, n_layers, seg_jrow, n_jrows, n_par, par_gas, par_w, jac_layer != nullptr, n_pt, &plan)) return SR_OK;
   LosDev D;
   rc = stage_los(los, n_layers, n_par, par_gas, par_w, st, &D);
   if (rc) return rc;
@@ -1446,7 +1452,7 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
   char *d = sg.d.as<char>();
   SegProg *prog = reinterpret_cast<SegProg *>(d + in_bytes);
   LAUNCHCHK(launch_adj_pack(reinterpret_cast<const int *>(d), D.col, los->n_gas, n_seg, prog, st));
-  LAUNCHCHK(launch_limb_adjoint(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, los->n_rays, D.seg_off, prog,
+  LAUNCHCHK(launch_limb_adjoint(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, n_jrows, los->n_rays, D.seg_off, prog,
                                 reinterpret_cast<const int *>(d + o_zo), reinterpret_cast<const int *>(d + o_zr), n_par,
                                 limb_opts(los, D.n_seg), rad, jac_layer, jac_par, st));
   rc = sg.mark(st);
@@ -1460,9 +1466,11 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
 extern "C" {
 
 int sr_limb_rays_jacobians_dev(const double *abs_c, const double *emi_c, const double *dabs, const double *demi,
-                               int n_layers, int64_t n_pts, const sr_los_desc *los, int n_par, const int32_t *par_gas,
-                               const double *par_w, double *rad, double *jac_layer, double *jac_par, void *stream) {
+                               int n_layers, int64_t n_pts, const sr_los_desc *los, const int32_t *seg_jac_row,
+                               int n_jac_rows, int n_par, const int32_t *par_gas, const double *par_w, double *rad,
+                               double *jac_layer, double *jac_par, void *stream) {
   if (!abs_c || !emi_c || n_layers <= 0 || n_pts <= 0 || n_par < 0) return SR_ERR_ARG;
+  if (seg_jac_row && n_jac_rows <= 0) return SR_ERR_ARG;
   if (n_pts > 2000000) return SR_ERR_LIMIT;
   const bool want_layer = jac_layer != nullptr, want_par = n_par > 0;
   if (want_layer != (dabs != nullptr && demi != nullptr) || (want_par && (!jac_par || !par_gas || !par_w))) return SR_ERR_ARG;
@@ -1477,12 +1485,16 @@ int sr_limb_rays_jacobians_dev(const double *abs_c, const double *emi_c, const d
   hipStream_t st = static_cast<hipStream_t>(stream);
   int done = 0;
   if (!g_jac_layer_forward.load()) {
-    const int rc = limb_adjoint(abs_c, emi_c, dabs, demi, n_layers, n_pts, los, n_par, par_gas, par_w, rad, jac_layer,
-                                jac_par, st, &done);
+    const int rc = limb_adjoint(abs_c, emi_c, dabs, demi, n_layers, n_pts, los, seg_jac_row, n_jac_rows, n_par, par_gas,
+                                par_w, rad, jac_layer, jac_par, st, &done);
     if (rc || done) return rc;
   }
   // forward-sensitivity kernels, one call per kind (a segment touching more than four parameters, or asked for)
-  std::vector<char> keep;
+  if (seg_jac_row && want_layer) {
+    g_err = "sr_limb_rays_jacobians_dev: Jacobian rows other than the coefficient rows need the one-pass kernel "
+            "(sr_set_jac_layer_mode(0) and at most four column parameters per segment)";
+    return SR_ERR_UNSUPPORTED;
+  }
   if (want_par) {
     if (!rad) return SR_ERR_ARG; // the forward kernel writes the radiances too
     const int rc = sr_limb_rays_jac_dev(abs_c, emi_c, n_layers, n_pts, los, n_par, par_gas, par_w, rad, jac_par, stream);
@@ -1506,8 +1518,8 @@ int sr_limb_rays_jac_dev(const double *abs_c, const double *emi_c, int n_layers,
   // (init_mode 1) is read by both kernels before they write
   if (n_par > 8 && !g_jac_layer_forward.load() && par_gas && par_w) {
     int done = 0;
-    const int rc = limb_adjoint(abs_c, emi_c, nullptr, nullptr, n_layers, n_pts, los, n_par, par_gas, par_w, rad,
-                                nullptr, jac, st, &done);
+    const int rc = limb_adjoint(abs_c, emi_c, nullptr, nullptr, n_layers, n_pts, los, nullptr, 0, n_par, par_gas, par_w,
+                                rad, nullptr, jac, st, &done);
     if (rc || done) return rc;
   }
   LosDev D;
@@ -1530,8 +1542,8 @@ int sr_limb_rays_jac_layer_dev(const double *abs_c, const double *emi_c, const d
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!g_jac_layer_forward.load() && n_layers > 8) {
     int done = 0;
-    const int rc = limb_adjoint(abs_c, emi_c, dabs, demi, n_layers, n_pts, los, 0, nullptr, nullptr, nullptr, jac,
-                                nullptr, st, &done);
+    const int rc = limb_adjoint(abs_c, emi_c, dabs, demi, n_layers, n_pts, los, nullptr, 0, 0, nullptr, nullptr, nullptr,
+                                jac, nullptr, st, &done);
     if (rc || done) return rc;
   }
   LosDev D;

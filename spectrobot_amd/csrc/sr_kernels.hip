@@ -2050,7 +2050,8 @@ __global__ __launch_bounds__(256) void sr_limb_jac_layer_kernel(
 //   w_tau = (-I_prev t + E f') T_after,   w_E = f T_after          (d I_final / d tau_s,  / d E_s)
 //   per-layer scalar (temperature):   J_k += w_tau dtau_k u + w_E dE_k u            over the segments in layer k
 //   column parameter p of gas g:      J_p += (w_tau a_g + w_E e_g) dcol[p][s]       over the segments p touches
-// T_after = exp(-(tau_total - tau(0..s))): a first sweep adds up tau_total (no exp), the second runs the recursion.
+// T_after = exp(-(tau_total - tau(0..s))): a first sweep adds up tau_total (no exp; error-free two-sums, see the
+// kernel), the second runs the recursion.
 // The forward-sensitivity kernels carry NP accumulators through the whole recursion and repeat it per block of NP
 // parameters: 80 per-layer VMR parameters cost five recursions of 160 x (60 + 16 x 4) instructions; here one of
 // 160 x ~100.  What remains is the traffic of the Jacobian rows (configs[3]: 2 x 1 GB per set of 8 rays), so the
@@ -2064,9 +2065,10 @@ __global__ __launch_bounds__(256) void sr_limb_jac_layer_kernel(
 // ------------------------------------------------------------------------
 constexpr int kAdjEnt = 4; // column parameters a segment may touch (more: the forward-sensitivity kernel is used)
 struct __attribute__((aligned(16))) SegProg {
-  int layer;
-  int flags;            // bit 0: first touch of the layer in this ray (store), else add
-  int n_ent, pad;
+  int layer;            // row of the coefficient tables
+  int flags;            // bit 0: first touch of the per-layer Jacobian row in this ray (store), else add
+  int n_ent;
+  int jrow;             // row of the per-layer Jacobian (= layer, or the altitude layer of a 3-D path's step)
   int ent_p[kAdjEnt];   // parameter
   int ent_gf[kAdjEnt];  // gas | slot << 8 | flags << 16: bit 0 run starts here (no carry in), bit 1 run ends here
                         // (write), bit 2 first write of the parameter in this ray (store)
@@ -2082,7 +2084,7 @@ __global__ void sr_adj_pack_kernel(const int *__restrict__ plan, // [n_seg][4 + 
   if (s >= n_seg) return;
   const int *pl = plan + (size_t)s * (4 + 2 * kAdjEnt);
   SegProg r;
-  r.layer = pl[0]; r.flags = pl[1]; r.n_ent = pl[2]; r.pad = 0;
+  r.layer = pl[0]; r.flags = pl[1]; r.n_ent = pl[2]; r.jrow = pl[3];
 #pragma unroll
   for (int i = 0; i < kAdjEnt; ++i) {
     r.ent_p[i] = pl[4 + i];
@@ -2097,28 +2099,39 @@ __global__ void sr_adj_pack_kernel(const int *__restrict__ plan, // [n_seg][4 + 
 template <int NG, bool LAYER, bool PAR>
 __global__ __launch_bounds__(256) void sr_limb_adjoint_kernel(
     const double *__restrict__ abs_c, const double *__restrict__ emi_c, const double *__restrict__ dabs,
-    const double *__restrict__ demi, int n_pts, int n_layers, const int *__restrict__ seg_off,
+    const double *__restrict__ demi, int n_pts, int n_layers, int n_jrows, const int *__restrict__ seg_off,
     const SegProg *__restrict__ prog, const int *__restrict__ zero_off, const int *__restrict__ zero_row, int n_par,
     LimbOpts o, double *__restrict__ rad, double *__restrict__ jac_layer, double *__restrict__ jac_par) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, ray = blockIdx.y;
   if (j >= n_pts) return;
   const int s0 = seg_off[ray], s1 = seg_off[ray + 1];
   const size_t gstride = (size_t)n_layers * n_pts;
-  // rows this ray never touches: row < n_layers: layer row, else parameter row - n_layers
+  // rows this ray never touches: row < n_jrows: per-layer Jacobian row, else parameter row - n_jrows
   for (int q = zero_off[ray]; q < zero_off[ray + 1]; ++q) {
     const int row = zero_row[q];
-    if (row < n_layers) {
-      if (LAYER) jac_layer[((size_t)ray * n_layers + row) * n_pts + j] = 0.0;
+    if (row < n_jrows) {
+      if (LAYER) jac_layer[((size_t)ray * n_jrows + row) * n_pts + j] = 0.0;
     } else if (PAR) {
-      jac_par[((size_t)ray * n_par + (row - n_layers)) * n_pts + j] = 0.0;
+      jac_par[((size_t)ray * n_par + (row - n_jrows)) * n_pts + j] = 0.0;
     }
   }
-  double rem = 0.0; // optical depth of the segments not yet passed
+  // Optical depth of the segments not yet passed, as an unevaluated sum rem + rem_lo (two-sum: every addition's
+  // rounding error is kept).  The first sweep adds the segments' tau up, the recursion takes the SAME values off again
+  // one by one: at a line centre the path's total can be 1e9 while the last segments' own depth is 0.1 -- carried in
+  // one double the difference would be good to 1e-7 only, and with it the transmission behind the near-side layers.
+  double rem = 0.0, rem_lo = 0.0;
   for (int s = s0; s < s1; ++s) {
     const SegProg &P = prog[s];
     const size_t ofs = (size_t)P.layer * n_pts + j;
+    double tau = 0.0;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) rem = fma(abs_c[g * gstride + ofs], P.u[g], rem);
+    for (int g = 0; g < NG; ++g) {
+      const double ag = abs_c[g * gstride + ofs];
+      tau = g == 0 ? ag * P.u[g] : tau + ag * P.u[g];   // as the recursion below forms it
+    }
+    const double sm = rem + tau, bb = sm - rem;
+    rem_lo += (rem - (sm - bb)) + (tau - bb);
+    rem = sm;
   }
   double I = limb_initial(o, rad, (size_t)ray * n_pts + j, j);
   double slot[4] = {0., 0., 0., 0.};
@@ -2157,13 +2170,17 @@ __global__ __launch_bounds__(256) void sr_limb_adjoint_kernel(
       }
       const Atten A = attenuation(tau);
       const double fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
-      rem -= tau;
-      const double Ta = exp_bounded(fmin(fmax(-rem, -700.0), 700.0)); // transmission of everything behind this segment
+      {
+        const double sm = rem - tau, bb = sm - rem;
+        rem_lo += (rem - (sm - bb)) + (-tau - bb);
+        rem = sm;
+      }
+      const double Ta = exp_bounded(fmin(fmax(-(rem + rem_lo), -700.0), 700.0)); // transmission of everything behind this segment
       const double w_tau = (o.solo_absorption ? -I * A.t : fma(E, fp, -I * A.t)) * Ta;
       const double w_E = o.solo_absorption ? 0.0 : A.f * Ta;
       if (LAYER) {
         const double d = fma(w_tau, dtau, w_E * dE);
-        double *out = jac_layer + ((size_t)ray * n_layers + P.layer) * n_pts + j;
+        double *out = jac_layer + ((size_t)ray * n_jrows + P.jrow) * n_pts + j;
         if (P.flags & 1) *out = d; else *out += d;
       }
       if (PAR) {
@@ -2201,13 +2218,13 @@ int launch_adj_pack(const int *plan, const double *col, int n_gas, int n_seg, Se
 }
 
 int launch_limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
-                        int n_layers, int n_rays, const int *seg_off, const SegProg *prog, const int *zero_off,
+                        int n_layers, int n_jrows, int n_rays, const int *seg_off, const SegProg *prog, const int *zero_off,
                         const int *zero_row, int n_par, const LimbOpts &o, double *rad, double *jac_layer,
                         double *jac_par, hipStream_t st) {
   if (n_pts <= 0 || n_rays <= 0) return 0;
   const dim3 grid((n_pts + 255) / 256, n_rays);
 #define SR_A(NG, L, P) hipLaunchKernelGGL((sr_limb_adjoint_kernel<NG, L, P>), grid, dim3(256), 0, st, abs_c, emi_c, dabs, demi, \
-                                          n_pts, n_layers, seg_off, prog, zero_off, zero_row, n_par, o, rad, jac_layer, jac_par)
+                                          n_pts, n_layers, n_jrows, seg_off, prog, zero_off, zero_row, n_par, o, rad, jac_layer, jac_par)
 #define SR_A3(NG)                                                      \
   do {                                                                 \
     if (jac_layer && jac_par) SR_A(NG, true, true);                    \

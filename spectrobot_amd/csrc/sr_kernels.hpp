@@ -153,11 +153,11 @@ int launch_limb_jac_layer(int forward, const double *abs_c, const double *emi_c,
                           const LimbOpts &o, double *jac, hipStream_t st);
 // One pass per ray for radiances, per-layer and column-parameter Jacobians (sr_limb_adjoint_kernel)
 struct SegProg;
-constexpr int kAdjPlanInts = 4 + 2 * 4; // ints per segment of the host plan: layer, flags, n_ent, 0, ent_p[4], ent_gf[4]
+constexpr int kAdjPlanInts = 4 + 2 * 4; // ints per segment of the host plan: layer, flags, n_ent, jrow, ent_p[4], ent_gf[4]
 int launch_adj_pack(const int *plan, const double *col, int n_gas, int n_seg, SegProg *out, hipStream_t st);
 size_t adj_prog_bytes(int n_seg);
 int launch_limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
-                        int n_layers, int n_rays, const int *seg_off, const SegProg *prog, const int *zero_off,
+                        int n_layers, int n_jrows, int n_rays, const int *seg_off, const SegProg *prog, const int *zero_off,
                         const int *zero_row, int n_par, const LimbOpts &o, double *rad, double *jac_layer,
                         double *jac_par, hipStream_t st);
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,

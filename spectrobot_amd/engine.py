@@ -348,10 +348,13 @@ def limb_rays_layer_jacobian(coeffs, dcoeffs, los, grid=None, g_lo=0):
     return jac
 
 
-def limb_rays_jacobians(coeffs, los, dcoeffs=None, par_gas=None, par_w=None, grid=None, g_lo=0, want_rad=True):
+def limb_rays_jacobians(coeffs, los, dcoeffs=None, par_gas=None, par_w=None, grid=None, g_lo=0, want_rad=True,
+                        seg_jac_row=None, n_jac_rows=None):
     """Radiances, per-layer Jacobian (dcoeffs given: d(abs, emi of layer k)/d(scalar of layer k) per gas) and
     column-parameter Jacobian (par_gas / par_w given, as limb_rays_jacobian) in ONE pass over each ray
-    (sr_limb_rays_jacobians_dev).  Returns (rad | None, jac_layer | None, jac_par | None)."""
+    (sr_limb_rays_jacobians_dev).  Returns (rad | None, jac_layer | None, jac_par | None).
+    seg_jac_row [n_seg] (with n_jac_rows): the per-layer Jacobian row of every segment when it is not the segment's
+    coefficient row (3-D paths: a coefficient row per LOS step, the Jacobian per altitude layer)."""
     a, e = _gas_stack(coeffs)
     n_gas, n_layers, n_pts = a.shape
     if n_gas != los.n_gas:
@@ -360,8 +363,12 @@ def limb_rays_jacobians(coeffs, los, dcoeffs=None, par_gas=None, par_w=None, gri
     if dcoeffs is not None:
         da, de = _gas_stack(dcoeffs)
         assert da.shape == a.shape
-        jl = torch.empty((los.n_rays, n_layers, n_pts), dtype=torch.float64, device="cuda")
+        jl = torch.empty((los.n_rays, n_layers if seg_jac_row is None else int(n_jac_rows), n_pts), dtype=torch.float64,
+                         device="cuda")
     n_par, pg, pw = 0, None, None
+    sjr, sjp = (None, None) if seg_jac_row is None else _i(seg_jac_row)
+    if sjr is not None and sjr.size != los.n_seg:
+        raise ValueError("seg_jac_row must be [n_seg]")
     if par_gas is not None:
         par_gas, pg = _i(par_gas)
         par_w, pw = _d(par_w)
@@ -373,8 +380,9 @@ def limb_rays_jacobians(coeffs, los, dcoeffs=None, par_gas=None, par_w=None, gri
         rad = torch.empty((los.n_rays, n_pts), dtype=torch.float64, device="cuda")
     d = los.desc(grid, g_lo)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-    check(lib.sr_limb_rays_jacobians_dev(ptr(a), ptr(e), ptr(da), ptr(de), n_layers, n_pts, C.byref(d), n_par, pg, pw,
-                                         ptr(rad), ptr(jl), ptr(jp), _stream_ptr()), "sr_limb_rays_jacobians_dev")
+    check(lib.sr_limb_rays_jacobians_dev(ptr(a), ptr(e), ptr(da), ptr(de), n_layers, n_pts, C.byref(d), sjp,
+                                         0 if sjr is None else int(n_jac_rows), n_par, pg, pw, ptr(rad), ptr(jl), ptr(jp),
+                                         _stream_ptr()), "sr_limb_rays_jacobians_dev")
     return rad, jl, jp
 
 

@@ -156,3 +156,35 @@ def limb_los(z, nd_levels, vmr_levels, z_tans, R=2575.0, n_sub=3):
     nd = np.exp(np.interp(alts, zz, ln))
     vmr = np.array([np.interp(alts, zz, v) for v in vv])
     return dict(seg_off=seg_off, seg_layer=seg_layer, pt_off=pt_off, x=x_cm, nd=nd, vmr=vmr, alt=alts)
+
+
+def limb_los_3d(z, nd_levels, vmr_levels, z_tans, sza_tangent_deg, azimuth_deg, R=2575.0, n_sub=3):
+    """limb_los for a 3-D atmosphere: every LOS step (shell crossing) is its own "layer" -- its own row of the
+    coefficient tables -- because the state along the path depends on the local illumination, not on altitude alone.
+    Stands in for the absent sbm LineOfSight.calc_atm_intersections + calc_SZA_along_los
+    (spect_main_module.py:2746-2757 with use_tangent_sza = False): the solar zenith angle at path coordinate s (km
+    from the tangent point, positive towards the observer) of a ray whose tangent point sees the sun at
+    sza_tangent and whose direction makes the azimuth angle with the sun's horizontal direction there is
+
+        cos SZA(s) = (r_t cos SZA_t + s sin SZA_t cos az) / sqrt(r_t^2 + s^2),     r_t = R + z_tan.
+
+    Returns limb_los's dict with seg_layer = 0 .. n_seg-1 (one coefficient row per step) plus, per step,
+    `seg_alt_layer` (the altitude shell, i.e. the row of a per-altitude Jacobian) and `seg_mu` = cos SZA at the
+    middle of the step.  z_tans, azimuth_deg: one per ray; sza_tangent_deg: scalar or one per ray."""
+    L = limb_los(z, nd_levels, vmr_levels, z_tans, R=R, n_sub=n_sub)
+    z_tans = np.atleast_1d(np.asarray(z_tans, float))
+    az = np.deg2rad(np.broadcast_to(np.asarray(azimuth_deg, float), z_tans.shape))
+    szt = np.deg2rad(np.broadcast_to(np.asarray(sza_tangent_deg, float), z_tans.shape))
+    n_seg = len(L["seg_layer"])
+    mu = np.empty(n_seg)
+    for r in range(len(z_tans)):
+        rt = R + z_tans[r]
+        for sg in range(L["seg_off"][r], L["seg_off"][r + 1]):
+            a, b = L["pt_off"][sg], L["pt_off"][sg + 1]
+            s_mid = 0.5 * (L["x"][a] + L["x"][b - 1]) * 1e-5      # km; x is the path coordinate, 0 at the tangent point
+            mu[sg] = (rt * np.cos(szt[r]) + s_mid * np.sin(szt[r]) * np.cos(az[r])) / np.sqrt(rt * rt + s_mid * s_mid)
+    out = dict(L)
+    out["seg_alt_layer"] = L["seg_layer"].copy()
+    out["seg_layer"] = np.arange(n_seg, dtype=np.int32)
+    out["seg_mu"] = mu
+    return out

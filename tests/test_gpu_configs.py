@@ -354,3 +354,81 @@ if world > 1:
         assert np.allclose(r["hist"], whole["hist"], rtol=1e-8)
         assert np.allclose(r["x"], whole["x"], rtol=1e-8)
     assert two[0]["hist"] == two[1]["hist"] and two[0]["x"] == two[1]["x"]      # the ranks agree bit for bit
+
+
+def test_config3_3d_path_per_step_state(eng, oracle):
+    """configs[3] in its 3-D form (radtran_3Dvs2D_sza30-80_test.py:353-379, use_tangent_sza = False): a coefficient
+    row per LOS step with (P, T, T_vib) at the step's own local SZA, Jacobians per ALTITUDE layer.  (a) With a state
+    that does not depend on the SZA the 3-D path must reproduce the 1-D one -- radiances and both Jacobians; (b) with
+    it, the far and the near side of a ray differ and the coefficient rows of sampled steps match the oracle;
+    (c) the per-altitude temperature Jacobian against finite differences of the whole chain (the temperature of one
+    altitude layer changed in every step that crosses it)."""
+    import torch
+    import bench_configs as bc
+    from spectrobot_amd import synthetic as syn
+    n, nl = 20000, 30
+    grid, L, atm, e_lev = bc.ch4_case(n, n, nl, config_id=3, w0=2950.0)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)
+    vm = np.full(nl, 0.0148)
+    tz = np.array([atm["z"][2] + 7.0, atm["z"][9] + 3.0, atm["z"][17] + 11.0])
+    az = np.array([0.0, 60.0, 150.0])
+    L3 = syn.limb_los_3d(atm["z"], atm["nd"], [vm], tz, 65.0, az)
+    L1 = syn.limb_los(atm["z"], atm["nd"], [vm], tz)
+    assert np.array_equal(L3["seg_alt_layer"], L1["seg_layer"]) and np.array_equal(L3["seg_layer"], np.arange(len(L1["seg_layer"])))
+    # mu: the tangent point sees SZA_t, the two ends of a ray differ unless it runs across the sun's direction
+    s0, s1 = L3["seg_off"][0], L3["seg_off"][1]
+    assert abs(L3["seg_mu"][(s0 + s1) // 2] - np.cos(np.deg2rad(65.0))) < 0.08 and abs(L3["seg_mu"][s0] - L3["seg_mu"][s1 - 1]) > 0.1
+    W = bc.layer_vmr_weights(atm["z"], L1["alt"])
+    pg = np.zeros(nl, np.int32)
+    mk = lambda Lx: eng.LimbLOS(Lx["seg_off"], Lx["seg_layer"], Lx["pt_off"], Lx["x"], Lx["nd"], Lx["vmr"], col_scale=[syn.CH4_ISO_RATIO])
+    los3, los1 = mk(L3), mk(L1)
+    dT = 0.05
+
+    def coef3(a):
+        co = ls.abscoeff_layers(a["temps"], a["press"], tvib=a["tvib"])
+        ap = ls.abscoeff_layers(a["temps"] + dT, a["press"], tvib=a["tvib"])
+        am = ls.abscoeff_layers(a["temps"] - dT, a["press"], tvib=a["tvib"])
+        return co, ((ap[0] - am[0]) / (2 * dT), (ap[1] - am[1]) / (2 * dT))
+
+    def close(x, y, tol):
+        # relative to the largest entry of the ray's whole Jacobian: rows of level parameters whose weight at the
+        # ray's sample points is a rounding residue (1e-16 at a shell boundary) hold nothing but noise
+        sc = y.abs().reshape(y.shape[0], -1).amax(dim=1).clamp_min(1e-300).reshape((-1,) + (1,) * (y.dim() - 1))
+        return float(((x - y).abs() / sc).max()) < tol
+
+    # (a) SZA-independent state: 3-D == 1-D (the coefficient rows agree to an ulp or two, their differences in T
+    # carry that noise divided by dT)
+    a1 = bc.sza_atmosphere(atm, 60.0)
+    a3 = bc.step_atmosphere(atm, L3["seg_alt_layer"], np.full(len(L3["seg_mu"]), np.cos(np.deg2rad(60.0))))   # the same mu everywhere
+    co1, dco1 = coef3(a1)
+    co3, dco3 = coef3(a3)
+    r1, jt1, jv1 = eng.limb_rays_jacobians(co1, los1, dcoeffs=dco1, par_gas=pg, par_w=W)
+    r3, jt3, jv3 = eng.limb_rays_jacobians(co3, los3, dcoeffs=dco3, par_gas=pg, par_w=W, seg_jac_row=L3["seg_alt_layer"], n_jac_rows=nl)
+    assert tuple(jt3.shape) == (3, nl, n)
+    assert close(r3, r1, 1e-12) and close(jt3, jt1, 1e-11) and close(jv3, jv1, 1e-11)
+    # (b) the real 3-D state
+    a3 = bc.step_atmosphere(atm, L3["seg_alt_layer"], L3["seg_mu"])
+    co3, dco3 = coef3(a3)
+    sel = np.array([s0, s0 + 5, s1 - 1, L3["seg_off"][2] + 3])
+    abo, emo = oracle.abscoeff_layers(L, syn.CH4_MM, e_lev, a3["temps"][sel], a3["press"][sel], _q(a3["temps"][sel]),
+                                      a3["tvib"][:, sel], grid, mode=1, n_threads=4)
+    assert relerr(co3[0][sel].cpu().numpy(), abo) < 1e-10 and relerr(co3[1][sel].cpu().numpy(), emo) < 1e-10
+    assert L3["seg_alt_layer"][s0] == L3["seg_alt_layer"][s1 - 1] and relerr(co3[1][s0].cpu().numpy(), co3[1][s1 - 1].cpu().numpy()) > 1e-3
+    r3, jt3, jv3 = eng.limb_rays_jacobians(co3, los3, dcoeffs=dco3, par_gas=pg, par_w=W, seg_jac_row=L3["seg_alt_layer"], n_jac_rows=nl)
+    assert not close(r3, r1, 1e-4)
+    # (c) per-altitude temperature Jacobian vs finite differences through the coefficient op
+    for k in (4, 12, 22):
+        steps = np.nonzero(L3["seg_alt_layer"] == k)[0]
+        def run(sign):
+            a2, e2 = co3[0].clone(), co3[1].clone()
+            ak, ek = ls.abscoeff_layers(a3["temps"][steps] + sign * dT, a3["press"][steps], tvib=a3["tvib"][:, steps])
+            a2[steps], e2[steps] = ak, ek
+            return eng.limb_rays((a2, e2), los3)
+        fd = (run(+1) - run(-1)) / (2 * dT)
+        # (a deep layer of an opaque ray contributes e^-500 of the radiance: the difference quotient is exactly 0
+        # there, the analytic value 1e-224; both are "nothing" on the scale of the ray's radiance per kelvin)
+        sc = torch.maximum(fd.abs().amax(dim=1, keepdim=True), 1e-9 * r3.abs().amax(dim=1, keepdim=True))
+        err = float(((jt3[:, k] - fd).abs() / sc).max())
+        assert err < 1e-5, (k, err)
+        assert float(fd[2].abs().max()) > 0 or k < 17
+    assert float(jt3[2, :17].abs().max()) == 0.0
