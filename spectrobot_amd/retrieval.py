@@ -209,6 +209,95 @@ def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10,
     return chi, obs, sims, bayes_set
 
 
+def lut_coefficients(scene, temp_step=5.0, pres_step_log=1.0, refresh=False, **_unused):
+    """(abs, emi) of every gas at the scene's layer stack through look-up tables, the route of the reference's
+    `inversion(..., useLUTs=True)` (spect_main_module.py:2447-2467 -> check_and_build_allluts; per LOS step
+    LutSet.calculate, :997-1066): per gas and level the three G spectra on a rectangular (P, T) lattice that
+    covers the atmosphere (temp_step [K], pres_step_log [ln hPa]: the reference's LUTopt keys) -- one
+    sr_gcoeff_layers_dev call per level, the table stays in HBM -- then per layer the bilinear interpolation and the
+    population-weighted combine on the device (LutSet.combine_steps).  Tables are built once per scene."""
+    import torch
+    from . import spect_classes as spcl
+    press, temps = scene.press, scene.temps
+    Ps = np.exp(np.arange(np.floor(np.log(press.min())), np.log(press.max()) + pres_step_log, pres_step_log))
+    Ts = np.arange(temp_step * np.floor(temps.min() / temp_step) - temp_step, temps.max() + 2 * temp_step, temp_step)
+    PT = [[float(P), float(T)] for P in Ps for T in Ts]
+    out = []
+    for g in scene.gases:
+        ls = g.lineset
+        n_lev = ls.level_energies.size
+        if getattr(g, "luts", None) is None or refresh:
+            g.luts = []
+            for lev in range(max(n_lev, 1)):
+                lut = smm.LutSet(ls.mol, ls.iso, ls.mm, level=None, level_index=lev if n_lev else None)
+                lut._append(ls.gcoeff_layers([pt[1] for pt in PT], [pt[0] for pt in PT], level=lev if n_lev else 0), PT)
+                g.luts.append(lut)
+        q = np.atleast_1d(spcl.CalcPartitionSum(ls.mol, ls.iso, temps))
+        ab = torch.zeros((len(temps), ls.n_grid), dtype=torch.float64, device="cuda")
+        em = torch.zeros_like(ab)
+        for lev, lut in enumerate(g.luts):
+            if n_lev:
+                tv = temps if g.tvib is None else np.asarray(g.tvib)[lev]
+                pops = np.exp(-spcl.c2 * ls.level_energies[lev] / tv) / q           # smm:2073
+            else:
+                pops = 1.0 / q                                                       # smm:2054
+            lut.combine_steps(press, temps, pops, ab, em)
+        out.append((ab, em))
+    return out
+
+
+def inversion(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10, lambda_LM=0.1, L1_reg=False, useLUTs=True,
+              LUTopt=None, debugfile=None, fov_closed_form=True):
+    """The reference's first retrieval driver, spect_main_module.inversion (:2422-2595; radtran_test_CO.py:189 calls
+    it with useLUTs=True): pixel by pixel the three lines of sight of the FOV (low / centre / up), radiances and
+    derivatives of every parameter involved, hires_to_lowres, FOV_integr_1D, then chi square over all pixels with
+    n_tot parameters (:2562 -- the fast loop uses the parameters in use), the same stopping rule and
+    inversion_algebra.  Coefficients through look-up tables (useLUTs, lut_coefficients) or directly.  Like the
+    reference it returns None: the result is the state of bayes_set (.history, .stop are added)."""
+    LUTopt = dict(LUTopt or {})
+    for name in bayes_set.sets.keys():                                                    # :2445-2446
+        scene.gas(name).add_clim(bayes_set.sets[name].profile())
+    coeffs = lut_coefficients(scene, **LUTopt) if useLUTs else scene.coefficients()
+    obs = [pix.observation for pix in pixels]
+    masks = None if all(pix.mask is None for pix in pixels) else [pix.mask for pix in pixels]
+    noise = [pix.noise for pix in pixels]
+    bayes_set.history, bayes_set.stop = [], 'max_it'
+    sims = [None] * len(pixels)
+    chi_old = None
+    for num_it in range(max_it):
+        for num, pix in enumerate(pixels):                                                 # :2487
+            los, alt = scene.los(pix.los_alts())                                           # low_LOS, LOS, up_LOS
+            par_gas, par_w = scene.profile_weights(bayes_set, alt)
+            rad, jac = engine.limb_rays_jacobian(coeffs, los, par_gas, par_w)
+            low = engine.hires_to_lowres(rad, scene.grid, scene.bands_nm, scene.widths_nm, out_units=scene.out_units)
+            dlow = engine.hires_to_lowres(jac.reshape(3 * len(par_gas), -1), scene.grid, scene.bands_nm, scene.widths_nm,
+                                          out_units=scene.out_units).reshape(3, len(par_gas), -1)
+            three = [Spectrum(low[q], scene.bands_nm) for q in range(3)]
+            sims[num] = smm.FOV_integr_1D(three, pix.pixel_rot, closed_form=fov_closed_form) if pix.fov_half > 0 else three[1]
+            for p, par in enumerate(bayes_set.params()):
+                if par.not_involved:                                                        # :2507-2509: zero derivative
+                    par.store_deriv(Spectrum(np.zeros_like(low[0]), scene.bands_nm), num=num)
+                    continue
+                d3 = [Spectrum(dlow[q, p], scene.bands_nm) for q in range(3)]
+                par.store_deriv(smm.FOV_integr_1D(d3, pix.pixel_rot, closed_form=fov_closed_form) if pix.fov_half > 0 else d3[1],
+                                num=num)
+                par.set_used()
+        chi = smm.chicalc(obs, sims, noise, masks, bayes_set.n_tot)                        # :2562
+        bayes_set.history.append(chi)
+        why = smm.retrieval_converged(chi, chi_old, chi_threshold)                        # :2564-2570
+        if why:
+            bayes_set.stop = why
+            return None
+        chi_old = chi
+        smm.inversion_algebra(obs, sims, noise, bayes_set, lambda_LM=lambda_LM, L1_reg=L1_reg, masks=masks)   # :2573
+        if debugfile is not None:
+            import pickle
+            pickle.dump([num_it, [o.spectrum for o in obs], [s_.spectrum for s_ in sims], bayes_set.values()], debugfile)
+        for name in bayes_set.sets.keys():                                                # :2581-2582
+            scene.gas(name).add_clim(bayes_set.sets[name].profile())
+    return None
+
+
 def radtrans(scene, pixels, fov_closed_form=True, shard=None):
     """Simulation only (spect_main_module.radtrans, :2990-3287): the FOV-integrated low-resolution spectra."""
     return simulate(scene, pixels, None, fov_closed_form=fov_closed_form, shard=shard)[0]

@@ -188,3 +188,40 @@ def limb_los_3d(z, nd_levels, vmr_levels, z_tans, sza_tangent_deg, azimuth_deg, 
     out["seg_layer"] = np.arange(n_seg, dtype=np.int32)
     out["seg_mu"] = mu
     return out
+
+
+def slant_los(z, nd_levels, vmr_levels, zenith_deg, R=2575.0, n_sub=3):
+    """Upward-looking-from-below / nadir-viewing paths: rays that leave the lowest level z[0] at the given zenith
+    angles (0 = nadir view / vertical path) and cross every shell once, in photon order (bottom -> top, the observer
+    is above the atmosphere).  The geometry of the reference's planetary (non-limb) cases -- BASELINE configs[0]
+    quotes a "40-layer 1D nadir" CO case -- whose LineOfSight code is in the absent spect_base_module: a ray of
+    impact parameter b = (R + z[0]) sin(zenith) has the path length sqrt(r_hi^2 - b^2) - sqrt(r_lo^2 - b^2) in the
+    shell [r_lo, r_hi].  Same dict as limb_los (LimbLOS arguments + `alt`); combine with
+    LimbLOS(initial_temperature=T_surface) for the surface emission behind the path."""
+    z = np.asarray(z, float)
+    nd_levels = np.asarray(nd_levels, float)
+    vmr_levels = np.atleast_2d(np.asarray(vmr_levels, float))
+    dz = np.diff(z)
+    top = z[-1] + (dz[-1] if len(dz) else 10.0)
+    zz = np.concatenate([z, [top]])
+    lognd = np.log(nd_levels)
+    ln = np.concatenate([lognd, [lognd[-1] + (lognd[-1] - lognd[-2]) / dz[-1] * (top - z[-1]) if len(dz) else lognd[-1]]])
+    vv = np.concatenate([vmr_levels, vmr_levels[:, -1:]], axis=1)
+    seg_off, seg_layer, pt_off, xs, alts = [0], [], [0], [], []
+    for zen in np.atleast_1d(np.asarray(zenith_deg, float)):
+        if not 0.0 <= zen < 90.0:
+            raise ValueError("zenith angle must be in [0, 90)")
+        b = (R + z[0]) * np.sin(np.deg2rad(zen))
+        for k in range(len(z)):
+            lo, hi = R + zz[k], R + zz[k + 1]
+            s = np.linspace(np.sqrt(lo * lo - b * b), np.sqrt(hi * hi - b * b), n_sub + 1)   # path coordinate from the closest approach
+            seg_layer.append(k)
+            xs += list(s)
+            alts += list(np.sqrt(s * s + b * b) - R)
+            pt_off.append(len(xs))
+        seg_off.append(len(seg_layer))
+    alts = np.clip(np.array(alts), z[0], top)
+    nd = np.exp(np.interp(alts, zz, ln))
+    vmr = np.array([np.interp(alts, zz, v) for v in vv])
+    return dict(seg_off=np.array(seg_off, np.int32), seg_layer=np.array(seg_layer, np.int32), pt_off=np.array(pt_off, np.int32),
+                x=np.array(xs) * 1e5, nd=nd, vmr=vmr, alt=alts)
