@@ -77,7 +77,19 @@ struct Stager {
   DevBuf d;
   hipEvent_t done = nullptr;
   bool pending = false;
+  int dev = -1; // device the mirror, the event and the pinned buffer belong to
   int prepare(size_t bytes) {
+    // the thread-local rings outlive a hipSetDevice(): a slot made on another device is rebuilt on this one
+    int cur = 0;
+    HIPCHK(hipGetDevice(&cur));
+    if (dev != cur) {
+      if (dev >= 0) {
+        HIPCHK(hipSetDevice(dev));
+        release();
+        HIPCHK(hipSetDevice(cur));
+      }
+      dev = cur;
+    }
     if (pending) {
       HIPCHK(hipEventSynchronize(done));
       pending = false;
@@ -105,7 +117,8 @@ struct Stager {
   // preparation of the next call's tables (+0.9 ms per step).  prepare() has already waited for the
   // slot's last consumers, so the copy may run at once.
   int push_early(size_t bytes, hipStream_t st) {
-    static thread_local hipStream_t copy_st = nullptr;
+    static thread_local std::map<int, hipStream_t> copy_streams; // one per device this thread has used
+    hipStream_t &copy_st = copy_streams[dev];
     if (!copy_st) HIPCHK(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking));
     if (bytes) HIPCHK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, copy_st));
     HIPCHK(hipEventRecord(done, copy_st));
@@ -195,31 +208,14 @@ std::atomic<size_t> g_table_budget{(size_t)48 << 30}; // bytes of FastRec + Cold
 
 } // namespace
 
-struct sr_lineset {
-  int64_t n_lines = 0; // main lines (centre inside its own window)
-  HostLines host, host_outer; // host copies: per-level subsets are cut from them (level_set)
-  int n_outer = 0;            // lines whose centre lies outside their window (outer branches)
-  DevBuf d_lines_outer, d_outer_recs;
-  LinesDev Lo{};
-  // per-level sub-linesets (lines whose upper or lower level is L), built on first use by the
-  // G-coefficient / tracked-level entry points; nullptr until then
-  std::vector<sr_lineset *> level_sets;
-  DevBuf d_gscratch;          // second output channel of the ind_emission pass
-  GridParams gp{};
-  int mol = 0, iso = 0, n_levels = 0;
-  double mm = 0.0;
-  std::vector<double> e_lev;
-  std::vector<int> ic; // host copy, sorted
-  double freq_max = 0.0;
-  double gamma_max = 0.0, ndep_min = 0.0, ndep_max = 0.0; // air broadening / its temperature exponent over the lines
-  int64_t n_disp_lo = 0, n_disp_hi = 0; // leading / trailing lines centred beyond the grid ends (window clamped to the end point)
-  DevBuf d_lines;      // one allocation, carved below
-  LinesDev L{};
+// Per-call scratch and stream / event state of the coefficient op.  A lineset owns one; the per-level sub-linesets
+// (level_set) SHARE their parent's -- calls on a handle and its children are serialised through ev_last_done anyway,
+// and twelve levels with their own record tables, far-field scratch, streams and events held twelve times the memory.
+struct CoefWork {
   // [2]: with sr_set_overlap(1) the tables of call c+1 are prepared (on prep_st) while the kernels
   // of call c still read theirs
   Stager s_layers[2];
-  DevBuf d_fast[2], d_cold[2], d_coef, d_first, d_zone, d_mom;
-  int first_x0 = 0, first_n = 0; // IcIndex table domain
+  DevBuf d_fast[2], d_cold[2], d_coef, d_zone, d_mom, d_outer_recs;
   hipStream_t aux = nullptr;     // second stream: zones kernel beside the far-field kernel
   hipStream_t prep_st = nullptr; // third stream: staging copy + sr_prep_kernel of the NEXT call
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_tables_free[2] = {nullptr, nullptr}, ev_op0 = nullptr;
@@ -242,6 +238,60 @@ struct sr_lineset {
   bool last_done_recorded = false;
   DevBuf d_counts; // kCntN executed-work counters of the last counting call
   bool counted = false;
+  int init() {
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventCreateWithFlags(&ev_last_done, hipEventDisableTiming));
+    return SR_OK;
+  }
+  void release() {
+    for (int b = 0; b < 2; ++b) {
+      s_layers[b].release();
+      d_fast[b].release();
+      d_cold[b].release();
+      if (ev_prep_done[b]) (void)hipEventDestroy(ev_prep_done[b]);
+      if (ev_tables_free[b]) (void)hipEventDestroy(ev_tables_free[b]);
+    }
+    if (ev_op0) (void)hipEventDestroy(ev_op0);
+    if (ev_last_done) (void)hipEventDestroy(ev_last_done);
+    d_counts.release();
+    d_outer_recs.release();
+    if (prep_st) (void)hipStreamDestroy(prep_st);
+    d_coef.release();
+    d_mom.release();
+    d_zone.release();
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_tail) (void)hipEventDestroy(ev_tail);
+    if (aux) (void)hipStreamDestroy(aux);
+    for (auto &e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+};
+
+struct sr_lineset {
+  int64_t n_lines = 0; // main lines (centre inside its own window)
+  HostLines host, host_outer; // host copies: per-level subsets are cut from them (level_set)
+  int n_outer = 0;            // lines whose centre lies outside their window (outer branches)
+  DevBuf d_lines_outer;
+  LinesDev Lo{};
+  // per-level sub-linesets (lines whose upper or lower level is L), built on first use by the
+  // G-coefficient / tracked-level entry points; nullptr until then
+  std::vector<sr_lineset *> level_sets;
+  DevBuf d_gscratch;          // second output channel of the ind_emission pass
+  GridParams gp{};
+  int mol = 0, iso = 0, n_levels = 0;
+  double mm = 0.0;
+  std::vector<double> e_lev;
+  std::vector<int> ic; // host copy, sorted
+  double freq_max = 0.0;
+  double gamma_max = 0.0, ndep_min = 0.0, ndep_max = 0.0; // air broadening / its temperature exponent over the lines
+  int64_t n_disp_lo = 0, n_disp_hi = 0; // leading / trailing lines centred beyond the grid ends (window clamped to the end point)
+  DevBuf d_lines;      // one allocation, carved below
+  LinesDev L{};
+  DevBuf d_first;
+  int first_x0 = 0, first_n = 0; // IcIndex table domain
+  CoefWork own_work;
+  CoefWork *work = nullptr;      // &own_work, or the parent's for a per-level sub-lineset
 };
 
 extern "C" {
@@ -419,8 +469,10 @@ static int lineset_upload(sr_lineset *ls) {
     ls->first_x0 = x0;
     ls->first_n = n_tab;
   }
-  for (auto &ev : ls->ev) HIPCHK(hipEventCreate(&ev));
-  HIPCHK(hipEventCreateWithFlags(&ls->ev_last_done, hipEventDisableTiming));
+  if (!ls->work) { // a lineset of its own (level_set points its children at the parent's before the upload)
+    ls->work = &ls->own_work;
+    return ls->own_work.init();
+  }
   return SR_OK;
 }
 
@@ -555,30 +607,10 @@ int sr_lineset_destroy(sr_lineset *ls) {
   for (sr_lineset *child : ls->level_sets) sr_lineset_destroy(child);
   ls->level_sets.clear();
   ls->d_lines_outer.release();
-  ls->d_outer_recs.release();
   ls->d_gscratch.release();
   ls->d_lines.release();
-  for (int b = 0; b < 2; ++b) {
-    ls->s_layers[b].release();
-    ls->d_fast[b].release();
-    ls->d_cold[b].release();
-    if (ls->ev_prep_done[b]) (void)hipEventDestroy(ls->ev_prep_done[b]);
-    if (ls->ev_tables_free[b]) (void)hipEventDestroy(ls->ev_tables_free[b]);
-  }
-  if (ls->ev_op0) (void)hipEventDestroy(ls->ev_op0);
-  if (ls->ev_last_done) (void)hipEventDestroy(ls->ev_last_done);
-  ls->d_counts.release();
-  if (ls->prep_st) (void)hipStreamDestroy(ls->prep_st);
-  ls->d_coef.release();
-  ls->d_mom.release();
   ls->d_first.release();
-  ls->d_zone.release();
-  if (ls->ev_fork) (void)hipEventDestroy(ls->ev_fork);
-  if (ls->ev_join) (void)hipEventDestroy(ls->ev_join);
-  if (ls->ev_tail) (void)hipEventDestroy(ls->ev_tail);
-  if (ls->aux) (void)hipStreamDestroy(ls->aux);
-  for (auto &ev : ls->ev)
-    if (ev) (void)hipEventDestroy(ev);
+  if (ls->work == &ls->own_work) ls->own_work.release();
   delete ls;
   return SR_OK;
 }
@@ -614,6 +646,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   if (atm->n_layers <= 0 || !atm->temps || !atm->press) return SR_ERR_ARG;
   if (g_lo < 0 || g_hi > ls->gp.n_grid || g_lo >= g_hi) return SR_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  CoefWork &w = *ls->work;
   const int nl = atm->n_layers, nlev = ls->n_levels, npop = nlev > 0 ? nlev : 1;
   for (int k = 0; k < nl; ++k)
     if (!(atm->temps[k] > 0.0) || !(atm->press[k] >= 0.0)) return SR_ERR_ARG;
@@ -632,7 +665,9 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         : (2 * (n_pts_b / 64 + 2)) * (size_t)(2 * kFC) * sizeof(double) +
           (far_field == 2 ? (2 * ((n_pts_b + 64 * kSrcPad + kHalf) / 64 + 16)) * (size_t)kMomPerBox * sizeof(double) : 0);
     const size_t per_layer = (size_t)std::max<int64_t>(ls->n_lines, 1) * (sizeof(FastRec) + sizeof(ColdRec)) *
-                                 (overlap ? 2 : 1) + far_per_layer; // two table sets with overlap
+                                 (overlap ? 2 : 1) + far_per_layer // two table sets with overlap
+                             + (overlap ? 2 * sizeof(double) * n_pts_b : 0)          // the zones kernel's private sums (small shards)
+                             + sizeof(OuterRec) * (size_t)std::max(ls->n_outer, 0);  // records of the outer lines
     const int nl_max = (int)std::max<size_t>(1, table_budget / per_layer);
     if (nl > nl_max) {
       const size_t n_pts_all = (size_t)(g_hi - g_lo);
@@ -664,24 +699,24 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   // Table set of this call and the stream its preparation runs on.  With overlap, call c + 1
   // prepares set (c + 1) % 2 on prep_st while the kernels of call c (which the caller's stream is
   // still running) read set c % 2: the HBM-write-bound prep kernel hides behind the VALU-bound ones.
-  const int b = overlap ? (ls->parity ^= 1) : 0;
+  const int b = overlap ? (w.parity ^= 1) : 0;
   hipStream_t pst = st;
   // Order this call after the previous one on this handle (see ev_last_done): a no-op when both use
   // the same stream.  The next call's table preparation (pst) needs only its own table set to be free.
-  if (ls->last_done_recorded) HIPCHK(hipStreamWaitEvent(st, ls->ev_last_done, 0));
+  if (w.last_done_recorded) HIPCHK(hipStreamWaitEvent(st, w.ev_last_done, 0));
   if (overlap) {
-    if (!ls->prep_st) {
-      HIPCHK(hipStreamCreateWithFlags(&ls->prep_st, hipStreamNonBlocking));
-      HIPCHK(hipEventCreateWithFlags(&ls->ev_op0, hipEventDefault));
+    if (!w.prep_st) {
+      HIPCHK(hipStreamCreateWithFlags(&w.prep_st, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&w.ev_op0, hipEventDefault));
       for (int i = 0; i < 2; ++i) {
-        HIPCHK(hipEventCreateWithFlags(&ls->ev_prep_done[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ls->ev_tables_free[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&w.ev_prep_done[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&w.ev_tables_free[i], hipEventDisableTiming));
       }
     }
-    pst = ls->prep_st;
+    pst = w.prep_st;
   }
-  Stager &SL = ls->s_layers[b];
-  DevBuf &d_fast = ls->d_fast[b], &d_cold = ls->d_cold[b];
+  Stager &SL = w.s_layers[b];
+  DevBuf &d_fast = w.d_fast[b], &d_cold = w.d_cold[b];
   int rc = SL.prepare(hl_bytes);
   if (rc) return rc;
   double *T = SL.host<double>(), *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *ltr = sq + nl, *pop = ltr + nl;
@@ -725,8 +760,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     }
   }
   // set b was last read by the kernels of the call before the previous one
-  if (overlap && ls->free_recorded[b]) HIPCHK(hipStreamWaitEvent(pst, ls->ev_tables_free[b], 0));
-  if (overlap == 2 && ls->tail_recorded) HIPCHK(hipStreamWaitEvent(pst, ls->ev_tail, 0));
+  if (overlap && w.free_recorded[b]) HIPCHK(hipStreamWaitEvent(pst, w.ev_tables_free[b], 0));
+  if (overlap == 2 && w.tail_recorded) HIPCHK(hipStreamWaitEvent(pst, w.ev_tail, 0));
   rc = SL.push(hl_bytes, pst);
   if (rc) return rc;
   LayersDev A;
@@ -747,22 +782,22 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
 
   const IcIndex ix{ls->d_first.as<int>(), ls->first_x0, ls->first_n, line_lo, n_sub};
 
-  ls->timed = false;
-  ls->overlapped = false;
-  ls->counted = false;
+  w.timed = false;
+  w.overlapped = false;
+  w.counted = false;
   unsigned long long *d_cnt = nullptr;
   if (counting) {
-    rc = ls->d_counts.ensure(sizeof(unsigned long long) * kCntN);
+    rc = w.d_counts.ensure(sizeof(unsigned long long) * kCntN);
     if (rc) return rc;
-    d_cnt = ls->d_counts.as<unsigned long long>();
+    d_cnt = w.d_counts.as<unsigned long long>();
     HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * kCntN, st));
   }
   // lines with their centre outside their own window: added after the main kernels (launch_outer)
   auto add_outer = [&]() -> int {
     if (ls->n_outer <= 0) return SR_OK;
-    int rc2 = ls->d_outer_recs.ensure(sizeof(OuterRec) * (size_t)ls->n_outer * nl);
+    int rc2 = w.d_outer_recs.ensure(sizeof(OuterRec) * (size_t)ls->n_outer * nl);
     if (rc2) return rc2;
-    LAUNCHCHK(launch_outer(ls->Lo, ls->n_outer, A, ls->gp, W, ls->d_outer_recs.as<OuterRec>(), (int)g_lo, (int)g_hi,
+    LAUNCHCHK(launch_outer(ls->Lo, ls->n_outer, A, ls->gp, W, w.d_outer_recs.as<OuterRec>(), (int)g_lo, (int)g_hi,
                            abs_out, emi_out, st));
     return SR_OK;
   };
@@ -772,17 +807,17 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     if (ls->n_outer > 0) {
       // the layer scalars were pushed on pst: the caller's stream must see them
       if (overlap) {
-        HIPCHK(hipEventRecord(ls->ev_prep_done[b], pst));
-        HIPCHK(hipStreamWaitEvent(st, ls->ev_prep_done[b], 0));
+        HIPCHK(hipEventRecord(w.ev_prep_done[b], pst));
+        HIPCHK(hipStreamWaitEvent(st, w.ev_prep_done[b], 0));
       }
       rc = add_outer();
       if (rc) return rc;
       if (overlap) {
-        HIPCHK(hipEventRecord(ls->ev_tables_free[b], st));
-        ls->free_recorded[b] = true;
+        HIPCHK(hipEventRecord(w.ev_tables_free[b], st));
+        w.free_recorded[b] = true;
       }
-      HIPCHK(hipEventRecord(ls->ev_last_done, st));
-      ls->last_done_recorded = true;
+      HIPCHK(hipEventRecord(w.ev_last_done, st));
+      w.last_done_recorded = true;
     }
     return SR_OK;
   }
@@ -792,15 +827,15 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   if (rc) return rc;
 
 
-  HIPCHK(hipEventRecord(ls->ev[0], pst));
+  HIPCHK(hipEventRecord(w.ev[0], pst));
   // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
   LAUNCHCHK(launch_prep(ls->L, A, ls->gp, W, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
                         far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), pst));
-  HIPCHK(hipEventRecord(ls->ev[1], pst));
+  HIPCHK(hipEventRecord(w.ev[1], pst));
   if (overlap) { // the caller's stream takes over once the tables are ready
-    HIPCHK(hipEventRecord(ls->ev_prep_done[b], pst));
-    HIPCHK(hipStreamWaitEvent(st, ls->ev_prep_done[b], 0));
-    HIPCHK(hipEventRecord(ls->ev_op0, st));
+    HIPCHK(hipEventRecord(w.ev_prep_done[b], pst));
+    HIPCHK(hipStreamWaitEvent(st, w.ev_prep_done[b], 0));
+    HIPCHK(hipEventRecord(w.ev_op0, st));
   }
   if (far_field) {
     FarParams fp;
@@ -814,10 +849,10 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       fp.box_off[lv] = fp.n_boxes_total;
       fp.n_boxes_total += fp.box_count[lv];
     }
-    rc = ls->d_coef.ensure(sizeof(double) * (size_t)nl * fp.n_boxes_total * 2 * kFC);
+    rc = w.d_coef.ensure(sizeof(double) * (size_t)nl * fp.n_boxes_total * 2 * kFC);
     if (rc) return rc;
     fp.pm = d_pm;
-    fp.coef = ls->d_coef.as<double>();
+    fp.coef = w.d_coef.as<double>();
     fp.m2l = far_field == 2 ? 1 : 0;
     fp.pm_src = d_pm + nl;
     fp.disp_lo_end = (int)std::min<int64_t>(std::max<int64_t>(ls->n_disp_lo - line_lo, 0), n_sub);
@@ -835,9 +870,9 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         fp.src_off[lv] = total;
         total += fp.n_src[lv];
       }
-      rc = ls->d_mom.ensure(sizeof(double) * (size_t)total * nl * kMomPerBox);
+      rc = w.d_mom.ensure(sizeof(double) * (size_t)total * nl * kMomPerBox);
       if (rc) return rc;
-      fp.mom = ls->d_mom.as<double>();
+      fp.mom = w.d_mom.as<double>();
       rc = m2l_table_dev(&fp.tab);
       if (rc) return rc;
     }
@@ -854,76 +889,76 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       // coefficients: zones runs on a second stream beside the far-field kernel and STORES its sums,
       // the wings kernel waits for both and adds (9.9 -> 9.2 ms on config 2: the two VALU-bound
       // kernels fill each other's idle issue slots and tails).
-      if (!ls->aux) {
-        HIPCHK(hipStreamCreateWithFlags(&ls->aux, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&ls->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ls->ev_join, hipEventDisableTiming));
+      if (!w.aux) {
+        HIPCHK(hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
       }
-      HIPCHK(hipEventRecord(ls->ev_fork, st));
-      HIPCHK(hipStreamWaitEvent(ls->aux, ls->ev_fork, 0));
+      HIPCHK(hipEventRecord(w.ev_fork, st));
+      HIPCHK(hipStreamWaitEvent(w.aux, w.ev_fork, 0));
       // Small shards do not fill the chip: there the wings kernel need not wait for the zones kernel
       // either -- zones writes a private buffer, one pass adds it at the end (on the full grid the
       // VALU is saturated and this variant measured slower: 9.26 vs 9.06 ms).
       const bool small = n_pts * (size_t)nl <= (size_t)3000000;
       double *z_abs = abs_out, *z_emi = emi_out;
       if (small) {
-        rc = ls->d_zone.ensure(sizeof(double) * 2 * n_pts * nl);
+        rc = w.d_zone.ensure(sizeof(double) * 2 * n_pts * nl);
         if (rc) return rc;
-        z_abs = ls->d_zone.as<double>();
+        z_abs = w.d_zone.as<double>();
         z_emi = z_abs + n_pts * nl;
       }
       LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub,
-                            nl, (int)g_lo, (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, ls->aux));
-      HIPCHK(hipEventRecord(ls->ev_join, ls->aux));
+                            nl, (int)g_lo, (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, w.aux));
+      HIPCHK(hipEventRecord(w.ev_join, w.aux));
       rc = far_pass();
       if (rc) return rc;
-      HIPCHK(hipEventRecord(ls->ev[2], st));
-      if (!small) HIPCHK(hipStreamWaitEvent(st, ls->ev_join, 0));
-      if (!ls->ev_tail) HIPCHK(hipEventCreateWithFlags(&ls->ev_tail, hipEventDisableTiming));
-      HIPCHK(hipEventRecord(ls->ev_tail, st));
-      ls->tail_recorded = true;
+      HIPCHK(hipEventRecord(w.ev[2], st));
+      if (!small) HIPCHK(hipStreamWaitEvent(st, w.ev_join, 0));
+      if (!w.ev_tail) HIPCHK(hipEventCreateWithFlags(&w.ev_tail, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(w.ev_tail, st));
+      w.tail_recorded = true;
       LAUNCHCHK(launch_near(1, small ? 0 : 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st));
-      HIPCHK(hipEventRecord(ls->ev[3], st));
+      HIPCHK(hipEventRecord(w.ev[3], st));
       if (small) {
-        HIPCHK(hipStreamWaitEvent(st, ls->ev_join, 0));
+        HIPCHK(hipStreamWaitEvent(st, w.ev_join, 0));
         LAUNCHCHK(launch_add2(abs_out, z_abs, emi_out, z_emi, n_pts * nl, st));
       }
-      HIPCHK(hipEventRecord(ls->ev[4], st));
-      ls->overlapped = true;
+      HIPCHK(hipEventRecord(w.ev[4], st));
+      w.overlapped = true;
     } else {
-      ls->overlapped = false;
+      w.overlapped = false;
       rc = far_pass();
       if (rc) return rc;
-      HIPCHK(hipEventRecord(ls->ev[2], st));
+      HIPCHK(hipEventRecord(w.ev[2], st));
       for (int part = 1; part <= 2; ++part) {
         LAUNCHCHK(launch_near(part, part == 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix,
                               zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out,
                               d_cnt, st));
-        HIPCHK(hipEventRecord(ls->ev[2 + part], st));
+        HIPCHK(hipEventRecord(w.ev[2 + part], st));
       }
     }
-    ls->n_timed = 4;
+    w.n_timed = 4;
   } else {
-    ls->n_timed = 3;
+    w.n_timed = 3;
     for (int which = 0; which < 2; ++which) {
       LAUNCHCHK(launch_abscoeff(variant, which, d_fast.as<FastRec>(), d_cold.as<ColdRec>(),
                                 ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
                                 abs_out, emi_out, st));
-      HIPCHK(hipEventRecord(ls->ev[2 + which], st));
+      HIPCHK(hipEventRecord(w.ev[2 + which], st));
     }
   }
   rc = add_outer(); // after the timing events: not part of the per-kernel times
   if (rc) return rc;
   if (overlap) {
-    HIPCHK(hipEventRecord(ls->ev_tables_free[b], st));
-    ls->free_recorded[b] = true;
+    HIPCHK(hipEventRecord(w.ev_tables_free[b], st));
+    w.free_recorded[b] = true;
   }
-  HIPCHK(hipEventRecord(ls->ev_last_done, st));
-  ls->last_done_recorded = true;
-  ls->pipelined = overlap != 0;
-  ls->timed = true;
-  ls->counted = counting;
+  HIPCHK(hipEventRecord(w.ev_last_done, st));
+  w.last_done_recorded = true;
+  w.pipelined = overlap != 0;
+  w.timed = true;
+  w.counted = counting;
   return SR_OK;
 }
 
@@ -949,6 +984,7 @@ static int level_set(sr_lineset *ls, int level, sr_lineset **out) {
     c->mm = ls->mm;
     c->n_levels = ls->n_levels;
     c->e_lev = ls->e_lev;
+    c->work = ls->work; // scratch, streams and events of the parent
     for (int which = 0; which < 2; ++which) {
       const HostLines &H = which ? ls->host_outer : ls->host;
       std::vector<int64_t> sel;
@@ -978,14 +1014,14 @@ int sr_gcoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, i
   int rc = level_set(ls, level, &c);
   if (rc) return rc;
   const size_t plane = (size_t)atm->n_layers * (size_t)(g_hi - g_lo);
-  rc = c->d_gscratch.ensure(sizeof(double) * plane);
+  rc = ls->d_gscratch.ensure(sizeof(double) * plane); // the parent's: one for all levels
   if (rc) return rc;
   // pass 1: abs channel = absorption (lines whose LOWER level is `level`), emi channel = sp_emission
   // (UPPER level); pass 2: abs channel = ind_emission (UPPER level), emi channel unused
   const int wl = ls->n_levels == 0 ? -1 : level; // no level table: lev_up = lev_lo = 0 for every line anyway
   rc = coef_op(c, atm, g_lo, g_hi, g_out + 2 * plane, g_out + 0 * plane, stream, WeightMode{kWeightGabsGsp, wl});
   if (rc) return rc;
-  return coef_op(c, atm, g_lo, g_hi, g_out + 1 * plane, c->d_gscratch.as<double>(), stream,
+  return coef_op(c, atm, g_lo, g_hi, g_out + 1 * plane, ls->d_gscratch.as<double>(), stream,
                  WeightMode{kWeightGind, wl});
 }
 
@@ -1019,27 +1055,27 @@ int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, 
 int sr_last_eval_counts(sr_lineset *ls, uint64_t *counts10) {
   uint64_t *counts8 = counts10;
   static_assert(kCntN == 10, "sr_last_eval_counts: the header documents ten counters");
-  if (!ls || !counts8 || !ls->counted) return SR_ERR_ARG;
-  HIPCHK(hipEventSynchronize(ls->ev_last_done));
+  if (!ls || !counts8 || !ls->work->counted) return SR_ERR_ARG;
+  HIPCHK(hipEventSynchronize(ls->work->ev_last_done));
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
-  HIPCHK(hipMemcpy(counts8, ls->d_counts.p, sizeof(uint64_t) * kCntN, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(counts8, ls->work->d_counts.p, sizeof(uint64_t) * kCntN, hipMemcpyDeviceToHost));
   return SR_OK;
 }
 
 int sr_last_kernel_ms(sr_lineset *ls, float *ms5) {
-  if (!ls || !ls->timed || !ms5) return SR_ERR_ARG;
-  HIPCHK(hipEventSynchronize(ls->ev[ls->n_timed]));
+  if (!ls || !ls->work->timed || !ms5) return SR_ERR_ARG;
+  HIPCHK(hipEventSynchronize(ls->work->ev[ls->work->n_timed]));
   for (int i = 0; i < 5; ++i) ms5[i] = 0.f;
   // ev[1] (end of prep) is on the prep stream when the call was pipelined: the kernels that follow
   // are measured from ev_op0, recorded on the caller's stream once it has the tables
-  hipEvent_t first = ls->pipelined ? ls->ev_op0 : ls->ev[1];
-  HIPCHK(hipEventElapsedTime(&ms5[0], ls->ev[0], ls->ev[1]));
-  if (ls->overlapped) { // kernels run side by side: only the whole coefficient op has a duration
-    HIPCHK(hipEventElapsedTime(&ms5[1], first, ls->ev[4]));
+  hipEvent_t first = ls->work->pipelined ? ls->work->ev_op0 : ls->work->ev[1];
+  HIPCHK(hipEventElapsedTime(&ms5[0], ls->work->ev[0], ls->work->ev[1]));
+  if (ls->work->overlapped) { // kernels run side by side: only the whole coefficient op has a duration
+    HIPCHK(hipEventElapsedTime(&ms5[1], first, ls->work->ev[4]));
     return SR_OK;
   }
-  for (int i = 1; i < ls->n_timed; ++i)
-    HIPCHK(hipEventElapsedTime(&ms5[i], i == 1 ? first : ls->ev[i], ls->ev[i + 1]));
+  for (int i = 1; i < ls->work->n_timed; ++i)
+    HIPCHK(hipEventElapsedTime(&ms5[i], i == 1 ? first : ls->work->ev[i], ls->work->ev[i + 1]));
   return SR_OK;
 }
 

@@ -91,6 +91,20 @@ class AbsSetLOS(object):
         return set_
 
 
+def find_free_name(filename, maxnum=1000, split_at='.'):
+    """First of filename, name_001.ext, name_002.ext, ... that does not exist yet (spect_main_module.py:34-51): a
+    second table built on the same day must not overwrite the first."""
+    form = '_{:02d}' if maxnum <= 100 else ('_{:03d}' if maxnum <= 1000 else '_{:05d}')
+    num, fileorig = 1, filename
+    ind = fileorig.index(split_at)
+    while os.path.isfile(filename):
+        filename = fileorig[:ind] + form.format(num) + fileorig[ind:]
+        num += 1
+        if num > maxnum:
+            raise ValueError('Check filenames! More than {} with the same name'.format(maxnum))
+    return filename
+
+
 def date_stamp():
     t = time.ctime().split()
     return '_' + t[2] + '-' + t[1] + '-' + t[4]          # spect_main_module.py:30-32
@@ -285,7 +299,8 @@ class LookUpTable(object):
         else:
             todo = [('all', None, -1 if self.isomolec.levels else 0)]
         for name, level, index in todo:
-            fn = None if cartLUTs is None else cartLUTs + self.tag + '_' + (name if level is not None else 'alllev') + date_stamp() + '.pic'
+            fn = None if cartLUTs is None else find_free_name(                                      # :737
+                cartLUTs + self.tag + '_' + (name if level is not None else 'alllev') + date_stamp() + '.pic', maxnum=10, split_at='.pic')
             st = LutSet(self.mol, self.iso, self.MM, level=level, filename=fn, level_index=index)
             st.spectral_grid = self.spectral_grid
             if fn is not None:
@@ -492,7 +507,13 @@ def make_abscoeff_isomolec(wn_range_tot, isomolec, Temps, Press, LTE=True, allLU
         # sic: the reference stores the level's EMISSION coefficient in abs_coeffs_tracked too
         # (spect_main_module.py:2097, 2106); the level's absorption share is kept beside it as .true_abs
         abs_tracked[lev] = fill(AbsSetLOS(name('tracklevel_abscoeff', '_' + lev), spectral_grid=spectral_grid), te)
-        abs_tracked[lev].true_abs = fill(AbsSetLOS(None, spectral_grid=spectral_grid), ta) if not store_in_memory else ta
+        # always an AbsSetLOS carrying .device (never written to a file: the reference has no such file)
+        tset = AbsSetLOS(None, spectral_grid=spectral_grid)
+        tset.device = ta
+        if to_host and not store_in_memory:
+            for row in ta.cpu().numpy():
+                tset.add_set(spcl.SpectralObject(row, spectral_grid, units='cm_1', link_grid=True))
+        abs_tracked[lev].true_abs = tset
     return abs_coeffs, emi_coeffs, emi_tracked, abs_tracked
 
 
