@@ -823,8 +823,13 @@ __global__ __launch_bounds__(64) void sr_s2m_kernel(const FastRec *__restrict__ 
                                                     FarParams fp, unsigned long long *__restrict__ cnt) {
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wid / fp.n_src[0], sb = wid - layer * fp.n_src[0];
-  const int lane = threadIdx.x, side = lane >> 5, sub = lane & 31;
+  const int lane = threadIdx.x;
   const int s_lo = g_lo + (sb - kSrcPad) * 64; // first centre position of the box
+  // A box wholly LEFT of the shard only ever serves targets to its right (side 0), one wholly right of it targets to
+  // its left (side 1) -- and so do all its ancestors: half of a 1/8 shard's source boxes are such halo boxes.  They
+  // take 64 lines of the one side per step; the side nobody reads is written as zeros (sr_m2m_kernel sums both).
+  const int only = s_lo + 64 <= g_lo ? 0 : (s_lo >= g_lo + fp.box_count[0] * 64 ? 1 : -1);
+  const int side = only >= 0 ? only : lane >> 5, sub = only >= 0 ? lane : lane & 31, per_step = only >= 0 ? 64 : 32;
   const int l0 = lower_bound_ic(ix, s_lo), l1 = lower_bound_ic(ix, s_lo + 64);
   constexpr int NE = kFD / 2; // terms of the Laurent series
   double v[2 * kMQ];          // [0, kMQ): abs, [kMQ, 2 kMQ): emi
@@ -832,7 +837,7 @@ __global__ __launch_bounds__(64) void sr_s2m_kernel(const FastRec *__restrict__ 
   for (int n = 0; n < 2 * kMQ; ++n) v[n] = 0.;
   const FastRec *frow = fast + (size_t)layer * n_sub;
   unsigned n_lines = 0;
-  for (int base = l0; base < l1; base += 32) {
+  for (int base = l0; base < l1; base += per_step) {
     const int l = base + sub;
     if (l >= l1 || l < fp.disp_lo_end || l >= fp.disp_hi_begin) continue;
     const FastRec r = frow[l];
@@ -870,12 +875,18 @@ __global__ __launch_bounds__(64) void sr_s2m_kernel(const FastRec *__restrict__ 
   // sums within each half-wave, one weight at a time (kMQ values over 32 lanes leave one per lane)
   lane_reduce<kMQ, 16>(v, lane);
   lane_reduce<kMQ, 16>(v + kMQ, lane);
+  if (only >= 0) { // the two half-waves hold partial sums of the same side
+    v[0] += __shfl_xor(v[0], 32);
+    v[kMQ] += __shfl_xor(v[kMQ], 32);
+  }
   bool primary = true;
-  const int n_out = lane_reduce_index<kMQ, 16>(sub, primary);
+  const int n_out = lane_reduce_index<kMQ, 16>(lane & 31, primary);
   if (primary) {
-    double *mo = fp.mom + ((size_t)(fp.src_off[0] + sb) * fp.n_layers + layer) * kMomPerBox + side * (2 * kMQ) + n_out;
-    mo[0] = v[0];
-    mo[kMQ] = v[kMQ];
+    const int wside = only >= 0 ? (lane < 32 ? only : 1 - only) : side;
+    const bool zero = only >= 0 && lane >= 32;
+    double *mo = fp.mom + ((size_t)(fp.src_off[0] + sb) * fp.n_layers + layer) * kMomPerBox + wside * (2 * kMQ) + n_out;
+    mo[0] = zero ? 0.0 : v[0];
+    mo[kMQ] = zero ? 0.0 : v[kMQ];
   }
   if (COUNT) count_add(cnt, kCntS2M, n_lines, lane);
 }
@@ -894,6 +905,8 @@ __global__ __launch_bounds__(64) void sr_m2m_kernel(FarParams fp) {
     const int per = 1 << (top - l);
     for (int i = 0; i < per; ++i) {
       const int p = tb * per + i;
+      // halo boxes: the side nobody reads is not built (see sr_s2m_kernel); sw = side * 2 + weight
+      if ((sw >> 1) == 1 ? ((p + 1) << l) <= kSrcPad : (p << l) - kSrcPad >= fp.box_count[0]) continue;
       const double *cl = fp.mom + ((size_t)(fp.src_off[l - 1] + 2 * p) * fp.n_layers + layer) * kMomPerBox + sw * kMQ;
       const double *cr = cl + (size_t)fp.n_layers * kMomPerBox;
       double *par = fp.mom + ((size_t)(fp.src_off[l] + p) * fp.n_layers + layer) * kMomPerBox + sw * kMQ;
@@ -1934,6 +1947,64 @@ __global__ __launch_bounds__(256) void sr_limb_kernel(const double *__restrict__
   rad[(size_t)ray * n_pts + j] = I;
 }
 
+// The same recursion for SMALL launches (one ray on a 1/8 spectral shard: 49 blocks on 256 CUs), where the run time
+// is the latency of one thread's chain of 160 dependent segments: the segments of a ray are cut into kLimbParts
+// consecutive stretches, one wave per stretch and 64 points; a stretch is the affine map I -> I T + S (T = product of
+// its transmissions, S its own emission attenuated by what follows inside the stretch), and maps compose in order.
+constexpr int kLimbParts = 4;
+template <int NG>
+__global__ __launch_bounds__(64 * kLimbParts) void sr_limb_split_kernel(
+    const double *__restrict__ abs_c, const double *__restrict__ emi_c, int n_pts, int n_layers,
+    const int *__restrict__ seg_off, const int *__restrict__ seg_layer, const double *__restrict__ col, LimbOpts o,
+    double *__restrict__ rad) {
+  __shared__ double s_T[kLimbParts][64], s_S[kLimbParts][64];
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane, ray = blockIdx.y;
+  const int jj = min(j, n_pts - 1);
+  const int r0 = seg_off[ray], r1 = seg_off[ray + 1], n = r1 - r0;
+  const int s0 = r0 + (int)(((long)n * part) / kLimbParts), s1 = r0 + (int)(((long)n * (part + 1)) / kLimbParts);
+  constexpr int kB = NG == 1 ? 8 : (NG == 2 ? 4 : 2);
+  const size_t gstride = (size_t)n_layers * n_pts;
+  double T = 1.0, S = 0.0;
+  for (int sb = s0; sb < s1; sb += kB) {
+    double a[kB][NG], e[kB][NG], u[kB][NG];
+#pragma unroll
+    for (int t = 0; t < kB; ++t) {
+      const int s = min(sb + t, s1 - 1);
+      const size_t ofs = (size_t)seg_layer[s] * n_pts + jj;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        a[t][g] = abs_c[g * gstride + ofs];
+        e[t][g] = emi_c[g * gstride + ofs];
+        u[t][g] = col[(size_t)g * o.n_seg_total + s];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kB; ++t) {
+      if (sb + t < s1) {
+        double tau = a[t][0] * u[t][0], E = e[t][0] * u[t][0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+          tau = tau + a[t][g] * u[t][g];
+          E = E + e[t][g] * u[t][g];
+        }
+        const Atten A = attenuation(tau);
+        T = T * A.t;
+        S = S * A.t + (o.solo_absorption ? 0.0 : E * A.f);
+      }
+    }
+  }
+  s_T[part][lane] = T;
+  s_S[part][lane] = S;
+  __syncthreads();
+  if (part == 0 && j < n_pts) {
+    double I = limb_initial(o, rad, (size_t)ray * n_pts + j, j);
+#pragma unroll
+    for (int p = 0; p < kLimbParts; ++p) I = I * s_T[p][lane] + s_S[p][lane];
+    rad[(size_t)ray * n_pts + j] = I;
+  }
+}
+
 // Derivatives w.r.t. NP parameters per thread; parameter p belongs to gas par_gas[p] and moves its columns
 // linearly, d u_g[s] / d x_p = dcol[p][s] (profile parameters of RetParam / LinearProfile, smm:319-375):
 //   d tau = a_g D,  d(E f) = e_g D f + E f'(tau) a_g D,  f' = (tau t - (1 - t))/tau^2
@@ -2243,6 +2314,15 @@ int launch_limb_adjoint(const double *abs_c, const double *emi_c, const double *
 int launch_limb(const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, const int *seg_off,
                 const int *seg_layer, const double *col, const LimbOpts &o, double *rad, hipStream_t st) {
   if (n_pts <= 0 || n_rays <= 0) return 0;
+  // fewer than two waves per SIMD: the latency-bound variant (a function of the launch shape only)
+  if ((long)((n_pts + 63) / 64) * n_rays < 2048) {
+    const dim3 gs((n_pts + 63) / 64, n_rays);
+#define SR_LS(NG) hipLaunchKernelGGL(sr_limb_split_kernel<NG>, gs, dim3(64 * kLimbParts), 0, st, abs_c, emi_c, n_pts, n_layers, \
+                                     seg_off, seg_layer, col, o, rad)
+    SR_BY_NGAS(o.n_gas, SR_LS(1), SR_LS(2), SR_LS(3), SR_LS(4))
+#undef SR_LS
+    return (int)hipGetLastError();
+  }
   const dim3 grid((n_pts + 255) / 256, n_rays);
 #define SR_L(NG) hipLaunchKernelGGL(sr_limb_kernel<NG>, grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, seg_off, \
                                     seg_layer, col, o, rad)

@@ -13,10 +13,15 @@ L = syn.make_lines(100000, grid, config_id=2, n_levels=12)
 atm = syn.make_atmosphere(80, 12)
 ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
 los, Lr = B.build_rays(syn, engine, atm, 1)
-ab = torch.empty((80, 100000), dtype=torch.float64, device="cuda"); em = torch.empty_like(ab)
+g_lo, g_hi = 0, 100000
+if os.environ.get("SHARD"):     # SHARD=r/W: that spectral shard only
+    from spectrobot_amd import distributed as sd
+    r_, w_ = (int(v) for v in os.environ["SHARD"].split("/"))
+    g_lo, g_hi = sd.shard_bounds(100000, w_, r_)
+ab = torch.empty((80, g_hi - g_lo), dtype=torch.float64, device="cuda"); em = torch.empty_like(ab)
 q = np.atleast_1d(spcl.CalcPartitionSum(6, 1, atm["temps"]))
 def step():
-    ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"], q_part=q, out=(ab, em))
+    ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"], q_part=q, g_lo=g_lo, g_hi=g_hi, out=(ab, em))
     return engine.limb_rays((ab, em), los)
 engine.set_overlap(0)
 for _ in range(3): step()
