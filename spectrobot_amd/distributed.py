@@ -21,12 +21,15 @@ def shard_bounds(n_grid, world_size, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def shard_bounds_balanced(line_freq, grid, world_size, zone_weight=1.5, align=64):
+def shard_bounds_balanced(line_freq, grid, world_size, zone_weight=1.5, align=64, point_weight=2.0):
     """Contiguous shards of (about) equal WORK instead of equal width (balance by line-window
     work): the cost of a grid point is the number of lines whose 13010-point window covers it (far-field and
     near-wings kernels) plus zone_weight x 13010 x the number of line centres on it (the zones kernel's
     ~240 region-2/3/4 evaluations per line and layer cost about zone_weight times the line's whole
-    region-1 share).  Real HITRAN line lists bunch in band centres: equal-width shards then differ several-fold.
+    region-1 share) plus point_weight x 13010 for the grid point itself (far-field polynomials, LDS images, candidate
+    searches, the recursion: measured on the band-head list of tools/balanced_shards.py, where a stretch with 0.3 lines
+    per point costs 0.61 of a stretch with 1).  Real HITRAN line lists bunch in band centres: equal-width shards then
+    differ several-fold.
     Returns [(lo, hi)] for all ranks; boundaries are multiples of `align` grid points."""
     import numpy as np
     grid = np.asarray(grid, dtype=float)
@@ -40,7 +43,7 @@ def shard_bounds_balanced(line_freq, grid, world_size, zone_weight=1.5, align=64
     centres = np.bincount(ic, minlength=n).astype(float)
     cum = np.concatenate([[0.0], np.cumsum(centres)])
     cover = cum[np.minimum(np.arange(n) + half, n)] - cum[np.maximum(np.arange(n) - half + 1, 0)]   # lines covering j
-    cost = cover + zone_weight * 13010.0 * centres + 1e-9        # + epsilon: empty stretches still split somewhere
+    cost = cover + zone_weight * 13010.0 * centres + point_weight * 13010.0
     c = np.concatenate([[0.0], np.cumsum(cost)])
     cuts = [0]
     for r in range(1, int(world_size)):

@@ -36,7 +36,8 @@ def main():
     coef = [k for k in kernels if any(s in k for s in ("sr_farfield_kernel<false", "near_wings_kernel<false>",
                                                         "near_zones_kernel<512, 1, false>", "sr_s2m_kernel<false>",
                                                         "sr_m2m_kernel", "sr_m2l_kernel<false>"))]
-    step = [k for k in kernels if k in coef or "sr_prep_kernel" in k or "sr_limb_kernel" in k or "sr_los_columns" in k]
+    step = [k for k in kernels if k in coef or "sr_prep_kernel" in k or "sr_limb_kernel" in k or "sr_limb_split_kernel" in k
+            or "sr_los_columns" in k]
     out = {
         "profile_tag": tag,
         "kernel_sources_sha256": sources_sha256(),
