@@ -21,15 +21,16 @@ def shard_bounds(n_grid, world_size, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def shard_bounds_balanced(line_freq, grid, world_size, zone_weight=1.5, align=64, point_weight=2.0):
+def shard_bounds_balanced(line_freq, grid, world_size, zone_weight=1.5, align=64, point_weight=0.0):
     """Contiguous shards of (about) equal WORK instead of equal width (balance by line-window
     work): the cost of a grid point is the number of lines whose 13010-point window covers it (far-field and
     near-wings kernels) plus zone_weight x 13010 x the number of line centres on it (the zones kernel's
     ~240 region-2/3/4 evaluations per line and layer cost about zone_weight times the line's whole
-    region-1 share) plus point_weight x 13010 for the grid point itself (far-field polynomials, LDS images, candidate
-    searches, the recursion: measured on the band-head list of tools/balanced_shards.py, where a stretch with 0.3 lines
-    per point costs 0.61 of a stretch with 1).  Real HITRAN line lists bunch in band centres: equal-width shards then
-    differ several-fold.
+    region-1 share) plus point_weight x 13010 for the grid point itself.  Measured on the band-head list of
+    tools/balanced_shards.py (profiles/r03_shards_one_gpu.txt): point_weight = 0 gives max / mean 1.12 over the 8
+    shards, 2.0 gives 1.41 -- a sparse stretch is cheaper per line than the model says, and below ~0.6 ms a step is
+    bound by the host's enqueue time (0.45 ms), which no split of the grid changes.  Real HITRAN line lists bunch in
+    band centres: equal-width shards then differ several-fold.
     Returns [(lo, hi)] for all ranks; boundaries are multiples of `align` grid points."""
     import numpy as np
     grid = np.asarray(grid, dtype=float)

@@ -244,7 +244,7 @@ def test_shard_bounds_balanced_on_skewed_line_density(tmp_path):
         out = []
         for lo, hi in bounds:
             cover = np.clip(np.minimum(ic + 6504, hi - 1) - np.maximum(ic - 6505, lo) + 1, 0, None).sum()   # (line, point) pairs
-            out.append(cover + 1.5 * 13010.0 * np.count_nonzero((ic >= lo) & (ic < hi)) + 2.0 * 13010.0 * (hi - lo))
+            out.append(cover + 1.5 * 13010.0 * np.count_nonzero((ic >= lo) & (ic < hi)))
         return np.array(out)
 
     for w in (2, 4, 8):
