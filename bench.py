@@ -374,7 +374,8 @@ def main():
             "config": {"workload": "CH4 Titan limb (BASELINE configs[1]): %d lines x %d-pt grid x %d layers, "
                                    "%d ray(s), 12 non-LTE levels" % (args.lines, args.grid, args.layers, args.rays),
                        "n_lines": args.lines, "n_grid": args.grid, "n_layers": args.layers, "n_rays": args.rays,
-                       "sharding": ("spectral window / %d, one RCCL all-gather" % world if world > 1 else
+                       "sharding": ("spectral window / %d, one all-gather per step (backend %s: nccl = RCCL over xGMI)"
+                                    % (world, dist_rec["backend"]) if world > 1 else
                                     ("ONLY shard %s timed (tuning aid)" % args.shard if args.shard else "none")),
                        "mode": "exact" if args.exact else ("far-field, box pairs" if args.far_field == 2 else "far-field, per line"), "device": info["name"],
                        "cu_count": info["cu_count"]},
