@@ -157,7 +157,12 @@ def test_config4_two_gas_retrieval_20_iterations(eng):
     """configs[4]: HCN (mol 23) + CH4 on one grid, forward model + analytic Jacobians of both gases' profile
     parameters for all LOS in one launch, Gauss-Newton / LM loop with the reference's stopping rule and at most
     20 iterations (spect_main_module.py:2725-2987).  The Jacobian inside the loop is checked against finite
-    differences of the low-resolution forward model first."""
+    differences of the low-resolution forward model first.
+    History of the acceptance criterion (an unpinned component: say so): the first version demanded that at least
+    four parameters end within 5 % of the a priori of the truth; it failed once on the GPU box in round 2 (two did:
+    the lowest nodes sit under an opaque path and are not constrained by the measurement) and was replaced (commit
+    0785807) by the statistical statement below -- nodes with averaging kernel > 0.5 end within 4 sigma of the
+    truth and closer to it than the a priori -- which is what optimal estimation promises."""
     import bench_configs as bc
     from spectrobot_amd import retrieval
     scene = bc.two_gas_scene(12000, 2500, 24000, 40)
