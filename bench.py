@@ -341,7 +341,11 @@ def main():
                 if pj.get("kernel_sources_sha256") == kernel_sources_sha256():
                     traffic = pj.get("coefficient_kernels_hbm_bytes_per_step")
                     traffic_src = {"file": "profiles/r03_pmc_hbm.json", "profile_tag": pj.get("profile_tag"),
-                                   "kernel_sources_sha256": pj.get("kernel_sources_sha256")[:16]}
+                                   "kernel_sources_sha256": pj.get("kernel_sources_sha256")[:16],
+                                   "raw_counter_bytes": pj.get("coefficient_kernels_hbm_bytes_per_step_raw"),
+                                   "note": "FETCH_SIZE doubled for vector reads (calibration: profiles/"
+                                           "r03_fetch_calibration.txt), WRITE_SIZE as reported; per step of the "
+                                           "coefficient kernels"}
                 else:
                     traffic_src = {"file": "profiles/r03_pmc_hbm.json", "stale": True,
                                    "note": "measured on other kernel sources than this build: not reported"}

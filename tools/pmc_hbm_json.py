@@ -38,18 +38,32 @@ def main():
                                                         "sr_m2m_kernel", "sr_m2l_kernel<false>"))]
     step = [k for k in kernels if k in coef or "sr_prep_kernel" in k or "sr_limb_kernel" in k or "sr_limb_split_kernel" in k
             or "sr_los_columns" in k]
+    # Calibration on this chip (tools/fetch_calib.sh, profiles/r03_fetch_calibration.txt): FETCH_SIZE reports exactly 1/2
+    # of every vector (global_load) read, whatever its width or stride, and the exact bytes of scalar loads; WRITE_SIZE
+    # is exact.  The exact-mode kernels read their records by scalar loads; every other kernel through vector loads.
+    scalar_kernels = ("sr_abscoeff_wings_kernel<", "sr_abscoeff_cores_kernel")
+    for k, v in kernels.items():
+        v["fetch_factor"] = 1.0 if any(s_ in k for s_ in scalar_kernels) else 2.0
+        v["fetch_bytes_corrected"] = v["fetch_bytes"] * v["fetch_factor"]
+    total = lambda names, key: sum(kernels[k][key] + kernels[k]["write_bytes"] for k in names)
     out = {
         "profile_tag": tag,
         "kernel_sources_sha256": sources_sha256(),
-        "units": "bytes per launch; rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB (x1024), raw: the guide's gfx950 x2 applies to "
-                 "16 B/lane streaming reads, these kernels read 64 B scalar and 8-16 B/lane vector loads (calibration of "
-                 "round 1 on sr_radiance_kernel: 128 MB of 8 B/lane reads are reported as 117 MB)",
+        "units": "bytes per launch; rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB (x1024).  Corrected as calibrated on this chip "
+                 "(profiles/r03_fetch_calibration.txt, tools/fetch_calib.sh): FETCH_SIZE reports exactly 1/2 of every vector "
+                 "(global_load) read -- 8 B/lane, 16 B/lane and the per-lane record-field gathers of the row walks alike -- "
+                 "and the exact bytes of scalar loads; WRITE_SIZE is exact.  fetch_bytes_corrected = 2 x fetch_bytes for the "
+                 "kernels that read through vector loads (an upper bound where part of a kernel's reads are scalar: the "
+                 "far-field polynomial coefficients of the near wings kernel, index-table look-ups), 1 x for the exact-mode "
+                 "kernels whose records are scalar loads.  The *_raw totals are the uncorrected sums (round 2's convention).",
         "source": "tools/profile.sh %s (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes; counter passes serialise "
                   "the kernels)" % tag,
         "per_kernel": kernels,
         "coefficient_kernels": coef,
-        "coefficient_kernels_hbm_bytes_per_step": sum(kernels[k]["fetch_bytes"] + kernels[k]["write_bytes"] for k in coef),
-        "step_hbm_bytes_incl_prep_and_radiance": sum(kernels[k]["fetch_bytes"] + kernels[k]["write_bytes"] for k in step),
+        "coefficient_kernels_hbm_bytes_per_step": total(coef, "fetch_bytes_corrected"),
+        "coefficient_kernels_hbm_bytes_per_step_raw": total(coef, "fetch_bytes"),
+        "step_hbm_bytes_incl_prep_and_radiance": total(step, "fetch_bytes_corrected"),
+        "step_hbm_bytes_incl_prep_and_radiance_raw": total(step, "fetch_bytes"),
     }
     print(json.dumps(out, indent=1))
 
