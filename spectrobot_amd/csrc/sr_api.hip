@@ -899,7 +899,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       // Small shards do not fill the chip: there the wings kernel need not wait for the zones kernel
       // either -- zones writes a private buffer, one pass adds it at the end (on the full grid the
       // VALU is saturated and this variant measured slower: 9.26 vs 9.06 ms).
-      const bool small = n_pts * (size_t)nl <= (size_t)3000000;
+      static const size_t small_limit = [] { const char *e = getenv("SR_SMALL_LIMIT"); return e ? (size_t)atoll(e) : (size_t)3000000; }();
+      const bool small = n_pts * (size_t)nl <= small_limit; // SR_SMALL_LIMIT: tuning override (point-layers)
       double *z_abs = abs_out, *z_emi = emi_out;
       if (small) {
         rc = w.d_zone.ensure(sizeof(double) * 2 * n_pts * nl);
