@@ -1533,8 +1533,15 @@ int sr_limb_rays_jacobians_dev(const double *abs_c, const double *emi_c, const d
     return SR_ERR_UNSUPPORTED;
   }
   if (want_par) {
-    if (!rad) return SR_ERR_ARG; // the forward kernel writes the radiances too
-    const int rc = sr_limb_rays_jac_dev(abs_c, emi_c, n_layers, n_pts, los, n_par, par_gas, par_w, rad, jac_par, stream);
+    double *rad_out = rad;
+    static thread_local DevBuf scratch_rad; // the forward kernel writes the radiances too: somewhere, if not wanted
+    if (!rad_out) {
+      if (los && los->init_mode == 1) return SR_ERR_ARG; // an initial intensity is read from rad
+      const int rc0 = scratch_rad.ensure(sizeof(double) * (size_t)los->n_rays * (size_t)n_pts);
+      if (rc0) return rc0;
+      rad_out = scratch_rad.as<double>();
+    }
+    const int rc = sr_limb_rays_jac_dev(abs_c, emi_c, n_layers, n_pts, los, n_par, par_gas, par_w, rad_out, jac_par, stream);
     if (rc) return rc;
   }
   if (want_layer) {

@@ -274,6 +274,7 @@ def test_one_pass_jacobians_vs_forward_sensitivity(eng):
     Wb = np.array([np.interp(L["alt"], zz, np.exp(-0.5 * ((zz - z[k]) / 300.0) ** 2)) for k in range(0, nl, 2)])
     los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827, 1.0])
     rb, _, jb = eng.limb_rays_jacobians(coeffs, los, par_gas=np.zeros(12, np.int32), par_w=Wb)
+    assert torch.equal(jb, eng.limb_rays_jacobians(coeffs, los, par_gas=np.zeros(12, np.int32), par_w=Wb, want_rad=False)[2])
     eng.set_jac_layer_mode(1)
     try:
         rbf, jbf = eng.limb_rays_jacobian(coeffs, los, np.zeros(12, np.int32), Wb)
