@@ -346,11 +346,16 @@ __device__ inline double cos_tiered(double t, int tier) {
 // per line (a is a single: a a is exact), m = (double)(float)rx >= 0.  The value is even in the sign of
 // Im c2 (P, Q have real coefficients: flipping b flips Im P, Im Q and Im(c2 P) together), so m stands in for
 // b = -rx; Re c1 = a^2 - m^2 in one fma (m m is exact too: the same rounding as a a - b b).  cos by tier.
-__device__ inline double core_region4_m(double a, double a2, double two_a, double m, int tier) {
+// p6_vgpr: the leading coefficient of P4 (SR_F32(.56419)) in a VGPR, made once per kernel by vgpr_constant().
+__device__ inline double vgpr_constant(double c) {
+  asm volatile("" : "+v"(c)); // opaque to the optimiser: stays a loop-invariant VGPR pair instead of a v_mov per use
+  return c;
+}
+__device__ inline double core_region4_m(double a, double a2, double two_a, double m, int tier, double p6_vgpr) {
   const double ur = fma(-m, m, a2), ui = two_a * m;
   const double r = ur + ur, s = fma(ur, ur, ui * ui);
   // P4 = sum p_k c1^k, k = 0..6 (quadratic-factor recurrence, see real_poly_at)
-  const double p6 = SR_F32(.56419);
+  const double p6 = p6_vgpr;
   double pa = fma3vs(r, p6, -SR_F32(1.320522)), pb = fma3vs_neg(s, p6, SR_F32(35.76683));
   {
     const double P4[4] = {SR_F32(36183.31), -SR_F32(3321.9905), SR_F32(1540.787), -SR_F32(219.0313)};
@@ -399,27 +404,39 @@ __device__ inline double core_point(double rx, double ry, double ryf) {
 // (middle branch, lineshape.f:443-490), with xf(k) giving x(k).
 struct Bounds {
   double ry, xstep, xl, xr;
+  double inv_dwp; // ~1/dw' (fast_rcp<2>): the divisions by dw' below and in make_cold share it
   int il, ir, il2, ir2;
 };
+// num / d with a reciprocal made once: q = num r, one residual correction -- the correctly rounded quotient (what the
+// IEEE division returns) in all but ~1e-16 of cases, 3 instructions instead of the ~14 slots of v_div_scale / v_rcp /
+// fma x 5 / v_div_fmas / v_div_fixup.  sr_prep_kernel had 31 IEEE divisions per record, 40 % of its instructions.
+__device__ inline double div_with(double num, double d, double inv_d) {
+  const double q = num * inv_d;
+  return fma(fma(-d, q, num), inv_d, q);
+}
 template <class XF>
 __device__ inline Bounds humliv_bounds(const XF &xf, int n, double x0, double lw, double dwp) {
   Bounds B;
-  B.ry = lw / dwp;                      // :261
-  B.xstep = (xf(2) - xf(1)) / dwp;      // :265-266
-  double rx = (x0 - xf(1)) / dwp;       // :444
+  B.inv_dwp = fast_rcp<2>(dwp);
+  auto by_dw = [&](double num) { return div_with(num, dwp, B.inv_dwp); };
+  B.ry = by_dw(lw);                     // :261
+  B.xstep = by_dw(xf(2) - xf(1));       // :265-266
+  const double inv_xs = fast_rcp<2>(B.xstep);
+  auto by_xs = [&](double num) { return div_with(num, B.xstep, inv_xs); };
+  double rx = by_dw(x0 - xf(1));        // :444
   B.xl = rx;                            // :462
   B.il = 1;
-  if (rx + B.ry >= 15.) B.il = nint_clamp0((rx - B.ry - 15.) / B.xstep) + 1; // :447-449
-  rx = (xf(n) - x0) / dwp;
+  if (rx + B.ry >= 15.) B.il = nint_clamp0(by_xs(rx - B.ry - 15.)) + 1; // :447-449
+  rx = by_dw(xf(n) - x0);
   B.ir = n;
-  if (rx + B.ry >= 15.) B.ir = n - nint_clamp0((rx - B.ry - 15.) / B.xstep); // :452-454
-  B.xr = (xf(B.ir) - x0) / dwp;         // :471
-  rx = (x0 - xf(B.il)) / dwp;           // :480
+  if (rx + B.ry >= 15.) B.ir = n - nint_clamp0(by_xs(rx - B.ry - 15.)); // :452-454
+  B.xr = by_dw(xf(B.ir) - x0);          // :471
+  rx = by_dw(x0 - xf(B.il));            // :480
   B.il2 = B.il;
-  if (rx + B.ry >= 5.5) B.il2 = B.il + nint_clamp0((rx - B.ry - 5.5) / B.xstep); // :483-485
+  if (rx + B.ry >= 5.5) B.il2 = B.il + nint_clamp0(by_xs(rx - B.ry - 5.5)); // :483-485
   rx = B.xr;                            // :487
   B.ir2 = B.ir;
-  if (rx + B.ry >= 5.5) B.ir2 = B.ir - nint_clamp0((rx - B.ry - 5.5) / B.xstep); // :488-490
+  if (rx + B.ry >= 5.5) B.ir2 = B.ir - nint_clamp0(by_xs(rx - B.ry - 5.5)); // :488-490
   return B;
 }
 
@@ -430,8 +447,8 @@ __device__ inline ColdRec make_cold(const Bounds &B, double dwp, double x0, cons
   c.ry = B.ry;
   c.dwp = dwp;
   c.x0 = x0;
-  c.xs2l = (x0 - xf(B.il)) / dwp;  // lineshape.f:504
-  c.xs2r = (xf(B.ir2) - x0) / dwp; // :514
+  c.xs2l = div_with(x0 - xf(B.il), dwp, B.inv_dwp);  // lineshape.f:504
+  c.xs2r = div_with(xf(B.ir2) - x0, dwp, B.inv_dwp); // :514
   c.il2ir2 = (uint32_t)B.il2 | ((uint32_t)B.ir2 << 16);
   // Region-3 interval inside the core (il2a, ir2a): rx = |x(k)-x0|/dw grows away from the
   // centre and the region test is monotone in rx, so region 3 is one interval around the
@@ -442,7 +459,7 @@ __device__ inline ColdRec make_cold(const Bounds &B, double dwp, double x0, cons
     const int clo = ((B.il2 == B.il) ? B.il - 1 : B.il2) + 1, chi = ((B.ir2 == B.ir) ? B.ir + 1 : B.ir2) - 1;
     int k3lo = 1, k3hi = 0; // empty
     if (clo <= chi) {
-      auto is3 = [&](int k) { return !core_is_region4(fabs(xf(k) - x0) / dwp, B.ry); };
+      auto is3 = [&](int k) { return !core_is_region4(div_with(fabs(xf(k) - x0), dwp, B.inv_dwp), B.ry); };
       if constexpr (std::is_same<XF, WinX>::value) {
         // The window grid is affine in k up to rounding, and region 3 is |x(k) - x0| <= (ry + 0.176)/0.195 dw up
         // to rounding: start each search at the index that formula gives and let the reference's own tests move it

@@ -39,7 +39,10 @@ __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, c
   LinePhys P;
   const double T = A.temps[k];
   const double x0 = L.freq[ln];
-  P.lw = exp(L.t_dep[ln] * A.ltrat[k]) * (L.air_broad[ln] * A.p_atm[k]); // (296/T)^n gamma P  (spcl:1972)
+  // exp_bounded: the library routine without its special cases (|argument| clamped to 700: e^-700 = 1e-304 is as good
+  // as the 0 the reference's exp underflows to much later); three of them were 12 % of this kernel's instructions
+  auto ex = [](double u) { return exp_bounded(fmin(fmax(u, -700.0), 700.0)); };
+  P.lw = ex(L.t_dep[ln] * A.ltrat[k]) * (L.air_broad[ln] * A.p_atm[k]); // (296/T)^n gamma P  (spcl:1972)
   const double dw = x0 / kCcgs * A.sqk[k];
   P.dwp = dw / A.sqrt_ln2;
   const double fac = dw * A.sqrt_pi_ln2;
@@ -48,8 +51,8 @@ __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, c
   if (a_co != 0.0 && gl != 0.0 && gu != 0.0) {
     const double four_pi = 4 * kPi;
     const double el = L.e_lower[ln];
-    const double rot_up = gu * exp(-kC2 * (el + x0 - L.evib_up[ln]) / T);
-    const double rot_lo = gl * exp(-kC2 * (el - L.evib_lo[ln]) / T);
+    const double rot_up = gu * ex(-kC2 * (el + x0 - L.evib_up[ln]) / T);
+    const double rot_lo = gl * ex(-kC2 * (el - L.evib_lo[ln]) / T);
     const double hcf = L.hcf[ln];
     g_sp = hcf * rot_up * a_co / four_pi;
     g_in = hcf * rot_up * L.b21[ln] / four_pi;
@@ -1331,17 +1334,18 @@ __device__ inline int rows_max(int v) {
   return m;
 }
 struct CorePend {
-  int k, base; // window index; idx in the image = k + base
+  int k, base; // window index; element of the image = k + base
   double gc, x0, dwp, inv_dwp, ryf, ryf2, two_ryf, wa, we;
 };
 // cos_tier: see cos_tiered (wave-uniform, from the largest 2 ry rx of the rows' runs)
-__device__ inline void core_eval4(const CorePend &P, bool on, const GridParams &gp, int cos_tier, double *s_a, double *s_e) {
+__device__ inline void core_eval4(const CorePend &P, bool on, const GridParams &gp, int cos_tier, double p6_vgpr, double *s_a,
+                                  double *s_e) {
   if (on) {
     const WinX xf{gp.lin_start, gp.lin_delta, P.gc};
     const double d = fabs(xf(P.k) - P.x0);
     double rx = d * P.inv_dwp; // |x(k)-x0|/dw correctly rounded: one residual correction
     rx = fma(fma(-P.dwp, rx, d), P.inv_dwp, rx);
-    const double y = core_region4_m(P.ryf, P.ryf2, P.two_ryf, (double)(float)rx, cos_tier);
+    const double y = core_region4_m(P.ryf, P.ryf2, P.two_ryf, (double)(float)rx, cos_tier, p6_vgpr);
     const int idx = P.k + P.base;
     atomicAdd(&s_a[idx], P.wa * y);
     atomicAdd(&s_e[idx], P.we * y);
@@ -1362,7 +1366,10 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, IcIndex ix,
     const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp, int add,
     double *__restrict__ abs_out, double *__restrict__ emi_out, unsigned long long *__restrict__ cnt) {
-  __shared__ double s_img[NW][2][WT]; // one private image per wave: abs, emi
+  // one private image per wave: abs, emi.  Point p of the group (window index k of a line: p = k + j1 - 1 - wlo) lives at
+  // element p + 1, i.e. element k + (j1 - wlo): the hot loops' address arithmetic carries no "- 1" (it cost a v_add per
+  // region-2 point: the offset field of ds_add cannot be negative)
+  __shared__ double s_img[NW][2][WT + 2];
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_groups, grp = wg - layer * n_groups;
   const int wlo = g_lo + grp * WT;
@@ -1374,8 +1381,9 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
   double *const s_a = s_img[wave][0], *const s_e = s_img[wave][1];
   const int zm = min(zmax[layer], kHalf - 1);
 #pragma unroll
-  for (int p = 0; p < WT / 64; ++p) s_a[lane + 64 * p] = s_e[lane + 64 * p] = 0.;
+  for (int p = 0; p < WT / 64; ++p) s_a[1 + lane + 64 * p] = s_e[1 + lane + 64 * p] = 0.;
   unsigned n_r2 = 0, n_r3 = 0, n_r4 = 0; // COUNT: evaluations of this lane per region
+  const double p6_vgpr = vgpr_constant(SR_F32(.56419)); // see core_region4_m
   // lines whose zone [ic - zm, ic + zm] can meet the group
   const int l0 = lower_bound_ic(ix, wlo - zm), l1 = lower_bound_ic(ix, whi + zm + 1);
   const FastRec *frow = fast + (size_t)layer * n_sub;
@@ -1429,7 +1437,7 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
       if (__any(n3 > 0)) {
         const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
         const double x0 = z.x0, dwp = z.dwp, inv_dwp = cold_inv_dwp(z.dwp), ryf = cold_ryf(z.ry), wa = r.wabs, we = r.wemi;
-        const int ibase = j1 - 1 - wlo;
+        const int ibase = j1 - wlo; // element = point + 1
         for (int t = 0; __any(t < n3); ++t) {
           if (t < n3) {
             const int k = e0 + t;
@@ -1479,10 +1487,11 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         const double xstep = r.xstep, wa = r.wabs, we = r.wemi;
         double q2[8];
         region2_coef(z.ry, q2); // rebuilt per line (ColdRec): 25 flops against ~19 steps of 30 instructions
-        const int base_idx = r.j1 - 1 - wlo;
+        const int base_idx = r.j1 - wlo; // element = point + 1
         const double c_left = fma((double)(a0 - r.il()), xstep, -z.xs2l);
         const double c_right = fma((double)(b0 - na - z.ir2()), xstep, z.xs2r);
-        const int i_left = a0 + base_idx, i_right = b0 - na + base_idx;
+        int i_left = a0 + base_idx, i_right = b0 - na + base_idx;
+        asm volatile("" : "+v"(i_left), "+v"(i_right)); // keep the two sums: re-associated, they cost a v_add per point
         const int n_steps = (rows_max(n) + kRowLanes - 1) / kRowLanes; // wave-uniform: a scalar loop counter
         for (int st = 0; st < n_steps; ++st) {
           const int t = col + kRowLanes * st;
@@ -1506,7 +1515,7 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         const int n = li >= 0 ? na + nb : 0;
         const int j1 = r.j1;
         CorePend P;
-        P.base = j1 - 1 - wlo;
+        P.base = j1 - wlo; // element = point + 1
         P.gc = grid_at(gp, j1 + kHalf);
         P.x0 = z.x0;
         P.dwp = z.dwp;
@@ -1529,7 +1538,7 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
           const int t = col + kRowLanes * st;
           P.k = t < na ? a0 + t : b0 + (t - na);
           if (COUNT) n_r4 += t < n;
-          core_eval4(P, t < n, gp, cos_tier, s_a, s_e);
+          core_eval4(P, t < n, gp, cos_tier, p6_vgpr, s_a, s_e);
         }
       }
     }
@@ -1544,11 +1553,11 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
   for (int p = threadIdx.x; p < WT; p += 64 * NW) {
     const int j = wlo + p;
     if (j <= whi) {
-      double ta = s_img[0][0][p], te = s_img[0][1][p];
+      double ta = s_img[0][0][p + 1], te = s_img[0][1][p + 1];
 #pragma unroll
       for (int w = 1; w < NW; ++w) {
-        ta += s_img[w][0][p];
-        te += s_img[w][1][p];
+        ta += s_img[w][0][p + 1];
+        te += s_img[w][1][p + 1];
       }
       if (add) {
         abs_out[row + (j - g_lo)] += ta;
