@@ -1187,12 +1187,16 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   for (int q = 0; q < kRows; ++q) ra[q] = rb[q] = 0.;
   const FastRec *frow = fast + (size_t)layer * n_sub;
   unsigned n_r1 = 0, n_we = 0; // COUNT: region-1 evaluations of this lane, window-end expansions
+#ifdef SR_DIAG_WINGS
+  unsigned n_diag = 0;
+#endif
   for (int rg = 0; rg < 3; ++rg) {
     for (int base = rs[rg]; base < re[rg]; base += 64) {
       const int lv = base + lane;
       // lane = line: does the line have region-1 points in this slot that no far-field level owns, and are they
       // cut by the window end / start only (then it can join the expansion + scan below)
       bool need = false, fastl = false;
+      bool has_l = false, has_r = false; // region-1 points of the lane's line in this slot: left wing (k < il), right wing (k > ir)
       int pos = 64; // lanes without a line: never selected by the scan
       if (lv < re[rg]) {
         const int j1 = frow[lv].j1;
@@ -1202,8 +1206,8 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
         // non-decreasing over the lanes), lines handled elsewhere with zero coefficients
         pos = rg == 0 ? min(max(jN - wlo, -1), 64) : min(max(j1 - wlo, 0), 64);
         if (jN >= wlo && j1 <= whi && !ff_admissible(j1, il, ir, wlo, wlo + 63, thr0)) {
-          const bool has_l = max(wlo, j1) <= min(whi, j1 + il - 2); // points with 1 <= k < il
-          const bool has_r = max(wlo, j1 + ir) <= min(whi, jN);     // points with ir < k <= 13010
+          has_l = max(wlo, j1) <= min(whi, j1 + il - 2); // points with 1 <= k < il
+          has_r = max(wlo, j1 + ir) <= min(whi, jN);     // points with ir < k <= 13010
           need = has_l || has_r;
           if (rg != 1 && classify(j1, il, ir, wlo, whi) == 0)
             fastl = rg == 0 ? (has_r && !has_l && j1 + ir <= wlo) : (has_l && !has_r && j1 + il - 2 >= wlo + 63);
@@ -1238,37 +1242,65 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
         }
       }
       // rows: region 1 is k < il (running x from k = 1: x = (k - 1) xstep - xl, i.e. -x) or k > ir
-      // (x = (k - ir) xstep + xr), inside the window and the grid (lineshape.f:461-477, last writer wins)
-      for (unsigned long long todo = __ballot(need); todo;) {
-        int li = -1;
+      // (x = (k - ir) xstep + xr), inside the window and the grid (lineshape.f:461-477, last writer wins).
+      // A row takes one (line, wing) ITEM: the wing's points in the slot are one run of window indices
+      // [k_a, k_b], so a step's lane mask is one add + one compare and x one fma from the row's x at step 0.
+      // (Round 2 walked lines, with the wing chosen per point and step: 6 instructions of tests for each of the
+      // 8 steps, executed or not, 17 per executed step, 27 to deal the lines to the rows and 16 unconditional
+      // accumulations: 183 per round of which 80 evaluated something -- tools/diag_counts.py: 2.2e6 rounds,
+      // 4.7 executed steps per round, 48 of 64 lanes on in an executed step on config 2.)
+      unsigned long long m_l = __ballot(need && has_l), m_r = __ballot(need && has_r);
+      while (m_l | m_r) {
+        int code = -1; // this row's item: line (index into the chunk) | wing << 6; -1: none left
 #pragma unroll
         for (int q = 0; q < kRows; ++q) {
-          if (todo) {
-            const int i = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            li = row == q ? i : li;
+          int c_ = -1; // wave-uniform
+          if (m_l) {
+            c_ = __builtin_ctzll(m_l);
+            m_l &= m_l - 1;
+          } else if (m_r) {
+            c_ = __builtin_ctzll(m_r) | 64;
+            m_r &= m_r - 1;
+          }
+          code = row == q ? c_ : code;
+        }
+#ifdef SR_DIAG_WINGS // diagnostic builds only: rounds of the row walk (in the window-end counter)
+        if (COUNT) n_we += 1; // summed over the 64 lanes
+#endif
+        const bool live = code >= 0, rw = live && (code & 64);
+        const FastRec &r = frow[base + (live ? (code & 63) : 0)];
+        const double xstep = r.xstep, a = r.a, b = r.b, c = r.c, d = r.d, wa = r.wabs, we = r.wemi;
+        const int j1 = r.j1, il = r.il(), ir = r.ir();
+        const int kb0 = wlo - j1 + 1 + col;              // window index of this lane's point at step 0
+        const int k_last = min(kImxsig, whi - j1 + 1);  // last window index inside the slot, the grid and the window
+        const int k_a = rw ? ir + 1 : 1, k_b = rw ? k_last : min(il - 1, k_last);
+        const unsigned n_on = live ? (unsigned)max(k_b - k_a + 1, 0) : 0u;
+        const int t0 = kb0 - k_a;                        // step q is on for this lane: (unsigned)(t0 + 8 q) < n_on
+        const double x0 = fma((double)(kb0 - (rw ? ir : 1)), xstep, rw ? r.xr : -r.xl);
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+          // a branch per step: steps no lane of the wave needs are skipped
+          if ((unsigned)(t0 + kRowLanes * q) < n_on) {
+            double x = x0;
+            if (q > 0) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(x) : "s"((double)(kRowLanes * q)), "v"(xstep), "v"(x0)); // one instruction
+            const double x2 = x * x;
+            const double y = fma(x2, b, a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, d), c));
+            if (COUNT) ++n_r1;
+#ifdef SR_DIAG_WINGS // executed steps (in the polynomial counter)
+            if (COUNT) n_diag |= 1u << q;
+#endif
+            ra[q] = fma(wa, y, ra[q]);
+            rb[q] = fma(we, y, rb[q]);
           }
         }
-        const FastRec &r = frow[base + max(li, 0)];
-        const double xl = r.xl, xr = r.xr, xstep = r.xstep, a = r.a, b = r.b, c = r.c, d = r.d;
-        const double wa = li >= 0 ? r.wabs : 0.0, we = li >= 0 ? r.wemi : 0.0;
-        const int j1 = r.j1, il = r.il(), ir = r.ir();
-        const int k0 = wlo + col - j1 + 1; // window index of this lane's first point
-        const int k_last = min(kImxsig, whi - j1 + 1);
+#ifdef SR_DIAG_WINGS
+        if (COUNT) {
+          unsigned any_ = n_diag & 0xffu;
 #pragma unroll
-        for (int q = 0; q < kRows; ++q) {
-          const int k = k0 + kRowLanes * q;
-          const bool left = k < il;
-          const double x = fma((double)(k - (left ? 1 : ir)), xstep, left ? -xl : xr);
-          const double x2 = x * x;
-          // the select compiles to a branch per step, which skips the steps no lane of the wave needs;
-          // evaluating all eight and selecting afterwards measured 13% slower (1.41 vs 1.25 ms)
-          const bool on = ((unsigned)(k - 1) < (unsigned)k_last) & ((unsigned)(k - il) > (unsigned)(ir - il));
-          const double y = on ? fma(x2, b, a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, d), c)) : 0.0;
-          if (COUNT) n_r1 += on && li >= 0;
-          ra[q] = fma(wa, y, ra[q]);
-          rb[q] = fma(we, y, rb[q]);
+          for (int m = 32; m >= 1; m >>= 1) any_ |= (unsigned)__shfl_xor((int)any_, m);
+          n_diag = (n_diag & ~0xffu) + ((unsigned)__builtin_popcount(any_) << 8);
         }
+#endif
       }
     }
   }
@@ -1289,7 +1321,11 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   if (COUNT) {
     count_add(cnt, kCntRegion1, n_r1, lane);
     count_add(cnt, kCntWindowEnds, n_we, lane);
+#ifdef SR_DIAG_WINGS
+    count_add(cnt, kCntPolyPoints, lane == 0 ? n_diag >> 8 : 0u, lane);
+#else
     count_add(cnt, kCntPolyPoints, (wlo + lane <= whi) ? (unsigned)fp.n_levels : 0u, lane);
+#endif
   }
   // far field: one polynomial per level
   const double *cl = fp.coef + (size_t)layer * fp.n_boxes_total * (2 * kFC);

@@ -8,6 +8,7 @@
 
 // PATTERN 0: 64 consecutive doubles.  1: 8 rows of 8, row r starts at r (neighbouring lines, 1 point apart: up to
 // 8 lanes on one address).  2: 8 rows of 8, row r starts at 9 r (disjoint windows).  3: 16 groups of 4, group g at g.
+// 7-11: rows on 8-ALIGNED windows (the candidate layout for the zones kernel's region 2), see below.
 // 4: 8 rows of 8, row r starts at 3 r.  5: all lanes one address.  6: rows at 8 r + (r & 1) (disjoint, unaligned)
 template <int PATTERN, int V>
 __global__ __launch_bounds__(256) void k(double *out, int iters) {
@@ -23,7 +24,12 @@ __global__ __launch_bounds__(256) void k(double *out, int iters) {
   else if (PATTERN == 3) idx = (lane >> 2) + (lane & 3);
   else if (PATTERN == 4) idx = 3 * row + col;
   else if (PATTERN == 5) idx = 0;
-  else idx = 8 * row + (row & 1) + col;
+  else if (PATTERN == 6) idx = 8 * row + (row & 1) + col;
+  else if (PATTERN == 7) idx = 8 * ((row * 3) & 7) + col;                  // aligned windows, a permutation of 64 consecutive
+  else if (PATTERN == 8) idx = 8 * (((row * 3) & 7) + (row >> 2)) + col;    // aligned windows, rows 4..7 one window on: two pairs share a window
+  else if (PATTERN == 9) idx = 8 * (((row * 3) & 7) + 2 * (row & 1)) + col; // aligned, spread over 10 windows, some shared
+  else if (PATTERN == 10) idx = 8 * (row >> 1) + col;                       // aligned, pairs of rows on one window (2 lanes per address)
+  else idx = 8 * (row >> 2) + col;                                          // aligned, four rows per window
   double v = 1.0 + lane * 1e-3, w = 0.5;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -68,6 +74,13 @@ int main() {
   run<6, 0>("8 rows of 8, rows 8 + (r&1) apart", d_out);
   run<3, 0>("16 groups of 4, groups 1 apart", d_out);
   run<5, 0>("all lanes one address", d_out);
+  run<7, 0>("aligned windows, permuted consecutive", d_out);
+  run<8, 0>("aligned windows, half shifted one window", d_out);
+  run<9, 0>("aligned windows, odd rows two windows on", d_out);
+  run<10, 0>("aligned windows, two rows per window", d_out);
+  run<11, 0>("aligned windows, four rows per window", d_out);
+  run<7, 23>("aligned windows, permuted consecutive", d_out);
+  run<8, 23>("aligned windows, half shifted one window", d_out);
   run<0, 23>("64 consecutive", d_out);
   run<1, 23>("8 rows of 8, rows 1 apart", d_out);
   run<2, 23>("8 rows of 8, rows 9 apart", d_out);
