@@ -155,6 +155,48 @@ __device__ inline void region2_coef(double ry, double (&q)[8]) {
   q[6] = 10.5 + ry2 * (-6. + 6. * ry2);
   q[7] = 4. * ry2 - 6.;
 }
+// The same coefficients with every Horner step as one fma (25 -> 14 instructions; <= 1 ulp from region2_coef: 1e-16
+// of a region-2 value).  For the zones kernel's rows, which rebuild the coefficients per round of eight lines; the
+// shim and the exact-mode kernels keep the reference's operation order.  The constants go through SGPR pairs
+// (fma_vvs: s_mov right where they are used): as plain fma() operands the compiler parked all 27 of them in VGPRs
+// for the whole kernel (120 -> 140 VGPRs: three waves per SIMD instead of four).
+__device__ inline double fma_vvs(double a, double b, double c_uniform) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+  return r;
+}
+__device__ inline double fma_svv(double a_uniform, double b, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "s"(a_uniform), "v"(b), "v"(c));
+  return r;
+}
+__device__ inline double mul_vs(double a, double c_uniform) {
+  double r;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c_uniform));
+  return r;
+}
+__device__ inline double add_vs(double a, double c_uniform) {
+  double r;
+  asm("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c_uniform));
+  return r;
+}
+__device__ inline double fma_v4s(double a, double c_uniform) { // 4 a + c
+  double r;
+  asm("v_fma_f64 %0, %1, 4.0, %2" : "=v"(r) : "v"(a), "s"(c_uniform));
+  return r;
+}
+__device__ inline void region2_coef_fma(double ry, double (&q)[8]) {
+  const double ry2 = ry * ry;
+  // a step with two constants is a multiply and an add (one constant-bus operand per VOP3; 4.0 is an inline constant)
+  q[0] = ry * fma_vvs(ry2, fma_vvs(ry2, add_vs(mul_vs(ry2, 0.5641896), 3.1030428), 4.6545642), 1.0578555);
+  q[1] = ry * fma_vvs(ry2, add_vs(mul_vs(ry2, 1.6925688), 0.5641896), 2.9619954);
+  q[2] = ry * add_vs(mul_vs(ry2, 1.6925688), -2.5388532);
+  q[3] = mul_vs(ry, 0.5641896);
+  q[4] = fma_vvs(ry2, fma_vvs(ry2, fma_vvs(ry2, add_vs(ry2, 6.), 10.5), 4.5), 0.5625);
+  q[5] = fma_vvs(ry2, fma_vvs(ry2, fma_v4s(ry2, 6.), 9.), -4.5);
+  q[6] = fma_vvs(ry2, add_vs(mul_vs(ry2, 6.), -6.), 10.5);
+  q[7] = fma_v4s(ry2, -6.);
+}
 __device__ inline double region2_val(const double (&q)[8], double x) {
   const double x2 = x * x;
   const double num = fma(x2, fma(x2, fma(q[3], x2, q[2]), q[1]), q[0]);

@@ -1406,6 +1406,10 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
   // element p + 1, i.e. element k + (j1 - wlo): the hot loops' address arithmetic carries no "- 1" (it cost a v_add per
   // region-2 point: the offset field of ds_add cannot be negative)
   __shared__ double s_img[NW][2][WT + 2];
+  // per wave and region (2, 4): the chunk's lines with work there, compacted in lane order -- lane id and the two run
+  // words -- written by the lanes = lines phase, read by the rows (dealing the lines to the rows with ballots and
+  // selects cost 27 VALU instructions per round of eight lines, two bpermutes fetched the run words)
+  __shared__ int s_item[NW][2][3][64];
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_groups, grp = wg - layer * n_groups;
   const int wlo = g_lo + grp * WT;
@@ -1436,6 +1440,7 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
     // runs of the lane's line inside this group, start | count << 16 (window indices <= 13010):
     // region 2 left / right (lineshape.f:503-522), region 4 left / right of the region-3 interval
     unsigned run2l, run2r, run4l, run4r;
+    int n_items2, n_items4; // lines of this chunk with region-2 / region-4 work (wave-uniform)
     {
       // ---- lane = line: which lines have work here, the interval arithmetic of every line (the walk
       // below reads it back with v_readlane: done there it was ~70 scalar instructions per line), and
@@ -1470,10 +1475,19 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
       }
       const int e0 = max(k3lo, c_lo), e1 = min(k3hi, c_hi);
       const int n3 = (act && has3) ? max(e1 - e0 + 1, 0) : 0;
-      if (__any(n3 > 0)) {
+      const bool w2 = act && ((run2l >> 16) + (run2r >> 16)) > 0, w4 = act && ((run4l >> 16) + (run4r >> 16)) > 0;
+      if (__any(n3 > 0 || w4)) {
         const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
         const double x0 = z.x0, dwp = z.dwp, inv_dwp = cold_inv_dwp(z.dwp), ryf = cold_ryf(z.ry), wa = r.wabs, we = r.wemi;
         const int ibase = j1 - wlo; // element = point + 1
+        {
+          // the cosine's argument range over the line's region-4 runs (cos_tiered), bits 30-31 of run4l (a count is
+          // < 2^14): |Im c1| = 2 ry rx is largest at the outer ends of the two runs
+          const double rx_max = fmax(fabs(xf((int)(run4l & 0xffffu)) - x0),
+                                     fabs(xf((int)(run4r & 0xffffu) + (int)(run4r >> 16) - 1) - x0)) * inv_dwp * 1.001;
+          const double ui_max = (ryf + ryf) * rx_max;
+          run4l |= (ui_max < 6.5e-3 ? 2u : (ui_max < 0.78 ? 1u : 0u)) << 30;
+        }
         for (int t = 0; __any(t < n3); ++t) {
           if (t < n3) {
             const int k = e0 + t;
@@ -1487,6 +1501,22 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
           }
         }
       }
+      // the lines with region-2 / region-4 work, compacted in lane order
+      const unsigned long long m2 = __ballot(w2), m4 = __ballot(w4);
+      n_items2 = __builtin_popcountll(m2);
+      n_items4 = __builtin_popcountll(m4);
+      if (w2) {
+        const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0u));
+        s_item[wave][0][0][at] = lane;
+        s_item[wave][0][1][at] = (int)run2l;
+        s_item[wave][0][2][at] = (int)run2r;
+      }
+      if (w4) {
+        const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m4 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m4, 0u));
+        s_item[wave][1][0][at] = lane;
+        s_item[wave][1][1][at] = (int)run4l;
+        s_item[wave][1][2][at] = (int)run4r;
+      }
     }
     // ---- regions 2 and 4, kRows lines at a time: each row of kRowLanes lanes walks the points of ONE line,
     // kRowLanes per step, with the line's data in its own registers (per-lane loads of the record fields: the four
@@ -1498,31 +1528,20 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
     {
       constexpr int kRowLanes = SR_ZONES_ROW, kRows = 64 / kRowLanes;
       const int row = lane / kRowLanes, col = lane % kRowLanes;
-      // this lane's line of the next kRows lines in `todo` (index into the chunk), -1 when there is none left
-      auto take = [&](unsigned long long &todo) {
-        int li = -1;
-#pragma unroll
-        for (int q = 0; q < kRows; ++q) {
-          if (todo) {
-            const int i = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            li = row == q ? i : li;
-          }
-        }
-        return li;
-      };
       // region 2 (lineshape.f:503-522): item t of a line: left k = a0 + t, x = xs2l - (k - il) xstep; right
       // k = b0 + (t - na), x = xs2r + (k - ir2) xstep.  Only x^2 enters, so both are t xstep + c with a per-line c.
-      for (unsigned long long todo = __ballot(act && ((run2l >> 16) + (run2r >> 16)) > 0); todo;) {
-        const int li = take(todo), ls_ = max(li, 0);
+      for (int g = 0; g < n_items2; g += kRows) {
+        const int it = min(g + row, n_items2 - 1);
+        const bool live = g + row < n_items2;
+        const int ls_ = s_item[wave][0][0][it];
         const FastRec &r = frow[base + ls_];
         const ColdRec &z = crow[base + ls_];
-        const unsigned ul = (unsigned)__shfl((int)run2l, ls_), ur = (unsigned)__shfl((int)run2r, ls_);
+        const unsigned ul = (unsigned)s_item[wave][0][1][it], ur = (unsigned)s_item[wave][0][2][it];
         const int a0 = (int)(ul & 0xffffu), na = (int)(ul >> 16), b0 = (int)(ur & 0xffffu), nb = (int)(ur >> 16);
-        const int n = li >= 0 ? na + nb : 0;
+        const int n = live ? na + nb : 0;
         const double xstep = r.xstep, wa = r.wabs, we = r.wemi;
         double q2[8];
-        region2_coef(z.ry, q2); // rebuilt per line (ColdRec): 25 flops against ~19 steps of 30 instructions
+        region2_coef_fma(z.ry, q2); // rebuilt per line (ColdRec): 25 flops against ~19 steps of 25 instructions
         const int base_idx = r.j1 - wlo; // element = point + 1
         const double c_left = fma((double)(a0 - r.il()), xstep, -z.xs2l);
         const double c_right = fma((double)(b0 - na - z.ir2()), xstep, z.xs2r);
@@ -1542,13 +1561,15 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         }
       }
       // region 4 (lineshape.f:530-546), on both sides of the region-3 interval
-      for (unsigned long long todo = __ballot(act && ((run4l >> 16) + (run4r >> 16)) > 0); todo;) {
-        const int li = take(todo), ls_ = max(li, 0);
+      for (int g = 0; g < n_items4; g += kRows) {
+        const int it = min(g + row, n_items4 - 1);
+        const bool live = g + row < n_items4;
+        const int ls_ = s_item[wave][1][0][it];
         const FastRec &r = frow[base + ls_];
         const ColdRec &z = crow[base + ls_];
-        const unsigned ul = (unsigned)__shfl((int)run4l, ls_), ur = (unsigned)__shfl((int)run4r, ls_);
-        const int a0 = (int)(ul & 0xffffu), na = (int)(ul >> 16), b0 = (int)(ur & 0xffffu), nb = (int)(ur >> 16);
-        const int n = li >= 0 ? na + nb : 0;
+        const unsigned ul = (unsigned)s_item[wave][1][1][it], ur = (unsigned)s_item[wave][1][2][it];
+        const int a0 = (int)(ul & 0xffffu), na = (int)((ul >> 16) & 0x3fffu), b0 = (int)(ur & 0xffffu), nb = (int)(ur >> 16);
+        const int n = live ? na + nb : 0;
         const int j1 = r.j1;
         CorePend P;
         P.base = j1 - wlo; // element = point + 1
@@ -1561,14 +1582,9 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         P.two_ryf = P.ryf + P.ryf;
         P.wa = r.wabs;
         P.we = r.wemi;
-        // largest |Im c1| = 2 ry rx of this round's runs (rx is largest at the outer ends of the two runs)
-        int cos_tier;
-        {
-          const WinX xf{gp.lin_start, gp.lin_delta, P.gc};
-          const double rx_max = fmax(fabs(xf(a0) - P.x0), fabs(xf(b0 + nb - 1) - P.x0)) * P.inv_dwp * 1.001;
-          const double ui_max = n > 0 ? P.two_ryf * rx_max : 0.0;
-          cos_tier = __all(ui_max < 6.5e-3) ? 2 : (__all(ui_max < 0.78) ? 1 : 0);
-        }
+        // the cosine's tier of this round: the smallest of its lines' (from the lanes = lines phase)
+        const int tier_ = live ? (int)(ul >> 30) : 2;
+        const int cos_tier = __all(tier_ == 2) ? 2 : (__all(tier_ >= 1) ? 1 : 0);
         const int n_steps = (rows_max(n) + kRowLanes - 1) / kRowLanes;
         for (int st = 0; st < n_steps; ++st) {
           const int t = col + kRowLanes * st;
