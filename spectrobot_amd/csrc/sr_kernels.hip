@@ -1392,11 +1392,23 @@ __device__ inline void core_eval4(const CorePend &P, bool on, const GridParams &
 #ifndef SR_ZONES_ROW
 #define SR_ZONES_ROW 8 // lanes per row of the region-2 / region-4 walk: eight lines at a time (16: 4.35, 8: 4.1, 4: 4.87, 32: 5.09 ms)
 #endif
-#ifndef SR_ZONES_WAVES_PER_EU
-#define SR_ZONES_ATTR
-#else
-#define SR_ZONES_ATTR __attribute__((amdgpu_waves_per_eu(SR_ZONES_WAVES_PER_EU)))
+#ifndef SR_RMAX
+#define SR_RMAX 0 // 1: the rows' step counts from the lanes = lines phase (s_rmax) instead of rows_max() per round
 #endif
+#ifndef SR_R2_SPLIT
+#define SR_R2_SPLIT 1 // region 2: the left and the right run of a line in two loops
+#endif
+#if SR_RMAX
+#define SR_RMAX_OR(lds_value, row_value) __builtin_amdgcn_readfirstlane(lds_value)
+#else
+#define SR_RMAX_OR(lds_value, row_value) rows_max(row_value)
+#endif
+// At least four waves per SIMD (<= 128 VGPRs): the kernel sits at 118-127; with 129 (one more feature in the rows)
+// the 8-wave blocks of a small shard went from two per CU to one and the shard's kernel from 0.50 to 0.63 ms.
+#ifndef SR_ZONES_WAVES_PER_EU
+#define SR_ZONES_WAVES_PER_EU 4
+#endif
+#define SR_ZONES_ATTR __attribute__((amdgpu_waves_per_eu(SR_ZONES_WAVES_PER_EU)))
 template <int WT, int NW, bool COUNT>
 __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_kernel(
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, IcIndex ix,
@@ -1410,6 +1422,9 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
   // words -- written by the lanes = lines phase, read by the rows (dealing the lines to the rows with ballots and
   // selects cost 27 VALU instructions per round of eight lines, two bpermutes fetched the run words)
   __shared__ int s_item[NW][2][3][64];
+  // longest run of each round of eight list entries: region-2 left, region-2 right, region 4 (both sides) -- the rows'
+  // step counts, wave-uniform (eight v_readlane + maxima per round when the rows worked them out themselves)
+  __shared__ int s_rmax[NW][3][8];
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_groups, grp = wg - layer * n_groups;
   const int wlo = g_lo + grp * WT;
@@ -1505,17 +1520,29 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
       const unsigned long long m2 = __ballot(w2), m4 = __ballot(w4);
       n_items2 = __builtin_popcountll(m2);
       n_items4 = __builtin_popcountll(m4);
+#if SR_RMAX
+      if (lane < 24) (&s_rmax[wave][0][0])[lane] = 0;
+#endif
       if (w2) {
         const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0u));
         s_item[wave][0][0][at] = lane;
         s_item[wave][0][1][at] = (int)run2l;
         s_item[wave][0][2][at] = (int)run2r;
+#if SR_RMAX && SR_R2_SPLIT
+        atomicMax(&s_rmax[wave][0][at >> 3], (int)(run2l >> 16));
+        atomicMax(&s_rmax[wave][1][at >> 3], (int)(run2r >> 16));
+#elif SR_RMAX
+        atomicMax(&s_rmax[wave][0][at >> 3], (int)(run2l >> 16) + (int)(run2r >> 16));
+#endif
       }
       if (w4) {
         const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m4 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m4, 0u));
         s_item[wave][1][0][at] = lane;
         s_item[wave][1][1][at] = (int)run4l;
         s_item[wave][1][2][at] = (int)run4r;
+#if SR_RMAX
+        atomicMax(&s_rmax[wave][2][at >> 3], (int)((run4l >> 16) & 0x3fffu) + (int)(run4r >> 16));
+#endif
       }
     }
     // ---- regions 2 and 4, kRows lines at a time: each row of kRowLanes lanes walks the points of ONE line,
@@ -1538,27 +1565,51 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         const ColdRec &z = crow[base + ls_];
         const unsigned ul = (unsigned)s_item[wave][0][1][it], ur = (unsigned)s_item[wave][0][2][it];
         const int a0 = (int)(ul & 0xffffu), na = (int)(ul >> 16), b0 = (int)(ur & 0xffffu), nb = (int)(ur >> 16);
-        const int n = live ? na + nb : 0;
         const double xstep = r.xstep, wa = r.wabs, we = r.wemi;
         double q2[8];
-        region2_coef_fma(z.ry, q2); // rebuilt per line (ColdRec): 25 flops against ~19 steps of 25 instructions
+        region2_coef_fma(z.ry, q2); // rebuilt per line (ColdRec): 25 flops against ~20 steps of 21 instructions
         const int base_idx = r.j1 - wlo; // element = point + 1
-        const double c_left = fma((double)(a0 - r.il()), xstep, -z.xs2l);
-        const double c_right = fma((double)(b0 - na - z.ir2()), xstep, z.xs2r);
-        int i_left = a0 + base_idx, i_right = b0 - na + base_idx;
-        asm volatile("" : "+v"(i_left), "+v"(i_right)); // keep the two sums: re-associated, they cost a v_add per point
-        const int n_steps = (rows_max(n) + kRowLanes - 1) / kRowLanes; // wave-uniform: a scalar loop counter
-        for (int st = 0; st < n_steps; ++st) {
-          const int t = col + kRowLanes * st;
-          if (t < n) {
-            const bool lf = t < na;
-            const double y = region2_val(q2, fma((double)t, xstep, lf ? c_left : c_right));
-            if (COUNT) ++n_r2;
-            const int idx = t + (lf ? i_left : i_right);
-            atomicAdd(&s_a[idx], wa * y); // return-less LDS adds: no wait for a read, runs of different lines overlap
-            atomicAdd(&s_e[idx], we * y);
+        // the two runs one after the other, t counted from each run's first point (one loop over both with the
+        // side chosen per point cost a compare and three selects per point: 25 -> 21 VALU instructions per point
+        // for ~5 % more steps)
+        auto run = [&](const int n, const int n_max, const double c, const int i0) {
+          const int n_steps = (n_max + kRowLanes - 1) / kRowLanes; // wave-uniform: a scalar loop counter
+          for (int st = 0; st < n_steps; ++st) {
+            const int t = col + kRowLanes * st;
+            if (t < n) {
+              const double y = region2_val(q2, fma((double)t, xstep, c));
+              if (COUNT) ++n_r2;
+              atomicAdd(&s_a[t + i0], wa * y); // return-less LDS adds: no wait for a read, runs of different lines overlap
+              atomicAdd(&s_e[t + i0], we * y);
+            }
+          }
+        };
+#if SR_R2_SPLIT
+        run(live ? na : 0, SR_RMAX_OR(s_rmax[wave][0][g >> 3], live ? na : 0),
+            fma((double)(a0 - r.il()), xstep, -z.xs2l), a0 + base_idx);
+        run(live ? nb : 0, SR_RMAX_OR(s_rmax[wave][1][g >> 3], live ? nb : 0),
+            fma((double)(b0 - z.ir2()), xstep, z.xs2r), b0 + base_idx);
+#else
+        {
+          const int n = live ? na + nb : 0;
+          const double c_left = fma((double)(a0 - r.il()), xstep, -z.xs2l);
+          const double c_right = fma((double)(b0 - na - z.ir2()), xstep, z.xs2r);
+          int i_left = a0 + base_idx, i_right = b0 - na + base_idx;
+          asm volatile("" : "+v"(i_left), "+v"(i_right)); // keep the two sums: re-associated, they cost a v_add per point
+          const int n_steps = (SR_RMAX_OR(s_rmax[wave][0][g >> 3], n) + kRowLanes - 1) / kRowLanes;
+          for (int st = 0; st < n_steps; ++st) {
+            const int t = col + kRowLanes * st;
+            if (t < n) {
+              const bool lf = t < na;
+              const double y = region2_val(q2, fma((double)t, xstep, lf ? c_left : c_right));
+              if (COUNT) ++n_r2;
+              const int idx = t + (lf ? i_left : i_right);
+              atomicAdd(&s_a[idx], wa * y);
+              atomicAdd(&s_e[idx], we * y);
+            }
           }
         }
+#endif
       }
       // region 4 (lineshape.f:530-546), on both sides of the region-3 interval
       for (int g = 0; g < n_items4; g += kRows) {
@@ -1585,7 +1636,7 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         // the cosine's tier of this round: the smallest of its lines' (from the lanes = lines phase)
         const int tier_ = live ? (int)(ul >> 30) : 2;
         const int cos_tier = __all(tier_ == 2) ? 2 : (__all(tier_ >= 1) ? 1 : 0);
-        const int n_steps = (rows_max(n) + kRowLanes - 1) / kRowLanes;
+        const int n_steps = (SR_RMAX_OR(s_rmax[wave][2][g >> 3], n) + kRowLanes - 1) / kRowLanes;
         for (int st = 0; st < n_steps; ++st) {
           const int t = col + kRowLanes * st;
           P.k = t < na ? a0 + t : b0 + (t - na);
