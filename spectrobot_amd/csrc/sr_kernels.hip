@@ -1424,7 +1424,9 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
   __shared__ int s_item[NW][2][3][64];
   // longest run of each round of eight list entries: region-2 left, region-2 right, region 4 (both sides) -- the rows'
   // step counts, wave-uniform (eight v_readlane + maxima per round when the rows worked them out themselves)
+#if SR_RMAX
   __shared__ int s_rmax[NW][3][8];
+#endif
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_groups, grp = wg - layer * n_groups;
   const int wlo = g_lo + grp * WT;
@@ -1783,11 +1785,15 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
     static const int nw_env = [] { const char *e = getenv("SR_ZONES_NW"); return e ? atoi(e) : 0; }();
     if (nw_env == 1 || nw_env == 2 || nw_env == 4 || nw_env == 8) {
       switch (nw_env) { case 1: SR_ZONES(1); break; case 2: SR_ZONES(2); break; case 4: SR_ZONES(4); break; default: SR_ZONES(8); }
-    } else if (waves512 >= 3 * 4096)
+    } else if (waves512 >= 3 * 1024)
+      // Chosen by the PIPELINED step (zones beside the far-field and wings kernels), not by the kernel alone: on
+      // config 2 (round 3) 1/8 shard 2000 images: NW = 1 / 2 / 4 / 8 -> 1.065 / 0.928 / 0.870 / 0.923 ms per step
+      // (alone: 0.765 / 0.550 / 0.520 / 0.518); 1/4 shard 3920 images: 1.554 / 1.588 / 1.589 / 1.602; 1/2 shard:
+      // 2.848 / 2.881 / 2.841 / 2.900; whole grid 15680: 5.49 / 5.52 (alone 3.53 / 3.34: two waves per image have
+      // the shorter tail, but beside the other kernels the tail is filled anyway).  5, 6 and 7 waves (14 chunks per
+      // image = 2 x 7) measured 0.68 / 0.81 / 0.59 ms alone on the 1/8 shard: not instantiated.
       SR_ZONES(1);
-    else if (waves512 >= 3 * 2048)
-      SR_ZONES(2);
-    else if (waves512 >= 3 * 1024)
+    else if (waves512 >= 3 * 512)
       SR_ZONES(4);
     else
       SR_ZONES(8);
