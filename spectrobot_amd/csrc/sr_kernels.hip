@@ -1785,15 +1785,19 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
     static const int nw_env = [] { const char *e = getenv("SR_ZONES_NW"); return e ? atoi(e) : 0; }();
     if (nw_env == 1 || nw_env == 2 || nw_env == 4 || nw_env == 8) {
       switch (nw_env) { case 1: SR_ZONES(1); break; case 2: SR_ZONES(2); break; case 4: SR_ZONES(4); break; default: SR_ZONES(8); }
-    } else if (waves512 >= 3 * 1024)
-      // Chosen by the PIPELINED step (zones beside the far-field and wings kernels), not by the kernel alone: on
-      // config 2 (round 3) 1/8 shard 2000 images: NW = 1 / 2 / 4 / 8 -> 1.065 / 0.928 / 0.870 / 0.923 ms per step
-      // (alone: 0.765 / 0.550 / 0.520 / 0.518); 1/4 shard 3920 images: 1.554 / 1.588 / 1.589 / 1.602; 1/2 shard:
-      // 2.848 / 2.881 / 2.841 / 2.900; whole grid 15680: 5.49 / 5.52 (alone 3.53 / 3.34: two waves per image have
-      // the shorter tail, but beside the other kernels the tail is filled anyway).  5, 6 and 7 waves (14 chunks per
-      // image = 2 x 7) measured 0.68 / 0.81 / 0.59 ms alone on the 1/8 shard: not instantiated.
+    } else if (waves512 >= 3 * 4096)
       SR_ZONES(1);
+    else if (waves512 >= 3 * 2048)
+      SR_ZONES(2);
     else if (waves512 >= 3 * 512)
+      // Judged by the PIPELINED step (zones beside the far-field and wings kernels), not by the kernel alone: on
+      // config 2 (round 3) 1/8 shard, 2000 images: NW = 1 / 2 / 4 / 8 -> 1.065 / 0.928 / 0.870 / 0.923 ms per step
+      // (alone: 0.765 / 0.550 / 0.520 / 0.518) -- round 2 took 8 below 3072 images; 1/4 shard, 3920 images:
+      // 1.554 / 1.588 / 1.589 / 1.602; 1/2 shard: 2.848 / 2.881 / 2.841 / 2.900; whole grid, 15680: 5.49 / 5.52
+      // (alone 3.53 / 3.34: two waves per image have the shorter tail, but beside the other kernels the tail is
+      // filled anyway).  One wave from 3072 images up looked as good on config 2 but left a sparse 20000-point
+      // shard (0.3 lines per point, 3300 images) at 2.8 instead of 1.5 ms: it is the WAVES that must fill the chip.
+      // 5, 6 and 7 waves (14 chunks per image = 2 x 7) measured 0.68 / 0.81 / 0.59 ms alone on the 1/8 shard.
       SR_ZONES(4);
     else
       SR_ZONES(8);
