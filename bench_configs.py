@@ -7,8 +7,8 @@ headline: that is configs[1], bench.py's default).
             batched on one coefficient op, spectral window sharded over the ranks, one all-gather
   config 3  radtran_3Dvs2D_sza30-80 shape: 8 solar zenith angles = 8 independent atmospheres (vibrational
             temperatures follow the illumination) x a set of 8 rays, 2e5-point grid, 2e5 lines, per-layer
-            Jacobians w.r.t. T (central differences of the coefficient op + forward sensitivity) and w.r.t.
-            the VMR of every layer (analytic)
+            Jacobians w.r.t. T (finite differences of the coefficient op, DT_SCHEME below, + the recursion's
+            sensitivity) and w.r.t. the VMR of every layer (analytic)
   config 4  retrieval loop: HCN (mol 23) + CH4 on one grid, VIMS-like bands, Gauss-Newton /
             Levenberg-Marquardt over up to 20 iterations with the reference's stopping rule; a step is one
             iteration (forward model + Jacobians of all LOS + algebra)
@@ -24,6 +24,17 @@ HCN_MM = 27.010899          # molparam.txt HCN 124
 HCN_ISO_RATIO = 0.985114
 HCN_LEVEL_ENERGIES = np.array([0., 711.98, 1411.41, 2096.85, 3311.48, 4004.17])   # HCN-like level ladder, cm^-1
 
+
+# d/dT of the coefficients in configs[3]: engine.coefficients_dT.  "forward": two coefficient ops per set -- the
+# quotient (c(T + 0.002 K) - c(T)) / 0.002 K with the region boundaries of the perturbed op frozen at T, 3e-4..5e-4 of a
+# layer's largest derivative from the frozen central reference, i.e. the accuracy class of rounds 1-3's three-op central
+# difference with moving boundaries (2e-4..3e-4: tests/test_gpu_configs.py::test_temperature_derivative_schemes);
+# SR_DT_SCHEME=central: three ops, frozen, 3e-5..5e-5.  The line reports the other scheme's time beside its own.
+import os as _os
+DT_SCHEME = _os.environ.get("SR_DT_SCHEME", "forward")
+DT_SCHEME_NOTE = ("forward difference of the coefficient op, 0.002 K, region boundaries frozen at T: two ops per set"
+                  if DT_SCHEME == "forward" else
+                  "central differences of the coefficient op, +-0.05 K, region boundaries frozen at T: three ops per set")
 
 def ch4_case(n_lines, n_grid, n_layers=80, n_levels=12, config_id=2, w0=2975.0):
     """SURVEY 8-d CH4 case: grid, lines, atmosphere, level energies."""
@@ -158,11 +169,7 @@ def config3_3d(args, rank, world, info, base):
         Lr = syn.limb_los_3d(atm["z"], atm["nd"], [vm], tz, sza, az)
         los = engine.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"], col_scale=[syn.CH4_ISO_RATIO])
         a = step_atmosphere(atm, Lr["seg_alt_layer"], Lr["seg_mu"])
-        co = ls.abscoeff_layers(a["temps"], a["press"], tvib=a["tvib"])
-        ap = ls.abscoeff_layers(a["temps"] + 0.05, a["press"], tvib=a["tvib"])
-        am = ls.abscoeff_layers(a["temps"] - 0.05, a["press"], tvib=a["tvib"])
-        dco = ((ap[0] - am[0]) / 0.1, (ap[1] - am[1]) / 0.1)
-        del ap, am
+        co, dco = engine.coefficients_dT(ls, a["temps"], a["press"], tvib=a["tvib"], scheme=DT_SCHEME)
         W = layer_vmr_weights(atm["z"], Lr["alt"])
         return engine.limb_rays_jacobians(co, los, dcoeffs=dco, par_gas=pg, par_w=W, seg_jac_row=Lr["seg_alt_layer"],
                                           n_jac_rows=args.layers), len(Lr["seg_layer"])
@@ -179,8 +186,8 @@ def config3_3d(args, rank, world, info, base):
                ms_per_step=dt * 1e3, scaling="weak" if world > 1 else "n/a",
                config={"workload": "3-D atmosphere (BASELINE configs[3], use_tangent_sza = False): %d tangent SZA x %d rays fanned in "
                                    "azimuth, %d lines x %d-pt grid, a coefficient row per LOS step (%d steps per set instead of %d "
-                                   "altitude layers), d/dT_k per altitude layer (central differences of the coefficient op over the "
-                                   "steps) and d/dVMR_k per level" % (len(szas), n_rays, n_lines, n_grid, n_steps, args.layers),
+                                   "altitude layers), d/dT_k per altitude layer (%s, over the steps) and d/dVMR_k per level"
+                                   % (len(szas), n_rays, n_lines, n_grid, n_steps, args.layers, DT_SCHEME_NOTE),
                        "device": info["name"]},
                checksum=float(res[0].sum().item()), los_steps_per_set=n_steps)
     if rank == 0:
@@ -277,11 +284,8 @@ def main(args):
         W = layer_vmr_weights(atm["z"], Lr["alt"])
         my = szas[rank::world]                       # independent ray batches: one SZA set per rank, no collective
 
-        def coef3(a):
-            co = ls.abscoeff_layers(a["temps"], a["press"], tvib=a["tvib"])
-            ap = ls.abscoeff_layers(a["temps"] + 0.05, a["press"], tvib=a["tvib"])
-            am = ls.abscoeff_layers(a["temps"] - 0.05, a["press"], tvib=a["tvib"])
-            return co, ((ap[0] - am[0]) / 0.1, (ap[1] - am[1]) / 0.1)
+        def coef3(a, scheme=DT_SCHEME):
+            return engine.coefficients_dT(ls, a["temps"], a["press"], tvib=a["tvib"], scheme=scheme)
 
         pg = np.zeros(args.layers, np.int32)
 
@@ -295,6 +299,24 @@ def main(args):
 
         dt, res = _sync_time(step, max(1, args.steps // 4), min(args.warmup, 1))
         extra = {}
+
+        def step_central():
+            res_ = None
+            for sza in my:
+                co, dco = coef3(sza_atmosphere(atm, sza), "central")
+                res_ = engine.limb_rays_jacobians(co, los, dcoeffs=dco, par_gas=pg, par_w=W)
+            return res_
+
+        dt_c, res_c = _sync_time(step_central, max(1, args.steps // 8), 1)
+        if rank == 0:
+            jt, jt_c = res[1], res_c[1]      # temperature Jacobians of the last set, both schemes
+            extra["temperature_derivative"] = {
+                "scheme": DT_SCHEME_NOTE, "coefficient_ops_per_set": 2 if DT_SCHEME == "forward" else 3,
+                "ms_per_step_with_central_differences": dt_c * 1e3,
+                "spectra_per_s_with_central_differences": len(szas) * n_rays / dt_c if world in (1, len(szas)) else None,
+                "max_rel_dev_of_T_jacobian_from_central": float(((jt - jt_c).abs().amax() / jt_c.abs().amax()).item())}
+            del jt, jt_c
+        del res_c
         if rank == 0:
             import bench as B
             a0 = sza_atmosphere(atm, my[0])
@@ -318,8 +340,9 @@ def main(args):
                                     (Lr["seg_off"], Lr["seg_layer"], B.cpu_columns(Lr, syn.CH4_ISO_RATIO)))
                 # the oracle leg is ONE coefficient op + the radiances of the set's 8 rays; a set with its temperature
                 # Jacobian costs three ops (T, T +- dT): the Jacobian recursions themselves are not in the CPU figure
-                cb["value"] = cb["value"] / 3.0
-                cb["sample"] += "; /3: a set needs the coefficient op at T, T + dT, T - dT (the CPU leg runs one and no Jacobian recursion)"
+                n_ops = 2.0 if DT_SCHEME == "forward" else 3.0
+                cb["value"] = cb["value"] / n_ops
+                cb["sample"] += "; /%d: a set needs the coefficient op at T and at T + dT%s (the CPU leg runs one and no Jacobian recursion)" % (n_ops, "" if n_ops == 2 else " and T - dT")
                 extra["cpu_baseline"] = cb
                 extra["speedup_vs_cpu_baseline"] = (len(szas) * n_rays / dt) / cb["value"]
         out = dict(base, **extra)
@@ -327,9 +350,9 @@ def main(args):
                    value=len(szas) * n_rays / dt if world == len(szas) or world == 1 else len(my) * n_rays * world / dt,
                    ms_per_step=dt * 1e3, scaling="weak" if world > 1 else "n/a",
                    config={"workload": "3D-atmosphere ray sets (BASELINE configs[3]): %d SZA x %d rays, %d lines x %d-pt grid x %d "
-                                       "layers, d/dT_k (central differences of the coefficient op) and d/dVMR_k (analytic) for "
+                                       "layers, d/dT_k (%s) and d/dVMR_k (analytic) for "
                                        "every layer; SZA sets are independent batches (split over ranks, no collective)"
-                                       % (len(szas), n_rays, n_lines, n_grid, args.layers), "device": info["name"]},
+                                       % (len(szas), n_rays, n_lines, n_grid, args.layers, DT_SCHEME_NOTE), "device": info["name"]},
                    checksum=float(res[0].sum().item()), jacobian_gb_per_sza=(res[1].numel() + res[2].numel()) * 8 / 1e9)
     elif args.config == 4:
         scene = two_gas_scene(40000, 8000, 60000, 60)

@@ -136,6 +136,16 @@ int sr_lineset_create(const sr_lines_desc *lines, const sr_isomolec_desc *iso,
                       int64_t *n_kept);
 int sr_lineset_destroy(sr_lineset *ls);
 
+/* Finite differences in temperature (no reference counterpart: the reference has no temperature Jacobian,
+ * spect_main_module.py:300-306 is commented out).  The Humlicek region boundaries of a (line, layer) are index
+ * computed (nint, lineshape.f:443-490) and the regions disagree by 1e-5..1e-4 at their seams, so c(T + dT) - c(T)
+ * jumps wherever a boundary moves by a point: spikes of (1e-5 y) / dT in a difference quotient.  After this call
+ * the coefficient calls on `ls` place il, ir, il2, ir2 and the region-3 interval of every (line, layer) as at the
+ * temperatures temps_bounds[n_layers] (HOST, copied) while every width, running x and weight follows the call's
+ * own temperatures: c(T + dT) and c(T) then share their region boundaries and the quotient is smooth, also for
+ * a one-sided difference with a small dT.  temps_bounds == NULL or n_layers == 0 restores the default. */
+int sr_lineset_set_bounds_temps(sr_lineset *ls, const double *temps_bounds, int n_layers);
+
 /* Layer stack (the Temps / Press lists of make_abscoeff_isomolec,
  * spect_main_module.py:1880, plus level.local_vibtemp, :2065). Host pointers.
  * tvib: [n_levels][n_layers] or NULL for LTE (:2062-2063).  q_part: [n_layers]

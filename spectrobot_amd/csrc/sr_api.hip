@@ -310,6 +310,7 @@ struct sr_lineset {
   int first_x0 = 0, first_n = 0; // IcIndex table domain
   CoefWork own_work;
   CoefWork *work = nullptr;      // &own_work, or the parent's for a per-level sub-lineset
+  std::vector<double> bounds_temps; // sr_lineset_set_bounds_temps: empty = boundaries at the call's own temperatures
 };
 
 extern "C" {
@@ -619,6 +620,18 @@ int sr_lineset_create(const sr_lines_desc *ld, const sr_isomolec_desc *iso, cons
   return SR_OK;
 }
 
+int sr_lineset_set_bounds_temps(sr_lineset *ls, const double *temps_bounds, int n_layers) {
+  if (!ls || n_layers < 0) return SR_ERR_ARG;
+  if (!temps_bounds || n_layers == 0) {
+    ls->bounds_temps.clear();
+    return SR_OK;
+  }
+  for (int k = 0; k < n_layers; ++k)
+    if (!(temps_bounds[k] > 0.0)) return SR_ERR_ARG;
+  ls->bounds_temps.assign(temps_bounds, temps_bounds + n_layers);
+  return SR_OK;
+}
+
 int sr_lineset_destroy(sr_lineset *ls) {
   if (!ls) return SR_OK;
   (void)hipDeviceSynchronize(); // work of the last calls may still be in flight on the internal streams
@@ -712,7 +725,12 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   }
 
   // per-layer scalars (host, fp64)
-  const size_t hl_doubles = (size_t)nl * (5 + npop);
+  const size_t hl_doubles = (size_t)nl * (7 + npop);
+  const bool frozen = !ls->bounds_temps.empty(); // sr_lineset_set_bounds_temps
+  if (frozen && (int)ls->bounds_temps.size() != nl) {
+    g_err = "sr_lineset_set_bounds_temps was given another number of layers than this call";
+    return SR_ERR_ARG;
+  }
   const size_t hl_bytes = sizeof(double) * hl_doubles + sizeof(int) * 3 * (size_t)nl; // + pole margins pm, pm_src, widest zone
   // Table set of this call and the stream its preparation runs on.  With overlap, call c + 1
   // prepares set (c + 1) % 2 on prep_st while the kernels of call c (which the caller's stream is
@@ -737,7 +755,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   DevBuf &d_fast = w.d_fast[b], &d_cold = w.d_cold[b];
   int rc = SL.prepare(hl_bytes);
   if (rc) return rc;
-  double *T = SL.host<double>(), *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *ltr = sq + nl, *pop = ltr + nl;
+  double *T = SL.host<double>(), *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *ltr = sq + nl, *ltrb = ltr + nl,
+         *sqb = ltrb + nl, *pop = sqb + nl;
   std::vector<double> q(nl);
   if (atm->q_part) {
     std::copy(atm->q_part, atm->q_part + nl, q.begin());
@@ -751,6 +770,11 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     tr[k] = kTref / T[k];                                                     // :1972
     sq[k] = std::sqrt(2 * kAvogadro * kKcgs * T[k] * kLn2 / ls->mm);          // :1984
     ltr[k] = std::log(tr[k]);
+    {
+      const double Tb = frozen ? ls->bounds_temps[k] : T[k]; // where the region boundaries are placed
+      ltrb[k] = std::log(kTref / Tb);
+      sqb[k] = std::sqrt(2 * kAvogadro * kKcgs * Tb * kLn2 / ls->mm);
+    }
     {
       // pole margin of the far-field expansions: the region-1 rational has its poles at
       // |x| = sqrt(1/2 + ry^2), i.e. within 0.71 dw' of the line centre on the real axis
@@ -784,7 +808,9 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   if (rc) return rc;
   LayersDev A;
   const double *dl = SL.d.as<double>();
-  A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.ltrat = dl + 4 * nl; A.pop = dl + 5 * nl;
+  A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.ltrat = dl + 4 * nl;
+  A.ltrat_b = dl + 5 * nl; A.sqk_b = dl + 6 * nl; A.pop = dl + 7 * nl;
+  A.frozen = frozen ? 1 : 0;
   A.n_layers = nl; A.n_pop = npop;
   const int *d_pm = reinterpret_cast<const int *>(dl + hl_doubles);
   const int *zmax_dev = d_pm + 2 * nl; // [n_layers] widest zone (host bound, see above)

@@ -103,7 +103,17 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
 
   const int ic = L.ic[ln];
   WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, ic)};
-  const Bounds B = humliv_bounds(xf, kImxsig, x0, lw, dwp);
+  Bounds B = humliv_bounds(xf, kImxsig, x0, lw, dwp), B0 = B;
+  double dwp0 = dwp;
+  if (A.frozen) {
+    // sr_lineset_set_bounds_temps: the region boundaries (indices) as at the layer's boundary temperature, every
+    // width and running x at the call's own -- c(T + dT) and c(T) then share their seams
+    const double lw_b = exp_bounded(fmin(fmax(L.t_dep[ln] * A.ltrat_b[k], -700.0), 700.0)) * (L.air_broad[ln] * A.p_atm[k]);
+    dwp0 = x0 / kCcgs * A.sqk_b[k] / A.sqrt_ln2;
+    B0 = humliv_bounds(xf, kImxsig, x0, lw_b, dwp0);
+    B.il = B0.il; B.ir = B0.ir; B.il2 = B0.il2; B.ir2 = B0.ir2;
+    B.xr = div_with(xf(B.ir) - x0, dwp, B.inv_dwp); // lineshape.f:471 at the frozen ir
+  }
 
   FastRec r;
   r.xl = B.xl;
@@ -135,7 +145,13 @@ __global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, G
     // passes the whole index range.
     const int zl = r.j1 + B.il - 1, zh = r.j1 + B.ir - 1;
     if (__any(valid && zl <= cold_hi && zh >= cold_lo)) {
-      const ColdRec c = make_cold(B, dwp, x0, xf);
+      ColdRec c = make_cold(B0, dwp0, x0, xf); // il2 | ir2 and the region-3 interval (at the boundary temperature)
+      if (A.frozen) {
+        c.ry = B.ry;
+        c.dwp = dwp;
+        c.xs2l = div_with(x0 - xf(B.il), dwp, B.inv_dwp);  // lineshape.f:504
+        c.xs2r = div_with(xf(B.ir2) - x0, dwp, B.inv_dwp); // :514
+      }
       const uint4 *cp = reinterpret_cast<const uint4 *>(&c);
       uint4 *gc = reinterpret_cast<uint4 *>(cold + o);
       // staged like the fast records: 64 x 48 bytes, consecutive in the table, 1 KB per store instruction

@@ -19,6 +19,8 @@ struct LayersDev {
   const double *temps, *p_atm, *trat, *sqk; // T, P[atm], 296/T, sqrt(2 N_A k T ln2 / MM)
   const double *ltrat;                      // log(296/T): (296/T)^n = exp(n log(296/T)), a third of pow()'s instructions
   const double *pop;                        // [n_layers][n_pop] level populations / Q
+  const double *ltrat_b, *sqk_b;            // the same two at the temperatures the region BOUNDARIES are placed at
+  int frozen;                               // (sr_lineset_set_bounds_temps), used when frozen != 0
   int n_layers, n_pop;
   double sqrt_ln2, sqrt_pi_ln2;
 };

@@ -130,6 +130,16 @@ class LineSet(object):
                                          C.c_void_p(em.data_ptr()), _stream_ptr()), "sr_abscoeff_layers_dev")
         return ab, em
 
+    def set_bounds_temps(self, temps=None):
+        """Place the Humlicek region boundaries of the next coefficient calls as at `temps` [n_layers] (None: at each
+        call's own temperatures again): sr_lineset_set_bounds_temps.  For finite differences in T: c(T + dT) and c(T)
+        then share their index-computed seams and the difference quotient is smooth (coefficients_dT)."""
+        if temps is None:
+            check(lib.sr_lineset_set_bounds_temps(self._h, None, 0), "sr_lineset_set_bounds_temps")
+        else:
+            t, tp = _d(temps)
+            check(lib.sr_lineset_set_bounds_temps(self._h, tp, int(t.size)), "sr_lineset_set_bounds_temps")
+
     def gcoeff_layers(self, temps, press, level=0, g_lo=0, g_hi=None):
         """Per-ctype G-coefficient spectra of one level at every (P, T): CUDA float64
         [3, n_layers, g_hi-g_lo], ctype 0 sp_emission, 1 ind_emission, 2 absorption
@@ -449,20 +459,56 @@ def gas_layer_jacobian(abs_mix, emi_mix, abs_g, emi_g, dratio_dx, seg_off, seg_l
                                    seg_off, seg_layer, seg_col)
 
 
+def coefficients_dT(ls, temps, press, tvib=None, q_part=None, g_lo=0, g_hi=None, scheme="central", dT=None,
+                    coeffs=None, frozen=True):
+    """(abs, emi) at T and their derivatives with respect to each layer's kinetic temperature (pressure and, in
+    non-LTE, the vibrational temperatures held fixed; with q_part=None the partition sum follows T).  The reference
+    has no temperature Jacobian (spect_main_module.py:300-306 is commented out): build's definition, by finite
+    differences of the coefficient op.
+
+    frozen (default): the perturbed ops place their Humlicek region boundaries as at T (LineSet.set_bounds_temps).
+    The regions disagree by 1e-5..1e-4 at their index-computed seams; with boundaries that move with T a difference
+    quotient carries a spike of (1e-5 y) / dT wherever a seam crosses a point.  What remains non-smooth in T is the
+    reference's single-precision cmplx(ry, -rx) (lineshape.f:529): a staircase of ~1e-7 of a core value, i.e. noise of
+    ~1e-7 |c| / dT in any quotient -- which is what bounds dT from below.
+      scheme "central" (default, THREE coefficient ops): (c(T + dT) - c(T - dT)) / 2 dT, dT = 0.05 K: ~3e-5 of a
+        layer's largest derivative (2e-4 with moving boundaries, frozen=False: rounds 1-3's definition).
+      scheme "forward" (TWO ops): (c(T + dT) - c(T)) / dT, dT = 0.002 K: ~5e-4 (truncation dT/2 |c''|, with c'' / c'
+        up to 0.3 / K from level populations and Doppler cores, against the staircase noise): good for a
+        Gauss-Newton step, a third cheaper.
+    tests/test_gpu_configs.py::test_temperature_derivative_schemes measures the three against each other."""
+    temps = np.ascontiguousarray(temps, dtype=np.float64)
+    kw = dict(tvib=tvib, q_part=q_part, g_lo=g_lo, g_hi=g_hi)
+    if scheme not in ("forward", "central"):
+        raise ValueError("scheme must be 'forward' or 'central'")
+    if coeffs is None:
+        coeffs = ls.abscoeff_layers(temps, press, **kw)
+    if frozen:
+        ls.set_bounds_temps(temps)
+    try:
+        if scheme == "forward":
+            dT = 0.002 if dT is None else dT
+            a_p, e_p = ls.abscoeff_layers(temps + dT, press, **kw)
+            return coeffs, ((a_p - coeffs[0]) / dT, (e_p - coeffs[1]) / dT)
+        dT = 0.05 if dT is None else dT
+        a_p, e_p = ls.abscoeff_layers(temps + dT, press, **kw)
+        a_m, e_m = ls.abscoeff_layers(temps - dT, press, **kw)
+        return coeffs, ((a_p - a_m) / (2.0 * dT), (e_p - e_m) / (2.0 * dT))
+    finally:
+        if frozen:
+            ls.set_bounds_temps(None)
+
+
 def temperature_jacobian(ls, temps, press, seg_off, seg_layer, seg_col, tvib=None, q_part=None, dT=0.05,
                          g_lo=0, g_hi=None, coeffs=None):
     """d rad / d T_k [n_rays, n_layers, n_pts] for the kinetic temperature of every layer (pressure,
     columns and, in non-LTE, the vibrational temperatures held fixed): the coefficient op at T + dT
-    and T - dT (central differences of the layer's own abs / emi; with q_part=None the partition sum
-    follows T), then the forward sensitivity of the radiance recursion.  `coeffs` = (abs, emi) at T
+    and T - dT (coefficients_dT: central differences of the layer's own abs / emi with the region boundaries
+    frozen at T; with q_part=None the partition sum follows T), then the forward sensitivity of the radiance
+    recursion.  `coeffs` = (abs, emi) at T
     if already computed.  The reference has no temperature Jacobian: build's definition."""
-    temps = np.ascontiguousarray(temps, dtype=np.float64)
-    if coeffs is None:
-        coeffs = ls.abscoeff_layers(temps, press, tvib=tvib, q_part=q_part, g_lo=g_lo, g_hi=g_hi)
-    a_p, e_p = ls.abscoeff_layers(temps + dT, press, tvib=tvib, q_part=q_part, g_lo=g_lo, g_hi=g_hi)
-    a_m, e_m = ls.abscoeff_layers(temps - dT, press, tvib=tvib, q_part=q_part, g_lo=g_lo, g_hi=g_hi)
-    dabs = (a_p - a_m) / (2.0 * dT)
-    demi = (e_p - e_m) / (2.0 * dT)
+    coeffs, (dabs, demi) = coefficients_dT(ls, temps, press, tvib=tvib, q_part=q_part, g_lo=g_lo, g_hi=g_hi,
+                                           scheme="central", dT=dT, coeffs=coeffs)
     return radiance_layer_jacobian(coeffs[0], coeffs[1], dabs, demi, seg_off, seg_layer, seg_col)
 
 

@@ -365,6 +365,45 @@ if world > 1:
     assert two[0]["hist"] == two[1]["hist"] and two[0]["x"] == two[1]["x"]      # the ranks agree bit for bit
 
 
+def test_temperature_derivative_schemes(eng):
+    """engine.coefficients_dT: finite differences of the coefficient op in T with the region boundaries of the
+    perturbed ops frozen at T (sr_lineset_set_bounds_temps).  Reference value: the frozen central difference of
+    +-0.01 K.  (i) The default (frozen central, +-0.05 K) agrees with it to ~3e-5 of a layer's largest derivative,
+    (ii) rounds 1-3's central difference with boundaries that move with T to ~2e-4 (the seams: 1e-5..1e-4 steps of a
+    line's value over 0.1 K), (iii) the two-op forward difference (0.002 K) to ~5e-4 (its truncation against the
+    1e-7 staircase of the reference's single-precision cmplx(ry, -rx)).  (iv) Frozen at its own temperatures a call
+    reproduces the unfrozen call bit for bit; another layer count than the frozen one is refused."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2990.0, 5e-4, 30000)
+    L = syn.make_lines(20000, grid, seed=5, n_levels=12, config_id=2)
+    atm = syn.make_atmosphere(12, 12)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    T, P, tv = atm["temps"], atm["press"], atm["tvib"]
+    co, (da_ref, de_ref) = eng.coefficients_dT(ls, T, P, tvib=tv, scheme="central", dT=0.01)
+    _, (da_c, de_c) = eng.coefficients_dT(ls, T, P, tvib=tv, coeffs=co)
+    _, (da_m, de_m) = eng.coefficients_dT(ls, T, P, tvib=tv, coeffs=co, frozen=False)
+    _, (da_f, de_f) = eng.coefficients_dT(ls, T, P, tvib=tv, coeffs=co, scheme="forward")
+    ls.set_bounds_temps(T)
+    try:
+        a_0, e_0 = ls.abscoeff_layers(T, P, tvib=tv)
+        with pytest.raises(RuntimeError):
+            ls.abscoeff_layers(T[:5], P[:5], tvib=tv[:, :5])
+    finally:
+        ls.set_bounds_temps(None)
+    assert torch.equal(a_0, co[0]) and torch.equal(e_0, co[1])
+
+    def rel(x, y):  # per layer, relative to the layer's largest derivative
+        return float(((x - y).abs().amax(dim=1) / y.abs().amax(dim=1)).max())
+    print("against the frozen central difference of 0.01 K: frozen central 0.05 K %.1e %.1e, moving central %.1e %.1e, "
+          "frozen forward 0.002 K %.1e %.1e" % (rel(da_c, da_ref), rel(de_c, de_ref), rel(da_m, da_ref), rel(de_m, de_ref),
+                                               rel(da_f, da_ref), rel(de_f, de_ref)))
+    assert rel(da_c, da_ref) < 1e-4 and rel(de_c, de_ref) < 1e-4
+    assert rel(da_m, da_ref) < 1e-3 and rel(de_m, de_ref) < 1e-3
+    assert rel(da_f, da_ref) < 2e-3 and rel(de_f, de_ref) < 2e-3
+    assert rel(da_c, da_ref) < rel(da_m, da_ref)      # freezing the seams is what makes the quotient smooth
+
+
 def test_config3_3d_path_per_step_state(eng, oracle):
     """configs[3] in its 3-D form (radtran_3Dvs2D_sza30-80_test.py:353-379, use_tangent_sza = False): a coefficient
     row per LOS step with (P, T, T_vib) at the step's own local SZA, Jacobians per ALTITUDE layer.  (a) With a state
