@@ -702,6 +702,16 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     const int nl_max = (int)std::max<size_t>(1, table_budget / per_layer);
     if (nl > nl_max) {
       const size_t n_pts_all = (size_t)(g_hi - g_lo);
+      // sr_lineset_set_bounds_temps: every batch sees its own slice of the boundary temperatures
+      const std::vector<double> bounds_all = ls->bounds_temps;
+      if (!bounds_all.empty() && (int)bounds_all.size() != nl) {
+        g_err = "sr_lineset_set_bounds_temps was given another number of layers than this call";
+        return SR_ERR_ARG;
+      }
+      struct Restore {
+        sr_lineset *ls; const std::vector<double> &all;
+        ~Restore() { ls->bounds_temps = all; }
+      } restore{ls, bounds_all};
       for (int k0 = 0; k0 < nl; k0 += nl_max) {
         sr_layers_desc sub = *atm;
         sub.n_layers = std::min(nl_max, nl - k0);
@@ -716,6 +726,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
                       tv.begin() + (size_t)lv * sub.n_layers);
           sub.tvib = tv.data();
         }
+        if (!bounds_all.empty()) ls->bounds_temps.assign(bounds_all.begin() + k0, bounds_all.begin() + k0 + sub.n_layers);
         const int rc = coef_op(ls, &sub, g_lo, g_hi, abs_out + (size_t)k0 * n_pts_all,
                                emi_out + (size_t)k0 * n_pts_all, stream, W);
         if (rc) return rc;

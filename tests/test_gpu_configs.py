@@ -392,6 +392,16 @@ def test_temperature_derivative_schemes(eng):
     finally:
         ls.set_bounds_temps(None)
     assert torch.equal(a_0, co[0]) and torch.equal(e_0, co[1])
+    # layer batches (a long LOS: the 3-D path of configs[3]) see their own slice of the boundary temperatures
+    ls.set_bounds_temps(T)
+    eng.set_table_budget(3 * ls.n_kept * 208)
+    try:
+        a_b, e_b = ls.abscoeff_layers(T + 0.002, P, tvib=tv)
+    finally:
+        eng.set_table_budget(48 << 30)
+    a_u, e_u = ls.abscoeff_layers(T + 0.002, P, tvib=tv)
+    ls.set_bounds_temps(None)
+    assert torch.equal(a_b, a_u) and torch.equal(e_b, e_u)
 
     def rel(x, y):  # per layer, relative to the layer's largest derivative
         return float(((x - y).abs().amax(dim=1) / y.abs().amax(dim=1)).max())
