@@ -5,7 +5,8 @@ s=${1:-3/8}
 out=gpurun_out/tl
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-timeout -k 10 200 rocprofv3 --kernel-trace -d $out/kt -o kt -- python3 bench.py --shard $s --cpu-seconds 0 --steps 30 --warmup 5 > $out/kt.log 2>&1
+sh="--shard $s"; [ "$s" = "full" ] && sh=""   # full: the whole grid
+timeout -k 10 200 rocprofv3 --kernel-trace -d $out/kt -o kt -- python3 bench.py $sh --cpu-seconds 0 --steps 30 --warmup 5 > $out/kt.log 2>&1
 echo "rc=$?"
 python3 - <<PY
 import sqlite3, re
