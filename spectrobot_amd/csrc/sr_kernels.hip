@@ -921,44 +921,36 @@ __global__ __launch_bounds__(64) void sr_s2m_kernel(const FastRec *__restrict__ 
   if (COUNT) count_add(cnt, kCntS2M, n_lines, lane);
 }
 
-// Upward pass: one thread per (widest-level source box, layer, side, weight) builds every wider level of its
-// subtree (15 boxes at 5 levels), children before parents, the two children's moments in registers.  70 us on
-// config 2; a block per subtree with a thread per order, reading the children from memory inside the sums, took
-// 440 us.  n_src[l - 1] = 2 n_src[l] (host).
-__global__ __launch_bounds__(64) void sr_m2m_kernel(FarParams fp) {
-  const int top = fp.n_levels - 1;
+// One thread per (parent box of level l, layer, side, weight); one launch per level, narrow to wide (round 3: one
+// thread per widest-level subtree walked all its 15 boxes in sequence -- 500 waves with 15 dependent rounds of loads:
+// 70 us alone on config 2, 130-210 us in the step's traces, where this kernel runs on an otherwise idle chip).
+__global__ __launch_bounds__(64) void sr_m2m_kernel(FarParams fp, int l) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= fp.n_src[top] * fp.n_layers * 4) return;
+  if (tid >= fp.n_src[l] * fp.n_layers * 4) return;
   const int sw = tid & 3, rest = tid >> 2;
-  const int layer = rest % fp.n_layers, tb = rest / fp.n_layers;
-  for (int l = 1; l <= top; ++l) {
-    const int per = 1 << (top - l);
-    for (int i = 0; i < per; ++i) {
-      const int p = tb * per + i;
-      // halo boxes: the side nobody reads is not built (see sr_s2m_kernel); sw = side * 2 + weight
-      if ((sw >> 1) == 1 ? ((p + 1) << l) <= kSrcPad : (p << l) - kSrcPad >= fp.box_count[0]) continue;
-      const double *cl = fp.mom + ((size_t)(fp.src_off[l - 1] + 2 * p) * fp.n_layers + layer) * kMomPerBox + sw * kMQ;
-      const double *cr = cl + (size_t)fp.n_layers * kMomPerBox;
-      double *par = fp.mom + ((size_t)(fp.src_off[l] + p) * fp.n_layers + layer) * kMomPerBox + sw * kMQ;
-      double a[kMQ], b[kMQ];
+  const int layer = rest % fp.n_layers, p = rest / fp.n_layers;
+  // halo boxes: the side nobody reads is not built (see sr_s2m_kernel); sw = side * 2 + weight
+  if ((sw >> 1) == 1 ? ((p + 1) << l) <= kSrcPad : (p << l) - kSrcPad >= fp.box_count[0]) return;
+  const double *cl = fp.mom + ((size_t)(fp.src_off[l - 1] + 2 * p) * fp.n_layers + layer) * kMomPerBox + sw * kMQ;
+  const double *cr = cl + (size_t)fp.n_layers * kMomPerBox;
+  double *par = fp.mom + ((size_t)(fp.src_off[l] + p) * fp.n_layers + layer) * kMomPerBox + sw * kMQ;
+  double a[kMQ], b[kMQ];
 #pragma unroll
-      for (int q = 0; q < kMQ; ++q) {
-        a[q] = cl[q];
-        b[q] = cr[q];
-      }
-      double scale = 0.25; // 2^-q
+  for (int q = 0; q < kMQ; ++q) {
+    a[q] = cl[q];
+    b[q] = cr[q];
+  }
+  double scale = 0.25; // 2^-q
 #pragma unroll
-      for (int q = 2; q <= kFD; ++q) {
-        double s = 0.;
+  for (int q = 2; q <= kFD; ++q) {
+    double s = 0.;
 #pragma unroll
-        for (int m = 0; m <= q - 2; ++m) {
-          const double pair = (m & 1) ? b[q - m - 2] - a[q - m - 2] : b[q - m - 2] + a[q - m - 2];
-          s = fma(pair, inv_factorial(m), s);
-        }
-        par[q - 2] = s * scale;
-        scale *= 0.5;
-      }
+    for (int m = 0; m <= q - 2; ++m) {
+      const double pair = (m & 1) ? b[q - m - 2] - a[q - m - 2] : b[q - m - 2] + a[q - m - 2];
+      s = fma(pair, inv_factorial(m), s);
     }
+    par[q - 2] = s * scale;
+    scale *= 0.5;
   }
 }
 
@@ -1739,8 +1731,10 @@ int launch_m2l(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_su
     hipLaunchKernelGGL(sr_s2m_kernel<true>, g1, dim3(64), 0, st, fast, ix, n_sub, g_lo, fp, cnt);
   else
     hipLaunchKernelGGL(sr_s2m_kernel<false>, g1, dim3(64), 0, st, fast, ix, n_sub, g_lo, fp, cnt);
-  const int n2 = fp.n_src[fp.n_levels - 1] * n_layers * 4;
-  hipLaunchKernelGGL(sr_m2m_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, st, fp);
+  for (int l = 1; l < fp.n_levels; ++l) { // upward pass, level by level
+    const int n2 = fp.n_src[l] * n_layers * 4;
+    hipLaunchKernelGGL(sr_m2m_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, st, fp, l);
+  }
   int chunks = 0;
   for (int lv = 0; lv < fp.n_levels; ++lv) chunks += (fp.box_count[lv] * n_layers + 15) / 16;
   if (cnt)
