@@ -198,6 +198,32 @@ int sr_gcoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, i
 int sr_abscoeff_level_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, int64_t g_lo, int64_t g_hi,
                           double *abs_out, double *emi_out, void *stream);
 
+/* Level-factored route (round 4).  The reference never re-evaluates a line shape when only the vibrational
+ * temperatures change: the G spectra of a level depend on (P, T) alone (LutSet.add_PT -> BuildCoeff,
+ * spect_main_module.py:1122-1168, spect_classes.py:1277-1337) and every LOS step is the population-weighted sum
+ * abs += pop_L (Gabs_L - Gind_L), emi += pop_L Gsp_L over the levels (make_abscoeff_isomolec :2036-2106,
+ * make_abscoeff_LUTS_fast :2200-2276).  Only the two spectra pop_L multiplies enter that sum, so the tables hold the
+ * PAIR  A_L = Gabs_L - Gind_L,  E_L = Gsp_L  per level and (P, T) row: one pass of the coefficient kernels per level
+ * over the lines whose upper or lower level is L (every line is evaluated twice in all; the three ctypes apart are
+ * sr_gcoeff_layers_dev).  An iso-molecule without levels has the one pair of its 'all' set (n_levels counts as 1).
+ * out: DEVICE [max(n_levels, 1)][2][n_layers][g_hi-g_lo] (level, A | E, row, point).  atm->tvib / q_part are not used.
+ * Frozen region boundaries (sr_lineset_set_bounds_temps) apply as in every coefficient op. */
+int sr_glevel_pairs_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *out, void *stream);
+
+/* The combine loop of the level-factored route for n_steps LOS steps at once, each step on one (P, T) row of the
+ * pair tables `tab` (as sr_glevel_pairs_dev writes them, n_rows rows):
+ *   abs[s] = sum_L pop[s][L] A_L[row[s]],   emi[s] = sum_L pop[s][L] E_L[row[s]]          (smm:2073-2080)
+ * in ONE pass over the tables: the steps of a row are taken together, its 2 n_levels spectra are read once.
+ * Temperature derivative (optional; the reference has none): with tab_dT = the pair tables at T + dT
+ * (region boundaries frozen at T), inv_dT = 1 / dT and dpop[s][L] = d pop_L / dT of the step,
+ *   dabs[s] = sum_L dpop[s][L] A_L + pop[s][L] (A'_L - A_L) inv_dT,   demi[s] likewise with E
+ * -- the population part analytic, only d G / d T by difference.  tab_dT == NULL: dabs_out / demi_out are not written.
+ * step_row [n_steps], pop / dpop [n_steps][n_levels]: HOST.  abs_out / emi_out / dabs_out / demi_out: DEVICE
+ * [n_steps][n_pts], rows in the caller's step order (a coefficient row per LOS step for the recursion kernels). */
+int sr_glevel_combine_dev(const double *tab, const double *tab_dT, int n_levels, int n_rows, int64_t n_pts, int n_steps,
+                          const int32_t *step_row, const double *pop, const double *dpop, double inv_dT,
+                          double *abs_out, double *emi_out, double *dabs_out, double *demi_out, void *stream);
+
 /* Look-up-table route: LutSet.calculate (spect_main_module.py:997-1066) for one level and
  * n_steps LOS steps on a table of G spectra resident in HBM, g_tab: DEVICE [3][n_pt][n_pts] (ctype-major,
  * one row per tabulated (P, T) couple, as sr_gcoeff_layers_dev writes them).  Per step, idx4[s] = table rows

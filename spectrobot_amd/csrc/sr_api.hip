@@ -233,10 +233,13 @@ struct CoefWork {
   // [2]: with sr_set_overlap(1) the tables of call c+1 are prepared (on prep_st) while the kernels
   // of call c still read theirs
   Stager s_layers[2];
-  DevBuf d_fast[2], d_cold[2], d_coef, d_zone, d_mom, d_outer_recs;
+  DevBuf d_fast[2], d_cold[2], d_coef[2], d_zone, d_mom[2], d_outer_recs;
   hipStream_t aux = nullptr;     // second stream: zones kernel beside the far-field kernel
   hipStream_t prep_st = nullptr; // third stream: staging copy + sr_prep_kernel of the NEXT call
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_tables_free[2] = {nullptr, nullptr}, ev_op0 = nullptr;
+  // the far-field chain (level-0 pass, moments, upward pass, translations) of call c + 1 runs on prep_st behind its
+  // table preparation, i.e. beside the zones / wings kernels of call c (its own coefficient / moment buffers)
+  hipEvent_t ev_far_done[2] = {nullptr, nullptr};
   bool free_recorded[2] = {false, false};
   int parity = 0;
   bool overlapped = false;       // last call ran that way (timing hook)
@@ -268,14 +271,15 @@ struct CoefWork {
       d_cold[b].release();
       if (ev_prep_done[b]) (void)hipEventDestroy(ev_prep_done[b]);
       if (ev_tables_free[b]) (void)hipEventDestroy(ev_tables_free[b]);
+      if (ev_far_done[b]) (void)hipEventDestroy(ev_far_done[b]);
+      d_coef[b].release();
+      d_mom[b].release();
     }
     if (ev_op0) (void)hipEventDestroy(ev_op0);
     if (ev_last_done) (void)hipEventDestroy(ev_last_done);
     d_counts.release();
     d_outer_recs.release();
     if (prep_st) (void)hipStreamDestroy(prep_st);
-    d_coef.release();
-    d_mom.release();
     d_zone.release();
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
@@ -311,6 +315,7 @@ struct sr_lineset {
   CoefWork own_work;
   CoefWork *work = nullptr;      // &own_work, or the parent's for a per-level sub-lineset
   std::vector<double> bounds_temps; // sr_lineset_set_bounds_temps: empty = boundaries at the call's own temperatures
+  sr_lineset *parent = nullptr;     // per-level sub-lineset: the handle it was cut from (its bounds_temps apply)
 };
 
 extern "C" {
@@ -678,6 +683,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   if (g_lo < 0 || g_hi > ls->gp.n_grid || g_lo >= g_hi) return SR_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   CoefWork &w = *ls->work;
+  // frozen region boundaries are set on the handle the caller holds: a per-level sub-lineset follows its parent's
+  sr_lineset *const bown = ls->parent ? ls->parent : ls;
   const int nl = atm->n_layers, nlev = ls->n_levels, npop = nlev > 0 ? nlev : 1;
   for (int k = 0; k < nl; ++k)
     if (!(atm->temps[k] > 0.0) || !(atm->press[k] >= 0.0)) return SR_ERR_ARG;
@@ -703,7 +710,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     if (nl > nl_max) {
       const size_t n_pts_all = (size_t)(g_hi - g_lo);
       // sr_lineset_set_bounds_temps: every batch sees its own slice of the boundary temperatures
-      const std::vector<double> bounds_all = ls->bounds_temps;
+      const std::vector<double> bounds_all = bown->bounds_temps;
       if (!bounds_all.empty() && (int)bounds_all.size() != nl) {
         g_err = "sr_lineset_set_bounds_temps was given another number of layers than this call";
         return SR_ERR_ARG;
@@ -711,7 +718,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       struct Restore {
         sr_lineset *ls; const std::vector<double> &all;
         ~Restore() { ls->bounds_temps = all; }
-      } restore{ls, bounds_all};
+      } restore{bown, bounds_all};
       for (int k0 = 0; k0 < nl; k0 += nl_max) {
         sr_layers_desc sub = *atm;
         sub.n_layers = std::min(nl_max, nl - k0);
@@ -726,7 +733,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
                       tv.begin() + (size_t)lv * sub.n_layers);
           sub.tvib = tv.data();
         }
-        if (!bounds_all.empty()) ls->bounds_temps.assign(bounds_all.begin() + k0, bounds_all.begin() + k0 + sub.n_layers);
+        if (!bounds_all.empty()) bown->bounds_temps.assign(bounds_all.begin() + k0, bounds_all.begin() + k0 + sub.n_layers);
         const int rc = coef_op(ls, &sub, g_lo, g_hi, abs_out + (size_t)k0 * n_pts_all,
                                emi_out + (size_t)k0 * n_pts_all, stream, W);
         if (rc) return rc;
@@ -737,8 +744,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
 
   // per-layer scalars (host, fp64)
   const size_t hl_doubles = (size_t)nl * (7 + npop);
-  const bool frozen = !ls->bounds_temps.empty(); // sr_lineset_set_bounds_temps
-  if (frozen && (int)ls->bounds_temps.size() != nl) {
+  const bool frozen = !bown->bounds_temps.empty(); // sr_lineset_set_bounds_temps
+  if (frozen && (int)bown->bounds_temps.size() != nl) {
     g_err = "sr_lineset_set_bounds_temps was given another number of layers than this call";
     return SR_ERR_ARG;
   }
@@ -758,6 +765,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       for (int i = 0; i < 2; ++i) {
         HIPCHK(hipEventCreateWithFlags(&w.ev_prep_done[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&w.ev_tables_free[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&w.ev_far_done[i], hipEventDisableTiming));
       }
     }
     pst = w.prep_st;
@@ -782,19 +790,26 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     sq[k] = std::sqrt(2 * kAvogadro * kKcgs * T[k] * kLn2 / ls->mm);          // :1984
     ltr[k] = std::log(tr[k]);
     {
-      const double Tb = frozen ? ls->bounds_temps[k] : T[k]; // where the region boundaries are placed
+      const double Tb = frozen ? bown->bounds_temps[k] : T[k]; // where the region boundaries are placed
       ltrb[k] = std::log(kTref / Tb);
       sqb[k] = std::sqrt(2 * kAvogadro * kKcgs * Tb * kLn2 / ls->mm);
     }
     {
       // pole margin of the far-field expansions: the region-1 rational has its poles at
-      // |x| = sqrt(1/2 + ry^2), i.e. within 0.71 dw' of the line centre on the real axis
-      const double dwp_max = ls->freq_max / kCcgs * sq[k] / std::sqrt(kLn2);
+      // |x| = sqrt(1/2 + ry^2), i.e. within 0.71 dw' of the line centre on the real axis.
+      // Frozen boundaries (sr_lineset_set_bounds_temps): the zone of a line is placed with the widths of the
+      // boundary temperature Tb, the poles sit where the call's own widths put them -- the bounds below cover both
+      // (with the call's T alone a frozen zone wider than zmax, Tb > T, lost its outer points: ADVICE round 3).
+      const double sq_w = std::max(sq[k], sqb[k]);
+      const double dwp_max = ls->freq_max / kCcgs * sq_w / std::sqrt(kLn2);
       int *pmh = reinterpret_cast<int *>(T + hl_doubles);
       pmh[k] = (int)std::ceil(0.71 * dwp_max / ls->gp.gstep) + 1;
       // box-pair mode: the multipole series of a source box converges outside the largest |pole| =
       // sqrt(1/2 + ry^2) dw' = sqrt(dw'^2 / 2 + lw^2) of its lines (bound over the lines of the layer)
-      const double lw_max = ls->gamma_max * pa[k] * std::max(std::pow(tr[k], ls->ndep_min), std::pow(tr[k], ls->ndep_max));
+      const double trb = frozen ? kTref / bown->bounds_temps[k] : tr[k];
+      const double lw_max = ls->gamma_max * pa[k] *
+                            std::max(std::max(std::pow(tr[k], ls->ndep_min), std::pow(tr[k], ls->ndep_max)),
+                                     std::max(std::pow(trb, ls->ndep_min), std::pow(trb, ls->ndep_max)));
       const double pole = std::sqrt(0.5 * dwp_max * dwp_max + lw_max * lw_max) / ls->gp.gstep;
       pmh[nl + k] = (int)std::ceil(std::min(pole, 1e6));
       // widest region-2/3/4 zone of the layer, in grid points from the line centre: region 1 starts where
@@ -904,10 +919,10 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       fp.box_off[lv] = fp.n_boxes_total;
       fp.n_boxes_total += fp.box_count[lv];
     }
-    rc = w.d_coef.ensure(sizeof(double) * (size_t)nl * fp.n_boxes_total * 2 * kFC);
+    rc = w.d_coef[b].ensure(sizeof(double) * (size_t)nl * fp.n_boxes_total * 2 * kFC);
     if (rc) return rc;
     fp.pm = d_pm;
-    fp.coef = w.d_coef.as<double>();
+    fp.coef = w.d_coef[b].as<double>();
     fp.m2l = far_field == 2 ? 1 : 0;
     fp.pm_src = d_pm + nl;
     fp.disp_lo_end = (int)std::min<int64_t>(std::max<int64_t>(ls->n_disp_lo - line_lo, 0), n_sub);
@@ -925,20 +940,34 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         fp.src_off[lv] = total;
         total += fp.n_src[lv];
       }
-      rc = w.d_mom.ensure(sizeof(double) * (size_t)total * nl * kMomPerBox);
+      rc = w.d_mom[b].ensure(sizeof(double) * (size_t)total * nl * kMomPerBox);
       if (rc) return rc;
-      fp.mom = w.d_mom.as<double>();
+      fp.mom = w.d_mom[b].as<double>();
       rc = m2l_table_dev(&fp.tab);
       if (rc) return rc;
     }
     // far-field pass(es): per-line expansions (all levels, or level 0 of the box-pair mode), then the box pairs
-    auto far_pass = [&]() -> int {
+    auto far_pass = [&](hipStream_t fs) -> int {
       LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp,
-                                d_cnt, st));
+                                d_cnt, fs));
       if (fp.m2l)
-        LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, st));
+        LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, fs));
       return SR_OK;
     };
+    // Round 4: the far-field chain needs the record tables only, like the preparation it follows: with overlap it
+    // runs on prep_st right behind sr_prep_kernel, into the coefficient / moment buffers of this call's parity --
+    // for back-to-back calls beside the zones and wings kernels of the PREVIOUS call.  On the caller's stream it sat
+    // between the zones kernel's start and the wings kernel: S2M -> M2M -> M2L are latency-bound and ran ALONE on
+    // the chip for ~0.75 ms of every step once the zones kernel's long waves had let the level-0 pass through
+    // ("where the step's last 10 % are").  Counting passes keep the chain on the caller's stream (their
+    // counters are zeroed there).
+    static const bool chain_env = [] { const char *e = getenv("SR_FAR_CHAIN_PIPELINED"); return e ? atoi(e) != 0 : true; }();
+    const bool chain_on_pst = overlap && !counting && chain_env;
+    if (chain_on_pst) {
+      rc = far_pass(pst);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(w.ev_far_done[b], pst));
+    }
     if (overlap) {
       // The zones kernel needs only the record tables, the wings kernel needs the far-field
       // coefficients: zones runs on a second stream beside the far-field kernel and STORES its sums,
@@ -966,8 +995,12 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, w.aux));
       HIPCHK(hipEventRecord(w.ev_join, w.aux));
-      rc = far_pass();
-      if (rc) return rc;
+      if (chain_on_pst) {
+        HIPCHK(hipStreamWaitEvent(st, w.ev_far_done[b], 0));
+      } else {
+        rc = far_pass(st);
+        if (rc) return rc;
+      }
       HIPCHK(hipEventRecord(w.ev[2], st));
       if (!small) HIPCHK(hipStreamWaitEvent(st, w.ev_join, 0));
       if (!w.ev_tail) HIPCHK(hipEventCreateWithFlags(&w.ev_tail, hipEventDisableTiming));
@@ -984,7 +1017,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       w.overlapped = true;
     } else {
       w.overlapped = false;
-      rc = far_pass();
+      rc = far_pass(st);
       if (rc) return rc;
       HIPCHK(hipEventRecord(w.ev[2], st));
       for (int part = 1; part <= 2; ++part) {
@@ -1041,6 +1074,7 @@ static int level_set(sr_lineset *ls, int level, sr_lineset **out) {
     c->n_levels = ls->n_levels;
     c->e_lev = ls->e_lev;
     c->work = ls->work; // scratch, streams and events of the parent
+    c->parent = ls;
     for (int which = 0; which < 2; ++which) {
       const HostLines &H = which ? ls->host_outer : ls->host;
       std::vector<int64_t> sel;
@@ -1088,6 +1122,71 @@ int sr_abscoeff_level_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, 
   const int rc = level_set(ls, level, &c);
   if (rc) return rc;
   return coef_op(c, atm, g_lo, g_hi, abs_out, emi_out, stream, WeightMode{kWeightTracked, level});
+}
+
+int sr_glevel_pairs_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *out, void *stream) {
+  if (!ls || !atm || !out || atm->n_layers <= 0 || g_lo < 0 || g_lo >= g_hi) return SR_ERR_ARG;
+  const size_t plane = (size_t)atm->n_layers * (size_t)(g_hi - g_lo);
+  if (ls->n_levels == 0) // the 'all' set: every line, pop = 1 / Q in the combine (smm:2052-2057)
+    return coef_op(ls, atm, g_lo, g_hi, out, out + plane, stream, WeightMode{kWeightLevelPair, -1});
+  for (int lv = 0; lv < ls->n_levels; ++lv) {
+    sr_lineset *c = nullptr;
+    int rc = level_set(ls, lv, &c); // lines whose upper or lower level is lv
+    if (rc) return rc;
+    rc = coef_op(c, atm, g_lo, g_hi, out + (size_t)(2 * lv) * plane, out + (size_t)(2 * lv + 1) * plane, stream,
+                 WeightMode{kWeightLevelPair, lv});
+    if (rc) return rc;
+  }
+  return SR_OK;
+}
+
+int sr_glevel_combine_dev(const double *tab, const double *tab_dT, int n_levels, int n_rows, int64_t n_pts, int n_steps,
+                          const int32_t *step_row, const double *pop, const double *dpop, double inv_dT,
+                          double *abs_out, double *emi_out, double *dabs_out, double *demi_out, void *stream) {
+  if (!tab || !step_row || !pop || !abs_out || !emi_out || n_levels <= 0 || n_rows <= 0 || n_pts <= 0 || n_steps <= 0)
+    return SR_ERR_ARG;
+  if (n_levels > SR_MAX_LEVELS || n_pts > 2000000) return SR_ERR_LIMIT;
+  if (tab_dT && (!dpop || !dabs_out || !demi_out || !(inv_dT == inv_dT))) return SR_ERR_ARG;
+  for (int s = 0; s < n_steps; ++s)
+    if (step_row[s] < 0 || step_row[s] >= n_rows) return SR_ERR_ARG; // would read out of the tables
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // the steps grouped by table row (counting sort: the order of the steps inside a row is the caller's)
+  std::vector<int> count((size_t)n_rows + 1, 0);
+  for (int s = 0; s < n_steps; ++s) ++count[(size_t)step_row[s] + 1];
+  std::vector<int> rows_used, row_off(1, 0), start((size_t)n_rows, 0);
+  for (int r = 0; r < n_rows; ++r)
+    if (count[(size_t)r + 1] > 0) {
+      start[(size_t)r] = row_off.back();
+      rows_used.push_back(r);
+      row_off.push_back(row_off.back() + count[(size_t)r + 1]);
+    }
+  std::vector<int> step_of((size_t)n_steps), fill(start);
+  for (int s = 0; s < n_steps; ++s) step_of[(size_t)fill[(size_t)step_row[s]]++] = s;
+  const int n_used = (int)rows_used.size();
+  static thread_local Stager s_ring[4];
+  static thread_local unsigned s_next = 0;
+  Stager &sg = s_ring[s_next++ & 3];
+  auto al = [](size_t v) { return (v + 15) / 16 * 16; };
+  const size_t b_pop = sizeof(double) * (size_t)n_steps * n_levels;
+  const size_t o_dpop = al(b_pop), o_used = al(o_dpop + (tab_dT ? b_pop : 0));
+  const size_t o_off = al(o_used + sizeof(int) * (size_t)n_used), o_step = al(o_off + sizeof(int) * (size_t)(n_used + 1));
+  const size_t total = al(o_step + sizeof(int) * (size_t)n_steps);
+  int rc = sg.prepare(total);
+  if (rc) return rc;
+  char *h = sg.host<char>();
+  std::memcpy(h, pop, b_pop);
+  if (tab_dT) std::memcpy(h + o_dpop, dpop, b_pop);
+  std::memcpy(h + o_used, rows_used.data(), sizeof(int) * (size_t)n_used);
+  std::memcpy(h + o_off, row_off.data(), sizeof(int) * (size_t)(n_used + 1));
+  std::memcpy(h + o_step, step_of.data(), sizeof(int) * (size_t)n_steps);
+  rc = sg.push_early(total, st);
+  if (rc) return rc;
+  const char *d = sg.d.as<char>();
+  LAUNCHCHK(launch_glevel_combine(tab, tab_dT, n_levels, n_rows, (int)n_pts, n_used, reinterpret_cast<const int *>(d + o_used),
+                                  reinterpret_cast<const int *>(d + o_off), reinterpret_cast<const int *>(d + o_step),
+                                  reinterpret_cast<const double *>(d), reinterpret_cast<const double *>(d + o_dpop), inv_dT,
+                                  abs_out, emi_out, dabs_out, demi_out, st));
+  return sg.mark(st);
 }
 
 int sr_abscoeff_layers(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi,
@@ -1518,6 +1617,7 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
   int n_seg = 0, n_pt = 0;
   int rc = check_los(los, n_layers, &n_seg, &n_pt);
   if (rc) return rc;
+  if (!rad && los->init_mode == 1) return SR_ERR_ARG; // limb_initial would read rad
   if (!seg_jrow) n_jrows = n_layers;
   if (seg_jrow)
     for (int q = 0; q < n_seg; ++q)
@@ -1568,6 +1668,10 @@ int sr_limb_rays_jacobians_dev(const double *abs_c, const double *emi_c, const d
   const bool want_layer = jac_layer != nullptr, want_par = n_par > 0;
   if (want_layer != (dabs != nullptr && demi != nullptr) || (want_par && (!jac_par || !par_gas || !par_w))) return SR_ERR_ARG;
   if (!want_layer && !want_par) return SR_ERR_ARG;
+  if (!rad && los && los->init_mode == 1) { // the initial intensity would be read from rad (a NULL read on the device)
+    g_err = "sr_limb_rays_jacobians_dev: init_mode 1 reads the initial intensity from rad, which is NULL";
+    return SR_ERR_ARG;
+  }
   if (want_layer && los && los->init_mode == 1) {
     g_err = "per-layer Jacobians: init_mode 1 (intensity read from a buffer) is not supported, use 0 or 2";
     return SR_ERR_UNSUPPORTED;

@@ -71,6 +71,10 @@ __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, c
   } else if (W.mode == kWeightGind) {    // ... ind_emission | nothing
     wabs = (W.level < 0 || lu == W.level) ? g_in : 0.0;
     wemi = 0.0;
+  } else if (W.mode == kWeightLevelPair) { // what pop_level multiplies in the combine loop (smm:2078-2080)
+    const bool all = W.level < 0;          // no level table: the 'all' set (smm:2052-2057)
+    wabs = ((all || ll == W.level) ? g_ab : 0.0) - ((all || lu == W.level) ? g_in : 0.0);
+    wemi = (all || lu == W.level) ? g_sp : 0.0;
   } else {                               // kWeightTracked: one level's share of abs / emi (smm:2083-2087)
     const double pu = pop[lu], pl = pop[ll];
     wabs = (ll == W.level ? pl * g_ab : 0.0) - (lu == W.level ? pu * g_in : 0.0);
@@ -2742,6 +2746,122 @@ int launch_lut(int combine, const double *tab, int n_pt, int n_pts, int n_steps,
     hipLaunchKernelGGL(sr_lut_kernel<true>, grid, dim3(256), 0, st, tab, n_pt, n_pts, idx, wgt, pop, out_a, out_e);
   else
     hipLaunchKernelGGL(sr_lut_kernel<false>, grid, dim3(256), 0, st, tab, n_pt, n_pts, idx, wgt, pop, out_a, out_e);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// Level-factored combine (spect_main_module.py:2036-2106 / 2200-2276 for all steps of a row at once): a block takes
+// 256 points of ONE (P, T) row, holds the row's 2 NL pair spectra (and their T-differences) in registers and walks the
+// row's steps; the populations of a step are wave-uniform (scalar loads).  HBM: the tables once + the outputs.
+// ------------------------------------------------------------------------
+template <int NL, bool DT>
+__global__ __launch_bounds__(256) void sr_glevel_combine_kernel(
+    const double *__restrict__ tab, const double *__restrict__ tab_dT, int n_levels, int n_rows, int n_pts,
+    const int *__restrict__ rows_used, const int *__restrict__ row_off, const int *__restrict__ step_of,
+    const double *__restrict__ pop, const double *__restrict__ dpop, double inv_dT, double *__restrict__ abs_out,
+    double *__restrict__ emi_out, double *__restrict__ dabs_out, double *__restrict__ demi_out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y;
+  if (j >= n_pts) return;
+  const int row = rows_used[u];
+  const size_t plane = (size_t)n_rows * n_pts; // one (level, A | E) plane of the tables
+  double A[NL], E[NL], DA[DT ? NL : 1], DE[DT ? NL : 1];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const bool on = l < n_levels;
+    const size_t o = (size_t)(2 * (on ? l : 0)) * plane + (size_t)row * n_pts + j;
+    A[l] = on ? tab[o] : 0.0;
+    E[l] = on ? tab[o + plane] : 0.0;
+    if (DT) {
+      DA[l] = on ? (tab_dT[o] - A[l]) * inv_dT : 0.0;
+      DE[l] = on ? (tab_dT[o + plane] - E[l]) * inv_dT : 0.0;
+    }
+  }
+  for (int q = row_off[u]; q < row_off[u + 1]; ++q) {
+    const int s = step_of[q];
+    const double *p = pop + (size_t)s * n_levels, *dp = DT ? dpop + (size_t)s * n_levels : nullptr;
+    double a = 0., e = 0., da = 0., de = 0.;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (l < n_levels) { // wave-uniform
+        const double pl = p[l];
+        a = fma(pl, A[l], a);
+        e = fma(pl, E[l], e);
+        if (DT) {
+          const double dl = dp[l];
+          da = fma(pl, DA[l], fma(dl, A[l], da));
+          de = fma(pl, DE[l], fma(dl, E[l], de));
+        }
+      }
+    }
+    const size_t o = (size_t)s * n_pts + j;
+    abs_out[o] = a;
+    emi_out[o] = e;
+    if (DT) {
+      dabs_out[o] = da;
+      demi_out[o] = de;
+    }
+  }
+}
+
+// More than 16 levels (SR_MAX_LEVELS is 64): the pair spectra do not fit the registers; every step re-reads them
+// (from L2: the steps of a row follow each other).
+template <bool DT>
+__global__ __launch_bounds__(256) void sr_glevel_combine_stream_kernel(
+    const double *__restrict__ tab, const double *__restrict__ tab_dT, int n_levels, int n_rows, int n_pts,
+    const int *__restrict__ rows_used, const int *__restrict__ row_off, const int *__restrict__ step_of,
+    const double *__restrict__ pop, const double *__restrict__ dpop, double inv_dT, double *__restrict__ abs_out,
+    double *__restrict__ emi_out, double *__restrict__ dabs_out, double *__restrict__ demi_out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y;
+  if (j >= n_pts) return;
+  const int row = rows_used[u];
+  const size_t plane = (size_t)n_rows * n_pts;
+  for (int q = row_off[u]; q < row_off[u + 1]; ++q) {
+    const int s = step_of[q];
+    double a = 0., e = 0., da = 0., de = 0.;
+    for (int l = 0; l < n_levels; ++l) {
+      const size_t o = (size_t)(2 * l) * plane + (size_t)row * n_pts + j;
+      const double pl = pop[(size_t)s * n_levels + l], Al = tab[o], El = tab[o + plane];
+      a = fma(pl, Al, a);
+      e = fma(pl, El, e);
+      if (DT) {
+        const double dl = dpop[(size_t)s * n_levels + l];
+        da = fma(pl, (tab_dT[o] - Al) * inv_dT, fma(dl, Al, da));
+        de = fma(pl, (tab_dT[o + plane] - El) * inv_dT, fma(dl, El, de));
+      }
+    }
+    const size_t o = (size_t)s * n_pts + j;
+    abs_out[o] = a;
+    emi_out[o] = e;
+    if (DT) {
+      dabs_out[o] = da;
+      demi_out[o] = de;
+    }
+  }
+}
+
+int launch_glevel_combine(const double *tab, const double *tab_dT, int n_levels, int n_rows, int n_pts, int n_used,
+                          const int *rows_used, const int *row_off, const int *step_of, const double *pop,
+                          const double *dpop, double inv_dT, double *abs_out, double *emi_out, double *dabs_out,
+                          double *demi_out, hipStream_t st) {
+  if (n_pts <= 0 || n_used <= 0) return 0;
+  const dim3 grid((n_pts + 255) / 256, n_used);
+#define SR_GLC(NL, DT)                                                                                               \
+  hipLaunchKernelGGL((sr_glevel_combine_kernel<NL, DT>), grid, dim3(256), 0, st, tab, tab_dT, n_levels, n_rows, n_pts, \
+                     rows_used, row_off, step_of, pop, dpop, inv_dT, abs_out, emi_out, dabs_out, demi_out)
+#define SR_GLC2(NL) do { if (tab_dT) SR_GLC(NL, true); else SR_GLC(NL, false); } while (0)
+  if (n_levels <= 1) SR_GLC2(1);
+  else if (n_levels <= 4) SR_GLC2(4);
+  else if (n_levels <= 8) SR_GLC2(8);
+  else if (n_levels <= 12) SR_GLC2(12);
+  else if (n_levels <= 16) SR_GLC2(16);
+  else if (tab_dT)
+    hipLaunchKernelGGL(sr_glevel_combine_stream_kernel<true>, grid, dim3(256), 0, st, tab, tab_dT, n_levels, n_rows, n_pts,
+                       rows_used, row_off, step_of, pop, dpop, inv_dT, abs_out, emi_out, dabs_out, demi_out);
+  else
+    hipLaunchKernelGGL(sr_glevel_combine_stream_kernel<false>, grid, dim3(256), 0, st, tab, tab_dT, n_levels, n_rows, n_pts,
+                       rows_used, row_off, step_of, pop, dpop, inv_dT, abs_out, emi_out, dabs_out, demi_out);
+#undef SR_GLC2
+#undef SR_GLC
   return (int)hipGetLastError();
 }
 

@@ -27,12 +27,15 @@ struct LayersDev {
 
 // What the two output channels ("abs", "emi") of the coefficient kernels accumulate, chosen per call:
 // the weights of line i in layer k, from its three G coefficients and its levels' populations.
-enum { kWeightFolded = 0, kWeightGabsGsp = 1, kWeightGind = 2, kWeightTracked = 3 };
+enum { kWeightFolded = 0, kWeightGabsGsp = 1, kWeightGind = 2, kWeightTracked = 3, kWeightLevelPair = 4 };
 struct WeightMode {
   int mode;  // kWeightFolded: abs = pop_lo G_abs - pop_up G_ind, emi = pop_up G_sp (smm:2073-2080)
              // kWeightGabsGsp: abs = [lev_lo == level] G_abs, emi = [lev_up == level] G_sp   (BuildCoeff)
              // kWeightGind:    abs = [lev_up == level] G_ind, emi = 0
              // kWeightTracked: the folded weights restricted to `level` (smm:2083-2087)
+             // kWeightLevelPair: abs = [lev_lo == level] G_abs - [lev_up == level] G_ind, emi = [lev_up == level] G_sp:
+             //                 the two spectra the combine loop multiplies by pop_level (smm:2078-2080), i.e. the
+             //                 tracked weights with unit populations -- the level-factored route (sr_glevel_pairs_dev)
   int level;
 };
 
@@ -180,6 +183,12 @@ int launch_lowres(const double *rad, int n_pts, int g_lo, int n_rays, double w0,
                   const double *wid, int n_bands, double n_sigma, int out_units, double *out, hipStream_t st);
 int launch_lut(int combine, const double *tab, int n_pt, int n_pts, int n_steps, const int *idx, const double *wgt,
                const double *pop, double *out_a, double *out_e, hipStream_t st);
+// Level-factored combine (sr_glevel_combine_dev): rows_used [n_used] table rows that have steps, row_off [n_used + 1]
+// into step_of [n_steps] (the steps of each used row), pop / dpop [n_steps][n_levels] in the caller's step order.
+int launch_glevel_combine(const double *tab, const double *tab_dT, int n_levels, int n_rows, int n_pts, int n_used,
+                          const int *rows_used, const int *row_off, const int *step_of, const double *pop,
+                          const double *dpop, double inv_dT, double *abs_out, double *emi_out, double *dabs_out,
+                          double *demi_out, hipStream_t st);
 int launch_curgod(int which, const double *nd, const double *vmr, const double *f, const double *x,
                   const int *off, int n_seg, double *res, hipStream_t st);
 

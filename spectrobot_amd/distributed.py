@@ -117,9 +117,15 @@ def all_gather_spectrum(shard, n_grid, world_size, rank, out=None, bounds=None, 
     n_rays = shard.shape[0]
     if bounds is None:
         bounds = [shard_bounds(n_grid, world_size, r) for r in range(world_size)]
+    bounds = [(int(lo), int(hi)) for lo, hi in bounds]
+    if len(bounds) != world_size or bounds[0][0] != 0:
+        raise ValueError("shard bounds must be one (lo, hi) per rank starting at 0, got %r for %d ranks" % (bounds, world_size))
     for (lo, hi), (lo2, _hi2) in zip(bounds, list(bounds[1:]) + [(n_grid, n_grid)]):
         if not (0 <= lo <= hi <= n_grid and hi == lo2):
             raise ValueError("shard bounds must tile [0, n_grid) in rank order, got %r" % (bounds,))
+    if shard.shape[1] != bounds[rank][1] - bounds[rank][0]:
+        raise ValueError("rank %d holds %d points, its bounds %r say %d" % (rank, shard.shape[1], bounds[rank],
+                                                                             bounds[rank][1] - bounds[rank][0]))
     q = max(hi - lo for lo, hi in bounds)
     staged = shard.is_cuda and dist.get_backend() == "gloo"  # rehearsal only: stage through the host
     if out is None:

@@ -154,6 +154,49 @@ class LineSet(object):
                                        C.c_void_p(g.data_ptr()), _stream_ptr()), "sr_gcoeff_layers_dev")
         return g
 
+    def glevel_pairs(self, temps, press, g_lo=0, g_hi=None, out=None):
+        """Level-pair tables of the level-factored route (sr_glevel_pairs_dev): CUDA float64
+        [n_levels or 1, 2, n_rows, g_hi-g_lo] with [L, 0] = Gabs_L - Gind_L and [L, 1] = Gsp_L at every (P, T) row --
+        what pop_L multiplies in the reference's combine loop (spect_main_module.py:2073-2080).  No populations enter:
+        the tables depend on (P, T) alone and serve every LOS step / SZA set that shares a row (glevel_combine)."""
+        g_hi = self.n_grid if g_hi is None else int(g_hi)
+        desc, keep, n = self._layers(temps, press, None, None)
+        npts = g_hi - int(g_lo)
+        if npts <= 0:
+            raise ValueError("empty shard")
+        nl = max(int(self.level_energies.size), 1)
+        if out is None:
+            out = torch.empty((nl, 2, n, npts), dtype=torch.float64, device="cuda")
+        assert out.shape == (nl, 2, n, npts) and out.is_contiguous() and out.dtype == torch.float64
+        check(lib.sr_glevel_pairs_dev(self._h, C.byref(desc), int(g_lo), g_hi, C.c_void_p(out.data_ptr()), _stream_ptr()),
+              "sr_glevel_pairs_dev")
+        return out
+
+    def level_populations(self, temps, tvib=None, q_part=None, derivative=False):
+        """pop [n_steps, n_levels or 1] = exp(-c2 E_L / Tvib_L) / Q(T) (spect_main_module.py:2049-2073; 1 / Q for the
+        'all' set), tvib [n_levels, n_steps] or None (LTE: Tvib = T).  derivative=True: also d pop / d T with the
+        vibrational temperatures held fixed when given (the definition of coefficients_dT), following T in LTE; Q'
+        from the derivative of CalcPartitionSum's own interpolant unless q_part pins Q (then Q' = 0)."""
+        from . import spect_classes as spcl
+        T = np.ascontiguousarray(temps, dtype=np.float64)
+        Q = np.asarray(q_part, float) if q_part is not None else np.atleast_1d(spcl.CalcPartitionSum(self.mol, self.iso, T))
+        E = self.level_energies
+        c2 = spcl.c2
+        if E.size == 0:
+            pop = (1.0 / Q)[:, None]
+            boltz_dT = np.zeros_like(pop)
+        else:
+            tv = np.broadcast_to(T, (E.size, T.size)) if tvib is None else np.asarray(tvib, float)
+            if tv.shape != (E.size, T.size):
+                raise ValueError("tvib must be [n_levels, n_steps]")
+            pop = (np.exp(-c2 * E[:, None] / tv) / Q[None, :]).T
+            boltz_dT = (c2 * E[:, None] / tv ** 2).T if tvib is None else np.zeros((T.size, E.size))
+        if not derivative:
+            return np.ascontiguousarray(pop)
+        dq = np.zeros_like(Q) if q_part is not None else np.atleast_1d(spcl.CalcPartitionSum_dT(self.mol, self.iso, T))
+        dpop = pop * (boltz_dT - (dq / Q)[:, None])
+        return np.ascontiguousarray(pop), np.ascontiguousarray(dpop)
+
     def abscoeff_level(self, temps, press, level, tvib=None, q_part=None, g_lo=0, g_hi=None):
         """One level's share of abs / emi (track_levels, spect_main_module.py:2083-2087)."""
         g_hi = self.n_grid if g_hi is None else int(g_hi)
@@ -217,6 +260,40 @@ def lut_interp(table, idx4, wgt4, pops=None, out=None):
                                 C.c_void_p(ab.data_ptr()), C.c_void_p(em.data_ptr()), _stream_ptr()),
           "sr_lut_interp_dev")
     return ab, em
+
+
+def glevel_combine(tab, step_row, pop, tab_dT=None, dpop=None, dT=None, out=None):
+    """The combine loop of the level-factored route for all LOS steps at once (sr_glevel_combine_dev):
+    abs[s] = sum_L pop[s, L] tab[L, 0, row[s]], emi[s] = sum_L pop[s, L] tab[L, 1, row[s]] -- one pass over the pair
+    tables (LineSet.glevel_pairs), the steps of a (P, T) row taken together.  With tab_dT (the tables at T + dT, region
+    boundaries frozen at T), dpop [n_steps, n_levels] and dT also d abs / d T and d emi / d T of every step: population
+    part analytic, d G / d T by difference.  Returns (abs, emi) or ((abs, emi), (dabs, demi)), CUDA [n_steps, n_pts]."""
+    assert tab.is_cuda and tab.dtype == torch.float64 and tab.is_contiguous() and tab.dim() == 4 and tab.shape[1] == 2
+    nl, _, n_rows, n_pts = tab.shape
+    step_row, sp = _i(step_row)
+    pop, pp = _d(pop)
+    n_steps = step_row.size
+    if pop.shape != (n_steps, nl):
+        raise ValueError("pop must be [n_steps, n_levels]")
+    want_dT = tab_dT is not None
+    if want_dT:
+        assert tab_dT.shape == tab.shape and tab_dT.is_contiguous() and tab_dT.dtype == torch.float64
+        dpop, dpp = _d(dpop)
+        if dpop.shape != pop.shape or not dT:
+            raise ValueError("the temperature derivative needs dpop [n_steps, n_levels] and dT")
+    else:
+        dpp = None
+    n_out = 4 if want_dT else 2
+    if out is None:
+        out = [torch.empty((n_steps, n_pts), dtype=torch.float64, device="cuda") for _ in range(n_out)]
+    for t in out:
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.shape == (n_steps, n_pts)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    check(lib.sr_glevel_combine_dev(ptr(tab), ptr(tab_dT) if want_dT else None, nl, n_rows, n_pts, n_steps, sp, pp, dpp,
+                                    (1.0 / dT) if want_dT else 0.0, ptr(out[0]), ptr(out[1]),
+                                    ptr(out[2]) if want_dT else None, ptr(out[3]) if want_dT else None, _stream_ptr()),
+          "sr_glevel_combine_dev")
+    return ((out[0], out[1]), (out[2], out[3])) if want_dT else (out[0], out[1])
 
 
 def set_counting(on):
@@ -540,14 +617,19 @@ def set_far_field(on):
 _UNITS = {"Wm2": 0, "ergscm2": 1, "nWcm2": 2}
 
 
-def hires_to_lowres(rad, grid, centers_nm, widths_nm, out_units="Wm2", n_sigma=5.0, g_lo=0):
+def hires_to_lowres(rad, grid, centers_nm, widths_nm, out_units="Wm2", n_sigma=5.0, g_lo=None):
     """Gaussian-ILS degradation of hi-res spectra (CUDA float64 [n_rays, n_grid], 'ergscm2' on the
     cm-1 grid) onto low-resolution bands given in nm: SpectralIntensity.hires_to_lowres
     (spect_classes.py:1180-1191).  Returns numpy [n_rays, n_bands] in out_units.
-    g_lo > 0: rad holds the grid points g_lo .. g_lo + rad.shape[-1] - 1 only (a spectral shard) and the PARTIAL band
-    integrals over them are returned (sr_hires_to_lowres_shard_dev); `grid` is always the whole grid."""
+    g_lo given: rad holds the grid points g_lo .. g_lo + rad.shape[-1] - 1 only (a spectral shard) and the PARTIAL band
+    integrals over them are returned (sr_hires_to_lowres_shard_dev); `grid` is always the whole grid.  Without g_lo
+    the spectrum must cover the whole grid (a mis-sized spectrum is an error, not a partial integral)."""
     w0, step, n = grid_params(grid)
     n_sh = rad.shape[-1]
+    if g_lo is None:
+        if n_sh != n:
+            raise ValueError("spectrum of %d points on a grid of %d (pass g_lo for the partial integrals of a shard)" % (n_sh, n))
+        g_lo = 0
     assert rad.is_cuda and rad.dtype == torch.float64 and rad.is_contiguous() and 0 <= g_lo and g_lo + n_sh <= n
     rad2 = rad.reshape(-1, n_sh)
     centers_nm, cp = _d(centers_nm)

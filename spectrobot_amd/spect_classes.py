@@ -18,6 +18,7 @@ lines (CheckWidths, Calc_Gcoeffs) and are not used by the GPU path, which
 computes the same quantities in sr_prep_kernel.
 """
 import copy
+import ctypes as C
 import math as mt
 
 import numpy as np
@@ -128,6 +129,29 @@ def CalcPartitionSum(mol, iso, temp=296.0):
     check(lib.sr_calc_partition_sum(int(mol), int(iso), t.ctypes.data_as(dp), t.size, q.ctypes.data_as(dp)),
           "CalcPartitionSum")
     return q if np.ndim(temp) else float(q[0])
+
+
+def CalcPartitionSum_dT(mol, iso, temp=296.0):
+    """d Q / d T of the interpolant CalcPartitionSum evaluates (spect_classes.py:1692-1710: the Lagrange polynomial
+    through the two table temperatures <= T and the two > T, three points where the table ends), differentiated
+    exactly -- the population part of a temperature Jacobian needs (1 / Q)' = -Q' / Q^2 and the reference has no
+    temperature derivative of its own.  Piecewise: at a table temperature the right-hand polynomial."""
+    gi = C.c_double(0)
+    tg, qg = np.zeros(119), np.zeros(119)
+    check(lib.sr_bd_tips_2003(int(mol), int(iso), C.byref(gi), tg.ctypes.data_as(dp), qg.ctypes.data_as(dp)), "bd_tips_2003")
+    t = np.atleast_1d(np.asarray(temp, dtype=np.float64))
+    out = np.zeros_like(t)
+    for i, T in enumerate(t):
+        n_le = int(np.searchsorted(tg, T, side="right"))
+        sel = list(range(max(0, n_le - 2), n_le)) + list(range(n_le, min(len(tg), n_le + 2)))
+        xs, qs = tg[sel], qg[sel]
+        d = 0.0
+        for j in range(len(xs)):          # sum_j q_j l_j'(T),  l_j' = sum_(m != j) prod_(k != j, m) (T - x_k) / prod_(k != j) (x_j - x_k)
+            den = np.prod([xs[j] - xs[k] for k in range(len(xs)) if k != j])
+            num = sum(np.prod([T - xs[k] for k in range(len(xs)) if k not in (j, m)]) for m in range(len(xs)) if m != j)
+            d += qs[j] * num / den
+        out[i] = d
+    return out if np.ndim(temp) else float(out[0])
 
 
 def closest_grid(wn_arr, wn_0):

@@ -22,8 +22,14 @@ def eng():
 
 
 def _q_of(mol, iso, temps):
-    from spectrobot_amd import spect_classes as spcl
-    return np.atleast_1d(spcl.CalcPartitionSum(mol, iso, np.asarray(temps, float)))
+    """Q(T) for the ORACLE's side of a comparison from the oracle itself: its Lagrange restatement over the table the
+    reference's Fortran returned (tests/golden/tips2003.npz) -- nothing of the product."""
+    from conftest import GOLDEN
+    from oracle import oracle as O
+    g = np.load(os.path.join(GOLDEN, "tips2003.npz"), allow_pickle=False)
+    keys = [tuple(int(v) for v in k) for k in g["keys"]]
+    tab = g["q_tab"][keys.index((int(mol), int(iso)))]
+    return np.array([O.calc_partition_sum(g["t_grid"], tab, float(t)) for t in np.atleast_1d(np.asarray(temps, float))])
 
 
 def _q(temps):
@@ -412,6 +418,37 @@ def test_temperature_derivative_schemes(eng):
     assert rel(da_m, da_ref) < 1e-3 and rel(de_m, de_ref) < 1e-3
     assert rel(da_f, da_ref) < 2e-3 and rel(de_f, de_ref) < 2e-3
     assert rel(da_c, da_ref) < rel(da_m, da_ref)      # freezing the seams is what makes the quotient smooth
+
+
+def test_frozen_boundaries_at_other_temperatures_lose_nothing(eng):
+    """sr_lineset_set_bounds_temps with boundary temperatures several K away from the call's own: the
+    zone of a line is then placed with the widths of Tb while the kernels' candidate bound (widest zone of the layer)
+    came from T alone -- for Tb > T a line's outermost region-2 points were never visited.  A frozen call differs from
+    the unfrozen one only by where the seams sit (the regions disagree by 1e-5..1e-4 there): sparse lines, so that a
+    dropped contribution would be an O(1) error of the point, in both far-field modes and the exact mode."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2990.0, 5e-4, 30000)
+    L = syn.make_lines(150, grid, seed=11, n_levels=12, config_id=2)
+    atm = syn.make_atmosphere(6, 12)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    T, P, tv = atm["temps"], atm["press"], atm["tvib"]
+    try:
+        for mode in (2, 1, 0):
+            eng.set_far_field(mode)
+            a0, e0 = ls.abscoeff_layers(T, P, tvib=tv)
+            for dTb in (8.0, -8.0, 25.0):
+                ls.set_bounds_temps(T + dTb)
+                try:
+                    a1, e1 = ls.abscoeff_layers(T, P, tvib=tv)
+                finally:
+                    ls.set_bounds_temps(None)
+                ra = float(((a1 - a0).abs() / a0.abs()).max())
+                re = float(((e1 - e0).abs() / e0.abs()).max())
+                print("far-field mode %d, boundaries at T%+.0f K: max rel deviation from the unfrozen call %.1e %.1e" % (mode, dTb, ra, re))
+                assert 0.0 < ra < 2e-3 and 0.0 < re < 2e-3
+    finally:
+        eng.set_far_field(eng.FAR_FIELD_DEFAULT)
 
 
 def test_config3_3d_path_per_step_state(eng, oracle):

@@ -1,0 +1,137 @@
+"""The level-factored route on the GPU (sr_glevel_pairs_dev + sr_glevel_combine_dev): the reference's own structure
+for paths whose steps share (P, T) -- per-level G spectra once per (P, T) (spect_main_module.py:1122-1168,
+spect_classes.py:1277-1337), then the population-weighted combine per LOS step (:2036-2106, :2200-2276)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from spectrobot_amd import engine
+    engine.set_device(0)
+    return engine
+
+
+@pytest.fixture(scope="module")
+def scene(eng):
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2990.0, 5e-4, 24000)
+    L = syn.make_lines(9000, grid, seed=21, n_levels=12, config_id=2)
+    atm = syn.make_atmosphere(7, 12)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    return dict(grid=grid, L=L, atm=atm, ls=ls)
+
+
+def test_level_pairs_are_the_ctype_spectra_the_combine_uses(eng, scene):
+    """tab[L, 0] = Gabs_L - Gind_L and tab[L, 1] = Gsp_L of sr_gcoeff_layers_dev (itself pinned to the reference's
+    LutSet.add_PT -> BuildCoeff run, test_gcoeff_levels_golden), for every level; the 'all' set of an iso-molecule
+    without levels likewise."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    ls, atm = scene["ls"], scene["atm"]
+    tab = ls.glevel_pairs(atm["temps"], atm["press"])
+    assert tuple(tab.shape) == (12, 2, 7, 24000)
+    for lv in range(12):
+        g = ls.gcoeff_layers(atm["temps"], atm["press"], level=lv)
+        a = g[2] - g[1]
+        sa = a.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+        se = g[0].abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+        assert float(((tab[lv, 0] - a).abs() / sa).max()) < 1e-13, lv
+        assert float(((tab[lv, 1] - g[0]).abs() / se).max()) < 1e-13, lv
+    # an iso-molecule without levels: one pair
+    grid = scene["grid"]
+    Lc = syn.make_lines(500, grid, seed=3, n_levels=0, co_like=True)
+    lc = eng.LineSet(Lc, grid, 5, 1, syn.CO_MM, [])
+    t1 = lc.glevel_pairs(atm["temps"], atm["press"])
+    g = lc.gcoeff_layers(atm["temps"], atm["press"], level=0)
+    assert tuple(t1.shape) == (1, 2, 7, 24000)
+    assert float(((t1[0, 0] - (g[2] - g[1])).abs() / (g[2] - g[1]).abs().amax()).max()) < 1e-13
+    assert float(((t1[0, 1] - g[0]).abs() / g[0].abs().amax()).max()) < 1e-13
+    pop = lc.level_populations(atm["temps"])
+    ab, em = eng.glevel_combine(t1, np.arange(7), pop)
+    a0, e0 = lc.abscoeff_layers(atm["temps"], atm["press"])
+    assert relerr(ab.cpu().numpy(), a0.cpu().numpy()) < 1e-12 and relerr(em.cpu().numpy(), e0.cpu().numpy()) < 1e-12
+
+
+def test_combine_equals_the_folded_op_step_by_step(eng, oracle, scene):
+    """40 LOS steps on 7 (P, T) rows, every step with its own vibrational temperatures (a 3-D path: T_vib by the
+    local SZA): the combine of the pair tables against the folded coefficient op run on the steps themselves
+    (<= 1e-12 of a row's largest value: the summation order differs) and against the oracle on sampled steps."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    from test_gpu_configs import _q
+    ls, atm, L, grid = scene["ls"], scene["atm"], scene["L"], scene["grid"]
+    rng = np.random.default_rng(5)
+    n_steps = 40
+    row = rng.integers(0, 7, n_steps).astype(np.int32)
+    row[:7] = np.arange(7)
+    T, P = atm["temps"][row], atm["press"][row]
+    tv = atm["tvib"][:, row] + rng.uniform(-15.0, 25.0, (12, n_steps))
+    tv[0] = T
+    tab = ls.glevel_pairs(atm["temps"], atm["press"])
+    pop = ls.level_populations(T, tvib=tv)
+    ab, em = eng.glevel_combine(tab, row, pop)
+    a0, e0 = ls.abscoeff_layers(T, P, tvib=tv)
+    sa, se = a0.abs().amax(dim=1, keepdim=True), e0.abs().amax(dim=1, keepdim=True)
+    assert float(((ab - a0).abs() / sa).max()) < 1e-12 and float(((em - e0).abs() / se).max()) < 1e-12
+    sel = np.array([0, 9, 23, 39])
+    abo, emo = oracle.abscoeff_layers(L, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES, T[sel], P[sel], _q(T[sel]), tv[:, sel], grid,
+                                      mode=1, n_threads=4)
+    assert float(np.max(np.abs(ab[sel].cpu().numpy() - abo) / np.abs(abo).max(axis=1, keepdims=True))) < 1e-11
+    assert relerr(em[sel].cpu().numpy(), emo) < 1e-10
+    # populations: the host mirror of smm:2073 against what the folded op used (q_part pinned = the same numbers)
+    q = _q(T)
+    assert relerr(ls.level_populations(T, tvib=tv, q_part=q), np.exp(-1.4387768775039338 * syn.CH4_LEVEL_ENERGIES[None, :] / tv.T) / q[:, None]) < 1e-14
+    # argument checks
+    with pytest.raises(RuntimeError):
+        eng.glevel_combine(tab, row + 7, pop)
+    with pytest.raises(ValueError):
+        eng.glevel_combine(tab, row, pop[:, :5])
+
+
+def test_combine_temperature_derivative(eng, scene):
+    """d abs / d T and d emi / d T of every step from two table builds (T and T + dT, boundaries frozen at T) with the
+    population part analytic (d pop_L / d T through Q's own interpolant), against the frozen central difference of the
+    folded op at +-0.01 K (engine.coefficients_dT).  The error is that of the forward difference of the G spectra
+    (the folded op's own two-op scheme lands on the same figures): 1e-7 |c| / dT of staircase noise from the
+    reference's single-precision cmplx(ry, -rx) against a derivative of ~0.05 |c| / K."""
+    import torch
+    ls, atm = scene["ls"], scene["atm"]
+    rng = np.random.default_rng(6)
+    n_steps = 20
+    row = rng.integers(0, 7, n_steps).astype(np.int32)
+    T, P = atm["temps"][row], atm["press"][row]
+    tv = atm["tvib"][:, row] + rng.uniform(-10.0, 20.0, (12, n_steps))
+    dT = 0.002
+    tab = ls.glevel_pairs(atm["temps"], atm["press"])
+    ls.set_bounds_temps(atm["temps"])
+    try:
+        tab_p = ls.glevel_pairs(atm["temps"] + dT, atm["press"])
+    finally:
+        ls.set_bounds_temps(None)
+    pop, dpop = ls.level_populations(T, tvib=tv, derivative=True)
+    (ab, em), (da, de) = eng.glevel_combine(tab, row, pop, tab_dT=tab_p, dpop=dpop, dT=dT)
+    co, (da_ref, de_ref) = eng.coefficients_dT(ls, T, P, tvib=tv, scheme="central", dT=0.01)
+    _, (da_f, de_f) = eng.coefficients_dT(ls, T, P, tvib=tv, coeffs=co, scheme="forward")
+
+    def rel(x, y):
+        return float(((x - y).abs().amax(dim=1) / y.abs().amax(dim=1)).max())
+    assert rel(ab, co[0]) < 1e-12 and rel(em, co[1]) < 1e-12
+    print("T derivative of 20 steps against the frozen central difference of 0.01 K: level-factored (two table builds, "
+          "analytic populations) %.1e %.1e; folded forward difference %.1e %.1e" % (rel(da, da_ref), rel(de, de_ref),
+                                                                                  rel(da_f, da_ref), rel(de_f, de_ref)))
+    assert rel(da, da_ref) < 2e-3 and rel(de, de_ref) < 2e-3
+    assert rel(da, da_ref) < 1.5 * rel(da_f, da_ref) + 1e-5 and rel(de, de_ref) < 1.5 * rel(de_f, de_ref) + 1e-5
+    # LTE (no vibrational temperatures given): the Boltzmann factors follow T too
+    pop2, dpop2 = ls.level_populations(T, derivative=True)
+    h = 1e-3
+    fd = (ls.level_populations(T + h) - ls.level_populations(T - h)) / (2 * h)
+    assert relerr(dpop2, fd) < 1e-6

@@ -615,3 +615,27 @@ def test_limb_los_geometry_cache():
     e = syn.limb_los(z + 1.0, nd, v2, [120.0, 250.0])
     assert len(syn._LOS_GEOMETRY) == 3
     assert not np.array_equal(d["x"], c["x"]) and not np.array_equal(e["alt"], c["alt"])
+
+
+def test_jacobians_entry_refuses_initial_intensity_without_rad(L):
+    """sr_limb_rays_jacobians_dev: init_mode 1 reads the initial intensity from `rad`; with rad = NULL that was a NULL
+    read on the device in the one-pass kernel.  The argument check runs on the host before anything
+    is staged or launched, so it is testable without a GPU: SR_ERR_ARG (-1)."""
+    seg_off = np.array([0, 1], np.int32)
+    seg_layer = np.zeros(1, np.int32)
+    pt_off = np.array([0, 2], np.int32)
+    x = np.array([0.0, 1.0e5])
+    nd = np.array([1.0e12, 0.9e12])
+    vmr = np.array([1.0e-3, 1.0e-3])
+    par_w = np.ones((1, 2))
+    par_gas = np.zeros(1, np.int32)
+    d = L.LosDesc()
+    d.n_rays, d.n_gas = 1, 1
+    d.seg_off, d.seg_layer, d.pt_off = (a.ctypes.data_as(L.ip) for a in (seg_off, seg_layer, pt_off))
+    d.x, d.nd, d.vmr = (a.ctypes.data_as(L.dp) for a in (x, nd, vmr))
+    d.col_scale = None
+    d.los_order, d.solo_absorption, d.init_mode, d.t_init, d.w0, d.step, d.g_lo = 0, 0, 1, 0.0, 0.0, 0.0, 0
+    fake = C.c_void_p(4096)          # never dereferenced: the call must return before touching the device
+    rc = L.lib.sr_limb_rays_jacobians_dev(fake, fake, None, None, 1, 64, C.byref(d), None, 0, 1,
+                                          par_gas.ctypes.data_as(L.ip), par_w.ctypes.data_as(L.dp), None, None, fake, None)
+    assert rc == -1 and b"init_mode 1" in L.lib.sr_last_error()
