@@ -233,13 +233,15 @@ struct CoefWork {
   // [2]: with sr_set_overlap(1) the tables of call c+1 are prepared (on prep_st) while the kernels
   // of call c still read theirs
   Stager s_layers[2];
-  DevBuf d_fast[2], d_cold[2], d_coef[2], d_zone, d_mom[2], d_outer_recs;
+  DevBuf d_fast[2], d_cold[2], d_coef[2], d_zone, d_zone2[2], d_mom[2], d_outer_recs;
   hipStream_t aux = nullptr;     // second stream: zones kernel beside the far-field kernel
   hipStream_t prep_st = nullptr; // third stream: staging copy + sr_prep_kernel of the NEXT call
   hipEvent_t ev_prep_done[2] = {nullptr, nullptr}, ev_tables_free[2] = {nullptr, nullptr}, ev_op0 = nullptr;
   // the far-field chain (level-0 pass, moments, upward pass, translations) of call c + 1 runs on prep_st behind its
   // table preparation, i.e. beside the zones / wings kernels of call c (its own coefficient / moment buffers)
-  hipEvent_t ev_far_done[2] = {nullptr, nullptr};
+  hipEvent_t ev_far_done[2] = {nullptr, nullptr}, ev_zones_done[2] = {nullptr, nullptr};
+  hipStream_t chain_st = nullptr, chain2_st = nullptr; // the far-field chain (decoupled pipeline): level-0 pass | moments, translations
+  hipEvent_t ev_l0_done[2] = {nullptr, nullptr}, ev_s2m_done[2] = {nullptr, nullptr};
   bool free_recorded[2] = {false, false};
   int parity = 0;
   bool overlapped = false;       // last call ran that way (timing hook)
@@ -272,6 +274,10 @@ struct CoefWork {
       if (ev_prep_done[b]) (void)hipEventDestroy(ev_prep_done[b]);
       if (ev_tables_free[b]) (void)hipEventDestroy(ev_tables_free[b]);
       if (ev_far_done[b]) (void)hipEventDestroy(ev_far_done[b]);
+      if (ev_zones_done[b]) (void)hipEventDestroy(ev_zones_done[b]);
+      if (ev_l0_done[b]) (void)hipEventDestroy(ev_l0_done[b]);
+      if (ev_s2m_done[b]) (void)hipEventDestroy(ev_s2m_done[b]);
+      d_zone2[b].release();
       d_coef[b].release();
       d_mom[b].release();
     }
@@ -280,6 +286,8 @@ struct CoefWork {
     d_counts.release();
     d_outer_recs.release();
     if (prep_st) (void)hipStreamDestroy(prep_st);
+    if (chain_st) (void)hipStreamDestroy(chain_st);
+    if (chain2_st) (void)hipStreamDestroy(chain2_st);
     d_zone.release();
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
@@ -766,6 +774,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         HIPCHK(hipEventCreateWithFlags(&w.ev_prep_done[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&w.ev_tables_free[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&w.ev_far_done[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&w.ev_zones_done[i], hipEventDisableTiming));
       }
     }
     pst = w.prep_st;
@@ -954,20 +963,74 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, fs));
       return SR_OK;
     };
-    // Round 4: the far-field chain needs the record tables only, like the preparation it follows: with overlap it
-    // runs on prep_st right behind sr_prep_kernel, into the coefficient / moment buffers of this call's parity --
-    // for back-to-back calls beside the zones and wings kernels of the PREVIOUS call.  On the caller's stream it sat
-    // between the zones kernel's start and the wings kernel: S2M -> M2M -> M2L are latency-bound and ran ALONE on
-    // the chip for ~0.75 ms of every step once the zones kernel's long waves had let the level-0 pass through
-    // ("where the step's last 10 % are").  Counting passes keep the chain on the caller's stream (their
-    // counters are zeroed there).
-    static const bool chain_env = [] { const char *e = getenv("SR_FAR_CHAIN_PIPELINED"); return e ? atoi(e) != 0 : true; }();
-    const bool chain_on_pst = overlap && !counting && chain_env;
-    if (chain_on_pst) {
-      rc = far_pass(pst);
+    // Round 4: a decoupled, phased pipeline.  Between consecutive calls only the caller-visible output orders things:
+    // the zones kernel (tables -> private sums), the far-field chain (tables -> coefficients) and the preparation of
+    // the tables touch scratch of the call's own parity and nothing of the caller's, so each runs on an internal stream
+    // of its own as soon as ITS inputs are ready; only the wings kernel (zones' sums + near region 1 + polynomials ->
+    // abs / emi) sits on the caller's stream.  Who runs beside whom is decided by what FITS beside whom
+    // (tools/r03_timeline.sh, tools/kernel_resources.sh): 16 zones waves fill a CU -- 120 VGPRs each, 4 x 120 of a
+    // SIMD's 512, and 16 x 10 KB = all of its LDS -- and a retiring zones wave frees exactly one such slot, which the
+    // next zones wave takes unless the other kernel's wave fits it: the wings kernel (80 VGPRs), M2M / M2L (106 / 104)
+    // and the one-wave blocks of the preparation (104 VGPRs, 5 KB) do, the level-0 pass (140) and S2M (154) do not and
+    // starved beside the zones kernel until it drained -- then S2M -> M2M -> M2L ran alone, latency-bound, for 0.66 ms
+    // of every 5.6 ms step (round 3: the zones kernel forked off the caller's stream, the chain on it; the four-wave
+    // blocks of the preparation, 20 KB of LDS each, ran only when everything else had drained).  So the step has two
+    // phases: B = [wings(c) | level-0 pass(c + 1) | S2M(c + 1)] -- short waves that share the chip fairly --, then
+    // A = [zones(c + 1) | M2M, M2L(c + 1) | prep(c + 2)]; the zones kernel is GATED behind the level-0 pass and S2M of
+    // its own call (it needs neither), which is what keeps it from flooding the chip before they are through.
+    // Counting passes keep the round-3 order (their counters are zeroed on the caller's stream).
+    static const int pipe_env = [] { const char *e = getenv("SR_PIPELINE"); return e ? atoi(e) : 2; }();
+    const bool decoupled = overlap && !counting && pipe_env != 0;
+    if (decoupled) {
+      if (!w.aux) {
+        HIPCHK(hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
+      }
+      if (!w.chain_st) {
+        HIPCHK(hipStreamCreateWithFlags(&w.chain_st, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&w.chain2_st, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+          HIPCHK(hipEventCreateWithFlags(&w.ev_l0_done[i], hipEventDisableTiming));
+          HIPCHK(hipEventCreateWithFlags(&w.ev_s2m_done[i], hipEventDisableTiming));
+        }
+      }
+      rc = w.d_zone2[b].ensure(sizeof(double) * 2 * n_pts * nl);
       if (rc) return rc;
-      HIPCHK(hipEventRecord(w.ev_far_done[b], pst));
-    }
+      double *z_abs = w.d_zone2[b].as<double>(), *z_emi = z_abs + n_pts * nl;
+      // (the buffers of parity b were last read by the wings kernel two calls ago: the preparation waited for that)
+      // far-field chain: level-0 pass on one stream, moments + upward pass on another, translations behind both
+      HIPCHK(hipStreamWaitEvent(w.chain_st, w.ev_prep_done[b], 0));
+      LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, w.chain_st));
+      HIPCHK(hipEventRecord(w.ev_l0_done[b], w.chain_st));
+      hipStream_t last = w.chain_st;
+      if (fp.m2l) {
+        HIPCHK(hipStreamWaitEvent(w.chain2_st, w.ev_prep_done[b], 0));
+        LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, w.chain2_st, 1));
+        HIPCHK(hipEventRecord(w.ev_s2m_done[b], w.chain2_st));
+        HIPCHK(hipStreamWaitEvent(w.chain2_st, w.ev_l0_done[b], 0));
+        LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, w.chain2_st, 2));
+        last = w.chain2_st;
+      }
+      HIPCHK(hipEventRecord(w.ev_far_done[b], last));
+      // zones: needs the tables only; gated (SR_PIPELINE=2, default) behind the kernels that cannot run beside it
+      HIPCHK(hipStreamWaitEvent(w.aux, w.ev_prep_done[b], 0));
+      if (pipe_env >= 2) {
+        HIPCHK(hipStreamWaitEvent(w.aux, w.ev_l0_done[b], 0));
+        if (fp.m2l) HIPCHK(hipStreamWaitEvent(w.aux, w.ev_s2m_done[b], 0));
+      }
+      LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo,
+                            (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, w.aux));
+      HIPCHK(hipEventRecord(w.ev_zones_done[b], w.aux));
+      HIPCHK(hipStreamWaitEvent(st, w.ev_far_done[b], 0));
+      HIPCHK(hipEventRecord(w.ev[2], st));
+      HIPCHK(hipStreamWaitEvent(st, w.ev_zones_done[b], 0));
+      LAUNCHCHK(launch_near(1, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo,
+                            (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st, z_abs, z_emi));
+      HIPCHK(hipEventRecord(w.ev[3], st));
+      HIPCHK(hipEventRecord(w.ev[4], st));
+      w.overlapped = true;
+    } else
     if (overlap) {
       // The zones kernel needs only the record tables, the wings kernel needs the far-field
       // coefficients: zones runs on a second stream beside the far-field kernel and STORES its sums,
@@ -995,12 +1058,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, w.aux));
       HIPCHK(hipEventRecord(w.ev_join, w.aux));
-      if (chain_on_pst) {
-        HIPCHK(hipStreamWaitEvent(st, w.ev_far_done[b], 0));
-      } else {
-        rc = far_pass(st);
-        if (rc) return rc;
-      }
+      rc = far_pass(st);
+      if (rc) return rc;
       HIPCHK(hipEventRecord(w.ev[2], st));
       if (!small) HIPCHK(hipStreamWaitEvent(st, w.ev_join, 0));
       if (!w.ev_tail) HIPCHK(hipEventCreateWithFlags(&w.ev_tail, hipEventDisableTiming));

@@ -85,14 +85,17 @@ __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, c
   return P;
 }
 
-__global__ __launch_bounds__(256) void sr_prep_kernel(LinesDev L, LayersDev A, GridParams gp, WeightMode W,
+constexpr int kPrepBlock = 64; // one wave per block: a four-wave block with 20 KB of LDS never found room beside the zones
+                               // kernel (16 one-wave blocks of 10 KB fill a CU's LDS; a retiring wave frees ONE slot)
+                               // or the wings kernel, and the next call's preparation ran after them instead of beside
+__global__ __launch_bounds__(kPrepBlock) void sr_prep_kernel(LinesDev L, LayersDev A, GridParams gp, WeightMode W,
                                                       int line_lo, int n_sub, int cold_lo, int cold_hi,
                                                       FastRec *__restrict__ fast,
                                                       ColdRec *__restrict__ cold) {
   // records leave through LDS: stored from the registers, a lane's 80 / 128 B record goes out in 16-byte pieces at
   // a 80 / 128 B stride across the lanes; the wave's 64 records are contiguous in the table, so they are transposed
   // and stored 1 KB of consecutive bytes per instruction instead (the kernel writes its 1.63 GB at 5.2 TB/s).
-  __shared__ uint4 s_rec[4][64 * sizeof(FastRec) / 16]; // per wave: 64 fast records, then its 64 cold records
+  __shared__ uint4 s_rec[kPrepBlock / 64][64 * sizeof(FastRec) / 16]; // per wave: 64 fast records, then its 64 cold records
   static_assert(sizeof(ColdRec) <= sizeof(FastRec), "the cold records share the fast records' staging buffer");
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
@@ -600,10 +603,18 @@ __device__ inline int lane_reduce_index(int lane, bool &primary) {
 // COUNT: the instantiation sr_set_counting(1) selects; it adds the number of (line, box) expansions
 // this launch performs to cnt[kCntExpansions] (bench.py's executed-work accounting).  The timed
 // instantiation carries no counting code.
+// Tuning knob: waves per SIMD to compile for (4: <= 128 VGPRs; 140 unconstrained, 48 B of scratch at 128).  0 (default):
+// unconstrained.  Round 4 built this kernel and S2M to 128 VGPRs and padded the zones kernel to 128 so that their waves
+// fit the slot a retiring zones wave frees: the pass still ran 4.8 ms beside the zones kernel (the dispatcher serves
+// the OLDER dispatch first whenever its next workgroup fits, whatever the younger one needs) and the spills cost
+// 0.6 ms of the far-field group alone (1.07 -> 1.66 ms): step 6.07 vs 5.61 ms.
 #ifndef SR_FAR_WAVES_PER_EU
-#define SR_FAR_ATTR
-#else
+#define SR_FAR_WAVES_PER_EU 0
+#endif
+#if SR_FAR_WAVES_PER_EU > 0
 #define SR_FAR_ATTR __attribute__((amdgpu_waves_per_eu(SR_FAR_WAVES_PER_EU)))
+#else
+#define SR_FAR_ATTR
 #endif
 template <bool COUNT, bool M2L>
 __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastRec *__restrict__ fast,
@@ -852,8 +863,17 @@ __device__ constexpr double inv_factorial(int n) {
 // of 32 lines at a time, the upper half the left-going ones of the same lines, and each half sums its 2 kMQ values
 // over its own 32 lanes.  (A box holds 64 +- 8 lines on config 2: with 64 lines per step and one wave per side the
 // second step of most boxes ran nearly empty.)
+// as SR_FAR_WAVES_PER_EU (154 VGPRs unconstrained, 104 B of scratch at 128).  0 (default): unconstrained.
+#ifndef SR_S2M_WAVES_PER_EU
+#define SR_S2M_WAVES_PER_EU 0
+#endif
+#if SR_S2M_WAVES_PER_EU > 0
+#define SR_S2M_ATTR __attribute__((amdgpu_waves_per_eu(SR_S2M_WAVES_PER_EU)))
+#else
+#define SR_S2M_ATTR
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(64) void sr_s2m_kernel(const FastRec *__restrict__ fast, IcIndex ix, int n_sub, int g_lo,
+__global__ __launch_bounds__(64) SR_S2M_ATTR void sr_s2m_kernel(const FastRec *__restrict__ fast, IcIndex ix, int n_sub, int g_lo,
                                                     FarParams fp, unsigned long long *__restrict__ cnt) {
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wid / fp.n_src[0], sb = wid - layer * fp.n_src[0];
@@ -1190,8 +1210,9 @@ __device__ inline void window_end_sum(bool ends, int pos, double c[2 * kWE], int
 template <bool COUNT>
 __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
     const FastRec *__restrict__ fast, IcIndex ix, const int *__restrict__ zmax, int n_sub,
-    int n_tiles, int g_lo, int g_hi, FarParams fp, int add, double *__restrict__ abs_out,
-    double *__restrict__ emi_out, unsigned long long *__restrict__ cnt) {
+    int n_tiles, int g_lo, int g_hi, FarParams fp, int add, const double *__restrict__ z_abs,
+    const double *__restrict__ z_emi, double *__restrict__ abs_out, double *__restrict__ emi_out,
+    unsigned long long *__restrict__ cnt) {
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
   const int wlo = g_lo + tile * 64;
@@ -1370,7 +1391,10 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
   const size_t orow = (size_t)layer * (size_t)(g_hi - g_lo);
   const int j = wlo + lane;
   if (j <= whi) {
-    if (add) { // the zones kernel ran first (overlapped with the far-field kernel) and stored its sums
+    if (z_abs) { // the zones kernel's sums sit in a buffer of their own (it runs decoupled from the caller's stream)
+      abs_out[orow + (j - g_lo)] = z_abs[orow + (j - g_lo)] + sum_a;
+      emi_out[orow + (j - g_lo)] = z_emi[orow + (j - g_lo)] + sum_e;
+    } else if (add) { // the zones kernel ran first (overlapped with the far-field kernel) and stored its sums
       abs_out[orow + (j - g_lo)] += sum_a;
       emi_out[orow + (j - g_lo)] += sum_e;
     } else {
@@ -1441,6 +1465,11 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
   // element p + 1, i.e. element k + (j1 - wlo): the hot loops' address arithmetic carries no "- 1" (it cost a v_add per
   // region-2 point: the offset field of ds_add cannot be negative)
   __shared__ double s_img[NW][2][WT + 2];
+#ifdef SR_ZONES_PAD
+  // Tuning knob (see SR_FAR_WAVES_PER_EU): the wave's register footprint rounded up to a whole quarter of the SIMD's
+  // file (118 -> 128 VGPRs; four waves per SIMD either way, LDS allows no fifth).
+  asm volatile("" ::: "v127");
+#endif
   // per wave and region (2, 4): the chunk's lines with work there, compacted in lane order -- lane id and the two run
   // words -- written by the lanes = lines phase, read by the rows (dealing the lines to the rows with ballots and
   // selects cost 27 VALU instructions per round of eight lines, two bpermutes fetched the run words)
@@ -1728,8 +1757,9 @@ int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int
 }
 
 int launch_m2l(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi,
-               const FarParams &fp, unsigned long long *cnt, hipStream_t st) {
+               const FarParams &fp, unsigned long long *cnt, hipStream_t st, int which) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
+  if (which & 1) {
   const dim3 g1((unsigned)(fp.n_src[0] * n_layers));
   if (cnt)
     hipLaunchKernelGGL(sr_s2m_kernel<true>, g1, dim3(64), 0, st, fast, ix, n_sub, g_lo, fp, cnt);
@@ -1739,6 +1769,8 @@ int launch_m2l(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_su
     const int n2 = fp.n_src[l] * n_layers * 4;
     hipLaunchKernelGGL(sr_m2m_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, st, fp, l);
   }
+  }
+  if (!(which & 2)) return (int)hipGetLastError();
   int chunks = 0;
   for (int lv = 0; lv < fp.n_levels; ++lv) chunks += (fp.box_count[lv] * n_layers + 15) / 16;
   if (cnt)
@@ -1783,7 +1815,8 @@ static void launch_zones(dim3 gz, const FastRec *fast, const ColdRec *cold, cons
 
 int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
                 int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp,
-                double *abs_out, double *emi_out, unsigned long long *cnt, hipStream_t st) {
+                double *abs_out, double *emi_out, unsigned long long *cnt, hipStream_t st, const double *z_abs,
+                const double *z_emi) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
   const int n_groups = (g_hi - g_lo + kGroup - 1) / kGroup;
   const dim3 grid((unsigned)(n_groups * n_layers));
@@ -1792,10 +1825,10 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
     const int n_g1 = (g_hi - g_lo + 63) / 64;
     if (cnt)
       hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<true>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
-                         fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, abs_out, emi_out, cnt);
+                         fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, z_abs, z_emi, abs_out, emi_out, cnt);
     else
       hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<false>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
-                         fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, abs_out, emi_out, cnt);
+                         fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, z_abs, z_emi, abs_out, emi_out, cnt);
   } else {
     // Image width: wider images cut fewer zones in two (fewer (line, group) pairs: 7.1 -> 6.7 ms on
     // 1e5 points x 80 layers with 512 instead of 256) as long as the waves still fill the chip
@@ -1834,8 +1867,8 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
 int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, const WeightMode &W, int line_lo,
                 int n_sub, int cold_lo, int cold_hi, FastRec *fast, ColdRec *cold, hipStream_t st) {
   if (n_sub <= 0 || A.n_layers <= 0) return 0;
-  dim3 grid((n_sub + 255) / 256, A.n_layers);
-  hipLaunchKernelGGL(sr_prep_kernel, grid, dim3(256), 0, st, L, A, gp, W, line_lo, n_sub, cold_lo, cold_hi, fast,
+  dim3 grid((n_sub + kPrepBlock - 1) / kPrepBlock, A.n_layers);
+  hipLaunchKernelGGL(sr_prep_kernel, grid, dim3(kPrepBlock), 0, st, L, A, gp, W, line_lo, n_sub, cold_lo, cold_hi, fast,
                      cold);
   return (int)hipGetLastError();
 }

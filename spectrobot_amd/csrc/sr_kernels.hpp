@@ -120,13 +120,16 @@ int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int
                     int g_hi, const FarParams &fp, unsigned long long *cnt, hipStream_t st);
 // box-pair mode: moments of the level-0 source boxes, the wider levels, the translations (after the level-0 pass
 // of launch_farfield, which stores; the translations add at level 0 and store above)
+// which: bit 0 = moments + upward pass (sr_s2m_kernel, sr_m2m_kernel), bit 1 = translations (sr_m2l_kernel)
 int launch_m2l(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi,
-               const FarParams &fp, unsigned long long *cnt, hipStream_t st);
+               const FarParams &fp, unsigned long long *cnt, hipStream_t st, int which = 3);
 void m2l_table_host(double *tab); // [2][kM2LOffsets][kM2LQ][kM2LRow]
 // part 1: wing-only pairs + far-field polynomials (writes); part 2: general pairs (adds)
+// z_abs / z_emi (part 1 only): the zones kernel's sums in a buffer of their own; the wings kernel writes z + its sums
 int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
                 int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const FarParams &fp,
-                double *abs_out, double *emi_out, unsigned long long *cnt, hipStream_t st);
+                double *abs_out, double *emi_out, unsigned long long *cnt, hipStream_t st, const double *z_abs = nullptr,
+                const double *z_emi = nullptr);
 
 int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, const WeightMode &W, int line_lo,
                 int n_sub, int cold_lo, int cold_hi, FastRec *fast, ColdRec *cold, hipStream_t st);

@@ -16,7 +16,7 @@ rows = c.execute("select name, start, end, stream_id from kernels order by start
 idx = [i for i, r in enumerate(rows) if "sr_prep_kernel" in r[0]]
 a = idx[20]
 t0 = rows[a][1]; busy_end = None
-for name, s, e, st in rows[a:a + 30]:
+for name, s, e, st in rows[a:a + 44]:
     short = re.sub(r"^void ", "", name).split("(")[0].replace("sr::", "")[:40]
     gap = "" if busy_end is None or s <= busy_end else "   <- idle %.1f us" % ((s - busy_end) / 1e3)
     print("%-42s start %9.1f dur %8.1f us stream %s%s" % (short, (s - t0) / 1e3, (e - s) / 1e3, st, gap))
