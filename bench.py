@@ -9,7 +9,8 @@ x 80 layers, 1 ray, fp64.  Inputs are uploaded before the timed region (HBM resi
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-  python bench.py --config 2|3|4      extra lines for BASELINE configs[2..4] (bench_configs.py; not the headline)
+  python bench.py --config 2|3|4|lut  extra lines for BASELINE configs[2..4] and the look-up-table build (bench_configs.py;
+                                      not the headline)
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
 (dominant kernel: EXECUTED flops, counted on the device, over its HIP-event time)
@@ -202,8 +203,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=1, help="1 (default): BASELINE configs[1], the headline; "
-                    "2, 3, 4: extra lines for configs[2..4] (bench_configs.py)")
+    ap.add_argument("--config", default="1", help="1 (default): BASELINE configs[1], the headline; "
+                    "2, 3, 4: extra lines for configs[2..4]; lut: the look-up-table / G-coefficient build, the one thing "
+                    "the reference publishes a figure for (bench_configs.py)")
     ap.add_argument("--lines", type=int, default=100000)
     ap.add_argument("--grid", type=int, default=100000)
     ap.add_argument("--layers", type=int, default=80)
@@ -218,6 +220,7 @@ def main():
     ap.add_argument("--far-field", type=int, default=2, choices=(1, 2), help="2 (default): far-field expansions from box "
                     "pairs (multipole -> local); 1: per line and box")
     args = ap.parse_args()
+    args.config = args.config if args.config == "lut" else int(args.config)
 
     import __graft_entry__
     __graft_entry__.ensure_built(builder=int(os.environ.get("LOCAL_RANK", "0")) == 0)  # fresh checkouts carry no library

@@ -50,25 +50,55 @@ def tangent_heights(n_rays):
     return 100.0 + 12.5 * np.arange(n_rays) + 1e-3      # z_t = 100 + 12.5 r km
 
 
-def sza_atmosphere(atm, sza_deg, n_levels=12):
-    """Atmosphere of one solar zenith angle: the excess of the vibrational temperatures over the kinetic one
-    scales with the illumination cos(SZA); the kinetic profile is warmer on the day side by a few K."""
+# 3-D atmosphere of configs[3], modelled as the reference's (radtran_3Dvs2D_sza30-80_test.py:66-116): kinetic
+# temperature and pressure on (latitude box, altitude) -- AtmProfile(grid, TT, 'temp', ['box', 'lin']) on the seven
+# boxes of lat_ext -- and only the vibrational temperatures by the local illumination.  (Rounds 1-3 made the kinetic
+# temperature a continuous function of the SZA too, which no two LOS steps share and the reference does not do.)
+LAT_BOX_DT = np.array([-6.0, -4.0, -2.0, 0.0, 1.5, -3.0, -7.0])      # K, offset of the box's kinetic profile
+TANGENT_LAT_DEG = 5.0        # the pixels' tangent points: one latitude band, the SZA varies with local time
+SUBSOLAR_LAT_DEG = -12.0     # Titan, 2006-07
+
+
+def vib_temps(atm, temps, alt_layer, mu):
+    """T_vib [n_levels, n] at altitude shells alt_layer for cos SZA mu: the excess over the kinetic temperature scales
+    with the illumination (clipped at the terminator)."""
+    mu = np.clip(np.asarray(mu, float), 0.0, 1.0)
+    exc = (atm["tvib"] - atm["temps"][None, :])[:, alt_layer]
+    return np.asarray(temps, float)[None, :] + exc * (0.4 + 1.2 * mu)[None, :]
+
+
+def sza_atmosphere(atm, sza_deg, n_levels=12, box=3):
+    """The 1-D column of one pixel (use_tangent_sza = True): the kinetic profile of its latitude box (all eight SZA
+    pixels sit in the equatorial box: they SHARE (P, T)), vibrational temperatures at the tangent point's SZA."""
     mu = np.cos(np.deg2rad(sza_deg))
     out = dict(atm)
-    out["temps"] = atm["temps"] + 4.0 * (mu - 0.5)
-    exc = atm["tvib"] - atm["temps"][None, :]
-    out["tvib"] = out["temps"][None, :] + exc * (0.4 + 1.2 * mu)
+    out["temps"] = atm["temps"] + LAT_BOX_DT[box]
+    k = np.arange(len(atm["temps"]))
+    out["tvib"] = vib_temps(atm, out["temps"], k, np.full(len(k), mu))
     return out
 
 
-def step_atmosphere(atm, seg_alt_layer, seg_mu):
-    """(T, P, T_vib) of every LOS step of a 3-D path: the altitude shell's profile with the illumination of the step's
-    own position (same law as sza_atmosphere, with the local cos SZA clipped at the terminator)."""
+def step_atmosphere(atm, seg_alt_layer, seg_mu, seg_box=None):
+    """(T, P, T_vib) of every LOS step of a 3-D path: the kinetic state of the step's (latitude box, altitude shell),
+    the vibrational temperatures of the step's own illumination."""
     k = np.asarray(seg_alt_layer)
-    mu = np.clip(np.asarray(seg_mu, float), 0.0, 1.0)
-    temps = atm["temps"][k] + 4.0 * (mu - 0.5)
-    exc = (atm["tvib"] - atm["temps"][None, :])[:, k]
-    return dict(temps=temps, press=atm["press"][k], tvib=temps[None, :] + exc * (0.4 + 1.2 * mu)[None, :])
+    box = np.full(len(k), 3) if seg_box is None else np.asarray(seg_box)
+    temps = atm["temps"][k] + LAT_BOX_DT[box]
+    return dict(temps=temps, press=atm["press"][k], tvib=vib_temps(atm, temps, k, seg_mu))
+
+
+def los_3d_set(atm, vm, tz, sza, az):
+    """One set of 3-D limb rays (tangent heights tz, headings az east of north, tangent points at TANGENT_LAT_DEG seeing
+    the sun at `sza`) with the state of every step."""
+    from spectrobot_amd import geometry as geo
+    Lr = geo.limb_los_3d(atm["z"], atm["nd"], [vm], tz, sza, az, tangent_lat_deg=TANGENT_LAT_DEG, subsolar_lat_deg=SUBSOLAR_LAT_DEG)
+    Lr["seg_box"] = geo.lat_box_index(Lr["seg_lat"])
+    Lr["state"] = step_atmosphere(atm, Lr["seg_alt_layer"], Lr["seg_mu"], Lr["seg_box"])
+    return Lr
+
+
+ROUTE = _os.environ.get("SR_CONFIG3_ROUTE", "factored")     # "direct": a folded coefficient op per set (rounds 1-3)
+DT_FACTORED = 0.002                                         # K, forward difference of the pair tables
 
 
 def layer_vmr_weights(z, alt):
@@ -149,9 +179,11 @@ def _sync_time(fn, steps, warmup):
 
 def config3_3d(args, rank, world, info, base):
     """configs[3] in its 3-D form (radtran_3Dvs2D_sza30-80_test.py:353-379: use_tangent_sza = False,
-    invert_LOS_direction = True): per ray and per LOS STEP its own (P, T, T_vib(local SZA)) -- the coefficient op
-    runs over the ~900 steps of a set of 8 rays instead of 80 altitude layers (layer batches under the table
-    budget), the temperature Jacobian is still per altitude layer (seg_jac_row), the VMR Jacobian per level."""
+    invert_LOS_direction = True): per ray and per LOS STEP its own state.  Level-factored route (default): the pair
+    tables once per step of 8 sets on the distinct (latitude box, altitude) rows the rays touch, at T and T + dT, then
+    one combine per set for the ~900 steps' coefficient rows and their T derivatives, then the one-pass Jacobians
+    (temperature per altitude layer through seg_jac_row, VMR per level).  SR_CONFIG3_ROUTE=direct: a folded
+    coefficient op over the steps themselves, twice per set (rounds 1-3)."""
     import torch
     from spectrobot_amd import engine, synthetic as syn
     n_grid, n_lines, n_rays, szas = 200000, 200000, 8, [30.0, 37.0, 44.0, 51.0, 58.0, 65.0, 72.0, 80.0]
@@ -164,30 +196,100 @@ def config3_3d(args, rank, world, info, base):
     az = 22.5 * np.arange(n_rays)                       # the ray set fans out in azimuth
     my = szas[rank::world]
     pg = np.zeros(args.layers, np.int32)
+    sets = [los_3d_set(atm, vm, tz, sza, az) for sza in my]
+    for Lr in sets:
+        Lr["los"] = engine.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"], col_scale=[syn.CH4_ISO_RATIO])
+        Lr["W"] = layer_vmr_weights(atm["z"], Lr["alt"])
+    n_steps = len(sets[0]["seg_layer"])
+    # the distinct (P, T) rows of all sets
+    allT = np.concatenate([Lr["state"]["temps"] for Lr in sets])
+    allP = np.concatenate([Lr["state"]["press"] for Lr in sets])
+    T_rows, P_rows, step_row = engine.LevelFactored.unique_rows(allT, allP)
+    at = 0
+    for Lr in sets:
+        Lr["row"] = step_row[at:at + len(Lr["seg_layer"])]
+        at += len(Lr["seg_layer"])
+    tv_all = np.concatenate([Lr["state"]["tvib"] for Lr in sets], axis=1)
+    timing = {}
 
-    def one_set(sza):
-        Lr = syn.limb_los_3d(atm["z"], atm["nd"], [vm], tz, sza, az)
-        los = engine.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"], col_scale=[syn.CH4_ISO_RATIO])
-        a = step_atmosphere(atm, Lr["seg_alt_layer"], Lr["seg_mu"])
-        co, dco = engine.coefficients_dT(ls, a["temps"], a["press"], tvib=a["tvib"], scheme=DT_SCHEME)
-        W = layer_vmr_weights(atm["z"], Lr["alt"])
-        return engine.limb_rays_jacobians(co, los, dcoeffs=dco, par_gas=pg, par_w=W, seg_jac_row=Lr["seg_alt_layer"],
-                                          n_jac_rows=args.layers), len(Lr["seg_layer"])
+    def jacobians(Lr, co, dco):
+        return engine.limb_rays_jacobians(co, Lr["los"], dcoeffs=dco, par_gas=pg, par_w=Lr["W"], seg_jac_row=Lr["seg_alt_layer"],
+                                          n_jac_rows=args.layers)
 
-    def step():
-        res = None
-        for sza in my:
-            res = one_set(sza)
+    def step_factored():
+        lf = engine.LevelFactored(ls, T_rows, P_rows, dT=DT_FACTORED)
+        # ONE combine for the steps of all sets: the tables are read once (per set: once per set)
+        (ca, ce), (da, de) = lf.steps(step_row, tvib=tv_all, derivative=True)
+        res, at = None, 0
+        for Lr in sets:
+            n = len(Lr["seg_layer"])
+            res = jacobians(Lr, (ca[at:at + n], ce[at:at + n]), (da[at:at + n], de[at:at + n]))
+            at += n
         return res
 
-    dt, (res, n_steps) = _sync_time(step, max(1, args.steps // 10), min(args.warmup, 1))
-    out = dict(base, metric="limb spectra/sec with per-layer T and VMR Jacobians, 3-D path (BASELINE configs[3])",
+    def step_direct():
+        res = None
+        for Lr in sets:
+            a = Lr["state"]
+            co, dco = engine.coefficients_dT(ls, a["temps"], a["press"], tvib=a["tvib"], scheme=DT_SCHEME)
+            res = jacobians(Lr, co, dco)
+        return res
+
+    step = step_direct if ROUTE == "direct" else step_factored
+    dt, res = _sync_time(step, max(1, args.steps // 10), min(args.warmup, 1))
+    extra = {}
+    if rank == 0 and ROUTE != "direct":
+        # roofline of the route's own kernel, the combine: HBM-bound (tables read once per call + outputs written)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lf = engine.LevelFactored(ls, T_rows, P_rows, dT=DT_FACTORED)
+        torch.cuda.synchronize()
+        timing["tables_ms"] = (time.perf_counter() - t0) * 1e3
+        Lr = sets[0]
+        pop, dpop = ls.level_populations(T_rows[Lr["row"]], tvib=Lr["state"]["tvib"], derivative=True)
+        outs = [torch.empty((len(Lr["row"]), n_grid), dtype=torch.float64, device="cuda") for _ in range(4)]
+        used = len(np.unique(Lr["row"]))
+        bytes_alg = 8.0 * n_grid * (2 * 2 * lf.tab.shape[0] * used + 4 * len(Lr["row"]))
+        extra["roofline"] = _event_time(
+            lambda: engine.glevel_combine(lf.tab, Lr["row"], pop, tab_dT=lf.tab_dT, dpop=dpop, dT=DT_FACTORED, out=outs),
+            "sr_glevel_combine_kernel<12, true>", bytes_alg,
+            "one set: the %d distinct (P, T) rows of its %d steps x 2 x 12 pair spectra x 2 tables read once + abs, emi, "
+            "d abs / d T, d emi / d T of every step written" % (used, len(Lr["row"])))
+        extra["roofline"]["traffic"] = None
+        del lf, outs
+        extra["tables"] = {"rows": int(len(T_rows)), "steps_all_sets": int(len(step_row)), "ms_per_build_T_and_T_plus_dT": timing.get("tables_ms"),
+                           "note": "distinct (latitude box, altitude) rows of the %d sets' rays; each row's 24 pair spectra are "
+                                   "built once at T and once at T + %.3f K and serve every step on it" % (len(sets), DT_FACTORED)}
+        if world == 1 and args.cpu_seconds > 0:
+            import bench as B
+            from spectrobot_amd._lib import lib, dp
+            a0 = sets[0]["state"]
+            sel = np.unique(np.linspace(0, n_steps - 1, 80).round().astype(int))   # 80 of the set's steps
+            a80 = dict(temps=a0["temps"][sel], press=a0["press"][sel], tvib=a0["tvib"][:, sel])
+            q_part = np.zeros(len(sel))
+            tt = np.ascontiguousarray(a80["temps"])
+            assert lib.sr_calc_partition_sum(6, 1, tt.ctypes.data_as(dp), len(sel), q_part.ctypes.data_as(dp)) == 0
+            one = np.array([0, 1], np.int32)
+            cb = B.cpu_baseline(L, a80, grid, syn.CH4_MM, e_lev, q_part, args.cpu_seconds, len(sel),
+                                (one, np.zeros(1, np.int32), np.ones(1)))
+            # the oracle leg: folded coefficient rows of `ns` steps (value = share of 80 steps per second); a set has
+            # n_steps step rows at T and at T + dT and 8 rays: spectra/s = 8 / (2 n_steps / 80 / value)
+            per80 = cb["value"]
+            cb["value"] = n_rays / (2.0 * n_steps / 80.0 / per80)
+            cb["sample"] += "; scaled to a set of %d step rows at T and T + dT (the CPU leg runs the folded per-step op, no recursion of the 8 rays' Jacobians)" % n_steps
+            extra["cpu_baseline"] = cb
+            extra["speedup_vs_cpu_baseline"] = (len(szas) * n_rays / dt) / cb["value"]
+    out = dict(base, **extra)
+    out = dict(out, metric="limb spectra/sec with per-layer T and VMR Jacobians, 3-D path (BASELINE configs[3])",
                value=len(szas) * n_rays / dt if world == len(szas) or world == 1 else len(my) * n_rays * world / dt,
                ms_per_step=dt * 1e3, scaling="weak" if world > 1 else "n/a",
                config={"workload": "3-D atmosphere (BASELINE configs[3], use_tangent_sza = False): %d tangent SZA x %d rays fanned in "
-                                   "azimuth, %d lines x %d-pt grid, a coefficient row per LOS step (%d steps per set instead of %d "
-                                   "altitude layers), d/dT_k per altitude layer (%s, over the steps) and d/dVMR_k per level"
-                                   % (len(szas), n_rays, n_lines, n_grid, n_steps, args.layers, DT_SCHEME_NOTE),
+                                   "azimuth, %d lines x %d-pt grid, kinetic T on (latitude box, altitude), T_vib by the local SZA: a "
+                                   "coefficient row per LOS step (%d steps per set), d/dT_k per altitude layer and d/dVMR_k per level"
+                                   % (len(szas), n_rays, n_lines, n_grid, n_steps),
+                       "route": ("level-factored: pair tables on the distinct (P, T) rows at T and T + %.3f K (boundaries frozen), one "
+                                 "combine per set with analytic d pop / d T" % DT_FACTORED) if ROUTE != "direct" else
+                                ("direct: " + DT_SCHEME_NOTE + ", over the steps themselves"),
                        "device": info["name"]},
                checksum=float(res[0].sum().item()), los_steps_per_set=n_steps)
     if rank == 0:
@@ -282,44 +384,57 @@ def main(args):
         Lr = syn.limb_los(atm["z"], atm["nd"], [vm], 120.0 + 60.0 * np.arange(n_rays))
         los = engine.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"], col_scale=[syn.CH4_ISO_RATIO])
         W = layer_vmr_weights(atm["z"], Lr["alt"])
-        my = szas[rank::world]                       # independent ray batches: one SZA set per rank, no collective
+        my = szas[rank::world]                       # independent ray batches: SZA sets split over the ranks, no collective
+        atms = [sza_atmosphere(atm, sza) for sza in my]
+        nl = args.layers
 
         def coef3(a, scheme=DT_SCHEME):
             return engine.coefficients_dT(ls, a["temps"], a["press"], tvib=a["tvib"], scheme=scheme)
 
         pg = np.zeros(args.layers, np.int32)
+        # level-factored route: the sets share their (P, T) rows (one latitude box); only T_vib differs
+        T_rows, P_rows, row0 = engine.LevelFactored.unique_rows(np.concatenate([a["temps"] for a in atms]),
+                                                                 np.concatenate([a["press"] for a in atms]))
+        tv_all = np.concatenate([a["tvib"] for a in atms], axis=1)
+        timing = {}
 
-        def step():
+        def step_factored():
+            lf = engine.LevelFactored(ls, T_rows, P_rows, dT=DT_FACTORED)
+            (ca, ce), (da, de) = lf.steps(row0, tvib=tv_all, derivative=True)     # all sets' layers in one combine
             res = None
-            for sza in my:
-                co, dco = coef3(sza_atmosphere(atm, sza))
+            for i in range(len(my)):
+                sl = slice(i * nl, (i + 1) * nl)
                 # radiances + d/dT_k + d/dVMR_k of the 8 rays in one pass per ray
+                res = engine.limb_rays_jacobians((ca[sl], ce[sl]), los, dcoeffs=(da[sl], de[sl]), par_gas=pg, par_w=W)
+            return res
+
+        def step_direct(scheme=DT_SCHEME):
+            res = None
+            for a in atms:
+                co, dco = coef3(a, scheme)
                 res = engine.limb_rays_jacobians(co, los, dcoeffs=dco, par_gas=pg, par_w=W)
             return res
 
+        step = step_direct if ROUTE == "direct" else step_factored
         dt, res = _sync_time(step, max(1, args.steps // 4), min(args.warmup, 1))
         extra = {}
-
-        def step_central():
-            res_ = None
-            for sza in my:
-                co, dco = coef3(sza_atmosphere(atm, sza), "central")
-                res_ = engine.limb_rays_jacobians(co, los, dcoeffs=dco, par_gas=pg, par_w=W)
-            return res_
-
-        dt_c, res_c = _sync_time(step_central, max(1, args.steps // 8), 1)
+        dt_c, res_c = _sync_time(lambda: step_direct("central"), max(1, args.steps // 8), 1)
+        dt_d = None
+        if ROUTE != "direct":
+            dt_d, _ = _sync_time(step_direct, max(1, args.steps // 8), 1)
         if rank == 0:
-            jt, jt_c = res[1], res_c[1]      # temperature Jacobians of the last set, both schemes
+            jt, jt_c = res[1], res_c[1]      # temperature Jacobians of the last set: this route / three folded ops, central
             extra["temperature_derivative"] = {
-                "scheme": DT_SCHEME_NOTE, "coefficient_ops_per_set": 2 if DT_SCHEME == "forward" else 3,
-                "ms_per_step_with_central_differences": dt_c * 1e3,
-                "spectra_per_s_with_central_differences": len(szas) * n_rays / dt_c if world in (1, len(szas)) else None,
+                "scheme": ("pair tables at T and T + %.3f K (boundaries frozen at T), d pop / d T analytic" % DT_FACTORED) if ROUTE != "direct" else DT_SCHEME_NOTE,
+                "ms_per_step_direct_central_differences": dt_c * 1e3,
+                "spectra_per_s_direct_central_differences": len(szas) * n_rays / dt_c if world in (1, len(szas)) else None,
+                "ms_per_step_direct_forward_difference": None if dt_d is None else dt_d * 1e3,
                 "max_rel_dev_of_T_jacobian_from_central": float(((jt - jt_c).abs().amax() / jt_c.abs().amax()).item())}
             del jt, jt_c
         del res_c
         if rank == 0:
             import bench as B
-            a0 = sza_atmosphere(atm, my[0])
+            a0 = atms[0]
             kms, counts = B.serial_kernel_times_and_counts(engine, ls, lambda: ls.abscoeff_layers(a0["temps"], a0["press"], tvib=a0["tvib"]), n=3)
             extra["roofline"] = B.coefficient_roofline(kms, counts)
             co, dco = coef3(a0)
@@ -331,6 +446,25 @@ def main(args):
                      "tables read once + the radiances; the plan stores a row at its first touch and adds at the second "
                      "(a limb path crosses a layer twice): ~1.5x the Jacobian bytes move" % (jac_bytes / 1e9))
             del co, dco
+            if ROUTE != "direct":
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                lf = engine.LevelFactored(ls, T_rows, P_rows, dT=DT_FACTORED)
+                torch.cuda.synchronize()
+                timing["tables_ms"] = (time.perf_counter() - t0) * 1e3
+                pop, dpop = ls.level_populations(T_rows[row0], tvib=tv_all, derivative=True)
+                outs = [torch.empty((len(row0), n_grid), dtype=torch.float64, device="cuda") for _ in range(4)]
+                extra["combine_kernel"] = _event_time(
+                    lambda: engine.glevel_combine(lf.tab, row0, pop, tab_dT=lf.tab_dT, dpop=dpop, dT=DT_FACTORED, out=outs),
+                    "sr_glevel_combine_kernel<12, true>", 8.0 * n_grid * (2 * 2 * lf.tab.shape[0] * len(T_rows) + 4 * len(row0)),
+                    "all %d sets at once: %d (P, T) rows x 2 x 12 pair spectra x 2 tables read once + abs, emi, d abs / d T, "
+                    "d emi / d T of %d (set, layer) steps written" % (len(my), len(T_rows), len(row0)))
+                del lf, outs
+                extra["tables"] = {"rows": int(len(T_rows)), "steps_all_sets": int(len(row0)),
+                                   "ms_per_build_T_and_T_plus_dT": timing.get("tables_ms"),
+                                   "note": "the %d SZA pixels lie in one latitude box and share its kinetic profile: the 24 pair "
+                                           "spectra of a layer are built once (at T and at T + %.3f K) for all of them"
+                                           % (len(my), DT_FACTORED)}
             if world == 1 and args.cpu_seconds > 0:
                 from spectrobot_amd._lib import lib, dp
                 q_part = np.zeros(args.layers)
@@ -338,11 +472,11 @@ def main(args):
                 assert lib.sr_calc_partition_sum(6, 1, tt.ctypes.data_as(dp), args.layers, q_part.ctypes.data_as(dp)) == 0
                 cb = B.cpu_baseline(L, a0, grid, syn.CH4_MM, e_lev, q_part, args.cpu_seconds, args.layers,
                                     (Lr["seg_off"], Lr["seg_layer"], B.cpu_columns(Lr, syn.CH4_ISO_RATIO)))
-                # the oracle leg is ONE coefficient op + the radiances of the set's 8 rays; a set with its temperature
-                # Jacobian costs three ops (T, T +- dT): the Jacobian recursions themselves are not in the CPU figure
-                n_ops = 2.0 if DT_SCHEME == "forward" else 3.0
-                cb["value"] = cb["value"] / n_ops
-                cb["sample"] += "; /%d: a set needs the coefficient op at T and at T + dT%s (the CPU leg runs one and no Jacobian recursion)" % (n_ops, "" if n_ops == 2 else " and T - dT")
+                # the oracle leg is ONE folded coefficient op + the radiances of the set's 8 rays; the reference-shaped
+                # CPU path needs it at T and at T + dT per set (it has no level-factored shortcut across sets unless it
+                # keeps 24 spectra per layer in memory): the Jacobian recursions themselves are not in the CPU figure
+                cb["value"] = cb["value"] / 2.0
+                cb["sample"] += "; /2: a set needs the coefficient op at T and at T + dT (the CPU leg runs one and no Jacobian recursion)"
                 extra["cpu_baseline"] = cb
                 extra["speedup_vs_cpu_baseline"] = (len(szas) * n_rays / dt) / cb["value"]
         out = dict(base, **extra)
@@ -350,9 +484,13 @@ def main(args):
                    value=len(szas) * n_rays / dt if world == len(szas) or world == 1 else len(my) * n_rays * world / dt,
                    ms_per_step=dt * 1e3, scaling="weak" if world > 1 else "n/a",
                    config={"workload": "3D-atmosphere ray sets (BASELINE configs[3]): %d SZA x %d rays, %d lines x %d-pt grid x %d "
-                                       "layers, d/dT_k (%s) and d/dVMR_k (analytic) for "
-                                       "every layer; SZA sets are independent batches (split over ranks, no collective)"
-                                       % (len(szas), n_rays, n_lines, n_grid, args.layers, DT_SCHEME_NOTE), "device": info["name"]},
+                                       "layers, d/dT_k and d/dVMR_k (analytic) for every layer; kinetic T on (latitude box, altitude) "
+                                       "-- the pixels share one box --, T_vib by the SZA; SZA sets are independent batches (split "
+                                       "over ranks, no collective)" % (len(szas), n_rays, n_lines, n_grid, args.layers),
+                           "route": ("level-factored: pair tables of the %d shared (P, T) rows at T and T + %.3f K, one combine for "
+                                     "all sets, analytic d pop / d T" % (len(T_rows), DT_FACTORED)) if ROUTE != "direct" else
+                                    ("direct: " + DT_SCHEME_NOTE + ", a folded op per set"),
+                           "device": info["name"]},
                    checksum=float(res[0].sum().item()), jacobian_gb_per_sza=(res[1].numel() + res[2].numel()) * 8 / 1e9)
     elif args.config == 4:
         scene = two_gas_scene(40000, 8000, 60000, 60)
@@ -396,8 +534,81 @@ def main(args):
                    max_rel_dev_from_truth=float(np.max(np.abs(bs.param_vector() - x_true) / x_true)))
         if world > 1:
             out["dist"] = sd.dist_info()
+    elif args.config == "lut":
+        # The one thing the reference publishes a figure for: the look-up-table / G-coefficient build,
+        # "n_lines x 3 / 30000 x n_PT minutes" = 6 ms per (line, P-T couple) with its n_threads worker processes
+        # (spect_main_module.py:791-801; :1863 "like 3 x len(PTcouples) minutes").  LookUpTable.make on the configs[1]
+        # case: 1e5 lines, 12 levels, 3 ctypes, the calc_PT_couples_atmosphere lattice of its 80-layer atmosphere with the
+        # LUTopt of the reference's 3-D driver (temp_step 5 K, pres_step_log 1.0: radtran_3Dvs2D_sza30-80_test.py:313-316).
+        from spectrobot_amd import spect_main_module as smm, spect_classes as spcl, spect_base_module as sbm
+        grid, L, atm, e_lev = ch4_case(args.lines, args.grid, args.layers)
+        iso = sbm.IsoMolec(6, 1, syn.CH4_MM, mol_name="CH4")
+        for i, e in enumerate(e_lev):
+            iso.add_level("L%02d" % i, e, local_vibtemp=atm["tvib"][i])
+        iw = int(np.argmax(L["air_broad"]))
+        widest = spcl.SpectLine([6, 1, L["freq"][iw], 0.0, L["a_coeff"][iw], L["air_broad"][iw], 0.0, L["e_lower"][iw],
+                                 L["t_dep_broad"][iw], 0.0, "L%02d" % L["lev_up"][iw], "L%02d" % L["lev_lo"][iw], "", "", "",
+                                 L["g_up"][iw], L["g_lo"][iw]], nomi=spcl.cose_hit)
+
+        class Atm(object):
+            pres, temp = atm["press"], atm["temps"]
+        PT = smm.calc_PT_couples_atmosphere([widest], iso, Atm, pres_step_log=1.0, temp_step=5.0)
+        ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)
+        sg = spcl.SpectralGrid(grid, units="cm_1")
+        lut = smm.LookUpTable(iso, [grid[0], grid[-1]], LTE=False)
+
+        def step():
+            lut.make(sg, ls, PT, pt_batch=len(PT))
+            return lut
+
+        dt, _ = _sync_time(step, max(1, args.steps // 10), 1)
+        n_pairs = float(ls.n_kept) * len(PT)
+        value = n_pairs / dt
+        gb = sum(st.device.numel() for st in lut.sets.values()) * 8 / 1e9
+        extra = {}
+        if rank == 0:
+            import bench as B
+            # roofline: the dominant kernel of the build is the coefficient op's zones kernel, on the level sub-linesets
+            kms, counts = B.serial_kernel_times_and_counts(engine, ls, lambda: ls.gcoeff_layers(
+                [pt[1] for pt in PT], [pt[0] for pt in PT], level=0), n=3)
+            extra["roofline"] = B.coefficient_roofline(kms, counts)
+            extra["roofline"]["note"] = ("one of the build's 24 coefficient ops (level 0: absorption | sp_emission of the lines "
+                                         "whose lower / upper level it is, %d (P, T) rows): executed flops of its dominant kernel / "
+                                         "its stand-alone HIP-event duration" % len(PT))
+            if world == 1 and args.cpu_seconds > 0:
+                from oracle import oracle as O
+                import time as _t
+                # the oracle's G-coefficient spectra (its restatement of add_PT -> BuildCoeff for every level and ctype) on a
+                # bounded sample of the couples, all host cores
+                cores = B.host_cores()
+                ns = int(max(1, min(len(PT), round(args.cpu_seconds * cores / (3 * 55e-6 * ls.n_kept)))))
+                sel = np.linspace(0, len(PT) - 1, ns).round().astype(int)
+                t0 = _t.time()
+                O.gcoeff_layers(L, syn.CH4_MM, e_lev, np.array([PT[i][1] for i in sel]), np.array([PT[i][0] for i in sel]),
+                                np.ones(len(sel)), None, grid, n_threads=cores)
+                t_cpu = _t.time() - t0
+                extra["cpu_baseline"] = {"value": float(ls.n_kept) * ns / t_cpu, "unit": "(line, PT couple) pairs/s", "cores": cores,
+                                         "kind": "port",
+                                         "sample": "%d of the %d couples, all %d lines, all 12 levels x 3 ctypes, full %d-point grid: "
+                                                   "%.1f s on %d threads" % (ns, len(PT), ls.n_kept, len(grid), t_cpu, cores)}
+                extra["speedup_vs_cpu_baseline"] = value / extra["cpu_baseline"]["value"]
+        out = dict(base, **extra)
+        ref_pairs_per_s = 1.0 / 6e-3
+        out = dict(out, metric="look-up-table build: (line, P-T couple) pairs per second (LookUpTable.make)",
+                   unit="(line, PT couple) pairs/s", value=value, ms_per_step=dt * 1e3, scaling="n/a",
+                   vs_baseline=value / ref_pairs_per_s,
+                   reference_estimate={"value": ref_pairs_per_s, "unit": "(line, PT couple) pairs/s",
+                                       "source": "spect_main_module.py:791-801: n_lines x 3 / 30000 x n_PT minutes = 6 ms per "
+                                                 "(line, PT couple) with n_threads worker processes, hardware not stated "
+                                                 "(BASELINE.md 1); for this table: %.0f minutes" % (n_pairs * 6e-3 / 60.0)},
+                   config={"workload": "LookUpTable.make (spect_main_module.py:718-788): %d lines x 12 levels x 3 ctypes x %d (P, T) "
+                                       "couples (calc_PT_couples_atmosphere of the configs[1] atmosphere, temp_step 5 K, pres_step_log "
+                                       "1.0) x %d-pt grid = %.1f GB of G spectra, resident in HBM" % (ls.n_kept, len(PT), len(grid), gb),
+                           "line_evaluations_per_line": "3: absorption + sp_emission in one pass over the lines whose lower or upper "
+                                                        "level is L, ind_emission in a second pass over the upper-level lines only",
+                           "device": info["name"]})
     else:
-        raise SystemExit("--config must be 1..4")
+        raise SystemExit("--config must be 1..4 or lut")
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -307,6 +307,7 @@ struct sr_lineset {
   // per-level sub-linesets (lines whose upper or lower level is L), built on first use by the
   // G-coefficient / tracked-level entry points; nullptr until then
   std::vector<sr_lineset *> level_sets;
+  std::vector<sr_lineset *> level_up_sets; // the lines whose UPPER level is L only (the ind_emission pass)
   DevBuf d_gscratch;          // second output channel of the ind_emission pass
   GridParams gp{};
   int mol = 0, iso = 0, n_levels = 0;
@@ -650,6 +651,8 @@ int sr_lineset_destroy(sr_lineset *ls) {
   (void)hipDeviceSynchronize(); // work of the last calls may still be in flight on the internal streams
   for (sr_lineset *child : ls->level_sets) sr_lineset_destroy(child);
   ls->level_sets.clear();
+  for (sr_lineset *child : ls->level_up_sets) sr_lineset_destroy(child);
+  ls->level_up_sets.clear();
   ls->d_lines_outer.release();
   ls->d_gscratch.release();
   ls->d_lines.release();
@@ -988,8 +991,12 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         HIPCHK(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
       }
       if (!w.chain_st) {
-        HIPCHK(hipStreamCreateWithFlags(&w.chain_st, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&w.chain2_st, hipStreamNonBlocking));
+        // SR_CHAIN_PRIO=1 (tuning): the chain's streams at the highest priority the device offers
+        static const int prio_env = [] { const char *e = getenv("SR_CHAIN_PRIO"); return e ? atoi(e) : 0; }();
+        int p_lo = 0, p_hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&p_lo, &p_hi));
+        HIPCHK(hipStreamCreateWithPriority(&w.chain_st, hipStreamNonBlocking, prio_env ? p_hi : 0));
+        HIPCHK(hipStreamCreateWithPriority(&w.chain2_st, hipStreamNonBlocking, prio_env ? p_hi : 0));
         for (int i = 0; i < 2; ++i) {
           HIPCHK(hipEventCreateWithFlags(&w.ev_l0_done[i], hipEventDisableTiming));
           HIPCHK(hipEventCreateWithFlags(&w.ev_s2m_done[i], hipEventDisableTiming));
@@ -1112,7 +1119,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
 
 // Sub-lineset of the lines whose upper or lower level is `level` (same grid, iso-molecule and level
 // table), built on first use.  For the 'all' set (no levels) the lineset itself.
-static int level_set(sr_lineset *ls, int level, sr_lineset **out) {
+// up_only: only the lines whose upper level is `level` (sp_emission / ind_emission select those, spcl:1304-1313).
+static int level_set(sr_lineset *ls, int level, sr_lineset **out, bool up_only = false) {
   if (level == -1) { // every line of the iso-molecule
     *out = ls;
     return SR_OK;
@@ -1123,8 +1131,9 @@ static int level_set(sr_lineset *ls, int level, sr_lineset **out) {
     return SR_OK;
   }
   if (level < 0 || level >= ls->n_levels) return SR_ERR_ARG;
-  if (ls->level_sets.empty()) ls->level_sets.assign((size_t)ls->n_levels, nullptr);
-  if (!ls->level_sets[(size_t)level]) {
+  std::vector<sr_lineset *> &sets = up_only ? ls->level_up_sets : ls->level_sets;
+  if (sets.empty()) sets.assign((size_t)ls->n_levels, nullptr);
+  if (!sets[(size_t)level]) {
     sr_lineset *c = new sr_lineset();
     c->gp = ls->gp;
     c->mol = ls->mol;
@@ -1138,14 +1147,14 @@ static int level_set(sr_lineset *ls, int level, sr_lineset **out) {
       const HostLines &H = which ? ls->host_outer : ls->host;
       std::vector<int64_t> sel;
       for (int64_t q = 0; q < H.m; ++q)
-        if (H.i[1 * H.md + q] == level || H.i[2 * H.md + q] == level) sel.push_back(q);
+        if (H.i[1 * H.md + q] == level || (!up_only && H.i[2 * H.md + q] == level)) sel.push_back(q);
       (which ? c->host_outer : c->host) = subset(H, sel);
     }
     const int rc = lineset_upload(c);
     if (rc) { sr_lineset_destroy(c); return rc; }
-    ls->level_sets[(size_t)level] = c;
+    sets[(size_t)level] = c;
   }
-  *out = ls->level_sets[(size_t)level];
+  *out = sets[(size_t)level];
   return SR_OK;
 }
 
@@ -1170,7 +1179,13 @@ int sr_gcoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, i
   const int wl = ls->n_levels == 0 ? -1 : level; // no level table: lev_up = lev_lo = 0 for every line anyway
   rc = coef_op(c, atm, g_lo, g_hi, g_out + 2 * plane, g_out + 0 * plane, stream, WeightMode{kWeightGabsGsp, wl});
   if (rc) return rc;
-  return coef_op(c, atm, g_lo, g_hi, g_out + 1 * plane, ls->d_gscratch.as<double>(), stream,
+  // ind_emission selects the lines whose UPPER level is `level`: the second pass runs on those alone (round 4; for
+  // the ground level, which 80 % of a hot-band list have as their lower level, that is an empty set instead of
+  // the whole list a second time)
+  sr_lineset *cu = nullptr;
+  rc = level_set(ls, level, &cu, true);
+  if (rc) return rc;
+  return coef_op(cu, atm, g_lo, g_hi, g_out + 1 * plane, ls->d_gscratch.as<double>(), stream,
                  WeightMode{kWeightGind, wl});
 }
 

@@ -179,7 +179,11 @@ class LineSet(object):
         from the derivative of CalcPartitionSum's own interpolant unless q_part pins Q (then Q' = 0)."""
         from . import spect_classes as spcl
         T = np.ascontiguousarray(temps, dtype=np.float64)
-        Q = np.asarray(q_part, float) if q_part is not None else np.atleast_1d(spcl.CalcPartitionSum(self.mol, self.iso, T))
+        if q_part is not None:
+            Q = np.asarray(q_part, float)
+        else:   # on the distinct temperatures only (thousands of LOS steps share a few hundred)
+            Tu, inv = np.unique(T, return_inverse=True)
+            Q = np.atleast_1d(spcl.CalcPartitionSum(self.mol, self.iso, Tu))[inv]
         E = self.level_energies
         c2 = spcl.c2
         if E.size == 0:
@@ -294,6 +298,52 @@ def glevel_combine(tab, step_row, pop, tab_dT=None, dpop=None, dT=None, out=None
                                     ptr(out[2]) if want_dT else None, ptr(out[3]) if want_dT else None, _stream_ptr()),
           "sr_glevel_combine_dev")
     return ((out[0], out[1]), (out[2], out[3])) if want_dT else (out[0], out[1])
+
+
+class LevelFactored(object):
+    """The level-factored route as one object: the pair tables of a LineSet on a set of (P, T) rows (LineSet.glevel_pairs;
+    with dT also at T + dT, region boundaries frozen at T) and the combine for any number of LOS steps on those rows
+    (glevel_combine).  The reference's own structure (make_abscoeff_isomolec: G spectra per (P, T) through
+    calc_shapes_lines + add_PT, spect_main_module.py:1963-1990, then the population loop :2036-2106): line shapes are
+    evaluated once per (P, T) row however many steps / SZA sets / vibrational-temperature states share it -- a 3-D path
+    whose kinetic temperature lives on (latitude box, altitude) and whose vibrational temperatures follow the local
+    SZA (radtran_3Dvs2D_sza30-80_test.py:66-116) has ~10x more steps than rows.
+
+    Worth it when rows are shared: the tables cost ~3.7 folded ops per 80 rows (24 output spectra instead of 2: twelve
+    passes over sub-linesets, tools/glevel_probe.py), a folded op per step costs 1 per 80 steps."""
+
+    def __init__(self, ls, temps_rows, press_rows, dT=None, g_lo=0, g_hi=None):
+        self.ls = ls
+        self.temps = np.ascontiguousarray(temps_rows, dtype=np.float64)
+        self.press = np.ascontiguousarray(press_rows, dtype=np.float64)
+        self.dT = dT
+        self.tab = ls.glevel_pairs(self.temps, self.press, g_lo=g_lo, g_hi=g_hi)
+        self.tab_dT = None
+        if dT:
+            ls.set_bounds_temps(self.temps)
+            try:
+                self.tab_dT = ls.glevel_pairs(self.temps + dT, self.press, g_lo=g_lo, g_hi=g_hi)
+            finally:
+                ls.set_bounds_temps(None)
+
+    @staticmethod
+    def unique_rows(temps, press):
+        """(T_rows, P_rows, step_row): the distinct (P, T) couples of a list of steps and every step's row."""
+        pt = np.stack([np.asarray(press, float), np.asarray(temps, float)], axis=1)
+        rows, inv = np.unique(pt, axis=0, return_inverse=True)
+        return rows[:, 1].copy(), rows[:, 0].copy(), np.asarray(inv, np.int32).reshape(-1)
+
+    def steps(self, step_row, tvib=None, q_part=None, derivative=False, out=None):
+        """(abs, emi) [n_steps, n_pts] of the steps (each on table row step_row[s], vibrational temperatures tvib
+        [n_levels, n_steps], None = LTE); derivative=True: ((abs, emi), (d abs / d T, d emi / d T)), needs dT."""
+        step_row = np.ascontiguousarray(step_row, dtype=np.int32)
+        T = self.temps[step_row]
+        if not derivative:
+            return glevel_combine(self.tab, step_row, self.ls.level_populations(T, tvib=tvib, q_part=q_part), out=out)
+        if self.tab_dT is None:
+            raise ValueError("LevelFactored was built without dT: no temperature derivative")
+        pop, dpop = self.ls.level_populations(T, tvib=tvib, q_part=q_part, derivative=True)
+        return glevel_combine(self.tab, step_row, pop, tab_dT=self.tab_dT, dpop=dpop, dT=self.dT, out=out)
 
 
 def set_counting(on):

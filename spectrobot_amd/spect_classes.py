@@ -139,7 +139,8 @@ def CalcPartitionSum_dT(mol, iso, temp=296.0):
     gi = C.c_double(0)
     tg, qg = np.zeros(119), np.zeros(119)
     check(lib.sr_bd_tips_2003(int(mol), int(iso), C.byref(gi), tg.ctypes.data_as(dp), qg.ctypes.data_as(dp)), "bd_tips_2003")
-    t = np.atleast_1d(np.asarray(temp, dtype=np.float64))
+    t_all = np.atleast_1d(np.asarray(temp, dtype=np.float64))
+    t, inv = np.unique(t_all, return_inverse=True)      # a 3-D path has thousands of steps on a few hundred temperatures
     out = np.zeros_like(t)
     for i, T in enumerate(t):
         n_le = int(np.searchsorted(tg, T, side="right"))
@@ -151,6 +152,7 @@ def CalcPartitionSum_dT(mol, iso, temp=296.0):
             num = sum(np.prod([T - xs[k] for k in range(len(xs)) if k not in (j, m)]) for m in range(len(xs)) if m != j)
             d += qs[j] * num / den
         out[i] = d
+    out = out[inv].reshape(t_all.shape)
     return out if np.ndim(temp) else float(out[0])
 
 

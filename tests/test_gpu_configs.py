@@ -423,9 +423,11 @@ def test_temperature_derivative_schemes(eng):
 def test_frozen_boundaries_at_other_temperatures_lose_nothing(eng):
     """sr_lineset_set_bounds_temps with boundary temperatures several K away from the call's own: the
     zone of a line is then placed with the widths of Tb while the kernels' candidate bound (widest zone of the layer)
-    came from T alone -- for Tb > T a line's outermost region-2 points were never visited.  A frozen call differs from
-    the unfrozen one only by where the seams sit (the regions disagree by 1e-5..1e-4 there): sparse lines, so that a
-    dropped contribution would be an O(1) error of the point, in both far-field modes and the exact mode."""
+    came from T alone -- for Tb > T a line's outermost region-2 points were never visited.  Sparse lines (one per 200
+    points: in its own outer zone a line is most of the sum), so a dropped contribution is an O(1) deviation from the
+    unfrozen call, while what freezing legitimately changes is where the Humlicek regions hand over: up to ~1e-2 when
+    region 2 (which has no Gaussian part) reaches inside |x| + y = 5.5 at Tb = T - 8 K and y -> 0, 1e-3 otherwise.
+    Both far-field modes and the exact mode."""
     import torch
     from spectrobot_amd import synthetic as syn
     grid = syn.make_grid(2990.0, 5e-4, 30000)
@@ -446,7 +448,7 @@ def test_frozen_boundaries_at_other_temperatures_lose_nothing(eng):
                 ra = float(((a1 - a0).abs() / a0.abs()).max())
                 re = float(((e1 - e0).abs() / e0.abs()).max())
                 print("far-field mode %d, boundaries at T%+.0f K: max rel deviation from the unfrozen call %.1e %.1e" % (mode, dTb, ra, re))
-                assert 0.0 < ra < 2e-3 and 0.0 < re < 2e-3
+                assert 0.0 < ra < 5e-2 and 0.0 < re < 5e-2
     finally:
         eng.set_far_field(eng.FAR_FIELD_DEFAULT)
 
@@ -527,6 +529,59 @@ def test_config3_3d_path_per_step_state(eng, oracle):
         assert err < 1e-5, (k, err)
         assert float(fd[2].abs().max()) > 0 or k < 17
     assert float(jt3[2, :17].abs().max()) == 0.0
+
+
+def test_config3_3d_level_factored_route(eng, oracle):
+    """configs[3], 3-D form, as bench.py --config 3 --3d runs it since round 4: kinetic T on (latitude box, altitude)
+    (radtran_3Dvs2D_sza30-80_test.py:66-90), T_vib by the local SZA.  The level-factored route -- pair tables on the
+    DISTINCT (P, T) rows the rays touch, one combine for all steps (spect_main_module.py:2036-2106) -- against the
+    folded coefficient op run on every step (<= 1e-12 of a row's largest value), against the oracle on sampled steps,
+    and the radiances / Jacobians through both sets of coefficient rows."""
+    import torch
+    import bench_configs as bc
+    from spectrobot_amd import synthetic as syn
+    n, nl = 20000, 30
+    grid, L, atm, e_lev = bc.ch4_case(n, n, nl, config_id=3, w0=2950.0)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)
+    vm = np.full(nl, 0.0148)
+    tz = np.array([atm["z"][2] + 7.0, atm["z"][9] + 3.0, atm["z"][17] + 11.0])
+    az = np.array([0.0, 60.0, 150.0])
+    sets = [bc.los_3d_set(atm, vm, tz, sza, az) for sza in (37.0, 72.0)]
+    # the north-south ray leaves the equatorial box, the steps of a ray see different suns
+    assert len(np.unique(sets[0]["seg_box"])) >= 2
+    a = sets[0]["state"]
+    T_all = np.concatenate([S["state"]["temps"] for S in sets])
+    P_all = np.concatenate([S["state"]["press"] for S in sets])
+    tv_all = np.concatenate([S["state"]["tvib"] for S in sets], axis=1)
+    T_rows, P_rows, row = eng.LevelFactored.unique_rows(T_all, P_all)
+    assert len(T_rows) < len(row) // 3 and np.array_equal(T_rows[row], T_all) and np.array_equal(P_rows[row], P_all)
+    dT = 0.002
+    lf = eng.LevelFactored(ls, T_rows, P_rows, dT=dT)
+    (ca, ce), (da, de) = lf.steps(row, tvib=tv_all, derivative=True)
+    co = ls.abscoeff_layers(T_all, P_all, tvib=tv_all)
+    sa, se = co[0].abs().amax(dim=1, keepdim=True), co[1].abs().amax(dim=1, keepdim=True)
+    assert float(((ca - co[0]).abs() / sa).max()) < 1e-12 and float(((ce - co[1]).abs() / se).max()) < 1e-12
+    sel = np.array([0, 7, len(sets[0]["seg_layer"]) - 1, len(row) - 3])
+    abo, emo = oracle.abscoeff_layers(L, syn.CH4_MM, e_lev, T_all[sel], P_all[sel], _q(T_all[sel]), tv_all[:, sel], grid, mode=1, n_threads=4)
+    assert float(np.max(np.abs(ca[sel].cpu().numpy() - abo) / np.abs(abo).max(axis=1, keepdims=True))) < 1e-11
+    assert relerr(ce[sel].cpu().numpy(), emo) < 1e-10
+    # the folded op's own two-op derivative (same dT, same frozen boundaries): equal up to the population part, which
+    # the combine differentiates exactly and the difference quotient to first order (dT / 2 pop'' / pop' ~ 1e-5)
+    _, (da_f, de_f) = eng.coefficients_dT(ls, T_all, P_all, tvib=tv_all, coeffs=co, scheme="forward", dT=dT)
+    rel = lambda x, y: float(((x - y).abs().amax(dim=1) / y.abs().amax(dim=1)).max())
+    assert rel(da, da_f) < 2e-4 and rel(de, de_f) < 2e-4
+    # radiances and Jacobians of the first set through both
+    S = sets[0]
+    ns = len(S["seg_layer"])
+    los = eng.LimbLOS(S["seg_off"], S["seg_layer"], S["pt_off"], S["x"], S["nd"], S["vmr"], col_scale=[syn.CH4_ISO_RATIO])
+    W = bc.layer_vmr_weights(atm["z"], S["alt"])
+    pg = np.zeros(nl, np.int32)
+    jac = lambda c, d: eng.limb_rays_jacobians(c, los, dcoeffs=d, par_gas=pg, par_w=W, seg_jac_row=S["seg_alt_layer"], n_jac_rows=nl)
+    r1, jt1, jv1 = jac((ca[:ns], ce[:ns]), (da[:ns], de[:ns]))
+    r2, jt2, jv2 = jac((co[0][:ns], co[1][:ns]), (da[:ns], de[:ns]))
+    sc = lambda y: y.abs().reshape(y.shape[0], -1).amax(dim=1).clamp_min(1e-300).reshape((-1,) + (1,) * (y.dim() - 1))
+    assert float(((r1 - r2).abs() / sc(r2)).max()) < 1e-11 and float(((jt1 - jt2).abs() / sc(jt2)).max()) < 1e-10
+    assert float(((jv1 - jv2).abs() / sc(jv2)).max()) < 1e-10
 
 
 def test_config0_co_nadir_and_slant_radiance(eng, oracle):
