@@ -98,7 +98,7 @@ def los_3d_set(atm, vm, tz, sza, az):
 
 
 ROUTE = _os.environ.get("SR_CONFIG3_ROUTE", "factored")     # "direct": a folded coefficient op per set (rounds 1-3)
-DT_FACTORED = 0.002                                         # K, forward difference of the pair tables
+DT_FACTORED = 0.05     # K, difference of the pair tables' SHAPES (line weights linearised about T: engine.LevelFactored)
 
 
 def layer_vmr_weights(z, alt):
@@ -425,7 +425,7 @@ def main(args):
         if rank == 0:
             jt, jt_c = res[1], res_c[1]      # temperature Jacobians of the last set: this route / three folded ops, central
             extra["temperature_derivative"] = {
-                "scheme": ("pair tables at T and T + %.3f K (boundaries frozen at T), d pop / d T analytic" % DT_FACTORED) if ROUTE != "direct" else DT_SCHEME_NOTE,
+                "scheme": ("pair tables at T and T + %.3f K (boundaries frozen at T, line weights linearised about T), d pop / d T analytic" % DT_FACTORED) if ROUTE != "direct" else DT_SCHEME_NOTE,
                 "ms_per_step_direct_central_differences": dt_c * 1e3,
                 "spectra_per_s_direct_central_differences": len(szas) * n_rays / dt_c if world in (1, len(szas)) else None,
                 "ms_per_step_direct_forward_difference": None if dt_d is None else dt_d * 1e3,
@@ -569,12 +569,13 @@ def main(args):
         if rank == 0:
             import bench as B
             # roofline: the dominant kernel of the build is the coefficient op's zones kernel, on the level sub-linesets
-            kms, counts = B.serial_kernel_times_and_counts(engine, ls, lambda: ls.gcoeff_layers(
-                [pt[1] for pt in PT], [pt[0] for pt in PT], level=0), n=3)
+            kms, counts = B.serial_kernel_times_and_counts(engine, ls, lambda: ls.abscoeff_level(
+                [pt[1] for pt in PT], [pt[0] for pt in PT], 0), n=3)
             extra["roofline"] = B.coefficient_roofline(kms, counts)
-            extra["roofline"]["note"] = ("one of the build's 24 coefficient ops (level 0: absorption | sp_emission of the lines "
-                                         "whose lower / upper level it is, %d (P, T) rows): executed flops of its dominant kernel / "
-                                         "its stand-alone HIP-event duration" % len(PT))
+            extra["roofline"]["note"] = ("the largest of the build's 24 coefficient ops (the pass over the lines whose lower or "
+                                         "upper level is level 0: 80 %% of the list, %d (P, T) rows; timed with the tracked-level "
+                                         "weights, the same kernels): executed flops of its dominant kernel / its stand-alone "
+                                         "HIP-event duration" % len(PT))
             if world == 1 and args.cpu_seconds > 0:
                 from oracle import oracle as O
                 import time as _t

@@ -146,6 +146,14 @@ int sr_lineset_destroy(sr_lineset *ls);
  * a one-sided difference with a small dT.  temps_bounds == NULL or n_layers == 0 restores the default. */
 int sr_lineset_set_bounds_temps(sr_lineset *ls, const double *temps_bounds, int n_layers);
 
+/* With frozen boundaries (sr_lineset_set_bounds_temps(T_b)): on != 0 makes the next coefficient ops take every line
+ * weight (G coefficients / normalisation; NOT the level populations, which the caller passes) at T_b and continue it to
+ * the call's temperature by its first-order Taylor term, w(T_b) (1 + (T - T_b) d ln w / d T), while widths, running x and
+ * shapes follow the call's T as always.  For temperature derivatives by difference (build's own: the reference has
+ * none): (c_lin(T_b + dT) - c(T_b)) / dT is then free of the Boltzmann factors' curvature, the step can grow from
+ * 0.002 to 0.05 K and the reference's single-precision staircase (1e-7 |c| / dT) shrinks with it.  0: exact weights. */
+int sr_lineset_set_linear_weights(sr_lineset *ls, int on);
+
 /* Layer stack (the Temps / Press lists of make_abscoeff_isomolec,
  * spect_main_module.py:1880, plus level.local_vibtemp, :2065). Host pointers.
  * tvib: [n_levels][n_layers] or NULL for LTE (:2062-2063).  q_part: [n_layers]

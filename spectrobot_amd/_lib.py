@@ -113,6 +113,7 @@ SYMBOLS = {
     "sr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sr_set_counting": (C.c_int, [C.c_int]),
     "sr_lineset_set_bounds_temps": (C.c_int, [C.c_void_p, dp, C.c_int]),
+    "sr_lineset_set_linear_weights": (C.c_int, [C.c_void_p, C.c_int]),
     "sr_last_eval_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
 }
 

@@ -325,6 +325,7 @@ struct sr_lineset {
   CoefWork *work = nullptr;      // &own_work, or the parent's for a per-level sub-lineset
   std::vector<double> bounds_temps; // sr_lineset_set_bounds_temps: empty = boundaries at the call's own temperatures
   sr_lineset *parent = nullptr;     // per-level sub-lineset: the handle it was cut from (its bounds_temps apply)
+  bool linear_weights = false;      // sr_lineset_set_linear_weights (takes effect with bounds_temps only)
 };
 
 extern "C" {
@@ -646,6 +647,12 @@ int sr_lineset_set_bounds_temps(sr_lineset *ls, const double *temps_bounds, int 
   return SR_OK;
 }
 
+int sr_lineset_set_linear_weights(sr_lineset *ls, int on) {
+  if (!ls) return SR_ERR_ARG;
+  ls->linear_weights = on != 0;
+  return SR_OK;
+}
+
 int sr_lineset_destroy(sr_lineset *ls) {
   if (!ls) return SR_OK;
   (void)hipDeviceSynchronize(); // work of the last calls may still be in flight on the internal streams
@@ -754,7 +761,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   }
 
   // per-layer scalars (host, fp64)
-  const size_t hl_doubles = (size_t)nl * (7 + npop);
+  const size_t hl_doubles = (size_t)nl * (8 + npop);
   const bool frozen = !bown->bounds_temps.empty(); // sr_lineset_set_bounds_temps
   if (frozen && (int)bown->bounds_temps.size() != nl) {
     g_err = "sr_lineset_set_bounds_temps was given another number of layers than this call";
@@ -787,7 +794,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   int rc = SL.prepare(hl_bytes);
   if (rc) return rc;
   double *T = SL.host<double>(), *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *ltr = sq + nl, *ltrb = ltr + nl,
-         *sqb = ltrb + nl, *pop = sqb + nl;
+         *sqb = ltrb + nl, *tb = sqb + nl, *pop = tb + nl;
   std::vector<double> q(nl);
   if (atm->q_part) {
     std::copy(atm->q_part, atm->q_part + nl, q.begin());
@@ -803,6 +810,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     ltr[k] = std::log(tr[k]);
     {
       const double Tb = frozen ? bown->bounds_temps[k] : T[k]; // where the region boundaries are placed
+      tb[k] = Tb;
       ltrb[k] = std::log(kTref / Tb);
       sqb[k] = std::sqrt(2 * kAvogadro * kKcgs * Tb * kLn2 / ls->mm);
     }
@@ -847,8 +855,9 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   LayersDev A;
   const double *dl = SL.d.as<double>();
   A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.ltrat = dl + 4 * nl;
-  A.ltrat_b = dl + 5 * nl; A.sqk_b = dl + 6 * nl; A.pop = dl + 7 * nl;
+  A.ltrat_b = dl + 5 * nl; A.sqk_b = dl + 6 * nl; A.temps_b = dl + 7 * nl; A.pop = dl + 8 * nl;
   A.frozen = frozen ? 1 : 0;
+  A.linear_w = frozen && bown->linear_weights ? 1 : 0;
   A.n_layers = nl; A.n_pop = npop;
   const int *d_pm = reinterpret_cast<const int *>(dl + hl_doubles);
   const int *zmax_dev = d_pm + 2 * nl; // [n_layers] widest zone (host bound, see above)

@@ -45,14 +45,28 @@ __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, c
   P.lw = ex(L.t_dep[ln] * A.ltrat[k]) * (L.air_broad[ln] * A.p_atm[k]); // (296/T)^n gamma P  (spcl:1972)
   const double dw = x0 / kCcgs * A.sqk[k];
   P.dwp = dw / A.sqrt_ln2;
-  const double fac = dw * A.sqrt_pi_ln2;
+  // Linearised weights (sr_lineset_set_linear_weights, with frozen boundaries): the G coefficients and the
+  // normalisation are taken at the BOUNDARY temperature Tb and continued to the call's T by their first-order Taylor
+  // term, w(Tb) (1 + (T - Tb) d ln w / d T): a difference quotient (c_lin(Tb + dT) - c(Tb)) / dT then carries no
+  // curvature of the Boltzmann factors (c2 eps / T^2 ~ 0.1 / K: the truncation that held its step to 0.002 K, where the
+  // reference's single-precision staircase is 1e-7 |c| / dT) and the step can be 25 times larger.  Widths and
+  // running x above follow the call's own T as always.
+  const bool lin = A.frozen && A.linear_w;
+  const double Tw = lin ? A.temps_b[k] : T;
+  const double fac = (lin ? x0 / kCcgs * A.sqk_b[k] : dw) * A.sqrt_pi_ln2;
+  const double dTl = T - Tw;
   double g_sp = 0., g_in = 0., g_ab = 0.;
   const double a_co = L.a_coeff[ln], gu = L.g_up[ln], gl = L.g_lo[ln];
   if (a_co != 0.0 && gl != 0.0 && gu != 0.0) {
     const double four_pi = 4 * kPi;
     const double el = L.e_lower[ln];
-    const double rot_up = gu * ex(-kC2 * (el + x0 - L.evib_up[ln]) / T);
-    const double rot_lo = gl * ex(-kC2 * (el - L.evib_lo[ln]) / T);
+    const double eps_up = el + x0 - L.evib_up[ln], eps_lo = el - L.evib_lo[ln];
+    double rot_up = gu * ex(-kC2 * eps_up / Tw);
+    double rot_lo = gl * ex(-kC2 * eps_lo / Tw);
+    if (lin) { // d ln(exp(-c2 eps / T) / sqrt(T)) / d T = c2 eps / T^2 - 1 / (2 T)   (fac ~ dw ~ sqrt(T))
+      rot_up *= fma(dTl, fma(kC2 * eps_up, 1.0 / (Tw * Tw), -0.5 / Tw), 1.0);
+      rot_lo *= fma(dTl, fma(kC2 * eps_lo, 1.0 / (Tw * Tw), -0.5 / Tw), 1.0);
+    }
     const double hcf = L.hcf[ln];
     g_sp = hcf * rot_up * a_co / four_pi;
     g_in = hcf * rot_up * L.b21[ln] / four_pi;

@@ -20,7 +20,9 @@ struct LayersDev {
   const double *ltrat;                      // log(296/T): (296/T)^n = exp(n log(296/T)), a third of pow()'s instructions
   const double *pop;                        // [n_layers][n_pop] level populations / Q
   const double *ltrat_b, *sqk_b;            // the same two at the temperatures the region BOUNDARIES are placed at
+  const double *temps_b;                    // those temperatures
   int frozen;                               // (sr_lineset_set_bounds_temps), used when frozen != 0
+  int linear_w;                             // frozen only: the line weights LINEARISED about temps_b (sr_lineset_set_linear_weights)
   int n_layers, n_pop;
   double sqrt_ln2, sqrt_pi_ln2;
 };

@@ -130,15 +130,20 @@ class LineSet(object):
                                          C.c_void_p(em.data_ptr()), _stream_ptr()), "sr_abscoeff_layers_dev")
         return ab, em
 
-    def set_bounds_temps(self, temps=None):
+    def set_bounds_temps(self, temps=None, linear_weights=False):
         """Place the Humlicek region boundaries of the next coefficient calls as at `temps` [n_layers] (None: at each
         call's own temperatures again): sr_lineset_set_bounds_temps.  For finite differences in T: c(T + dT) and c(T)
-        then share their index-computed seams and the difference quotient is smooth (coefficients_dT)."""
+        then share their index-computed seams and the difference quotient is smooth (coefficients_dT).
+        linear_weights: the line weights (G coefficients, normalisation) taken at `temps` and continued to the call's
+        temperature to first order (sr_lineset_set_linear_weights): the quotient then has no curvature term from the
+        Boltzmann factors and its step can be 0.05 K instead of 0.002 K (LevelFactored)."""
         if temps is None:
             check(lib.sr_lineset_set_bounds_temps(self._h, None, 0), "sr_lineset_set_bounds_temps")
+            check(lib.sr_lineset_set_linear_weights(self._h, 0), "sr_lineset_set_linear_weights")
         else:
             t, tp = _d(temps)
             check(lib.sr_lineset_set_bounds_temps(self._h, tp, int(t.size)), "sr_lineset_set_bounds_temps")
+            check(lib.sr_lineset_set_linear_weights(self._h, int(bool(linear_weights))), "sr_lineset_set_linear_weights")
 
     def gcoeff_layers(self, temps, press, level=0, g_lo=0, g_hi=None):
         """Per-ctype G-coefficient spectra of one level at every (P, T): CUDA float64
@@ -312,7 +317,13 @@ class LevelFactored(object):
     Worth it when rows are shared: the tables cost ~3.7 folded ops per 80 rows (24 output spectra instead of 2: twelve
     passes over sub-linesets, tools/glevel_probe.py), a folded op per step costs 1 per 80 steps."""
 
-    def __init__(self, ls, temps_rows, press_rows, dT=None, g_lo=0, g_hi=None):
+    def __init__(self, ls, temps_rows, press_rows, dT=None, g_lo=0, g_hi=None, linear_weights=True):
+        """dT: also build the tables at T + dT for the temperature derivative of `steps` -- region boundaries frozen at
+        T and (linear_weights, default) the line weights linearised about T, so that (A(T + dT) - A(T)) / dT is
+        sum_i w_i' y_i(T + dT) + sum_i w_i (y_i(T + dT) - y_i(T)) / dT: the weights' part exact, only the shapes
+        differenced -- their dependence on T is weak (d ln y / d T ~ 1 / 2T) and smooth, so dT = 0.05 K carries
+        1.5e-4 of truncation where the exact-weight quotient needed 0.002 K and sat on the reference's
+        single-precision staircase (1e-7 |c| / dT = 1e-3 of the derivative)."""
         self.ls = ls
         self.temps = np.ascontiguousarray(temps_rows, dtype=np.float64)
         self.press = np.ascontiguousarray(press_rows, dtype=np.float64)
@@ -320,7 +331,7 @@ class LevelFactored(object):
         self.tab = ls.glevel_pairs(self.temps, self.press, g_lo=g_lo, g_hi=g_hi)
         self.tab_dT = None
         if dT:
-            ls.set_bounds_temps(self.temps)
+            ls.set_bounds_temps(self.temps, linear_weights=linear_weights)
             try:
                 self.tab_dT = ls.glevel_pairs(self.temps + dT, self.press, g_lo=g_lo, g_hi=g_hi)
             finally:

@@ -110,26 +110,24 @@ def test_combine_temperature_derivative(eng, scene):
     row = rng.integers(0, 7, n_steps).astype(np.int32)
     T, P = atm["temps"][row], atm["press"][row]
     tv = atm["tvib"][:, row] + rng.uniform(-10.0, 20.0, (12, n_steps))
-    dT = 0.002
-    tab = ls.glevel_pairs(atm["temps"], atm["press"])
-    ls.set_bounds_temps(atm["temps"])
-    try:
-        tab_p = ls.glevel_pairs(atm["temps"] + dT, atm["press"])
-    finally:
-        ls.set_bounds_temps(None)
-    pop, dpop = ls.level_populations(T, tvib=tv, derivative=True)
-    (ab, em), (da, de) = eng.glevel_combine(tab, row, pop, tab_dT=tab_p, dpop=dpop, dT=dT)
     co, (da_ref, de_ref) = eng.coefficients_dT(ls, T, P, tvib=tv, scheme="central", dT=0.01)
+    _, (da_r5, de_r5) = eng.coefficients_dT(ls, T, P, tvib=tv, coeffs=co, scheme="central", dT=0.05)
     _, (da_f, de_f) = eng.coefficients_dT(ls, T, P, tvib=tv, coeffs=co, scheme="forward")
 
     def rel(x, y):
         return float(((x - y).abs().amax(dim=1) / y.abs().amax(dim=1)).max())
-    assert rel(ab, co[0]) < 1e-12 and rel(em, co[1]) < 1e-12
-    print("T derivative of 20 steps against the frozen central difference of 0.01 K: level-factored (two table builds, "
-          "analytic populations) %.1e %.1e; folded forward difference %.1e %.1e" % (rel(da, da_ref), rel(de, de_ref),
-                                                                                  rel(da_f, da_ref), rel(de_f, de_ref)))
-    assert rel(da, da_ref) < 2e-3 and rel(de, de_ref) < 2e-3
-    assert rel(da, da_ref) < 1.5 * rel(da_f, da_ref) + 1e-5 and rel(de, de_ref) < 1.5 * rel(de_f, de_ref) + 1e-5
+    print("the two central references against each other: %.1e %.1e" % (rel(da_r5, da_ref), rel(de_r5, de_ref)))
+    errs = {}
+    for name, dT, lin in (("exact weights, dT 0.002 K", 0.002, False), ("linearised weights, dT 0.05 K", 0.05, True)):
+        lf = eng.LevelFactored(ls, atm["temps"], atm["press"], dT=dT, linear_weights=lin)
+        (ab, em), (da, de) = lf.steps(row, tvib=tv, derivative=True)
+        assert rel(ab, co[0]) < 1e-12 and rel(em, co[1]) < 1e-12
+        errs[name] = (min(rel(da, da_ref), rel(da, da_r5)), min(rel(de, de_ref), rel(de, de_r5)))
+    print("T derivative of 20 steps against the frozen central difference of 0.01 K: folded forward difference %.1e %.1e; "
+          "level-factored, two table builds, analytic populations: %s" % (rel(da_f, da_ref), rel(de_f, de_ref), errs))
+    e_x, e_l = errs["exact weights, dT 0.002 K"], errs["linearised weights, dT 0.05 K"]
+    assert max(e_x) < 2e-3 and e_x[0] < 1.5 * rel(da_f, da_ref) + 1e-5 and e_x[1] < 1.5 * rel(de_f, de_ref) + 1e-5
+    assert max(e_l) < 4e-4 and max(e_l) < max(e_x)        # the linearised weights are what two builds can do
     # LTE (no vibrational temperatures given): the Boltzmann factors follow T too
     pop2, dpop2 = ls.level_populations(T, derivative=True)
     h = 1e-3
