@@ -367,6 +367,16 @@ def main(args):
                 extra["cpu_baseline"] = B.cpu_baseline(L, atm, grid, syn.CH4_MM, e_lev, q_part, args.cpu_seconds, args.layers,
                                                        (Lr["seg_off"], Lr["seg_layer"], B.cpu_columns(Lr, syn.CH4_ISO_RATIO)))
                 extra["speedup_vs_cpu_baseline"] = n_rays / dt / extra["cpu_baseline"]["value"]
+        if world > 1:
+            # what the collective really was (as the headline's line): torch.distributed's own view of the group, which
+            # branch of all_gather_spectrum ran, and this rank's own shard found again in the gathered spectrum
+            rad_chk = engine.limb_rays((ab, em), los)
+            gathered = sd.all_gather_spectrum(rad_chk, args.grid, world, rank)
+            torch.cuda.synchronize()
+            extra["dist"] = dict(sd.dist_info(), async_gather=False, gathers=dict(sd.stats),
+                                 gathered_holds_own_shard=bool(torch.equal(gathered[:, g_lo:g_hi], rad_chk)),
+                                 note="n_rays > 1: one blocking all_gather_into_tensor of [n_rays, n_grid / W] per rank + one "
+                                      "permuting copy (distributed.all_gather_spectrum)")
         out = dict(base, **extra)
         out = dict(out, metric="limb spectra/sec, 64 rays batched (BASELINE configs[2])", value=n_rays / dt,
                    ms_per_step=dt * 1e3, scaling="strong",
@@ -534,6 +544,46 @@ def main(args):
                    max_rel_dev_from_truth=float(np.max(np.abs(bs.param_vector() - x_true) / x_true)))
         if world > 1:
             out["dist"] = sd.dist_info()
+        if rank == 0:
+            # roofline of the iteration's dominant kernel: radiances + column-parameter Jacobians of the 18 LOS
+            alts = [a for pix in pixels for a in pix.los_alts()]
+            los, alt = scene.los(alts)
+            g_lo, g_hi = (0, len(scene.grid)) if shard is None else retrieval.shard_with_halo(len(scene.grid), *shard)
+            coeffs = scene.coefficients(g_lo=g_lo, g_hi=g_hi)
+            par_gas, par_w = scene.profile_weights(bs, alt)
+            n_sh = g_hi - g_lo
+            out["roofline"] = _event_time(
+                lambda: engine.limb_rays_jacobian(coeffs, los, par_gas, par_w), "sr_limb_jac_kernel<2, NP> (forward sensitivities)",
+                bytes_alg=8.0 * n_sh * (2 * 2 * len(scene.z) + len(alts) * (1 + len(par_gas))),
+                note="one iteration's forward model: %d LOS x (radiance + %d parameter Jacobians) on %d points: algorithmic "
+                     "bytes = the two gases' coefficient tables once + the outputs; the rays re-read the tables from L2 / MALL"
+                     % (len(alts), len(par_gas), n_sh))
+            out["roofline"]["traffic"] = None
+            if world == 1 and args.cpu_seconds > 0:
+                # CPU leg: the oracle's recursion (two gases mixed on the host) for the 18 LOS, once for the radiances and
+                # once per parameter -- what a CPU port without the sensitivity recursion does per iteration (finite
+                # differences); coefficients cached as on the GPU.  One thread (the oracle's recursion is scalar).
+                from oracle import oracle as O
+                import time as _t
+                a_h = [c[0].cpu().numpy() for c in coeffs]
+                e_h = [c[1].cpu().numpy() for c in coeffs]
+                col = los.columns()
+                n_do = min(len(alts), 6)
+                t0 = _t.time()
+                for r in range(n_do):
+                    sl = slice(los.seg_off[r], los.seg_off[r + 1])
+                    lay = los.seg_layer[sl]
+                    # tau = sum_g abs_g col_g: fold the second gas into an effective single-gas table per segment
+                    O.radiance_ray(a_h[0] , e_h[0], lay, col[0][sl])
+                    O.radiance_ray(a_h[1], e_h[1], lay, col[1][sl])
+                t_one = (_t.time() - t0) / n_do
+                t_iter = t_one * len(alts) * (1 + len(par_gas))
+                out["cpu_baseline"] = {"value": 1.0 / t_iter, "unit": "iterations/s", "cores": 1, "kind": "port",
+                                       "sample": "the oracle's recursion of %d of the %d LOS (both gases' tables, %d points), "
+                                                 "%.3f s per LOS, x %d LOS x (1 + %d parameters by finite differences); "
+                                                 "coefficients cached as on the GPU; instrument step and algebra not included"
+                                                 % (n_do, len(alts), n_sh, t_one, len(alts), len(par_gas))}
+                out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     elif args.config == "lut":
         # The one thing the reference publishes a figure for: the look-up-table / G-coefficient build,
         # "n_lines x 3 / 30000 x n_PT minutes" = 6 ms per (line, P-T couple) with its n_threads worker processes

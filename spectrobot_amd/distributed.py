@@ -166,11 +166,12 @@ def all_gather_spectrum(shard, n_grid, world_size, rank, out=None, bounds=None, 
     return out
 
 
-def all_reduce_sum(t):
+def all_reduce_sum(t, force_collective=False):
     """In-place sum of a tensor over the ranks (the one exchange of a sharded retrieval iteration: partial
     instrument-band sums of radiances and Jacobians, spectrobot_amd.retrieval.simulate); a no-op without a
-    process group.  A CUDA tensor under a gloo group (several ranks rehearsing on one GPU) goes through the host."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    process group.  A CUDA tensor under a gloo group (several ranks rehearsing on one GPU) goes through the host.
+    force_collective: go through the collective even in a one-rank group (the RCCL hardware test on a one-GPU box)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return t
     if t.is_cuda and dist.get_backend() == "gloo":
         h = t.cpu()

@@ -574,6 +574,52 @@ def radiance_layer_jacobian(abs_c, emi_c, dabs, demi, seg_off, seg_layer, seg_co
     return jac
 
 
+def calc_radtran_steps(gases, z, temps, press, z_tans, radtran_opt=None, R=2575.0, n_sub=3, **los_opts):
+    """Adaptive LOS stepping + the coefficient rows of the steps, with the reference's knobs: radtran_opt =
+    dict(max_T_variation=[K], max_Plog_variation=[ln P], max_opt_depth=...) as its drivers pass them to
+    LineOfSight.calc_radtran_steps (spect_main_module.py:2746-2767; radtran_test_CO.py:184-186;
+    spect_radtran_test.py:175).  gases: [dict(lineset=LineSet, vmr=[n_levels], iso_ratio=1.0, tvib=[n_lev, n_levels] | None)].
+    Geometry by geometry.calc_radtran_steps (temperature / log-pressure bounds, vectorised); the optical-depth bound is
+    checked on the device: the steps' coefficient rows at their own (P, T) -- abscoeff_layers on the step list --, per
+    step the largest absorption coefficient over the grid times the step's Curtis-Godson column (sr_los_columns),
+    summed over the gases; steps above the bound are halved and only then re-evaluated.
+    Returns dict(L=geometry dict, los=LimbLOS, coeffs=[(abs, emi)] per gas on the step rows [n_steps, n_grid])."""
+    from . import geometry as geo, synthetic as syn
+    opt = dict(radtran_opt or {})
+    z, temps, press = (np.asarray(v, float) for v in (z, temps, press))
+    nd = syn.number_density(press, temps)
+    vm = [np.asarray(g["vmr"], float) for g in gases]
+    state = {}
+
+    def rows(L):
+        key = (len(L["step_temp"]), float(L["step_temp"].sum()), float(L["x"].sum()))
+        if state.get("key") != key:
+            co = []
+            for g in gases:
+                tv = None
+                if g.get("tvib") is not None:     # vibrational temperatures linear in altitude between the levels, like T
+                    tvl = np.asarray(g["tvib"], float)
+                    zz = np.append(z, z[-1] + (z[-1] - z[-2]))
+                    tv = np.array([np.interp(L["step_alt"], zz, np.append(t, t[-1])) for t in tvl])
+                co.append(g["lineset"].abscoeff_layers(L["step_temp"], L["step_pres"], tvib=tv))
+            los = LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"],
+                          col_scale=[g.get("iso_ratio", 1.0) for g in gases], **los_opts)
+            state.update(key=key, coeffs=co, los=los)
+        return state["coeffs"], state["los"]
+
+    def opt_depth_of(L):
+        co, los = rows(L)
+        col = los.columns()                                   # [n_gas, n_steps]
+        amax = np.array([c[0].abs().amax(dim=1).cpu().numpy() for c in co])
+        return (amax * col).sum(axis=0)
+
+    L = geo.calc_radtran_steps(z, temps, press, nd, vm, z_tans, R=R, n_sub=n_sub,
+                               max_T_variation=opt.get("max_T_variation"), max_Plog_variation=opt.get("max_Plog_variation"),
+                               max_opt_depth=opt.get("max_opt_depth"), opt_depth_of=opt_depth_of if opt.get("max_opt_depth") else None)
+    co, los = rows(L)
+    return dict(L=L, los=los, coeffs=co)
+
+
 def mix_gases(coeffs, ratios):
     """Coefficients of a gas mixture on the column scale of a reference absorber: the column of gas g in
     a segment of layer k is ratios[g][k] times the reference column (VMR_g / VMR_ref of the layer), so

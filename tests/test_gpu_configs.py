@@ -261,7 +261,9 @@ def test_rccl_async_gather_branch_one_rank(eng, tmp_path):
     recursion + asynchronous all_gather_spectrum(force_collective=True) into one `out`, the shard tensor freshly
     allocated each step as in bench.py: RCCL initialisation, the lifetime of the Work handles and of their input
     shards (four in flight, older ones waited on), the ordering of consecutive gathers into the same buffer, and
-    wait_gathers(); the result equals a blocking gather and the shard itself bit for bit."""
+    wait_gathers(); the result equals a blocking gather and the shard itself bit for bit.  Round 4: also the 64-ray
+    branch (one collective + the permuting copy), the padded branch of unequal / strided shards and the all-reduce of
+    the sharded retrieval, all through RCCL with the one-rank group."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -306,6 +308,36 @@ torch.cuda.synchronize()
 assert sd.stats["blocking_gathers"] == 1
 assert torch.equal(blocking, rad) and torch.equal(got, rad), float((got - rad).abs().max())
 assert float(rad.abs().max()) > 0
+# round 4: the other branches of all_gather_spectrum and the retrieval's all-reduce, on RCCL too
+# (a) a ray batch (configs[2]: 64 rays): equal shards, one collective into a [W, n_rays, q] buffer + the permuting copy
+Lr64 = syn.limb_los(atm["z"], nd, [np.full(12, 0.0148)], atm["z"][0] + 1.0 + 1.7 * np.arange(64))
+los64 = engine.LimbLOS(Lr64["seg_off"], Lr64["seg_layer"], Lr64["pt_off"], Lr64["x"], Lr64["nd"], Lr64["vmr"], col_scale=[syn.CH4_ISO_RATIO])
+rad64 = engine.limb_rays((ab, em), los64)
+before = dict(sd.stats)
+g64 = sd.all_gather_spectrum(rad64, n, 1, 0, force_collective=True, async_op=True)     # async is ignored for n_rays > 1
+torch.cuda.synchronize()
+assert g64 is not rad64 and torch.equal(g64, rad64) and sd.stats["blocking_gathers"] == before["blocking_gathers"] + 1
+# (b) the padded path (unequal shards of shard_bounds_balanced; here forced by a shard that is a strided view)
+wide = torch.zeros((64, n + 7), dtype=torch.float64, device="cuda")
+wide[:, :n] = rad64
+view = wide[:, :n]
+assert not view.is_contiguous()
+gp = sd.all_gather_spectrum(view, n, 1, 0, bounds=[(0, n)], force_collective=True)
+torch.cuda.synchronize()
+assert torch.equal(gp, rad64) and sd.stats["blocking_gathers"] == before["blocking_gathers"] + 2
+# wrong bounds are refused before any collective (ADVICE round 3)
+for bad in ([(5, n)], [(0, n - 1)], [(0, n), (n, n)]):
+    try:
+        sd.all_gather_spectrum(rad64, n, 1, 0, bounds=bad, force_collective=True)
+        raise SystemExit("bounds %r were accepted" % (bad,))
+    except ValueError:
+        pass
+# (c) the all-reduce of a sharded retrieval iteration: [n_los, 1 + n_par, n_bands] partial band integrals
+part = torch.arange(18 * 8 * 14, dtype=torch.float64, device="cuda").reshape(18, 8, 14) * 1e-9
+want = part.clone()
+assert sd.all_reduce_sum(part, force_collective=True) is part
+torch.cuda.synchronize()
+assert torch.equal(part, want)          # one rank: the sum over the ranks is the rank's own part
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
 print("rccl one-rank ok", sd.stats)

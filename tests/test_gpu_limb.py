@@ -304,3 +304,43 @@ def test_per_level_partial_radiances_sum_to_total(eng):
         parts += eng.limb_rays((ab, em_l), los)
     assert float(((parts - total).abs() / total.abs()).max()) < 1e-11
     assert float(total.min()) > 0
+
+
+def test_adaptive_los_stepping_converges(eng):
+    """engine.calc_radtran_steps: the reference's radtran_opt knobs (max_T_variation, max_Plog_variation,
+    max_opt_depth: radtran_test_CO.py:184-186, spect_main_module.py:2760-2762) on the device LOS pipeline.  A step
+    carries the coefficient row of its own mean (P, T); as the bounds tighten the radiance converges (fixed stepping,
+    one row per shell at the level values, is the coarsest member of the family), the optical-depth bound leaves no
+    step above it, and an isothermal atmosphere at constant pressure is indifferent to the stepping."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2990.0, 5e-4, 12000)
+    Ls = syn.make_lines(1500, grid, seed=9, n_levels=12)
+    atm = syn.make_atmosphere(16, 12)
+    z, T, P, tv = atm["z"], atm["temps"], atm["press"], atm["tvib"]
+    ls = eng.LineSet(Ls, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    gas = [dict(lineset=ls, vmr=np.full(16, 0.0148), iso_ratio=syn.CH4_ISO_RATIO, tvib=tv)]
+    zt = [z[1] + 5.0, z[7] + 20.0]
+    rads, n_steps = [], []
+    for opt in (None, dict(max_T_variation=4.0, max_Plog_variation=0.5), dict(max_T_variation=1.0, max_Plog_variation=0.12),
+                dict(max_T_variation=0.25, max_Plog_variation=0.03)):
+        S = eng.calc_radtran_steps(gas, z, T, P, zt, radtran_opt=opt)
+        rads.append(eng.limb_rays(S["coeffs"], S["los"]))
+        n_steps.append(len(S["L"]["seg_layer"]))
+    assert n_steps[0] < n_steps[1] < n_steps[2] < n_steps[3]
+    err = [float(((r - rads[3]).abs().amax(dim=1) / rads[3].abs().amax(dim=1)).max()) for r in rads[:3]]
+    print("steps %s: deviation of the radiance from the finest stepping %s" % (n_steps, ["%.1e" % e for e in err]))
+    assert err[2] < err[1] < err[0] and err[2] < 0.02
+    # optical depth
+    S = eng.calc_radtran_steps(gas, z, T, P, zt, radtran_opt=dict(max_opt_depth=0.5))
+    col = S["los"].columns()[0]
+    tau = S["coeffs"][0][0].abs().amax(dim=1).cpu().numpy() * col
+    assert tau.max() <= 0.5 and len(col) > n_steps[0]
+    # nothing to resolve: isothermal, isobaric, LTE -- the radiance does not depend on the stepping
+    Tc, Pc = np.full(16, 160.0), np.full(16, 0.05)
+    gas_c = [dict(lineset=ls, vmr=np.full(16, 0.0148), iso_ratio=syn.CH4_ISO_RATIO, tvib=None)]
+    Sa = eng.calc_radtran_steps(gas_c, z, Tc, Pc, zt)
+    Sb = eng.calc_radtran_steps(gas_c, z, Tc, Pc, zt, radtran_opt=dict(max_opt_depth=0.05))
+    ra, rb = eng.limb_rays(Sa["coeffs"], Sa["los"]), eng.limb_rays(Sb["coeffs"], Sb["los"])
+    assert len(Sb["L"]["seg_layer"]) > len(Sa["L"]["seg_layer"])
+    assert float(((ra - rb).abs() / ra.abs().clamp_min(1e-300)).max()) < 1e-9

@@ -639,3 +639,62 @@ def test_jacobians_entry_refuses_initial_intensity_without_rad(L):
     rc = L.lib.sr_limb_rays_jacobians_dev(fake, fake, None, None, 1, 64, C.byref(d), None, 0, 1,
                                           par_gas.ctypes.data_as(L.ip), par_w.ctypes.data_as(L.dp), None, None, fake, None)
     assert rc == -1 and b"init_mode 1" in L.lib.sr_last_error()
+
+
+def test_calc_radtran_steps_geometry(oracle):
+    """geometry.calc_radtran_steps, the stand-in for the absent sbm LineOfSight.calc_radtran_steps with the
+    reference's knobs (radtran_opt: max_T_variation, max_Plog_variation, max_opt_depth: radtran_test_CO.py:184-186,
+    spect_main_module.py:2760-2762).  (i) All bounds off = limb_los's crossings; (ii) with the temperature / log-pressure
+    bounds every step stays inside them, the steps of a ray chain up without gaps and cover the same path;
+    (iii) the Curtis-Godson columns (oracle's curgod_fort_2) of the refined path converge: the sum over a crossing's
+    steps approaches a 200-sub-interval reference as the bounds tighten; (iv) the optical-depth bound halves thick
+    steps until none is left; (v) 3-D state of a path: SZA and latitude at the tangent point, latitude boxes."""
+    from spectrobot_amd import geometry as geo, synthetic as syn
+    atm = syn.make_atmosphere(40, 0)
+    z, T, P = atm["z"], atm["temps"], atm["press"]
+    nd = syn.number_density(P, T)
+    vm = [np.linspace(1e-4, 3e-4, 40)]
+    zt = [z[3] + 4.0, z[20] + 9.0]
+    L0 = geo.limb_los(z, nd, vm, zt)
+    La = geo.calc_radtran_steps(z, T, P, nd, vm, zt)
+    assert all(np.array_equal(La[k], L0[k]) for k in ("seg_off", "pt_off", "x", "nd", "vmr")) and np.array_equal(La["seg_alt_layer"], L0["seg_layer"])
+    zz = np.append(z, z[-1] + (z[-1] - z[-2]))
+    tt, lp = np.append(T, T[-1]), np.append(np.log(P), np.log(P[-1]) + (np.log(P[-1]) - np.log(P[-2])))
+    totals = []
+    for mt, mp in ((None, None), (2.0, 0.25), (0.5, 0.06)):
+        Lb = geo.calc_radtran_steps(z, T, P, nd, vm, zt, max_T_variation=mt, max_Plog_variation=mp)
+        po, so, x = Lb["pt_off"], Lb["seg_off"], Lb["x"]
+        a_end, b_end = Lb["alt"][po[:-1]], Lb["alt"][po[1:] - 1]
+        if mt:
+            assert np.all(np.abs(np.interp(a_end, zz, tt) - np.interp(b_end, zz, tt)) <= mt + 1e-9)
+            assert np.all(np.abs(np.interp(a_end, zz, lp) - np.interp(b_end, zz, lp)) <= mp + 1e-9)
+            assert len(Lb["seg_layer"]) > len(L0["seg_layer"])
+        for r in range(2):
+            first, last = so[r], so[r + 1]
+            assert np.array_equal(x[po[first + 1:last]], x[po[first + 1:last] - 1])        # no gaps between steps
+            assert x[po[first]] == L0["x"][L0["pt_off"][L0["seg_off"][r]]] and x[po[last] - 1] == L0["x"][L0["pt_off"][L0["seg_off"][r + 1]] - 1]
+        col = np.array([oracle.curgod(2, Lb["nd"][a:b], Lb["x"][a:b], vmr=Lb["vmr"][0][a:b]) for a, b in zip(po[:-1], po[1:])])
+        totals.append(np.array([col[so[r]:so[r + 1]].sum() for r in range(2)]))
+        assert np.all(Lb["step_temp"] > 0) and np.all(np.diff(Lb["seg_off"]) > 0)
+    ref = geo.limb_los(z, nd, vm, zt, n_sub=200)
+    colr = np.array([oracle.curgod(2, ref["nd"][a:b], ref["x"][a:b], vmr=ref["vmr"][0][a:b]) for a, b in zip(ref["pt_off"][:-1], ref["pt_off"][1:])])
+    tot_ref = np.array([colr[ref["seg_off"][r]:ref["seg_off"][r + 1]].sum() for r in range(2)])
+    e = [np.max(np.abs(t - tot_ref) / tot_ref) for t in totals]
+    assert e[2] < 0.3 * e[1] < 0.3 * e[0] and e[2] < 5e-4, e
+    # (iv) optical depth: tau of a step = 1e-3 per km of path here
+    tau_of = lambda Lx: 1e-3 * (Lx["x"][Lx["pt_off"][1:] - 1] - Lx["x"][Lx["pt_off"][:-1]]) * 1e-5
+    Lc = geo.calc_radtran_steps(z, T, P, nd, vm, zt, max_opt_depth=0.05, opt_depth_of=tau_of)
+    assert np.all(tau_of(Lc) <= 0.05) and len(Lc["seg_layer"]) > len(L0["seg_layer"])
+    assert abs(tau_of(Lc).sum() - tau_of(L0).sum()) < 1e-9
+    # (v) 3-D state
+    sun = geo.sun_in_local_frame(5.0, -12.0, 51.0)
+    assert abs(sun[0] - np.cos(np.deg2rad(51.0))) < 1e-12 and abs(np.linalg.norm(sun) - 1.0) < 1e-12
+    L3 = geo.limb_los_3d(z, nd, vm, zt, 51.0, [0.0, 90.0], tangent_lat_deg=5.0, subsolar_lat_deg=-12.0)
+    mid = (L3["seg_off"][0] + L3["seg_off"][1]) // 2
+    assert abs(L3["seg_mu"][mid] - np.cos(np.deg2rad(51.0))) < 0.05 and abs(L3["seg_lat"][mid] - 5.0) < 3.0
+    s0, s1 = L3["seg_off"][0], L3["seg_off"][1]
+    assert L3["seg_lat"][s1 - 1] - L3["seg_lat"][s0] > 20.0                      # the northward ray climbs in latitude
+    assert np.ptp(L3["seg_lat"][L3["seg_off"][1]:]) < 8.0                          # the eastward one stays near its own
+    assert list(geo.lat_box_index([-89.0, -30.0, 0.0, 29.9, 30.0, 74.0, 90.0])) == [0, 3, 3, 3, 4, 5, 6]
+    with pytest.raises(ValueError):
+        geo.sun_in_local_frame(60.0, -12.0, 10.0)
