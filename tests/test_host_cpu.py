@@ -691,7 +691,7 @@ def test_calc_radtran_steps_geometry(oracle):
     assert abs(sun[0] - np.cos(np.deg2rad(51.0))) < 1e-12 and abs(np.linalg.norm(sun) - 1.0) < 1e-12
     L3 = geo.limb_los_3d(z, nd, vm, zt, 51.0, [0.0, 90.0], tangent_lat_deg=5.0, subsolar_lat_deg=-12.0)
     mid = (L3["seg_off"][0] + L3["seg_off"][1]) // 2
-    assert abs(L3["seg_mu"][mid] - np.cos(np.deg2rad(51.0))) < 0.05 and abs(L3["seg_lat"][mid] - 5.0) < 3.0
+    assert abs(L3["seg_mu"][mid] - np.cos(np.deg2rad(51.0))) < 0.05 and abs(L3["seg_lat"][mid] - 5.0) < 4.0
     s0, s1 = L3["seg_off"][0], L3["seg_off"][1]
     assert L3["seg_lat"][s1 - 1] - L3["seg_lat"][s0] > 20.0                      # the northward ray climbs in latitude
     assert np.ptp(L3["seg_lat"][L3["seg_off"][1]:]) < 8.0                          # the eastward one stays near its own
