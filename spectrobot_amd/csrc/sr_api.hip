@@ -242,6 +242,8 @@ struct CoefWork {
   hipEvent_t ev_far_done[2] = {nullptr, nullptr}, ev_zones_done[2] = {nullptr, nullptr};
   hipStream_t chain_st = nullptr, chain2_st = nullptr; // the far-field chain (decoupled pipeline): level-0 pass | moments, translations
   hipEvent_t ev_l0_done[2] = {nullptr, nullptr}, ev_s2m_done[2] = {nullptr, nullptr};
+  hipEvent_t ev_wings_done[2] = {nullptr, nullptr};
+  bool wings_recorded[2] = {false, false};
   bool free_recorded[2] = {false, false};
   int parity = 0;
   bool overlapped = false;       // last call ran that way (timing hook)
@@ -277,6 +279,7 @@ struct CoefWork {
       if (ev_zones_done[b]) (void)hipEventDestroy(ev_zones_done[b]);
       if (ev_l0_done[b]) (void)hipEventDestroy(ev_l0_done[b]);
       if (ev_s2m_done[b]) (void)hipEventDestroy(ev_s2m_done[b]);
+      if (ev_wings_done[b]) (void)hipEventDestroy(ev_wings_done[b]);
       d_zone2[b].release();
       d_coef[b].release();
       d_mom[b].release();
@@ -1009,6 +1012,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         for (int i = 0; i < 2; ++i) {
           HIPCHK(hipEventCreateWithFlags(&w.ev_l0_done[i], hipEventDisableTiming));
           HIPCHK(hipEventCreateWithFlags(&w.ev_s2m_done[i], hipEventDisableTiming));
+          HIPCHK(hipEventCreateWithFlags(&w.ev_wings_done[i], hipEventDisableTiming));
         }
       }
       rc = w.d_zone2[b].ensure(sizeof(double) * 2 * n_pts * nl);
@@ -1016,12 +1020,18 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       double *z_abs = w.d_zone2[b].as<double>(), *z_emi = z_abs + n_pts * nl;
       // (the buffers of parity b were last read by the wings kernel two calls ago: the preparation waited for that)
       // far-field chain: level-0 pass on one stream, moments + upward pass on another, translations behind both
+      // SR_CHAIN_AFTER_WINGS (tuning): 1: S2M, 2: S2M and the level-0 pass start only when the PREVIOUS call's wings
+      // kernel is through (beside it S2M's 154-VGPR waves lose every slot race: 1.45 instead of 0.38 ms)
+      static const int after_env = [] { const char *e = getenv("SR_CHAIN_AFTER_WINGS"); return e ? atoi(e) : 0; }();
+      const bool prev_wings = w.wings_recorded[b ^ 1];
       HIPCHK(hipStreamWaitEvent(w.chain_st, w.ev_prep_done[b], 0));
+      if (after_env >= 2 && prev_wings) HIPCHK(hipStreamWaitEvent(w.chain_st, w.ev_wings_done[b ^ 1], 0));
       LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, w.chain_st));
       HIPCHK(hipEventRecord(w.ev_l0_done[b], w.chain_st));
       hipStream_t last = w.chain_st;
       if (fp.m2l) {
         HIPCHK(hipStreamWaitEvent(w.chain2_st, w.ev_prep_done[b], 0));
+        if (after_env >= 1 && prev_wings) HIPCHK(hipStreamWaitEvent(w.chain2_st, w.ev_wings_done[b ^ 1], 0));
         LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, w.chain2_st, 1));
         HIPCHK(hipEventRecord(w.ev_s2m_done[b], w.chain2_st));
         HIPCHK(hipStreamWaitEvent(w.chain2_st, w.ev_l0_done[b], 0));
@@ -1043,6 +1053,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       HIPCHK(hipStreamWaitEvent(st, w.ev_zones_done[b], 0));
       LAUNCHCHK(launch_near(1, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo,
                             (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st, z_abs, z_emi));
+      HIPCHK(hipEventRecord(w.ev_wings_done[b], st));
+      w.wings_recorded[b] = true;
       HIPCHK(hipEventRecord(w.ev[3], st));
       HIPCHK(hipEventRecord(w.ev[4], st));
       w.overlapped = true;

@@ -1474,7 +1474,7 @@ template <int WT, int NW, bool COUNT>
 __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_kernel(
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, IcIndex ix,
     const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo, int g_hi, GridParams gp, int add,
-    double *__restrict__ abs_out, double *__restrict__ emi_out, unsigned long long *__restrict__ cnt) {
+    double *__restrict__ abs_out, double *__restrict__ emi_out, unsigned long long *__restrict__ cnt, int layer0) {
   // one private image per wave: abs, emi.  Point p of the group (window index k of a line: p = k + j1 - 1 - wlo) lives at
   // element p + 1, i.e. element k + (j1 - wlo): the hot loops' address arithmetic carries no "- 1" (it cost a v_add per
   // region-2 point: the offset field of ds_add cannot be negative)
@@ -1494,7 +1494,7 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
   __shared__ int s_rmax[NW][3][8];
 #endif
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int layer = wg / n_groups, grp = wg - layer * n_groups;
+  const int layer = layer0 + wg / n_groups, grp = wg - (layer - layer0) * n_groups; // layer0: the launch's first layer (layer chunks)
   const int wlo = g_lo + grp * WT;
   const int whi = min(wlo + WT, g_hi) - 1;
   // NW waves work on the same group and take its 64-line chunks in turn, each into its own image
@@ -1822,9 +1822,20 @@ constexpr int kZoneImage = SR_ZONES_WT; // grid points per LDS image of sr_absco
 template <int NW, bool COUNT>
 static void launch_zones(dim3 gz, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
                          int n_sub, int n_t, int g_lo, int g_hi, const GridParams &gp, int add, double *abs_out,
-                         double *emi_out, unsigned long long *cnt, hipStream_t st) {
-  hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<kZoneImage, NW, COUNT>), gz, dim3(64 * NW), 0, st, fast, cold, ix, zmax,
-                     n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt);
+                         double *emi_out, unsigned long long *cnt, hipStream_t st, int n_layers, int n_chunks) {
+  // Layer chunks (one launch each, same stream): a single dispatch of 15 680 one-millisecond waves keeps every wave
+  // slot it is given -- the dispatcher serves the OLDER dispatch first whenever its next workgroup fits, so kernels of
+  // the other streams (the far-field chain, the next call's preparation) sat in their queues until it drained
+  // (tools/r03_timeline.sh).  Between two chunks they are the older ones and get in; the next chunk fills what they
+  // leave.  (gz.x = n_t * n_layers on entry.)
+  n_chunks = n_chunks < 1 ? 1 : (n_chunks > n_layers ? n_layers : n_chunks);
+  for (int c = 0; c < n_chunks; ++c) {
+    const int l0 = (int)((long)n_layers * c / n_chunks), l1 = (int)((long)n_layers * (c + 1) / n_chunks);
+    if (l1 <= l0) continue;
+    hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<kZoneImage, NW, COUNT>), dim3((unsigned)(n_t * (l1 - l0))), dim3(64 * NW), 0,
+                       st, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, l0);
+  }
+  (void)gz;
 }
 
 int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
@@ -1850,9 +1861,11 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
     const long waves512 = (long)((g_hi - g_lo + kZoneImage - 1) / kZoneImage) * n_layers;
     const int n_t = (g_hi - g_lo + kZoneImage - 1) / kZoneImage;
     const dim3 gz((unsigned)(n_t * n_layers));
+    static const int chunks_env = [] { const char *e = getenv("SR_ZONES_CHUNKS"); return e ? atoi(e) : 1; }();
+    const int n_chunks = waves512 >= 3 * 4096 ? chunks_env : 1; // whole grids only: a small shard's launch is short as it is
 #define SR_ZONES(NW)                                                                                         \
-  (cnt ? launch_zones<NW, true>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st) \
-       : launch_zones<NW, false>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st))
+  (cnt ? launch_zones<NW, true>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st, n_layers, n_chunks) \
+       : launch_zones<NW, false>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st, n_layers, n_chunks))
     // SR_ZONES_NW=1|2|4|8 (environment, read once): tuning override of the waves per image
     static const int nw_env = [] { const char *e = getenv("SR_ZONES_NW"); return e ? atoi(e) : 0; }();
     if (nw_env == 1 || nw_env == 2 || nw_env == 4 || nw_env == 8) {
