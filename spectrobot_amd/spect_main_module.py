@@ -468,7 +468,16 @@ def make_abscoeff_isomolec(wn_range_tot, isomolec, Temps, Press, LTE=True, allLU
         tvib = None
         if levels and not LTE:
             tvib = np.array([lv.local_vibtemp for lv in levels], dtype=float)      # :2065
-        ab, em = lineset.abscoeff_layers(Temps, Press, tvib=tvib)
+        # The reference evaluates the shapes once per DISTINCT (P, T) of the step list only in its LUT routes; its direct
+        # route repeats them per step (:1974-1990).  Here: when at least three steps share every (P, T) row on average
+        # (a 3-D path: kinetic state on (latitude box, altitude), vibrational temperatures by the local SZA), the
+        # level-factored route -- per-level pair spectra on the distinct rows + one population-weighted combine
+        # (:2036-2106), engine.LevelFactored -- replaces the folded op over the steps.  Same numbers to ~1e-13.
+        T_rows, P_rows, step_row = engine.LevelFactored.unique_rows(Temps, Press)
+        if len(T_rows) * 3 <= len(Temps):
+            ab, em = engine.LevelFactored(lineset, T_rows, P_rows).steps(step_row, tvib=tvib)
+        else:
+            ab, em = lineset.abscoeff_layers(Temps, Press, tvib=tvib)
         for lev in (track_levels or []):
             tracked[lev] = lineset.abscoeff_level(Temps, Press, isomolec.levels.index(lev), tvib=tvib)
 

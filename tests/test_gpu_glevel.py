@@ -133,3 +133,25 @@ def test_combine_temperature_derivative(eng, scene):
     h = 1e-3
     fd = (ls.level_populations(T + h) - ls.level_populations(T - h)) / (2 * h)
     assert relerr(dpop2, fd) < 1e-6
+
+
+def test_make_abscoeff_isomolec_takes_the_factored_route_for_shared_rows(eng, scene):
+    """smm.make_abscoeff_isomolec(useLUTs=False) on a step list whose (P, T) couples repeat (12 steps on 3 rows, every
+    step with its own vibrational temperatures): the level-factored route it then takes gives what the folded op gives
+    on the steps themselves."""
+    import torch
+    from spectrobot_amd import spect_main_module as smm, spect_base_module as sbm, synthetic as syn
+    ls, atm, grid = scene["ls"], scene["atm"], scene["grid"]
+    rng = np.random.default_rng(8)
+    row = np.repeat(np.array([1, 3, 5]), 4)
+    T, P = atm["temps"][row], atm["press"][row]
+    tv = atm["tvib"][:, row] + rng.uniform(-10.0, 20.0, (12, 12))
+    tv[0] = T
+    iso = sbm.IsoMolec(6, 1, syn.CH4_MM, mol_name="CH4")
+    for i, e in enumerate(syn.CH4_LEVEL_ENERGIES):
+        iso.add_level("L%02d" % i, e, local_vibtemp=tv[i])
+    a_set, e_set = smm.make_abscoeff_isomolec([grid[0], grid[-1]], iso, T, P, LTE=False, lineset=ls, to_host=False)
+    a0, e0 = ls.abscoeff_layers(T, P, tvib=tv)
+    sa, se = a0.abs().amax(dim=1, keepdim=True), e0.abs().amax(dim=1, keepdim=True)
+    assert float(((a_set.device - a0).abs() / sa).max()) < 1e-12 and float(((e_set.device - e0).abs() / se).max()) < 1e-12
+    assert not torch.equal(a_set.device, a0)          # (it did take the other route)

@@ -310,8 +310,9 @@ def test_adaptive_los_stepping_converges(eng):
     """engine.calc_radtran_steps: the reference's radtran_opt knobs (max_T_variation, max_Plog_variation,
     max_opt_depth: radtran_test_CO.py:184-186, spect_main_module.py:2760-2762) on the device LOS pipeline.  A step
     carries the coefficient row of its own mean (P, T); as the bounds tighten the radiance converges (fixed stepping,
-    one row per shell at the level values, is the coarsest member of the family), the optical-depth bound leaves no
-    step above it, and an isothermal atmosphere at constant pressure is indifferent to the stepping."""
+    one row per shell at the level values, is the coarsest member of the family) and the optical-depth bound leaves no
+    step above it.  (A constant-density test atmosphere is not an option: curgod_fort_2 is singular for n(i+1) = n(i),
+    curgods.f:33-41, as in the reference.)"""
     import torch
     from spectrobot_amd import synthetic as syn
     grid = syn.make_grid(2990.0, 5e-4, 12000)
@@ -341,11 +342,9 @@ def test_adaptive_los_stepping_converges(eng):
     col = S["los"].columns()[0]
     tau = S["coeffs"][0][0].abs().amax(dim=1).cpu().numpy() * col
     assert tau.max() <= bound and len(col) > n_steps[0] and tau0.max() > bound
-    # nothing to resolve: isothermal, isobaric, LTE -- the radiance does not depend on the stepping
-    Tc, Pc = np.full(16, 160.0), np.full(16, 0.05)
-    gas_c = [dict(lineset=ls, vmr=np.full(16, 0.0148), iso_ratio=syn.CH4_ISO_RATIO, tvib=None)]
-    Sa = eng.calc_radtran_steps(gas_c, z, Tc, Pc, zt)
-    Sb = eng.calc_radtran_steps(gas_c, z, Tc, Pc, zt, radtran_opt=dict(max_opt_depth=0.05))
-    ra, rb = eng.limb_rays(Sa["coeffs"], Sa["los"]), eng.limb_rays(Sb["coeffs"], Sb["los"])
-    assert len(Sb["L"]["seg_layer"]) > len(Sa["L"]["seg_layer"])
-    assert float(((ra - rb).abs() / ra.abs().clamp_min(1e-300)).max()) < 1e-9
+    # halving steps by optical depth refines the same path: the radiance moves towards the finely stepped one
+    r0, r1 = eng.limb_rays(S0["coeffs"], S0["los"]), eng.limb_rays(S["coeffs"], S["los"])
+    Sf = eng.calc_radtran_steps(thin, z, T, P, zt, radtran_opt=dict(max_T_variation=0.25, max_Plog_variation=0.03))
+    rf = eng.limb_rays(Sf["coeffs"], Sf["los"])
+    dev = lambda r: float(((r - rf).abs().amax(dim=1) / rf.abs().amax(dim=1)).max())
+    assert dev(r1) < dev(r0)
