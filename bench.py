@@ -337,20 +337,22 @@ def main():
         gbs = alg_bytes / (main_ms * 1e-3) / 1e9
         # HBM traffic from the PMC counters: only for the build it was measured on (sources hash)
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_hbm.json")
+        pmc_name = next((f for f in ("r04_pmc_hbm.json", "r03_pmc_hbm.json")
+                         if os.path.exists(os.path.join(ROOT, "profiles", f))), "r04_pmc_hbm.json")
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc) and world == 1 and args.lines == 100000 and args.grid == 100000 and not args.shard:
             try:
                 pj = json.load(open(pmc))
                 if pj.get("kernel_sources_sha256") == kernel_sources_sha256():
                     traffic = pj.get("coefficient_kernels_hbm_bytes_per_step")
-                    traffic_src = {"file": "profiles/r03_pmc_hbm.json", "profile_tag": pj.get("profile_tag"),
+                    traffic_src = {"file": "profiles/" + pmc_name, "profile_tag": pj.get("profile_tag"),
                                    "kernel_sources_sha256": pj.get("kernel_sources_sha256")[:16],
                                    "raw_counter_bytes": pj.get("coefficient_kernels_hbm_bytes_per_step_raw"),
                                    "note": "FETCH_SIZE doubled for vector reads (calibration: profiles/"
                                            "r03_fetch_calibration.txt), WRITE_SIZE as reported; per step of the "
                                            "coefficient kernels"}
                 else:
-                    traffic_src = {"file": "profiles/r03_pmc_hbm.json", "stale": True,
+                    traffic_src = {"file": "profiles/" + pmc_name, "stale": True,
                                    "note": "measured on other kernel sources than this build: not reported"}
             except Exception:
                 traffic = None
