@@ -39,14 +39,15 @@ FLOP_PER_EVAL = 16             # SURVEY 8-d flop model per (line, layer, grid po
 # sr_farfield_kernel's source (setup 42, reciprocal 9, f0..f3 14, 23 coefficients x 2 outputs).  Per
 # (point, level) polynomial: 2 outputs x degree 22 Horner.  Per window-end expansion: series + its share
 # of the lane scan.
-# Box-pair far field (default): per (line, side) multipole expansion 430 (Laurent series 52, anchor 14, powers 40,
-# convolution 121 fma, two weighted accumulations 42 fma); per (source box, target box, layer) translation
+# Box-pair far field (default): per (line, side) multipole expansion 233 -- since round 4 ONE convolution per line serves
+# both sides (per line: Laurent series 52, two anchors 28, powers 40, convolution 121 fma, two weighted accumulations 42
+# fma, first-order anchor corrections 8 fma + 4 = 466; 430 per side before); per (source box, target box, layer) translation
 # 21 x 23 x 2 outputs fma = 1932 (the MFMA tiles execute 24 x 32: padding not counted); the short series of the
 # window-band lines in the level-0 pass are not counted at all.
 ASYNC_GATHER = os.environ.get("SR_GATHER_ASYNC", "1") != "0"   # SR_GATHER_ASYNC=0: every step waits for its all-gather
 FLOP = {"region1_evals": 15, "region2_evals": 23, "region3_evals": 70, "region4_evals": 146,
         "farfield_expansions": 281, "poly_point_levels": 93, "window_end_expansions": 187,
-        "multipole_line_sides": 430, "box_pair_translations": 1932}
+        "multipole_line_sides": 233, "box_pair_translations": 1932}
 KERNEL_COUNTERS = {
     "sr_farfield_kernel": ("farfield_expansions", "multipole_line_sides", "box_pair_translations"),
     "sr_abscoeff_near_wings_kernel": ("region1_evals", "window_end_expansions", "poly_point_levels"),

@@ -886,6 +886,109 @@ __device__ constexpr double inv_factorial(int n) {
 #else
 #define SR_S2M_ATTR
 #endif
+#ifndef SR_S2M_ONE_SET
+#define SR_S2M_ONE_SET 1 // 1 (round 4): one convolution per line about the MEAN of its two anchors + first-order corrections; 0: one per side
+#endif
+#if SR_S2M_ONE_SET
+// Round 4: one moment set per line instead of one per side.  The two wings of a line use different anchors (the zero of
+// the reference's running x: xl from x(1), xr from x(ir): lineshape.f:462, 471), eps ~ 1e-9 grid points apart (the
+// rounding of the grid).  The moments are analytic in the anchor: M_q(delta +- eps / 2) = M_q(delta) +- (eps / 2) d M_q /
+// d delta + O(eps^2 ~ 1e-18), and d m_q / d delta = m_(q-1) / h for the scaled per-line moments (the delta-series
+// D_m = (delta / h)^m / m! shifts by one index).  So: ONE convolution per line about the mean anchor (lane = line, 64
+// lines per step instead of 32 per side: a box holds 64 +- 8 lines -- 1.5 steps on average instead of 2.5), the sums
+// v_q, and correction sums c_q = sum_i w_i (eps_i / 2 h) m_(q-1, i) for q = 3..6 only -- the correction of order q
+// reaches a target J >= 192 points away with (h / J)^(q - 2) of a term that is 1e-11 of the pair's contribution to begin
+// with: beyond q = 6 that is < 1e-15.  Written out: side 0 (right-going) = v + c, side 1 (left-going) = v - c: M2M and
+// M2L read what they always read.
+constexpr int kS2MCorr = 4; // corrected orders q = 3 .. 2 + kS2MCorr
+template <bool COUNT>
+__global__ __launch_bounds__(64) SR_S2M_ATTR void sr_s2m_kernel(const FastRec *__restrict__ fast, IcIndex ix, int n_sub, int g_lo,
+                                                    FarParams fp, unsigned long long *__restrict__ cnt) {
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int layer = wid / fp.n_src[0], sb = wid - layer * fp.n_src[0];
+  const int lane = threadIdx.x;
+  const int s_lo = g_lo + (sb - kSrcPad) * 64; // first centre position of the box
+  // A box wholly LEFT of the shard only ever serves targets to its right (side 0), one wholly right of it targets to
+  // its left (side 1) -- and so do all its ancestors: the side nobody reads is written as zeros (sr_m2m_kernel skips it).
+  const int only = s_lo + 64 <= g_lo ? 0 : (s_lo >= g_lo + fp.box_count[0] * 64 ? 1 : -1);
+  const int l0 = lower_bound_ic(ix, s_lo), l1 = lower_bound_ic(ix, s_lo + 64);
+  constexpr int NE = kFD / 2; // terms of the Laurent series
+  double v[2 * kMQ];          // [0, kMQ): abs, [kMQ, 2 kMQ): emi -- about the mean anchor
+  double c[2 * kS2MCorr];     // first-order anchor corrections of orders 3 .. 2 + kS2MCorr: abs, emi
+#pragma unroll
+  for (int n = 0; n < 2 * kMQ; ++n) v[n] = 0.;
+#pragma unroll
+  for (int n = 0; n < 2 * kS2MCorr; ++n) c[n] = 0.;
+  const FastRec *frow = fast + (size_t)layer * n_sub;
+  unsigned n_lines = 0;
+  for (int base = l0; base < l1; base += 64) {
+    const int l = base + lane;
+    if (l >= l1 || l < fp.disp_lo_end || l >= fp.disp_hi_begin) continue;
+    const FastRec r = frow[l];
+    if (COUNT) n_lines += 2; // (line, side) pairs served
+    constexpr double h = 32.0;
+    const double sh = r.xstep * h;
+    const double V = fast_rcp<2>(sh * sh);
+    double E[NE]; // e_(n-1) (xstep h)^(-2n) / (2n-1)!
+    {
+      const double dV = 0.25 * r.d * V, cV = 0.25 * r.c * (V * V);
+      E[0] = 0.25 * r.b * V;
+      E[1] = fma(0.25 * r.a * V, V, -dV * E[0]);
+#pragma unroll
+      for (int k = 2; k < NE; ++k) E[k] = -fma(dV, E[k - 1], cV * E[k - 2]);
+#pragma unroll
+      for (int k = 1; k < NE; ++k) E[k] *= inv_factorial(2 * k + 1);
+    }
+    // zeros of the two running x, relative to the box centre s_lo + 31.5 (grid points)
+    const double inv_xs = fast_rcp<2>(r.xstep);
+    const double off_r = (double)(r.j1 + r.ir() - 1 - s_lo - 32) + (0.5 - r.xr * inv_xs);
+    const double off_l = (double)(r.j1 - s_lo - 32) + (0.5 + r.xl * inv_xs);
+    const double dt = (0.5 / h) * (off_r + off_l);   // mean anchor / h
+    const double eh = (0.5 / h) * (off_r - off_l);   // eps / 2 h: side 0 sits at dt + eh, side 1 at dt - eh
+    double D[kMQ]; // (delta/h)^m / m!, m = 0..kFD-2
+    D[0] = 1.0;
+#pragma unroll
+    for (int m = 1; m < kMQ; ++m) D[m] = D[m - 1] * (dt * (1.0 / (double)m));
+    const double wa_e = r.wabs * eh, we_e = r.wemi * eh;
+#pragma unroll
+    for (int q = 2; q <= kFD; ++q) {
+      double mq = 0.;
+#pragma unroll
+      for (int n = 1; 2 * n <= q; ++n) mq = fma(E[n - 1], D[q - 2 * n], mq);
+      v[q - 2] = fma(r.wabs, mq, v[q - 2]);
+      v[kMQ + q - 2] = fma(r.wemi, mq, v[kMQ + q - 2]);
+      if (q - 2 < kS2MCorr) { // d m_(q+1) / d delta = m_q / h
+        c[q - 2] = fma(wa_e, mq, c[q - 2]);
+        c[kS2MCorr + q - 2] = fma(we_e, mq, c[kS2MCorr + q - 2]);
+      }
+    }
+  }
+  // sums over the 64 lanes: the moments by halving exchanges (one finished value per lane), the few corrections by butterflies
+  lane_reduce<kMQ, 32>(v, lane);
+  lane_reduce<kMQ, 32>(v + kMQ, lane);
+#pragma unroll
+  for (int n = 0; n < 2 * kS2MCorr; ++n)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c[n] += __shfl_xor(c[n], m);
+  bool primary = true;
+  const int n_out = lane_reduce_index<kMQ, 32>(lane, primary); // this lane holds order q = n_out + 2
+  if (primary) {
+    double ca = 0., ce = 0.; // correction of order q = n_out + 2: c index q - 3
+#pragma unroll
+    for (int i = 0; i < kS2MCorr; ++i) {
+      ca = n_out == i + 1 ? c[i] : ca;
+      ce = n_out == i + 1 ? c[kS2MCorr + i] : ce;
+    }
+    double *mo = fp.mom + ((size_t)(fp.src_off[0] + sb) * fp.n_layers + layer) * kMomPerBox + n_out;
+    const bool z0 = only == 1, z1 = only == 0; // the side a halo box never serves
+    mo[0] = z0 ? 0.0 : v[0] + ca;                       // side 0 (right-going), abs
+    mo[kMQ] = z0 ? 0.0 : v[kMQ] + ce;                   //                       emi
+    mo[2 * kMQ] = z1 ? 0.0 : v[0] - ca;                 // side 1 (left-going), abs
+    mo[3 * kMQ] = z1 ? 0.0 : v[kMQ] - ce;
+  }
+  if (COUNT) count_add(cnt, kCntS2M, n_lines, lane);
+}
+#else
 template <bool COUNT>
 __global__ __launch_bounds__(64) SR_S2M_ATTR void sr_s2m_kernel(const FastRec *__restrict__ fast, IcIndex ix, int n_sub, int g_lo,
                                                     FarParams fp, unsigned long long *__restrict__ cnt) {
@@ -958,6 +1061,8 @@ __global__ __launch_bounds__(64) SR_S2M_ATTR void sr_s2m_kernel(const FastRec *_
   }
   if (COUNT) count_add(cnt, kCntS2M, n_lines, lane);
 }
+
+#endif // SR_S2M_ONE_SET
 
 // One thread per (parent box of level l, layer, side, weight); one launch per level, narrow to wide (round 3: one
 // thread per widest-level subtree walked all its 15 boxes in sequence -- 500 waves with 15 dependent rounds of loads:
