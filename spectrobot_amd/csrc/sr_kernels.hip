@@ -1953,11 +1953,16 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
   if (part == 1) {
     // slots per wave: 4 (256-point groups) measured 2.53 ms on config 2, 2: 2.31 ms, 1: see DESIGN.md
     const int n_g1 = (g_hi - g_lo + 63) / 64;
+    // SR_WINGS_LDS (bytes, tuning): dynamic LDS requested per block to CAP this kernel's occupancy (it uses none): 80 VGPRs
+    // pack six waves per SIMD and leave 32 registers -- no wave of S2M (168) or of the level-0 pass (140) of the next call
+    // ever fits beside it; 10240 B holds it to four waves per SIMD (16 blocks per CU) and leaves 192 registers free.
+    static const unsigned wings_lds = [] { const char *e = getenv("SR_WINGS_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
+    const unsigned w_lds = z_abs ? wings_lds : 0u; // decoupled pipeline only
     if (cnt)
       hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<true>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
                          fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, z_abs, z_emi, abs_out, emi_out, cnt);
     else
-      hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<false>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
+      hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<false>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), w_lds, st,
                          fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, z_abs, z_emi, abs_out, emi_out, cnt);
   } else {
     // Image width: wider images cut fewer zones in two (fewer (line, group) pairs: 7.1 -> 6.7 ms on
