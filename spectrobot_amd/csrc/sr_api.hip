@@ -244,6 +244,18 @@ struct CoefWork {
   hipEvent_t ev_l0_done[2] = {nullptr, nullptr}, ev_s2m_done[2] = {nullptr, nullptr};
   hipEvent_t ev_wings_done[2] = {nullptr, nullptr};
   bool wings_recorded[2] = {false, false};
+  // hipGraph of everything a call issues on the internal streams (staging copy, preparation, far-field chain, zones
+  // kernel and the events between them), per parity and call shape: replayed by ONE hipGraphLaunch on graph_st[b]
+  struct GraphEntry {
+    std::vector<uintptr_t> key;
+    hipGraphExec_t exec = nullptr;
+    unsigned long long last_use = 0;
+  };
+  std::vector<GraphEntry> graphs[2];
+  hipStream_t graph_st[2] = {nullptr, nullptr};
+  hipEvent_t ev_pre_done[2] = {nullptr, nullptr};
+  unsigned long long graph_clock = 0;
+  bool graphs_broken = false; // a capture failed once: direct launches from then on
   bool free_recorded[2] = {false, false};
   int parity = 0;
   bool overlapped = false;       // last call ran that way (timing hook)
@@ -280,6 +292,11 @@ struct CoefWork {
       if (ev_l0_done[b]) (void)hipEventDestroy(ev_l0_done[b]);
       if (ev_s2m_done[b]) (void)hipEventDestroy(ev_s2m_done[b]);
       if (ev_wings_done[b]) (void)hipEventDestroy(ev_wings_done[b]);
+      for (auto &g : graphs[b])
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      graphs[b].clear();
+      if (graph_st[b]) (void)hipStreamDestroy(graph_st[b]);
+      if (ev_pre_done[b]) (void)hipEventDestroy(ev_pre_done[b]);
       d_zone2[b].release();
       d_coef[b].release();
       d_mom[b].release();
@@ -792,6 +809,23 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     }
     pst = w.prep_st;
   }
+  // Round 4: the decoupled pipeline (see the far-field branch below) and its hipGraph
+  static const int pipe_env = [] { const char *e = getenv("SR_PIPELINE"); return e ? atoi(e) : 2; }();
+  // SR_GRAPH=1: hipGraph of the internal-stream part of a call (below).  Built, tested (the whole -m gpu suite passes
+  // with it) and MEASURED SLOWER on ROCm 7.2 / gfx950: hipGraphLaunch of the 11-kernel, 4-branch graph costs the host
+  // 406 us per step against 322 us for the direct launches it replaces (tools/host_overhead.py), and the device runs
+  // the graph's branches less concurrently than the streams did: 5.78 vs 5.48 ms per step on the whole grid, 0.883 vs
+  // 0.805 ms on a 1/8 shard.  Off by default.
+  static const int graph_env = [] { const char *e = getenv("SR_GRAPH"); return e ? atoi(e) : 0; }();
+  const bool decoupled = overlap && far_field && !counting && pipe_env != 0;
+  bool want_graph = decoupled && graph_env != 0 && !w.graphs_broken;
+  if (want_graph) {
+    if (!w.graph_st[b]) {
+      HIPCHK(hipStreamCreateWithFlags(&w.graph_st[b], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&w.ev_pre_done[b], hipEventDisableTiming));
+    }
+    pst = w.graph_st[b];
+  }
   Stager &SL = w.s_layers[b];
   DevBuf &d_fast = w.d_fast[b], &d_cold = w.d_cold[b];
   int rc = SL.prepare(hl_bytes);
@@ -853,8 +887,95 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   // set b was last read by the kernels of the call before the previous one
   if (overlap && w.free_recorded[b]) HIPCHK(hipStreamWaitEvent(pst, w.ev_tables_free[b], 0));
   if (overlap == 2 && w.tail_recorded) HIPCHK(hipStreamWaitEvent(pst, w.ev_tail, 0));
-  rc = SL.push(hl_bytes, pst);
-  if (rc) return rc;
+  // hipGraph (SR_GRAPH=1; off by default, see graph_env above): every launch between here and the wings kernel goes to internal streams and
+  // scratch of parity b -- staging copy, sr_prep_kernel, level-0 pass, S2M, M2M x 4, M2L, zones kernel, ~20 event
+  // operations: ~30 API calls of ~9 us each on the host.  They are captured once per call shape (the key below: every
+  // value and pointer a node bakes in) and replayed with one hipGraphLaunch; the host then only fills the pinned
+  // staging buffer.  A per-call graph of the WHOLE op would serialise consecutive calls on one stream; this one
+  // covers exactly the part that never touches the caller's buffers, on a stream of the call's parity, so the
+  // pipeline across calls stays what it is.  All allocations happen before the capture begins (pre-flight).
+  hipGraphExec_t g_exec = nullptr;
+  bool capturing = false;
+  std::vector<uintptr_t> g_key;
+  struct CaptureGuard { // an early return inside the captured span must not leave the stream capturing
+    hipStream_t s = nullptr;
+    bool active = false;
+    ~CaptureGuard() {
+      if (!active) return;
+      hipGraph_t g = nullptr;
+      (void)hipStreamEndCapture(s, &g);
+      if (g) (void)hipGraphDestroy(g);
+    }
+  } cap_guard;
+  if (want_graph) {
+    const auto lo_p = std::lower_bound(ls->ic.begin(), ls->ic.end(), (int)g_lo - (kHalf - 1));
+    const auto hi_p = std::upper_bound(ls->ic.begin(), ls->ic.end(), (int)g_hi - 1 + kHalf);
+    const int n_sub_p = (int)(hi_p - lo_p);
+    const size_t n_pts_p = (size_t)(g_hi - g_lo);
+    if (n_sub_p <= 0) {
+      want_graph = false;
+    } else {
+      rc = d_fast.ensure(sizeof(FastRec) * ((size_t)n_sub_p * nl + 1));
+      if (!rc) rc = d_cold.ensure(sizeof(ColdRec) * ((size_t)n_sub_p * nl + 1));
+      size_t boxes = 0;
+      for (int lv = 0; lv < kMaxFarLevels; ++lv) boxes += (n_pts_p + (64u << lv) - 1) / (64u << lv);
+      if (!rc) rc = w.d_coef[b].ensure(sizeof(double) * (size_t)nl * boxes * 2 * kFC);
+      if (!rc && far_field == 2) {
+        const size_t top_boxes = (((size_t)kSrcPad * 64 + n_pts_p + kHalf + 64) >> (6 + kMaxFarLevels - 1)) + 1;
+        rc = w.d_mom[b].ensure(sizeof(double) * (top_boxes * ((1u << kMaxFarLevels) - 1)) * nl * kMomPerBox);
+        const double *tab_p = nullptr;
+        if (!rc) rc = m2l_table_dev(&tab_p);
+      }
+      if (!rc) rc = w.d_zone2[b].ensure(sizeof(double) * 2 * n_pts_p * nl);
+      if (rc) return rc;
+      if (!w.aux) {
+        HIPCHK(hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
+      }
+      if (!w.chain_st) {
+        HIPCHK(hipStreamCreateWithFlags(&w.chain_st, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&w.chain2_st, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+          HIPCHK(hipEventCreateWithFlags(&w.ev_l0_done[i], hipEventDisableTiming));
+          HIPCHK(hipEventCreateWithFlags(&w.ev_s2m_done[i], hipEventDisableTiming));
+          HIPCHK(hipEventCreateWithFlags(&w.ev_wings_done[i], hipEventDisableTiming));
+        }
+      }
+      g_key = {(uintptr_t)ls, (uintptr_t)g_lo, (uintptr_t)g_hi, (uintptr_t)nl, (uintptr_t)W.mode, (uintptr_t)(W.level + 1),
+               (uintptr_t)far_field, (uintptr_t)(frozen ? 1 : 0), (uintptr_t)(frozen && bown->linear_weights ? 1 : 0),
+               (uintptr_t)pipe_env, (uintptr_t)n_sub_p, (uintptr_t)(lo_p - ls->ic.begin()), (uintptr_t)d_fast.p,
+               (uintptr_t)d_cold.p, (uintptr_t)w.d_coef[b].p, (uintptr_t)w.d_mom[b].p, (uintptr_t)w.d_zone2[b].p,
+               (uintptr_t)SL.d.p, (uintptr_t)SL.h, (uintptr_t)hl_bytes, (uintptr_t)ls->d_lines.p, (uintptr_t)ls->d_first.p,
+               (uintptr_t)ls->n_disp_lo, (uintptr_t)ls->n_disp_hi};
+      for (auto &g : w.graphs[b])
+        if (g.key == g_key) {
+          g_exec = g.exec;
+          g.last_use = ++w.graph_clock;
+          break;
+        }
+      if (!g_exec) {
+        if (hipStreamBeginCapture(pst, hipStreamCaptureModeRelaxed) == hipSuccess) {
+          capturing = true;
+          cap_guard.s = pst;
+          cap_guard.active = true;
+        } else {
+          (void)hipGetLastError();
+          w.graphs_broken = true;
+          want_graph = false;
+        }
+      }
+    }
+  }
+  const bool emit = g_exec == nullptr; // false: the launches below are in the graph that will be replayed
+  if (emit) {
+    if (want_graph) { // the copy alone: its completion event is recorded behind the graph launch
+      if (hl_bytes) HIPCHK(hipMemcpyAsync(SL.d.p, SL.h, hl_bytes, hipMemcpyHostToDevice, pst));
+    } else {
+      rc = SL.push(hl_bytes, pst);
+      if (rc) return rc;
+    }
+  }
   LayersDev A;
   const double *dl = SL.d.as<double>();
   A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.ltrat = dl + 4 * nl;
@@ -921,14 +1042,17 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   if (rc) return rc;
 
 
-  HIPCHK(hipEventRecord(w.ev[0], pst));
-  // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
-  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, W, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
-                        far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), pst));
-  HIPCHK(hipEventRecord(w.ev[1], pst));
-  if (overlap) { // the caller's stream takes over once the tables are ready
-    HIPCHK(hipEventRecord(w.ev_prep_done[b], pst));
-    HIPCHK(hipStreamWaitEvent(st, w.ev_prep_done[b], 0));
+  if (emit) {
+    // (timing events stay out of a capture: ev[0] / ev[1] then bracket the whole graph, see below)
+    if (!want_graph) HIPCHK(hipEventRecord(w.ev[0], pst));
+    // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
+    LAUNCHCHK(launch_prep(ls->L, A, ls->gp, W, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
+                          far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), pst));
+    if (!want_graph) HIPCHK(hipEventRecord(w.ev[1], pst));
+    if (overlap) HIPCHK(hipEventRecord(w.ev_prep_done[b], pst));
+  }
+  if (overlap) { // the caller's stream takes over once the tables are ready (graph: it waits for the whole graph below)
+    if (!want_graph) HIPCHK(hipStreamWaitEvent(st, w.ev_prep_done[b], 0));
     HIPCHK(hipEventRecord(w.ev_op0, st));
   }
   if (far_field) {
@@ -994,8 +1118,6 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     // A = [zones(c + 1) | M2M, M2L(c + 1) | prep(c + 2)]; the zones kernel is GATED behind the level-0 pass and S2M of
     // its own call (it needs neither), which is what keeps it from flooding the chip before they are through.
     // Counting passes keep the round-3 order (their counters are zeroed on the caller's stream).
-    static const int pipe_env = [] { const char *e = getenv("SR_PIPELINE"); return e ? atoi(e) : 2; }();
-    const bool decoupled = overlap && !counting && pipe_env != 0;
     if (decoupled) {
       if (!w.aux) {
         HIPCHK(hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
@@ -1023,7 +1145,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       // SR_CHAIN_AFTER_WINGS (tuning): 1: S2M, 2: S2M and the level-0 pass start only when the PREVIOUS call's wings
       // kernel is through (beside it S2M's 154-VGPR waves lose every slot race: 1.45 instead of 0.38 ms)
       static const int after_env = [] { const char *e = getenv("SR_CHAIN_AFTER_WINGS"); return e ? atoi(e) : 0; }();
-      const bool prev_wings = w.wings_recorded[b ^ 1];
+      const bool prev_wings = w.wings_recorded[b ^ 1] && !want_graph; // (an event from outside cannot be waited on inside a capture)
+      if (emit) {
       HIPCHK(hipStreamWaitEvent(w.chain_st, w.ev_prep_done[b], 0));
       if (after_env >= 2 && prev_wings) HIPCHK(hipStreamWaitEvent(w.chain_st, w.ev_wings_done[b ^ 1], 0));
       LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, w.chain_st));
@@ -1048,9 +1171,51 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo,
                             (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, w.aux));
       HIPCHK(hipEventRecord(w.ev_zones_done[b], w.aux));
-      HIPCHK(hipStreamWaitEvent(st, w.ev_far_done[b], 0));
-      HIPCHK(hipEventRecord(w.ev[2], st));
-      HIPCHK(hipStreamWaitEvent(st, w.ev_zones_done[b], 0));
+      } // emit
+      if (capturing) { // join the forked streams, close the capture, instantiate
+        HIPCHK(hipStreamWaitEvent(pst, w.ev_far_done[b], 0));
+        HIPCHK(hipStreamWaitEvent(pst, w.ev_zones_done[b], 0));
+        hipGraph_t graph = nullptr;
+        cap_guard.active = false;
+        hipError_t ge = hipStreamEndCapture(pst, &graph);
+        if (ge == hipSuccess && graph) ge = hipGraphInstantiate(&g_exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ge != hipSuccess || !g_exec) {
+          (void)hipGetLastError();
+          w.graphs_broken = true;
+          g_err = std::string("hipGraph capture of the coefficient op failed: ") + hipGetErrorString(ge);
+          return SR_ERR_HIP;
+        }
+        auto &cache = w.graphs[b];
+        if (cache.size() >= 32) { // evict the least recently used shape
+          size_t victim = 0;
+          for (size_t i = 1; i < cache.size(); ++i)
+            if (cache[i].last_use < cache[victim].last_use) victim = i;
+          (void)hipGraphExecDestroy(cache[victim].exec);
+          cache.erase(cache.begin() + (long)victim);
+        }
+        CoefWork::GraphEntry ge_new;
+        ge_new.key = g_key;
+        ge_new.exec = g_exec;
+        ge_new.last_use = ++w.graph_clock;
+        cache.push_back(ge_new);
+      }
+      if (want_graph) {
+        HIPCHK(hipEventRecord(w.ev[0], pst));
+        HIPCHK(hipGraphLaunch(g_exec, pst));
+        HIPCHK(hipEventRecord(w.ev[1], pst));
+        // the graph's copy node reads the pinned staging buffer: the slot is free again when the graph is through (an
+        // event record node inside the graph is not relied upon for host-side synchronisation)
+        HIPCHK(hipEventRecord(SL.done, pst));
+        SL.pending = true;
+        HIPCHK(hipEventRecord(w.ev_pre_done[b], pst));
+        HIPCHK(hipStreamWaitEvent(st, w.ev_pre_done[b], 0));
+        HIPCHK(hipEventRecord(w.ev[2], st));
+      } else {
+        HIPCHK(hipStreamWaitEvent(st, w.ev_far_done[b], 0));
+        HIPCHK(hipEventRecord(w.ev[2], st));
+        HIPCHK(hipStreamWaitEvent(st, w.ev_zones_done[b], 0));
+      }
       LAUNCHCHK(launch_near(1, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo,
                             (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st, z_abs, z_emi));
       HIPCHK(hipEventRecord(w.ev_wings_done[b], st));

@@ -2,6 +2,7 @@
 fixtures.  Needs a real MI355X: run with `pytest -m gpu`."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -962,3 +963,45 @@ def test_per_line_dropin_route(eng, golden):
     gc = spcl.SpectralGcoeff("absorption", sg, 6, 1, float(g["mm"]), "L00")
     gc.BuildCoeff(lines, T, P, isomolec=iso)          # computes the shapes itself
     assert relerr(gc.spectrum[g["G_lev"][0, 0, 2] != 0], g["G_lev"][0, 0, 2][g["G_lev"][0, 0, 2] != 0]) < TOL
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_of_the_internal_streams(tmp_path):
+    """SR_GRAPH=1 (off by default: measured slower on this ROCm, sr_api.hip): the staging copy, sr_prep_kernel, the
+    far-field chain and the zones kernel of a call captured once per call shape and replayed by one hipGraphLaunch.
+    Same results bit for bit as the direct launches over changing inputs, shapes and weight modes (a new shape captures,
+    a known one replays: the pinned staging buffer is the only thing the host touches)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "g.py"
+    script.write_text("""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from spectrobot_amd import engine, synthetic as syn
+engine.set_device(0)
+grid = syn.make_grid(2980.0, 5e-4, 30000)
+L = syn.make_lines(6000, grid, seed=7, n_levels=12)
+ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+out = []
+for rep in range(3):
+    for nl, lo, hi in ((10, 0, 30000), (7, 4000, 22000), (10, 0, 30000)):
+        atm = syn.make_atmosphere(nl, 12)
+        for shift in (0.0, 1.5, 3.0):
+            a, e = ls.abscoeff_layers(atm["temps"] + shift, atm["press"], tvib=atm["tvib"] + shift, g_lo=lo, g_hi=hi)
+            out.append(a.sum().item()); out.append(e.sum().item())
+        g = ls.glevel_pairs(atm["temps"], atm["press"], g_lo=lo, g_hi=hi)
+        out.append(g.sum().item())
+torch.cuda.synchronize()
+np.save(sys.argv[1], np.array(out))
+print("ok")
+""" % root)
+    res = []
+    for g in ("0", "1"):
+        env = dict(os.environ, SR_GRAPH=g)
+        f = str(tmp_path / ("r%s.npy" % g))
+        p = subprocess.run([sys.executable, str(script), f], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0 and "ok" in p.stdout.decode(), p.stdout.decode()
+        res.append(np.load(f))
+    assert res[0].size == 63 and np.array_equal(res[0], res[1])
