@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kPrepBlock) void sr_prep_kernel(LinesDev L, LayersD
   __shared__ uint4 s_rec[kPrepBlock / 64][64 * sizeof(FastRec) / 16]; // per wave: 64 fast records, then its 64 cold records
   static_assert(sizeof(ColdRec) <= sizeof(FastRec), "the cold records share the fast records' staging buffer");
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
+  const int k = blockIdx.y; // (layers on the fast grid axis instead -- the line arrays then stay in L2 -- measured slower: 0.32 vs 0.29 ms, the record rows of consecutive blocks lie 8 MB apart)
   const int wave_first = i0 - (threadIdx.x & 63);
   if (wave_first >= n_sub) return; // whole wave out of range
   const bool valid = i0 < n_sub;
