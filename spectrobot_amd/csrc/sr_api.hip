@@ -411,7 +411,7 @@ int sr_set_counting(int on) {
 }
 
 int sr_set_jac_layer_mode(int forward) {
-  g_jac_layer_forward.store(forward ? 1 : 0);
+  g_jac_layer_forward.store(forward == 2 ? 2 : (forward ? 1 : 0)); // 2: the one-pass kernel with one ray per thread (no layer-synchronous batches)
   return SR_OK;
 }
 
@@ -1887,24 +1887,91 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
   LosDev D;
   rc = stage_los(los, n_layers, n_par, par_gas, par_w, st, &D);
   if (rc) return rc;
+  // Layer-synchronous schedule (sr_limb_adjoint_sync_kernel): when the rays share their coefficient rows (no per-step
+  // rows: seg_jrow == NULL) and every ray walks them monotonically down to a turning shell and monotonically up again
+  // (limb rays; slant / nadir rays are the upward half alone), the shells are listed once -- far side from the
+  // outermost shell inwards, near side outwards -- with every ray's segment in each: the kernel then loads a shell's
+  // coefficients once for kAdjSyncRays rays.  Anything else (3-D paths, unordered LOS) keeps one ray per thread.
+  std::vector<int> sched;
+  int n_visits = 0;
+  const int nr = los->n_rays, n_batches = (nr + kAdjSyncRays - 1) / kAdjSyncRays;
+  if (!seg_jrow && nr >= 2 && g_jac_layer_forward.load() != 2) {
+    bool ok = true;
+    // per ray: far[layer] / near[layer] = walk-order segment index or -1
+    std::vector<int> far((size_t)nr * n_layers, -1), near((size_t)nr * n_layers, -1);
+    int l_min = n_layers, l_max = -1;
+    for (int r = 0; r < nr && ok; ++r) {
+      const int a = los->seg_off[r], m = los->seg_off[r + 1] - a;
+      int q = 0, prev = INT_MAX;
+      for (; q < m; ++q) { // far side: strictly inwards
+        const int k = plan.seg[(size_t)(a + q) * kAdjPlanInts];
+        if (k >= prev) break;
+        far[(size_t)r * n_layers + k] = a + q;
+        prev = k;
+        l_min = std::min(l_min, k); l_max = std::max(l_max, k);
+      }
+      prev = q < m ? plan.seg[(size_t)(a + q) * kAdjPlanInts] - 1 : prev;
+      if (q < m && q > 0 && plan.seg[(size_t)(a + q) * kAdjPlanInts] < plan.seg[(size_t)(a + q - 1) * kAdjPlanInts]) ok = false;
+      for (; q < m && ok; ++q) { // near side: strictly outwards (its first shell may be the far side's last)
+        const int k = plan.seg[(size_t)(a + q) * kAdjPlanInts];
+        if (k <= prev) { ok = false; break; }
+        near[(size_t)r * n_layers + k] = a + q;
+        prev = k;
+        l_min = std::min(l_min, k); l_max = std::max(l_max, k);
+      }
+    }
+    if (ok && l_max >= l_min) {
+      // the visits every batch walks (a batch skips nothing: a visit none of its rays takes costs one load)
+      std::vector<std::pair<int, int>> visits; // (side, layer)
+      for (int k = l_max; k >= l_min; --k) {
+        bool any = false;
+        for (int r = 0; r < nr && !any; ++r) any = far[(size_t)r * n_layers + k] >= 0;
+        if (any) visits.push_back({0, k});
+      }
+      for (int k = l_min; k <= l_max; ++k) {
+        bool any = false;
+        for (int r = 0; r < nr && !any; ++r) any = near[(size_t)r * n_layers + k] >= 0;
+        if (any) visits.push_back({1, k});
+      }
+      n_visits = (int)visits.size();
+      sched.assign((size_t)n_batches * n_visits * (1 + kAdjSyncRays), -1);
+      for (int bt = 0; bt < n_batches; ++bt)
+        for (int v = 0; v < n_visits; ++v) {
+          int *sv = &sched[((size_t)bt * n_visits + v) * (1 + kAdjSyncRays)];
+          sv[0] = visits[v].second;
+          for (int i = 0; i < kAdjSyncRays; ++i) {
+            const int r = bt * kAdjSyncRays + i;
+            if (r < nr) sv[1 + i] = (visits[v].first ? near : far)[(size_t)r * n_layers + visits[v].second];
+          }
+        }
+    }
+  }
   static thread_local Stager s_ring[4];
   static thread_local unsigned s_next = 0;
   Stager &sg = s_ring[s_next++ & 3];
   auto al = [](size_t v) { return (v + 15) / 16 * 16; };
   const size_t b_plan = sizeof(int) * plan.seg.size(), o_zo = al(b_plan);
   const size_t o_zr = al(o_zo + sizeof(int) * plan.zero_off.size());
-  const size_t in_bytes = al(o_zr + sizeof(int) * std::max<size_t>(plan.zero_row.size(), 1));
+  const size_t o_sc = al(o_zr + sizeof(int) * std::max<size_t>(plan.zero_row.size(), 1));
+  const size_t in_bytes = al(o_sc + sizeof(int) * std::max<size_t>(sched.size(), 1));
   rc = sg.prepare(in_bytes + adj_prog_bytes(n_seg));
   if (rc) return rc;
   char *h = sg.host<char>();
   std::memcpy(h, plan.seg.data(), b_plan);
   std::memcpy(h + o_zo, plan.zero_off.data(), sizeof(int) * plan.zero_off.size());
   if (!plan.zero_row.empty()) std::memcpy(h + o_zr, plan.zero_row.data(), sizeof(int) * plan.zero_row.size());
+  if (!sched.empty()) std::memcpy(h + o_sc, sched.data(), sizeof(int) * sched.size());
   rc = sg.push_early(in_bytes, st);
   if (rc) return rc;
   char *d = sg.d.as<char>();
   SegProg *prog = reinterpret_cast<SegProg *>(d + in_bytes);
   LAUNCHCHK(launch_adj_pack(reinterpret_cast<const int *>(d), D.col, los->n_gas, n_seg, prog, st));
+  if (n_visits > 0)
+    LAUNCHCHK(launch_limb_adjoint_sync(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, n_jrows, nr, prog,
+                                       reinterpret_cast<const int *>(d + o_zo), reinterpret_cast<const int *>(d + o_zr), n_par,
+                                       limb_opts(los, D.n_seg), reinterpret_cast<const int *>(d + o_sc), n_visits, rad,
+                                       jac_layer, jac_par, st));
+  else
   LAUNCHCHK(launch_limb_adjoint(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, n_jrows, los->n_rays, D.seg_off, prog,
                                 reinterpret_cast<const int *>(d + o_zo), reinterpret_cast<const int *>(d + o_zr), n_par,
                                 limb_opts(los, D.n_seg), rad, jac_layer, jac_par, st));
@@ -1941,7 +2008,7 @@ int sr_limb_rays_jacobians_dev(const double *abs_c, const double *emi_c, const d
       if (par_gas[p] < 0 || par_gas[p] >= los->n_gas) return SR_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int done = 0;
-  if (!g_jac_layer_forward.load()) {
+  if (g_jac_layer_forward.load() != 1) {
     const int rc = limb_adjoint(abs_c, emi_c, dabs, demi, n_layers, n_pts, los, seg_jac_row, n_jac_rows, n_par, par_gas,
                                 par_w, rad, jac_layer, jac_par, st, &done);
     if (rc || done) return rc;
@@ -1980,7 +2047,7 @@ int sr_limb_rays_jac_dev(const double *abs_c, const double *emi_c, int n_layers,
   hipStream_t st = static_cast<hipStream_t>(stream);
   // many parameters: one pass per ray (the forward kernel repeats the recursion per 16 parameters); rad0 given
   // (init_mode 1) is read by both kernels before they write
-  if (n_par > 8 && !g_jac_layer_forward.load() && par_gas && par_w) {
+  if (n_par > 8 && g_jac_layer_forward.load() != 1 && par_gas && par_w) {
     int done = 0;
     const int rc = limb_adjoint(abs_c, emi_c, nullptr, nullptr, n_layers, n_pts, los, nullptr, 0, n_par, par_gas, par_w,
                                 rad, nullptr, jac, st, &done);
@@ -2004,7 +2071,7 @@ int sr_limb_rays_jac_layer_dev(const double *abs_c, const double *emi_c, const d
     return SR_ERR_UNSUPPORTED;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (!g_jac_layer_forward.load() && n_layers > 8) {
+  if (g_jac_layer_forward.load() != 1 && n_layers > 8) {
     int done = 0;
     const int rc = limb_adjoint(abs_c, emi_c, dabs, demi, n_layers, n_pts, los, nullptr, 0, 0, nullptr, nullptr, nullptr,
                                 jac, nullptr, st, &done);

@@ -2615,6 +2615,167 @@ __global__ __launch_bounds__(256) void sr_limb_adjoint_kernel(
   if (rad) rad[(size_t)ray * n_pts + j] = I;
 }
 
+// ------------------------------------------------------------------------
+// The same recursion, LAYER-SYNCHRONOUS over a batch of NR rays (round 4).  sr_limb_adjoint_kernel gives every ray
+// its own threads, and every ray streams the four coefficient tables from HBM again, twice (the optical-depth sweep
+// and the recursion): configs[3], 8 rays: 8.4 GB fetched + 3.5 GB written per set for 2.6 GB of algorithmic bytes, the
+// kernel bound by that (profiles/r03_config3_pmc_limb_kernels.txt).  In a 1-D atmosphere all rays walk the SAME
+// coefficient rows, down to their tangent shells and up again: a thread here owns one grid point for NR rays, the host
+// lists the shells in that order (`sched`: per visit the layer and every ray's segment there, -1 = the ray is not in
+// this shell on this side), the shell's coefficients are loaded ONCE per visit and every ray that crosses it takes its
+// step -- per ray exactly the operations of sr_limb_adjoint_kernel in exactly its order, so the results are bit for
+// bit the same.  State per ray: I, the two-sum of the remaining optical depth, four carry slots.
+// ------------------------------------------------------------------------
+template <int NG, bool LAYER, bool PAR, int NR>
+__global__ __launch_bounds__(256) void sr_limb_adjoint_sync_kernel(
+    const double *__restrict__ abs_c, const double *__restrict__ emi_c, const double *__restrict__ dabs,
+    const double *__restrict__ demi, int n_pts, int n_layers, int n_jrows, const SegProg *__restrict__ prog,
+    const int *__restrict__ zero_off, const int *__restrict__ zero_row, int n_par, LimbOpts o,
+    const int *__restrict__ sched, // [n_batches][n_visits][1 + NR]: layer, segment of each ray of the batch (or -1)
+    int n_visits, int n_rays, double *__restrict__ rad, double *__restrict__ jac_layer, double *__restrict__ jac_par) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, batch = blockIdx.y;
+  if (j >= n_pts) return;
+  const int ray0 = batch * NR;
+  const int *sc = sched + (size_t)batch * n_visits * (1 + NR);
+  const size_t gstride = (size_t)n_layers * n_pts;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int ray = ray0 + r;
+    if (ray >= n_rays) continue;
+    for (int q = zero_off[ray]; q < zero_off[ray + 1]; ++q) { // rows this ray never touches
+      const int row = zero_row[q];
+      if (row < n_jrows) {
+        if (LAYER) jac_layer[((size_t)ray * n_jrows + row) * n_pts + j] = 0.0;
+      } else if (PAR) {
+        jac_par[((size_t)ray * n_par + (row - n_jrows)) * n_pts + j] = 0.0;
+      }
+    }
+  }
+  double rem[NR], rem_lo[NR], I[NR], slot[NR][4];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    rem[r] = rem_lo[r] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) slot[r][q] = 0.0;
+  }
+  // sweep 1: the optical depth of every ray's path, two-sums (see sr_limb_adjoint_kernel)
+  for (int v = 0; v < n_visits; ++v) {
+    const int *sv = sc + (size_t)v * (1 + NR);
+    const size_t ofs = (size_t)sv[0] * n_pts + j;
+    double a[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) a[g] = abs_c[g * gstride + ofs];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int sg = sv[1 + r];
+      if (sg < 0) continue; // wave-uniform
+      const SegProg &P = prog[sg];
+      double tau = 0.0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) tau = g == 0 ? a[g] * P.u[g] : tau + a[g] * P.u[g];
+      const double sm = rem[r] + tau, bb = sm - rem[r];
+      rem_lo[r] += (rem[r] - (sm - bb)) + (tau - bb);
+      rem[r] = sm;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) I[r] = ray0 + r < n_rays ? limb_initial(o, rad, (size_t)(ray0 + r) * n_pts + j, j) : 0.0;
+  // sweep 2: the recursion, shell by shell
+  for (int v = 0; v < n_visits; ++v) {
+    const int *sv = sc + (size_t)v * (1 + NR);
+    const size_t ofs = (size_t)sv[0] * n_pts + j;
+    double a[NG], e[NG], da[NG], de[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      a[g] = abs_c[g * gstride + ofs];
+      e[g] = emi_c[g * gstride + ofs];
+      if (LAYER) {
+        da[g] = dabs[g * gstride + ofs];
+        de[g] = demi[g * gstride + ofs];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int sg = sv[1 + r];
+      if (sg < 0) continue;
+      const int ray = ray0 + r;
+      const SegProg &P = prog[sg];
+      double tau = 0.0, E = 0.0, dtau = 0.0, dE = 0.0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const double u = P.u[g];
+        tau = g == 0 ? a[g] * u : tau + a[g] * u;
+        E = g == 0 ? e[g] * u : E + e[g] * u;
+        if (LAYER) {
+          dtau = fma(da[g], u, dtau);
+          dE = fma(de[g], u, dE);
+        }
+      }
+      const Atten A = attenuation(tau);
+      const double fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
+      {
+        const double sm = rem[r] - tau, bb = sm - rem[r];
+        rem_lo[r] += (rem[r] - (sm - bb)) + (-tau - bb);
+        rem[r] = sm;
+      }
+      const double Ta = exp_bounded(fmin(fmax(-(rem[r] + rem_lo[r]), -700.0), 700.0));
+      const double w_tau = (o.solo_absorption ? -I[r] * A.t : fma(E, fp, -I[r] * A.t)) * Ta;
+      const double w_E = o.solo_absorption ? 0.0 : A.f * Ta;
+      if (LAYER) {
+        const double d = fma(w_tau, dtau, w_E * dE);
+        double *out = jac_layer + ((size_t)ray * n_jrows + P.jrow) * n_pts + j;
+        if (P.flags & 1) *out = d; else *out += d;
+      }
+      if (PAR) {
+        for (int i = 0; i < P.n_ent; ++i) {
+          const int gf = P.ent_gf[i], g = gf & 0xff, sl = (gf >> 8) & 0xff, fl = gf >> 16;
+          double ag = a[0], eg = e[0];
+#pragma unroll
+          for (int q = 1; q < NG; ++q) {
+            ag = g == q ? a[q] : ag;
+            eg = g == q ? e[q] : eg;
+          }
+          double val = fma(w_tau, ag, w_E * eg) * P.dc[i];
+          if (!(fl & 1)) val += sl == 0 ? slot[r][0] : (sl == 1 ? slot[r][1] : (sl == 2 ? slot[r][2] : slot[r][3]));
+          if (fl & 2) {
+            double *out = jac_par + ((size_t)ray * n_par + P.ent_p[i]) * n_pts + j;
+            if (fl & 4) *out = val; else *out += val;
+          } else {
+            if (sl == 0) slot[r][0] = val; else if (sl == 1) slot[r][1] = val; else if (sl == 2) slot[r][2] = val; else slot[r][3] = val;
+          }
+        }
+      }
+      I[r] = I[r] * A.t + (o.solo_absorption ? 0.0 : E * A.f);
+    }
+  }
+  if (rad) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if (ray0 + r < n_rays) rad[(size_t)(ray0 + r) * n_pts + j] = I[r];
+  }
+}
+
+int launch_limb_adjoint_sync(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
+                             int n_layers, int n_jrows, int n_rays, const SegProg *prog, const int *zero_off,
+                             const int *zero_row, int n_par, const LimbOpts &o, const int *sched, int n_visits, double *rad,
+                             double *jac_layer, double *jac_par, hipStream_t st) {
+  if (n_pts <= 0 || n_rays <= 0 || n_visits <= 0) return 0;
+  const dim3 grid((n_pts + 255) / 256, (n_rays + kAdjSyncRays - 1) / kAdjSyncRays);
+#define SR_AS(NG, L, P) hipLaunchKernelGGL((sr_limb_adjoint_sync_kernel<NG, L, P, kAdjSyncRays>), grid, dim3(256), 0, st, abs_c, emi_c, \
+                                           dabs, demi, n_pts, n_layers, n_jrows, prog, zero_off, zero_row, n_par, o, sched, n_visits,   \
+                                           n_rays, rad, jac_layer, jac_par)
+#define SR_AS3(NG)                                                     \
+  do {                                                                 \
+    if (jac_layer && jac_par) SR_AS(NG, true, true);                   \
+    else if (jac_layer) SR_AS(NG, true, false);                        \
+    else SR_AS(NG, false, true);                                       \
+  } while (0)
+  switch (o.n_gas) { case 1: SR_AS3(1); break; case 2: SR_AS3(2); break; case 3: SR_AS3(3); break; default: SR_AS3(4); break; }
+#undef SR_AS3
+#undef SR_AS
+  return (int)hipGetLastError();
+}
+
 size_t adj_prog_bytes(int n_seg) { return sizeof(SegProg) * (size_t)n_seg; }
 static_assert(kAdjPlanInts == 4 + 2 * kAdjEnt, "host plan layout");
 

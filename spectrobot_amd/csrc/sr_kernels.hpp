@@ -170,6 +170,16 @@ int launch_limb_adjoint(const double *abs_c, const double *emi_c, const double *
                         int n_layers, int n_jrows, int n_rays, const int *seg_off, const SegProg *prog, const int *zero_off,
                         const int *zero_row, int n_par, const LimbOpts &o, double *rad, double *jac_layer,
                         double *jac_par, hipStream_t st);
+// The layer-synchronous variant for rays that share their coefficient rows (1-D atmospheres): kAdjSyncRays rays per
+// thread, sched [n_batches][n_visits][1 + kAdjSyncRays] = layer, segment of each ray in that shell on that side (or -1)
+#ifndef SR_ADJ_SYNC_RAYS
+#define SR_ADJ_SYNC_RAYS 2 // rays per thread: 2: 1.98 ms per configs[3] set, 4: 2.14-2.19, 8: 3.69; one ray per thread (mode 2): 2.05-2.16 (tools/adjoint_probe.py)
+#endif
+constexpr int kAdjSyncRays = SR_ADJ_SYNC_RAYS;
+int launch_limb_adjoint_sync(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
+                             int n_layers, int n_jrows, int n_rays, const SegProg *prog, const int *zero_off,
+                             const int *zero_row, int n_par, const LimbOpts &o, const int *sched, int n_visits, double *rad,
+                             double *jac_layer, double *jac_par, hipStream_t st);
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                     const int *seg_layer, const double *seg_col, int init_from_rad, double *rad,
                     hipStream_t st);

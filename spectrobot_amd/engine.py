@@ -707,8 +707,9 @@ def set_overlap(on):
 
 
 def set_jac_layer_mode(forward):
-    """0 (default): Jacobians of the device LOS pipeline in one pass per ray; 1: the forward-sensitivity kernels
-    (sr_set_jac_layer_mode)."""
+    """0 (default): Jacobians of the device LOS pipeline in one pass per ray -- layer-synchronous over batches of four
+    rays where the rays share their coefficient rows (1-D atmospheres); 1: the forward-sensitivity kernels; 2: one
+    pass per ray with one ray per thread always (sr_set_jac_layer_mode)."""
     check(lib.sr_set_jac_layer_mode(int(forward)), "sr_set_jac_layer_mode")
 
 
