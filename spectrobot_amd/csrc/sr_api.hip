@@ -1327,7 +1327,10 @@ static int level_set(sr_lineset *ls, int level, sr_lineset **out, bool up_only =
     c->mm = ls->mm;
     c->n_levels = ls->n_levels;
     c->e_lev = ls->e_lev;
-    c->work = ls->work; // scratch, streams and events of the parent
+    // scratch, streams and events of the parent (SR_LEVEL_OWN_WORK=1, tuning: a CoefWork of its own per level, so that
+    // the internal kernels of ALL levels of a pair-table build can run ahead of the one caller's stream)
+    static const int own_env = [] { const char *e = getenv("SR_LEVEL_OWN_WORK"); return e ? atoi(e) : 0; }();
+    if (!own_env) c->work = ls->work;
     c->parent = ls;
     for (int which = 0; which < 2; ++which) {
       const HostLines &H = which ? ls->host_outer : ls->host;
