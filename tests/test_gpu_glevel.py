@@ -155,3 +155,40 @@ def test_make_abscoeff_isomolec_takes_the_factored_route_for_shared_rows(eng, sc
     sa, se = a0.abs().amax(dim=1, keepdim=True), e0.abs().amax(dim=1, keepdim=True)
     assert float(((a_set.device - a0).abs() / sa).max()) < 1e-12 and float(((e_set.device - e0).abs() / se).max()) < 1e-12
     assert not torch.equal(a_set.device, a0)          # (it did take the other route)
+
+
+def test_level_pairs_on_a_shard_with_lines_beyond_the_grid(eng):
+    """The level-factored route on a spectral shard (one rank's [g_lo, g_hi) of a multi-GPU run) and with lines whose
+    centre lies outside their own window (the outer branches of humliv_bb): the shard's tables are the whole grid's
+    tables cut to the shard, and their combine equals the folded op on the shard -- outer lines included."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2990.0, 5e-4, 26000)
+    L = syn.make_lines(2500, grid, seed=31, n_levels=12, config_id=2)
+    step = grid[1] - grid[0]
+    # eight lines 3.3 .. 9 cm-1 outside the grid ends: their windows sit on the first / last grid point
+    L["freq"][:4] = grid[0] - np.array([3.3, 4.1, 6.0, 9.0])
+    L["freq"][-4:] = grid[-1] + np.array([3.3, 3.9, 5.5, 8.0])
+    atm = syn.make_atmosphere(5, 12)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    T, P = atm["temps"], atm["press"] * 20.0      # wide Lorentz wings: the outer lines reach well into the grid
+    full = ls.glevel_pairs(T, P)
+    lo, hi = 9000, 21000
+    part = ls.glevel_pairs(T, P, g_lo=lo, g_hi=hi)
+    sc = full[..., lo:hi].abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+    assert float(((part - full[..., lo:hi]).abs() / sc).max()) < 1e-12
+    rng = np.random.default_rng(3)
+    row = rng.integers(0, 5, 16).astype(np.int32)
+    tv = atm["tvib"][:, row] + rng.uniform(-8.0, 15.0, (12, 16))
+    pop = ls.level_populations(T[row], tvib=tv)
+    for (a, b, tab) in ((0, 26000, full), (lo, hi, part)):
+        ab, em = eng.glevel_combine(tab, row, pop)
+        a0, e0 = ls.abscoeff_layers(T[row], P[row], tvib=tv, g_lo=a, g_hi=b)
+        sa, se = a0.abs().amax(dim=1, keepdim=True), e0.abs().amax(dim=1, keepdim=True)
+        assert float(((ab - a0).abs() / sa).max()) < 1e-12 and float(((em - e0).abs() / se).max()) < 1e-12
+    # the outer lines do contribute at the grid ends (the check would be empty otherwise)
+    Li = {k: v[4:-4] for k, v in L.items()}
+    lsi = eng.LineSet(Li, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    a_in, _ = lsi.abscoeff_layers(T[:1], P[:1], tvib=atm["tvib"][:, :1])
+    a_all, _ = ls.abscoeff_layers(T[:1], P[:1], tvib=atm["tvib"][:, :1])
+    assert float(((a_all - a_in).abs() / a_all.abs()).max()) > 1e-6

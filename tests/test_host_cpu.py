@@ -698,3 +698,24 @@ def test_calc_radtran_steps_geometry(oracle):
     assert list(geo.lat_box_index([-89.0, -30.0, 0.0, 29.9, 30.0, 74.0, 90.0])) == [0, 3, 3, 3, 4, 5, 6]
     with pytest.raises(ValueError):
         geo.sun_in_local_frame(60.0, -12.0, 10.0)
+
+
+def test_partition_sum_derivative_and_level_rows():
+    """CalcPartitionSum_dT: the exact derivative of the Lagrange cubic CalcPartitionSum evaluates (spect_classes.py:1692-1710),
+    against central differences inside an interval of the table, one-sided at a table temperature (the interpolant
+    changes its four points there); LevelFactored.unique_rows: distinct (P, T) couples and every step's row."""
+    from spectrobot_amd import spect_classes as spcl, engine
+    for mol, iso in ((6, 1), (23, 1), (5, 1)):
+        for T in (61.0, 97.3, 150.0, 212.5, 296.0):
+            h = 1e-4
+            fd = (spcl.CalcPartitionSum(mol, iso, T + h) - spcl.CalcPartitionSum(mol, iso, T - h)) / (2 * h)
+            assert abs(spcl.CalcPartitionSum_dT(mol, iso, T) - fd) <= 1e-8 * abs(fd), (mol, T)
+        fd = (spcl.CalcPartitionSum(mol, iso, 110.0 + 1e-5) - spcl.CalcPartitionSum(mol, iso, 110.0)) / 1e-5
+        assert abs(spcl.CalcPartitionSum_dT(mol, iso, 110.0) - fd) <= 1e-5 * abs(fd)
+    v = spcl.CalcPartitionSum_dT(6, 1, np.array([150.0, 97.3, 150.0]))
+    assert v.shape == (3,) and v[0] == v[2] == spcl.CalcPartitionSum_dT(6, 1, 150.0)
+    T = np.array([150.0, 160.0, 150.0, 150.0, 160.0])
+    P = np.array([1.0, 1.0, 2.0, 1.0, 1.0])
+    Tr, Pr, row = engine.LevelFactored.unique_rows(T, P)
+    assert len(Tr) == 3 and np.array_equal(Tr[row], T) and np.array_equal(Pr[row], P) and row.dtype == np.int32
+    assert row[0] == row[3] and row[1] == row[4] and len(set(row)) == 3
