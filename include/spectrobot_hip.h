@@ -393,10 +393,13 @@ int sr_set_table_budget(int64_t bytes);
  * sr_limb_rays_jac_layer_dev with more than 8 layers, sr_limb_rays_jacobians_dev).  0 (default): one pass over each
  * ray, every segment's sensitivity times the transmission behind it added to the rows it acts on
  * (sr_limb_adjoint_kernel); where the rays share their coefficient rows (no seg_jac_row) and walk them monotonically
- * inwards and outwards again, four rays per thread and a shell's coefficients loaded once for all of them
- * (sr_limb_adjoint_sync_kernel; same operations per ray, same bits).  1: the forward-sensitivity kernels always (they
- * carry 16 derivatives through the recursion and repeat it per block of 16) -- kept as the check of the other.
- * 2: one pass per ray with one ray per thread always. */
+ * inwards and outwards again (limb, slant and nadir paths of a 1-D atmosphere), the FOLDED kernel: the shells are
+ * walked once per sweep, a ray's far-side and near-side segment of a shell together, two rays per thread, every
+ * Jacobian value stored once (sr_limb_adjoint_fold_kernel; what enters a near-side segment is taken as the observed
+ * radiance minus what the segments in front of it emit: values agree with mode 2 to ~1e-15 of the radiance x d tau).
+ * 1: the forward-sensitivity kernels always (they carry 16 derivatives through the recursion and repeat it per block
+ * of 16) -- kept as the check of the others.  2: one pass per ray in path order, one ray per thread, always.
+ * 3: path order, two rays per thread sharing a shell's coefficient loads (sr_limb_adjoint_sync_kernel; the bits of 2). */
 int sr_set_jac_layer_mode(int forward);
 /* Tuning knob of the exact wings kernel: grid points per lane (4 or 8; default 8). */
 int sr_set_points_per_lane(int p);

@@ -411,7 +411,7 @@ int sr_set_counting(int on) {
 }
 
 int sr_set_jac_layer_mode(int forward) {
-  g_jac_layer_forward.store(forward == 2 ? 2 : (forward ? 1 : 0)); // 2: the one-pass kernel with one ray per thread (no layer-synchronous batches)
+  g_jac_layer_forward.store(forward == 2 || forward == 3 ? forward : (forward ? 1 : 0)); // see spectrobot_hip.h
   return SR_OK;
 }
 
@@ -1895,10 +1895,11 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
   // (limb rays; slant / nadir rays are the upward half alone), the shells are listed once -- far side from the
   // outermost shell inwards, near side outwards -- with every ray's segment in each: the kernel then loads a shell's
   // coefficients once for kAdjSyncRays rays.  Anything else (3-D paths, unordered LOS) keeps one ray per thread.
-  std::vector<int> sched;
-  int n_visits = 0;
+  std::vector<int> sched, fplan;
+  int n_visits = 0, n_fvis = 0, n_frec = 0;
   const int nr = los->n_rays, n_batches = (nr + kAdjSyncRays - 1) / kAdjSyncRays;
-  if (!seg_jrow && nr >= 2 && g_jac_layer_forward.load() != 2) {
+  const int jmode = g_jac_layer_forward.load();
+  if (!seg_jrow && (jmode == 0 || (jmode == 3 && nr >= 2))) {
     bool ok = true;
     // per ray: far[layer] / near[layer] = walk-order segment index or -1
     std::vector<int> far((size_t)nr * n_layers, -1), near((size_t)nr * n_layers, -1);
@@ -1923,6 +1924,85 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
         l_min = std::min(l_min, k); l_max = std::max(l_max, k);
       }
     }
+    // The folded plan (sr_limb_adjoint_fold_kernel, the default): one visit per shell, outermost first, with every
+    // ray's far-side and near-side segment there; a column parameter's touches -- read off the per-segment plan -- are
+    // planned over the VISITS (a level acts on the same shells on both sides: one run, one register, one store).
+    if (ok && l_max >= l_min && jmode == 0) {
+      std::vector<int> shells;
+      for (int k = l_max; k >= l_min; --k) {
+        bool any = false;
+        for (int r = 0; r < nr && !any; ++r) any = far[(size_t)r * n_layers + k] >= 0 || near[(size_t)r * n_layers + k] >= 0;
+        if (any) shells.push_back(k);
+      }
+      n_fvis = (int)shells.size();
+      const int nb = (nr + kAdjFoldRays - 1) / kAdjFoldRays;
+      n_frec = nb * n_fvis * kAdjFoldRays;
+      fplan.assign((size_t)n_frec * kAdjPlanInts, 0);
+      bool fits = true;
+      std::vector<std::vector<int>> touch(n_par);
+      std::vector<int> slot_of(std::max(n_par, 1)), pos(std::max(n_par, 1));
+      std::vector<char> par_seen(std::max(n_par, 1));
+      for (int rr = 0; rr < nb * kAdjFoldRays && fits; ++rr) {
+        const int bt = rr / kAdjFoldRays, i = rr % kAdjFoldRays;
+        auto rec_at = [&](int v) { return &fplan[(((size_t)bt * n_fvis + v) * kAdjFoldRays + i) * kAdjPlanInts]; };
+        for (int v = 0; v < n_fvis; ++v) {
+          int *pl = rec_at(v);
+          pl[0] = shells[v];
+          pl[1] = rr < nr ? far[(size_t)rr * n_layers + shells[v]] : -1;
+          pl[2] = rr < nr ? near[(size_t)rr * n_layers + shells[v]] : -1;
+        }
+        if (rr >= nr || n_par == 0) continue;
+        for (int p = 0; p < n_par; ++p) touch[p].clear();
+        for (int v = 0; v < n_fvis; ++v) {
+          const int *pl = rec_at(v);
+          for (int side = 1; side <= 2; ++side) {
+            if (pl[side] < 0) continue;
+            const int *sp = &plan.seg[(size_t)pl[side] * kAdjPlanInts];
+            for (int e = 0; e < sp[2]; ++e)
+              if (touch[sp[4 + e]].empty() || touch[sp[4 + e]].back() != v) touch[sp[4 + e]].push_back(v);
+          }
+        }
+        bool slot_busy[4] = {false, false, false, false};
+        std::fill(slot_of.begin(), slot_of.end(), -1);
+        std::fill(pos.begin(), pos.end(), 0);
+        std::fill(par_seen.begin(), par_seen.end(), 0);
+        for (int v = 0; v < n_fvis && fits; ++v) {
+          int *pl = rec_at(v);
+          int n_ent = 0;
+          for (int p = 0; p < n_par; ++p) {
+            if (pos[p] >= (int)touch[p].size() || touch[p][pos[p]] != v) continue;
+            if (n_ent == 4) { fits = false; break; }
+            const bool next_too = pos[p] + 1 < (int)touch[p].size() && touch[p][pos[p] + 1] == v + 1;
+            int fl = 0, sl = slot_of[p];
+            if (sl < 0) { // a run starts here
+              fl |= 1;
+              if (next_too)
+                for (int c = 0; c < 4; ++c)
+                  if (!slot_busy[c]) { sl = c; slot_busy[c] = true; break; }
+            }
+            const bool carry_out = next_too && sl >= 0;
+            if (!carry_out) {
+              fl |= 2;
+              if (!par_seen[p]) fl |= 4;
+              par_seen[p] = 1;
+              if (sl >= 0) slot_busy[sl] = false;
+              slot_of[p] = -1;
+            } else {
+              slot_of[p] = sl;
+            }
+            pl[4 + n_ent] = p;
+            pl[4 + 4 + n_ent] = par_gas[p] | (std::max(sl, 0) << 8) | (fl << 16);
+            ++n_ent;
+            ++pos[p];
+          }
+          pl[3] = n_ent;
+        }
+      }
+      if (!fits) { // a shell's two segments touch more than four parameters between them: one ray per thread
+        fplan.clear();
+        n_fvis = n_frec = 0;
+      }
+    } else
     if (ok && l_max >= l_min) {
       // the visits every batch walks (a batch skips nothing: a visit none of its rays takes costs one load)
       std::vector<std::pair<int, int>> visits; // (side, layer)
@@ -1956,17 +2036,30 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
   const size_t b_plan = sizeof(int) * plan.seg.size(), o_zo = al(b_plan);
   const size_t o_zr = al(o_zo + sizeof(int) * plan.zero_off.size());
   const size_t o_sc = al(o_zr + sizeof(int) * std::max<size_t>(plan.zero_row.size(), 1));
-  const size_t in_bytes = al(o_sc + sizeof(int) * std::max<size_t>(sched.size(), 1));
-  rc = sg.prepare(in_bytes + adj_prog_bytes(n_seg));
+  const size_t o_fp = al(o_sc + sizeof(int) * std::max<size_t>(sched.size(), 1));
+  const size_t in_bytes = al(o_fp + sizeof(int) * std::max<size_t>(fplan.size(), 1));
+  rc = sg.prepare(in_bytes + std::max(adj_prog_bytes(n_seg), fold_rec_bytes(n_frec)));
   if (rc) return rc;
   char *h = sg.host<char>();
   std::memcpy(h, plan.seg.data(), b_plan);
   std::memcpy(h + o_zo, plan.zero_off.data(), sizeof(int) * plan.zero_off.size());
   if (!plan.zero_row.empty()) std::memcpy(h + o_zr, plan.zero_row.data(), sizeof(int) * plan.zero_row.size());
   if (!sched.empty()) std::memcpy(h + o_sc, sched.data(), sizeof(int) * sched.size());
+  if (!fplan.empty()) std::memcpy(h + o_fp, fplan.data(), sizeof(int) * fplan.size());
   rc = sg.push_early(in_bytes, st);
   if (rc) return rc;
   char *d = sg.d.as<char>();
+  if (n_fvis > 0) {
+    FoldRec *frec = reinterpret_cast<FoldRec *>(d + in_bytes);
+    LAUNCHCHK(launch_fold_pack(reinterpret_cast<const int *>(d + o_fp), D.col, los->n_gas, n_seg, n_frec, frec, st));
+    LAUNCHCHK(launch_limb_adjoint_fold(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, nr, frec,
+                                       reinterpret_cast<const int *>(d + o_zo), reinterpret_cast<const int *>(d + o_zr), n_par,
+                                       limb_opts(los, D.n_seg), n_fvis, rad, jac_layer, jac_par, st));
+    rc = sg.mark(st);
+    if (rc) return rc;
+    *done = 1;
+    return D.slot->mark(st);
+  }
   SegProg *prog = reinterpret_cast<SegProg *>(d + in_bytes);
   LAUNCHCHK(launch_adj_pack(reinterpret_cast<const int *>(d), D.col, los->n_gas, n_seg, prog, st));
   if (n_visits > 0)

@@ -2776,6 +2776,296 @@ int launch_limb_adjoint_sync(const double *abs_c, const double *emi_c, const dou
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------
+// The FOLDED one-pass kernel (round 4): a limb ray crosses every shell above its tangent point twice, and both one-pass
+// kernels above touch the shell's Jacobian row twice -- a store on the far side, a read-add-store on the near side --
+// and stream the coefficient tables along the path, 2 x 80 visits per sweep.  Here a thread walks the SHELLS once per
+// sweep, from the outermost inwards, and takes a ray's far-side and near-side segment of a shell TOGETHER:
+//   far side, in path order:   I_f <- I_f t + E f  (the recursion itself), the transmission behind the segment from
+//                              the two-sum of the remaining optical depth (as sr_limb_adjoint_kernel);
+//   near side, from the observer inwards:  Tn = prod t of the near-side segments outside this one (the transmission
+//                              behind it, no subtraction), cs = sum of E f Tn over them (what they contribute to the
+//                              observed radiance), and what ENTERS the segment, seen at the observer, is the rest:
+//                              I_in t Tn = I_obs - cs(including this segment) -- I_obs from sweep 1,
+//                              I_obs = I_f(tangent) Tn(all) + cs(all).
+// The weights are those of sr_limb_adjoint_kernel, w_tau = (E f' - I_in t) Ta, w_E = f Ta, the two segments' values
+// of a row are added in registers and stored ONCE; a column parameter's touches on both sides fall into the same run
+// of shells and are carried in one register.  Per set of configs[3]: 80 visits x (2 + 4) table rows per ray batch
+// instead of 160 x (1 + 4), 1 access per Jacobian value instead of 1.7.  I_obs and cs are carried as error-free sums
+// of two doubles, so that the difference keeps the relative accuracy of what is still to come (see sweep 2).
+// Segments of one shell with the same columns (a 1-D limb path is symmetric) share one attenuation().
+// ------------------------------------------------------------------------
+#ifndef SR_FOLD_XCD
+#define SR_FOLD_XCD 1 // all rays of a point block on one XCD, one after the other (limb_block): 1.22 vs 1.28 ms per configs[3] set
+#endif
+#ifndef SR_FOLD_WAVES
+#define SR_FOLD_WAVES 4 // waves per SIMD the register allocation of the folded kernel aims at
+#endif
+struct __attribute__((aligned(16))) FoldRec { // one ray in one shell
+  int layer;            // row of the coefficient tables and of the per-layer Jacobian
+  int has;              // bit 0: far-side segment, bit 1: near-side segment, bit 2: both, with the same columns
+  int n_ent, pad;
+  int ent_p[kAdjEnt], ent_gf[kAdjEnt]; // as SegProg
+  double u_f[4], u_n[4];               // columns of the two segments
+  double dc_f[kAdjEnt], dc_n[kAdjEnt]; // d col / d x_p of the entries, per side (0: that side does not touch it)
+};
+static_assert(sizeof(FoldRec) == 176, "FoldRec layout");
+
+// plan: [n_rec][kAdjPlanInts] ints: layer, far segment, near segment (-1: none), n_ent, ent_p, ent_gf
+__global__ void sr_fold_pack_kernel(const int *__restrict__ plan, const double *__restrict__ col, int n_gas, int n_seg, int n_rec,
+                                    FoldRec *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rec) return;
+  const int *pl = plan + (size_t)i * kAdjPlanInts;
+  const int sf = pl[1], sn = pl[2];
+  FoldRec r;
+  r.layer = pl[0]; r.n_ent = pl[3]; r.pad = 0;
+  bool same = sf >= 0 && sn >= 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    r.u_f[g] = g < n_gas && sf >= 0 ? col[(size_t)g * n_seg + sf] : 0.0;
+    r.u_n[g] = g < n_gas && sn >= 0 ? col[(size_t)g * n_seg + sn] : 0.0;
+    same = same && r.u_f[g] == r.u_n[g];
+  }
+#pragma unroll
+  for (int e = 0; e < kAdjEnt; ++e) {
+    r.ent_p[e] = pl[4 + e];
+    r.ent_gf[e] = pl[4 + kAdjEnt + e];
+    r.dc_f[e] = e < r.n_ent && sf >= 0 ? col[(size_t)(n_gas + r.ent_p[e]) * n_seg + sf] : 0.0;
+    r.dc_n[e] = e < r.n_ent && sn >= 0 ? col[(size_t)(n_gas + r.ent_p[e]) * n_seg + sn] : 0.0;
+  }
+  r.has = (sf >= 0 ? 1 : 0) | (sn >= 0 ? 2 : 0) | (same ? 4 : 0);
+  out[i] = r;
+}
+
+template <int NG, bool LAYER, bool PAR, int NR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAVES, SR_FOLD_WAVES))) void sr_limb_adjoint_fold_kernel(
+    const double *__restrict__ abs_c, const double *__restrict__ emi_c, const double *__restrict__ dabs,
+    const double *__restrict__ demi, int n_pts, int n_layers, const FoldRec *__restrict__ rec, // [n_batches][n_visits][NR]
+    const int *__restrict__ zero_off, const int *__restrict__ zero_row, int n_par, LimbOpts o, int n_visits, int n_rays,
+    double *__restrict__ rad, double *__restrict__ jac_layer, double *__restrict__ jac_par) {
+#if SR_FOLD_XCD
+  int pb, batch; // all batches of a point block on one XCD, one after the other (limb_block)
+  if (!limb_block((n_pts + 255) / 256, (n_rays + NR - 1) / NR, pb, batch)) return;
+  const int j = pb * 256 + threadIdx.x;
+#else
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, batch = blockIdx.y;
+#endif
+  if (j >= n_pts) return;
+  const int ray0 = batch * NR;
+  const FoldRec *rc = rec + (size_t)batch * n_visits * NR;
+  const size_t gstride = (size_t)n_layers * n_pts;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int ray = ray0 + r;
+    if (ray >= n_rays) continue;
+    for (int q = zero_off[ray]; q < zero_off[ray + 1]; ++q) { // rows this ray never touches
+      const int row = zero_row[q];
+      if (row < n_layers) {
+        if (LAYER) jac_layer[((size_t)ray * n_layers + row) * n_pts + j] = 0.0;
+      } else if (PAR) {
+        jac_par[((size_t)ray * n_par + (row - n_layers)) * n_pts + j] = 0.0;
+      }
+    }
+  }
+  double If[NR], rem[NR], rem_lo[NR], Tn[NR], cs[NR], cs_lo[NR], Iobs[NR], Iobs_lo[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    If[r] = ray0 + r < n_rays ? limb_initial(o, rad, (size_t)(ray0 + r) * n_pts + j, j) : 0.0;
+    rem[r] = rem_lo[r] = cs[r] = cs_lo[r] = 0.0;
+    Tn[r] = 1.0;
+  }
+  auto two_sum_add = [](double &hi, double &lo, double x) {
+    const double sm = hi + x, bb = sm - hi;
+    lo += (hi - (sm - bb)) + (x - bb);
+    hi = sm;
+  };
+  // sweep 1: the observed radiance and the path's optical depth
+  for (int v = 0; v < n_visits; ++v) {
+    const FoldRec *rv = rc + (size_t)v * NR;
+    const size_t ofs = (size_t)rv[0].layer * n_pts + j;
+    double a[NG], e[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      a[g] = abs_c[g * gstride + ofs];
+      e[g] = emi_c[g * gstride + ofs];
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const FoldRec &R = rv[r];
+      if (!R.has) continue; // wave-uniform
+      Atten A;
+      if (R.has & 1) {
+        double tau = 0.0, E = 0.0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          tau = g == 0 ? a[g] * R.u_f[g] : tau + a[g] * R.u_f[g];
+          E = g == 0 ? e[g] * R.u_f[g] : E + e[g] * R.u_f[g];
+        }
+        two_sum_add(rem[r], rem_lo[r], tau);
+        A = attenuation(tau);
+        If[r] = If[r] * A.t + (o.solo_absorption ? 0.0 : E * A.f);
+      }
+      if (R.has & 2) {
+        double tau = 0.0, E = 0.0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          tau = g == 0 ? a[g] * R.u_n[g] : tau + a[g] * R.u_n[g];
+          E = g == 0 ? e[g] * R.u_n[g] : E + e[g] * R.u_n[g];
+        }
+        two_sum_add(rem[r], rem_lo[r], tau);
+        if (!(R.has & 4)) A = attenuation(tau);
+        two_sum_add(cs[r], cs_lo[r], (o.solo_absorption ? 0.0 : E * Tn[r]) * A.f);
+        Tn[r] *= A.t;
+      }
+    }
+  }
+  double slot[NR][4];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    // I_obs = I_f Tn + cs as an unevaluated sum of two doubles (exact product, two-sums): see sweep 2
+    const double p_hi = If[r] * Tn[r], p_lo = fma(If[r], Tn[r], -p_hi);
+    Iobs[r] = cs[r];
+    Iobs_lo[r] = cs_lo[r] + p_lo;
+    two_sum_add(Iobs[r], Iobs_lo[r], p_hi);
+    If[r] = ray0 + r < n_rays ? limb_initial(o, rad, (size_t)(ray0 + r) * n_pts + j, j) : 0.0; // (rad is written at the very end)
+    cs[r] = cs_lo[r] = 0.0;
+    Tn[r] = 1.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) slot[r][q] = 0.0;
+  }
+  // sweep 2: the weights, shell by shell
+  for (int v = 0; v < n_visits; ++v) {
+    const FoldRec *rv = rc + (size_t)v * NR;
+    const size_t ofs = (size_t)rv[0].layer * n_pts + j;
+    double a[NG], e[NG], da[NG], de[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      a[g] = abs_c[g * gstride + ofs];
+      e[g] = emi_c[g * gstride + ofs];
+      if (LAYER) {
+        da[g] = dabs[g * gstride + ofs];
+        de[g] = demi[g * gstride + ofs];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const FoldRec &R = rv[r];
+      if (!R.has) continue;
+      const int ray = ray0 + r;
+      Atten A;
+      double fp = 0.0, d = 0.0, wt_f = 0.0, we_f = 0.0, wt_n = 0.0, we_n = 0.0;
+      if (R.has & 1) {
+        double tau = 0.0, E = 0.0, dtau = 0.0, dE = 0.0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const double u = R.u_f[g];
+          tau = g == 0 ? a[g] * u : tau + a[g] * u;
+          E = g == 0 ? e[g] * u : E + e[g] * u;
+          if (LAYER) {
+            dtau = fma(da[g], u, dtau);
+            dE = fma(de[g], u, dE);
+          }
+        }
+        A = attenuation(tau);
+        fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
+        two_sum_add(rem[r], rem_lo[r], -tau);
+        const double Ta = exp_bounded(fmin(fmax(-(rem[r] + rem_lo[r]), -700.0), 700.0)); // everything behind: the inner far side and the near side
+        wt_f = (o.solo_absorption ? -If[r] * A.t : fma(E, fp, -If[r] * A.t)) * Ta;
+        we_f = o.solo_absorption ? 0.0 : A.f * Ta;
+        if (LAYER) d = fma(wt_f, dtau, we_f * dE);
+        If[r] = If[r] * A.t + (o.solo_absorption ? 0.0 : E * A.f);
+      }
+      if (R.has & 2) {
+        double tau = 0.0, E = 0.0, dtau = 0.0, dE = 0.0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const double u = R.u_n[g];
+          tau = g == 0 ? a[g] * u : tau + a[g] * u;
+          E = g == 0 ? e[g] * u : E + e[g] * u;
+          if (LAYER) {
+            dtau = fma(da[g], u, dtau);
+            dE = fma(de[g], u, dE);
+          }
+        }
+        if (!(R.has & 4)) {
+          A = attenuation(tau);
+          fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
+        }
+        const double ETn = o.solo_absorption ? 0.0 : E * Tn[r];
+        // I_in t Tn = I_obs - cs.  Both are carried as error-free sums (two doubles) of the SAME rounded terms -- the
+        // operations of sweep 1, bit for bit -- so the difference is the sum of the terms still to come, I_f Tn(all) and
+        // the inner segments' E f Tn, to THEIR relative accuracy: in one double it was good to eps x I_obs only, which
+        // at a point whose tangent shells are hidden behind tau ~ 25 left 4e-22 on a value of 1e-25 (configs[3]: 1e-9
+        // of a row's largest value)
+        two_sum_add(cs[r], cs_lo[r], ETn * A.f);
+        const double X = (Iobs[r] - cs[r]) + (Iobs_lo[r] - cs_lo[r]);
+        wt_n = fma(ETn, fp, -X); // E f' Tn - I_in t Tn
+        we_n = o.solo_absorption ? 0.0 : A.f * Tn[r];
+        if (LAYER) d += fma(wt_n, dtau, we_n * dE);
+        Tn[r] *= A.t;
+      }
+      if (LAYER) jac_layer[((size_t)ray * n_layers + R.layer) * n_pts + j] = d;
+      if (PAR) {
+        for (int i = 0; i < R.n_ent; ++i) {
+          const int gf = R.ent_gf[i], g = gf & 0xff, sl = (gf >> 8) & 0xff, fl = gf >> 16;
+          double ag = a[0], eg = e[0];
+#pragma unroll
+          for (int q = 1; q < NG; ++q) {
+            ag = g == q ? a[q] : ag;
+            eg = g == q ? e[q] : eg;
+          }
+          double val = fma(fma(wt_f, ag, we_f * eg), R.dc_f[i], fma(wt_n, ag, we_n * eg) * R.dc_n[i]);
+          if (!(fl & 1)) val += sl == 0 ? slot[r][0] : (sl == 1 ? slot[r][1] : (sl == 2 ? slot[r][2] : slot[r][3]));
+          if (fl & 2) {
+            double *out = jac_par + ((size_t)ray * n_par + R.ent_p[i]) * n_pts + j;
+            if (fl & 4) *out = val; else *out += val;
+          } else {
+            if (sl == 0) slot[r][0] = val; else if (sl == 1) slot[r][1] = val; else if (sl == 2) slot[r][2] = val; else slot[r][3] = val;
+          }
+        }
+      }
+    }
+  }
+  if (rad) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if (ray0 + r < n_rays) rad[(size_t)(ray0 + r) * n_pts + j] = Iobs[r] + Iobs_lo[r];
+  }
+}
+
+size_t fold_rec_bytes(int n_rec) { return sizeof(FoldRec) * (size_t)n_rec; }
+
+int launch_fold_pack(const int *plan, const double *col, int n_gas, int n_seg, int n_rec, FoldRec *out, hipStream_t st) {
+  if (n_rec <= 0) return 0;
+  hipLaunchKernelGGL(sr_fold_pack_kernel, dim3((n_rec + 63) / 64), dim3(64), 0, st, plan, col, n_gas, n_seg, n_rec, out);
+  return (int)hipGetLastError();
+}
+
+int launch_limb_adjoint_fold(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
+                             int n_layers, int n_rays, const FoldRec *rec, const int *zero_off, const int *zero_row, int n_par,
+                             const LimbOpts &o, int n_visits, double *rad, double *jac_layer, double *jac_par, hipStream_t st) {
+  if (n_pts <= 0 || n_rays <= 0 || n_visits <= 0) return 0;
+#if SR_FOLD_XCD
+  const dim3 grid(limb_grid((n_pts + 255) / 256, (n_rays + kAdjFoldRays - 1) / kAdjFoldRays));
+#else
+  const dim3 grid((n_pts + 255) / 256, (n_rays + kAdjFoldRays - 1) / kAdjFoldRays);
+#endif
+#define SR_AF(NG, L, P) hipLaunchKernelGGL((sr_limb_adjoint_fold_kernel<NG, L, P, kAdjFoldRays>), grid, dim3(256), 0, st, abs_c, emi_c, \
+                                           dabs, demi, n_pts, n_layers, rec, zero_off, zero_row, n_par, o, n_visits, n_rays, rad,      \
+                                           jac_layer, jac_par)
+#define SR_AF3(NG)                                                     \
+  do {                                                                 \
+    if (jac_layer && jac_par) SR_AF(NG, true, true);                   \
+    else if (jac_layer) SR_AF(NG, true, false);                        \
+    else SR_AF(NG, false, true);                                       \
+  } while (0)
+  switch (o.n_gas) { case 1: SR_AF3(1); break; case 2: SR_AF3(2); break; case 3: SR_AF3(3); break; default: SR_AF3(4); break; }
+#undef SR_AF3
+#undef SR_AF
+  return (int)hipGetLastError();
+}
+
 size_t adj_prog_bytes(int n_seg) { return sizeof(SegProg) * (size_t)n_seg; }
 static_assert(kAdjPlanInts == 4 + 2 * kAdjEnt, "host plan layout");
 

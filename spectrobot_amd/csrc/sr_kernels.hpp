@@ -180,6 +180,18 @@ int launch_limb_adjoint_sync(const double *abs_c, const double *emi_c, const dou
                              int n_layers, int n_jrows, int n_rays, const SegProg *prog, const int *zero_off,
                              const int *zero_row, int n_par, const LimbOpts &o, const int *sched, int n_visits, double *rad,
                              double *jac_layer, double *jac_par, hipStream_t st);
+// The folded variant (sr_limb_adjoint_fold_kernel): both segments of a ray in a shell together, every Jacobian value
+// stored once.  plan [n_batches][n_visits][kAdjFoldRays][kAdjPlanInts] = layer, far segment, near segment, n_ent, ent_p[4], ent_gf[4]
+#ifndef SR_ADJ_FOLD_RAYS
+#define SR_ADJ_FOLD_RAYS 1 // rays per thread: 1: 1.28-1.39 ms per configs[3] set, 2: 1.45-1.53, 4: 2.3 (spills); path order: 2.1 (tools/adjoint_probe.py)
+#endif
+constexpr int kAdjFoldRays = SR_ADJ_FOLD_RAYS;
+struct FoldRec;
+size_t fold_rec_bytes(int n_rec);
+int launch_fold_pack(const int *plan, const double *col, int n_gas, int n_seg, int n_rec, FoldRec *out, hipStream_t st);
+int launch_limb_adjoint_fold(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
+                             int n_layers, int n_rays, const FoldRec *rec, const int *zero_off, const int *zero_row, int n_par,
+                             const LimbOpts &o, int n_visits, double *rad, double *jac_layer, double *jac_par, hipStream_t st);
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                     const int *seg_layer, const double *seg_col, int init_from_rad, double *rad,
                     hipStream_t st);

@@ -707,9 +707,10 @@ def set_overlap(on):
 
 
 def set_jac_layer_mode(forward):
-    """0 (default): Jacobians of the device LOS pipeline in one pass per ray -- layer-synchronous over batches of four
-    rays where the rays share their coefficient rows (1-D atmospheres); 1: the forward-sensitivity kernels; 2: one
-    pass per ray with one ray per thread always (sr_set_jac_layer_mode)."""
+    """0 (default): Jacobians of the device LOS pipeline in one pass -- folded (a ray's two segments of a shell together,
+    every value stored once) where the rays share their coefficient rows (1-D atmospheres), else in path order; 1: the
+    forward-sensitivity kernels; 2: path order, one ray per thread, always; 3: path order, two rays per thread sharing
+    a shell's loads (sr_set_jac_layer_mode)."""
     check(lib.sr_set_jac_layer_mode(int(forward)), "sr_set_jac_layer_mode")
 
 

@@ -266,14 +266,18 @@ def test_one_pass_jacobians_vs_forward_sensitivity(eng):
         finally:
             eng.set_jac_layer_mode(0)
         assert torch.equal(jl3, jlf) and torch.equal(jp3, jpf)              # mode 1: the forward kernels
-        # round 4: the default is the LAYER-SYNCHRONOUS one-pass kernel (four rays per thread, a shell's coefficients loaded
-        # once for all of them); mode 2 = one ray per thread: per ray the same operations in the same order, bit for bit
+        # round 4: the default is the FOLDED one-pass kernel (both segments of a ray in a shell together, every value
+        # stored once; the intensity entering a near-side segment from the observed radiance); mode 2 = path order, one
+        # ray per thread; mode 3 = path order, two rays per thread sharing the loads: the bits of mode 2
         eng.set_jac_layer_mode(2)
         try:
             r4, jl4, jp4 = eng.limb_rays_jacobians(coeffs, los, dcoeffs=dco, par_gas=par_gas, par_w=W, grid=g)
+            eng.set_jac_layer_mode(3)
+            r5, jl5, jp5 = eng.limb_rays_jacobians(coeffs, los, dcoeffs=dco, par_gas=par_gas, par_w=W, grid=g)
         finally:
             eng.set_jac_layer_mode(0)
-        assert torch.equal(rad, r4) and torch.equal(jl, jl4) and torch.equal(jp, jp4), opts
+        assert torch.equal(r5, r4) and torch.equal(jl5, jl4) and torch.equal(jp5, jp4), opts
+        assert cmp(rad, r4, 1e-14) and cmp(jl, jl4, 1e-13) and cmp(jp, jp4, 1e-13), opts
         assert cmp(rad, rf, 1e-13) and cmp(jl, jlf) and cmp(jp, jpf), opts
         assert cmp(rad, eng.limb_rays(coeffs, los, grid=g), 1e-13)
         assert float(jl[2, :15].abs().max()) == 0.0 and float(jp[2, :7].abs().max()) == 0.0   # rows the third ray never touches

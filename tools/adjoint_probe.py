@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The one-pass Jacobian kernel on the configs[3] set (8 rays x 80 layers x 2e5 points, T + VMR Jacobians): per-ray
-threads (mode 2) against the layer-synchronous batches (mode 0), HIP-event times."""
+"""The one-pass Jacobian kernels on the configs[3] set (8 rays x 80 layers x 2e5 points, T + VMR Jacobians): path order
+with one ray per thread (mode 2), with two rays per thread sharing the loads (3), folded (0, the default); HIP-event
+times and the largest deviation of the folded kernel's values from mode 2's, relative to each row's largest."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,10 +20,11 @@ Lr = syn.limb_los(atm["z"], atm["nd"], [vm], 120.0 + 60.0 * np.arange(8))
 los = engine.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"], col_scale=[syn.CH4_ISO_RATIO])
 W = bc.layer_vmr_weights(atm["z"], Lr["alt"])
 pg = np.zeros(nl, np.int32)
-for mode in (2, 0, 2, 0):
+res = {}
+for mode in (2, 3, 0, 2, 3, 0):
     engine.set_jac_layer_mode(mode)
     f = lambda: engine.limb_rays_jacobians(co, los, dcoeffs=dco, par_gas=pg, par_w=W)
-    f(); torch.cuda.synchronize()
+    res[mode] = [x.clone() for x in f()]; torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
@@ -30,3 +32,6 @@ for mode in (2, 0, 2, 0):
     e1.record(); torch.cuda.synchronize()
     print("mode %d: %.3f ms per set" % (mode, e0.elapsed_time(e1) / 10))
 engine.set_jac_layer_mode(0)
+for name, x, y in zip(("rad", "jac_layer", "jac_par"), res[0], res[2]):
+    sc = y.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+    print("folded vs path order, %s: %.2e of the row maximum" % (name, float(((x - y).abs() / sc).max())))

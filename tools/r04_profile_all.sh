@@ -27,6 +27,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY
   p=$(echo $pass | cut -d' ' -f1)
   timeout -k 10 300 rocprofv3 --pmc $pass -d /tmp/lp_$p -o p -- python3 bench.py --config 3 --steps 4 --warmup 1 --cpu-seconds 0 > $out/pmc_c3_$p.log 2>&1
   echo "config 3 pmc $p exit=$?"
-  python3 tools/rocprof_summary.py /tmp/lp_$p/p_results.db 2>/dev/null | grep -i "adjoint\|sr_limb\|los_col\|adj_pack\|glevel\|^kernel " >> $out/config3_pmc_limb_kernels.txt
+  python3 tools/rocprof_summary.py /tmp/lp_$p/p_results.db 2>/dev/null | grep -i "adjoint\|sr_limb\|los_col\|adj_pack\|fold_pack\|glevel\|^kernel " >> $out/config3_pmc_limb_kernels.txt
 done
 head -12 $out/config3_kernel_trace_stats.txt
