@@ -1870,6 +1870,44 @@ bool build_adj_plan(const sr_los_desc *los, int n_layers, const int32_t *seg_jro
   return true;
 }
 
+// The two sides of rays that walk the shells strictly inwards down to a turning shell and strictly outwards again (limb
+// rays; slant / nadir rays are the outward half, their first segment counted as the inward one): far / near
+// [n_rays][n_layers] = the segment's index in WALK order (LOS_order 'observer' reverses every ray, as stage_los lists the
+// columns) or -1, and the range of shells touched.  false: some ray is not of that shape.
+bool fold_sides(const sr_los_desc *los, int n_layers, std::vector<int> *far_out, std::vector<int> *near_out, int *l_min_out,
+                int *l_max_out) {
+  const int nr = los->n_rays;
+  std::vector<int> &far = *far_out, &near = *near_out;
+  far.assign((size_t)nr * n_layers, -1);
+  near.assign((size_t)nr * n_layers, -1);
+  int l_min = n_layers, l_max = -1;
+  bool ok = true;
+  for (int r = 0; r < nr && ok; ++r) {
+    const int a = los->seg_off[r], m = los->seg_off[r + 1] - a;
+    auto lay = [&](int q) { return los->seg_layer[los->los_order == 0 ? a + q : a + (m - 1 - q)]; };
+    int q = 0, prev = INT_MAX;
+    for (; q < m; ++q) { // far side: strictly inwards
+      const int k = lay(q);
+      if (k >= prev) break;
+      far[(size_t)r * n_layers + k] = a + q;
+      prev = k;
+      l_min = std::min(l_min, k); l_max = std::max(l_max, k);
+    }
+    prev = q < m ? lay(q) - 1 : prev;
+    if (q < m && q > 0 && lay(q) < lay(q - 1)) ok = false;
+    for (; q < m && ok; ++q) { // near side: strictly outwards (its first shell may be the far side's last)
+      const int k = lay(q);
+      if (k <= prev) { ok = false; break; }
+      near[(size_t)r * n_layers + k] = a + q;
+      prev = k;
+      l_min = std::min(l_min, k); l_max = std::max(l_max, k);
+    }
+  }
+  *l_min_out = l_min;
+  *l_max_out = l_max;
+  return ok && l_max >= l_min;
+}
+
 // Radiances (rad may be NULL) + per-layer Jacobian (dabs / demi / jac_layer may be NULL) + column-parameter Jacobian
 // (n_par may be 0) in one pass.  *done = 0 when the plan does not fit the kernel (nothing launched).
 int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_layers,
@@ -1900,30 +1938,10 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
   const int nr = los->n_rays, n_batches = (nr + kAdjSyncRays - 1) / kAdjSyncRays;
   const int jmode = g_jac_layer_forward.load();
   if (!seg_jrow && (jmode == 0 || (jmode == 3 && nr >= 2))) {
-    bool ok = true;
     // per ray: far[layer] / near[layer] = walk-order segment index or -1
-    std::vector<int> far((size_t)nr * n_layers, -1), near((size_t)nr * n_layers, -1);
+    std::vector<int> far, near;
     int l_min = n_layers, l_max = -1;
-    for (int r = 0; r < nr && ok; ++r) {
-      const int a = los->seg_off[r], m = los->seg_off[r + 1] - a;
-      int q = 0, prev = INT_MAX;
-      for (; q < m; ++q) { // far side: strictly inwards
-        const int k = plan.seg[(size_t)(a + q) * kAdjPlanInts];
-        if (k >= prev) break;
-        far[(size_t)r * n_layers + k] = a + q;
-        prev = k;
-        l_min = std::min(l_min, k); l_max = std::max(l_max, k);
-      }
-      prev = q < m ? plan.seg[(size_t)(a + q) * kAdjPlanInts] - 1 : prev;
-      if (q < m && q > 0 && plan.seg[(size_t)(a + q) * kAdjPlanInts] < plan.seg[(size_t)(a + q - 1) * kAdjPlanInts]) ok = false;
-      for (; q < m && ok; ++q) { // near side: strictly outwards (its first shell may be the far side's last)
-        const int k = plan.seg[(size_t)(a + q) * kAdjPlanInts];
-        if (k <= prev) { ok = false; break; }
-        near[(size_t)r * n_layers + k] = a + q;
-        prev = k;
-        l_min = std::min(l_min, k); l_max = std::max(l_max, k);
-      }
-    }
+    const bool ok = fold_sides(los, n_layers, &far, &near, &l_min, &l_max);
     // The folded plan (sr_limb_adjoint_fold_kernel, the default): one visit per shell, outermost first, with every
     // ray's far-side and near-side segment there; a column parameter's touches -- read off the per-segment plan -- are
     // planned over the VISITS (a level acts on the same shells on both sides: one run, one register, one store).
@@ -2152,6 +2170,46 @@ int sr_limb_rays_jac_dev(const double *abs_c, const double *emi_c, int n_layers,
   LosDev D;
   int rc = stage_los(los, n_layers, n_par, par_gas, par_w, st, &D);
   if (rc) return rc;
+  // Few parameters, 1-D limb / slant / nadir rays: the folded recursion with an accumulator per parameter
+  // (sr_limb_fold_dense_kernel) instead of the forward sensitivities (which repeat the recursion per four parameters)
+  if (n_par <= kFoldDensePar && g_jac_layer_forward.load() == 0) {
+    std::vector<int> far, near;
+    int l_min = 0, l_max = -1;
+    if (fold_sides(los, n_layers, &far, &near, &l_min, &l_max)) {
+      const int nr = los->n_rays;
+      std::vector<int> shells;
+      for (int k = l_max; k >= l_min; --k) {
+        bool any = false;
+        for (int r = 0; r < nr && !any; ++r) any = far[(size_t)r * n_layers + k] >= 0 || near[(size_t)r * n_layers + k] >= 0;
+        if (any) shells.push_back(k);
+      }
+      const int n_vis = (int)shells.size(), n_rec = nr * n_vis;
+      static thread_local Stager s_ring[4];
+      static thread_local unsigned s_next = 0;
+      Stager &sg = s_ring[s_next++ & 3];
+      const size_t plan_bytes = (sizeof(int) * 4 * (size_t)n_rec + 15) / 16 * 16;
+      rc = sg.prepare(plan_bytes + fold_dense_bytes(n_rec));
+      if (rc) return rc;
+      int *pl = sg.host<int>();
+      for (int r = 0; r < nr; ++r)
+        for (int v = 0; v < n_vis; ++v) {
+          int *q = pl + ((size_t)r * n_vis + v) * 4;
+          q[0] = shells[v];
+          q[1] = far[(size_t)r * n_layers + shells[v]];
+          q[2] = near[(size_t)r * n_layers + shells[v]];
+          q[3] = 0;
+        }
+      rc = sg.push_early(plan_bytes, st);
+      if (rc) return rc;
+      char *d = sg.d.as<char>();
+      LAUNCHCHK(launch_fold_dense(reinterpret_cast<const int *>(d), D.col, par_gas, n_par, D.n_seg, n_rec,
+                                  reinterpret_cast<FoldDense *>(d + plan_bytes), abs_c, emi_c, (int)n_pts, n_layers, nr, n_vis,
+                                  limb_opts(los, D.n_seg), rad, jac, st));
+      rc = sg.mark(st);
+      if (rc) return rc;
+      return D.slot->mark(st);
+    }
+  }
   LAUNCHCHK(launch_limb_jac(abs_c, emi_c, (int)n_pts, n_layers, los->n_rays, D.seg_off, D.seg_layer, D.col,
                             D.col + (size_t)los->n_gas * D.n_seg, D.par_gas, n_par, limb_opts(los, D.n_seg), rad, jac,
                             st));

@@ -3034,6 +3034,196 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAV
   }
 }
 
+// ------------------------------------------------------------------------
+// The folded recursion for FEW, BROAD column parameters (round 4; the retrieval loop of configs[4]: 7 profile parameters
+// whose masks cover the whole path): the forward-sensitivity kernel carries four derivatives through the recursion and
+// repeats it per block of four; here the recursion runs once (two sweeps over the shells, sr_limb_adjoint_fold_kernel's
+// quantities) and every parameter has an accumulator, acc_p += (w_tau a_g + w_E e_g)(far) dc_far,p + (..)(near) dc_near,p,
+// stored once at the end.  Up to kFoldDensePar parameters.
+// ------------------------------------------------------------------------
+struct __attribute__((aligned(16))) FoldDense { // one ray in one shell
+  int layer, has, pad0, pad1;                // has: as FoldRec
+  double u_f[4], u_n[4];
+  double dc_f[kFoldDensePar], dc_n[kFoldDensePar]; // d col / d x_p of the two segments
+};
+static_assert(sizeof(FoldDense) == 16 + 64 + 16 * kFoldDensePar, "FoldDense layout");
+struct ParGas { int g[kFoldDensePar]; };
+
+// plan: [n_rec][4] ints: layer, far segment, near segment (-1: none), 0
+__global__ void sr_fold_dense_pack_kernel(const int *__restrict__ plan, const double *__restrict__ col, int n_gas, int n_par,
+                                          int n_seg, int n_rec, FoldDense *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rec) return;
+  const int *pl = plan + (size_t)i * 4;
+  const int sf = pl[1], sn = pl[2];
+  FoldDense r;
+  r.layer = pl[0]; r.pad0 = r.pad1 = 0;
+  bool same = sf >= 0 && sn >= 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    r.u_f[g] = g < n_gas && sf >= 0 ? col[(size_t)g * n_seg + sf] : 0.0;
+    r.u_n[g] = g < n_gas && sn >= 0 ? col[(size_t)g * n_seg + sn] : 0.0;
+    same = same && r.u_f[g] == r.u_n[g];
+  }
+#pragma unroll
+  for (int p = 0; p < kFoldDensePar; ++p) {
+    r.dc_f[p] = p < n_par && sf >= 0 ? col[(size_t)(n_gas + p) * n_seg + sf] : 0.0;
+    r.dc_n[p] = p < n_par && sn >= 0 ? col[(size_t)(n_gas + p) * n_seg + sn] : 0.0;
+  }
+  r.has = (sf >= 0 ? 1 : 0) | (sn >= 0 ? 2 : 0) | (same ? 4 : 0);
+  out[i] = r;
+}
+
+template <int NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void sr_limb_fold_dense_kernel(
+    const double *__restrict__ abs_c, const double *__restrict__ emi_c, int n_pts, int n_layers,
+    const FoldDense *__restrict__ rec, // [n_rays][n_visits]
+    int n_par, ParGas pg, LimbOpts o, int n_visits, int n_rays, double *__restrict__ rad, double *__restrict__ jac_par) {
+  int pb, ray; // all rays of a point block on one XCD, one after the other
+  if (!limb_block((n_pts + 255) / 256, n_rays, pb, ray)) return;
+  const int j = pb * 256 + threadIdx.x;
+  if (j >= n_pts) return;
+  const FoldDense *rc = rec + (size_t)ray * n_visits;
+  const size_t gstride = (size_t)n_layers * n_pts;
+  auto two_sum_add = [](double &hi, double &lo, double x) {
+    const double sm = hi + x, bb = sm - hi;
+    lo += (hi - (sm - bb)) + (x - bb);
+    hi = sm;
+  };
+  double If = limb_initial(o, rad, (size_t)ray * n_pts + j, j), rem = 0.0, rem_lo = 0.0, Tn = 1.0, cs = 0.0, cs_lo = 0.0;
+  // sweep 1: the observed radiance and the path's optical depth (see sr_limb_adjoint_fold_kernel)
+  for (int v = 0; v < n_visits; ++v) {
+    const FoldDense &R = rc[v];
+    if (!R.has) continue;
+    const size_t ofs = (size_t)R.layer * n_pts + j;
+    double a[NG], e[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      a[g] = abs_c[g * gstride + ofs];
+      e[g] = emi_c[g * gstride + ofs];
+    }
+    Atten A;
+    if (R.has & 1) {
+      double tau = 0.0, E = 0.0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        tau = g == 0 ? a[g] * R.u_f[g] : tau + a[g] * R.u_f[g];
+        E = g == 0 ? e[g] * R.u_f[g] : E + e[g] * R.u_f[g];
+      }
+      two_sum_add(rem, rem_lo, tau);
+      A = attenuation(tau);
+      If = If * A.t + (o.solo_absorption ? 0.0 : E * A.f);
+    }
+    if (R.has & 2) {
+      double tau = 0.0, E = 0.0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        tau = g == 0 ? a[g] * R.u_n[g] : tau + a[g] * R.u_n[g];
+        E = g == 0 ? e[g] * R.u_n[g] : E + e[g] * R.u_n[g];
+      }
+      two_sum_add(rem, rem_lo, tau);
+      if (!(R.has & 4)) A = attenuation(tau);
+      two_sum_add(cs, cs_lo, (o.solo_absorption ? 0.0 : E * Tn) * A.f);
+      Tn *= A.t;
+    }
+  }
+  const double p_hi = If * Tn, p_lo = fma(If, Tn, -p_hi);
+  double Iobs = cs, Iobs_lo = cs_lo + p_lo;
+  two_sum_add(Iobs, Iobs_lo, p_hi);
+  If = limb_initial(o, rad, (size_t)ray * n_pts + j, j); // (rad is written at the very end)
+  cs = cs_lo = 0.0;
+  Tn = 1.0;
+  double acc[kFoldDensePar];
+#pragma unroll
+  for (int p = 0; p < kFoldDensePar; ++p) acc[p] = 0.0;
+  // sweep 2: the weights, shell by shell
+  for (int v = 0; v < n_visits; ++v) {
+    const FoldDense &R = rc[v];
+    if (!R.has) continue;
+    const size_t ofs = (size_t)R.layer * n_pts + j;
+    double a[NG], e[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      a[g] = abs_c[g * gstride + ofs];
+      e[g] = emi_c[g * gstride + ofs];
+    }
+    Atten A;
+    double fp = 0.0, wt_f = 0.0, we_f = 0.0, wt_n = 0.0, we_n = 0.0;
+    if (R.has & 1) {
+      double tau = 0.0, E = 0.0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        tau = g == 0 ? a[g] * R.u_f[g] : tau + a[g] * R.u_f[g];
+        E = g == 0 ? e[g] * R.u_f[g] : E + e[g] * R.u_f[g];
+      }
+      A = attenuation(tau);
+      fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
+      two_sum_add(rem, rem_lo, -tau);
+      const double Ta = exp_bounded(fmin(fmax(-(rem + rem_lo), -700.0), 700.0));
+      wt_f = (o.solo_absorption ? -If * A.t : fma(E, fp, -If * A.t)) * Ta;
+      we_f = o.solo_absorption ? 0.0 : A.f * Ta;
+      If = If * A.t + (o.solo_absorption ? 0.0 : E * A.f);
+    }
+    if (R.has & 2) {
+      double tau = 0.0, E = 0.0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        tau = g == 0 ? a[g] * R.u_n[g] : tau + a[g] * R.u_n[g];
+        E = g == 0 ? e[g] * R.u_n[g] : E + e[g] * R.u_n[g];
+      }
+      if (!(R.has & 4)) {
+        A = attenuation(tau);
+        fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
+      }
+      const double ETn = o.solo_absorption ? 0.0 : E * Tn;
+      two_sum_add(cs, cs_lo, ETn * A.f);
+      const double X = (Iobs - cs) + (Iobs_lo - cs_lo); // I_in t Tn (sr_limb_adjoint_fold_kernel)
+      wt_n = fma(ETn, fp, -X);
+      we_n = o.solo_absorption ? 0.0 : A.f * Tn;
+      Tn *= A.t;
+    }
+    double bf[NG], bn[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      bf[g] = fma(wt_f, a[g], we_f * e[g]);
+      bn[g] = fma(wt_n, a[g], we_n * e[g]);
+    }
+#pragma unroll
+    for (int p = 0; p < kFoldDensePar; ++p) {
+      if (p >= n_par) break;
+      const int g = pg.g[p];
+      double vf = bf[0], vn = bn[0];
+#pragma unroll
+      for (int q = 1; q < NG; ++q) {
+        vf = g == q ? bf[q] : vf;
+        vn = g == q ? bn[q] : vn;
+      }
+      acc[p] = fma(vf, R.dc_f[p], fma(vn, R.dc_n[p], acc[p]));
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < kFoldDensePar; ++p)
+    if (p < n_par) jac_par[((size_t)ray * n_par + p) * n_pts + j] = acc[p];
+  rad[(size_t)ray * n_pts + j] = Iobs + Iobs_lo;
+}
+
+size_t fold_dense_bytes(int n_rec) { return sizeof(FoldDense) * (size_t)n_rec; }
+
+int launch_fold_dense(const int *plan, const double *col, const int *par_gas_host, int n_par, int n_seg, int n_rec, FoldDense *rec,
+                      const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, int n_visits,
+                      const LimbOpts &o, double *rad, double *jac_par, hipStream_t st) {
+  if (n_rec <= 0 || n_pts <= 0 || n_rays <= 0 || n_par <= 0 || n_par > kFoldDensePar) return 0;
+  hipLaunchKernelGGL(sr_fold_dense_pack_kernel, dim3((n_rec + 63) / 64), dim3(64), 0, st, plan, col, o.n_gas, n_par, n_seg, n_rec, rec);
+  ParGas pg;
+  for (int p = 0; p < kFoldDensePar; ++p) pg.g[p] = p < n_par ? par_gas_host[p] : 0;
+  const dim3 grid(limb_grid((n_pts + 255) / 256, n_rays));
+#define SR_FD(NG) hipLaunchKernelGGL(sr_limb_fold_dense_kernel<NG>, grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, rec, n_par, pg, \
+                                     o, n_visits, n_rays, rad, jac_par)
+  switch (o.n_gas) { case 1: SR_FD(1); break; case 2: SR_FD(2); break; case 3: SR_FD(3); break; default: SR_FD(4); break; }
+#undef SR_FD
+  return (int)hipGetLastError();
+}
+
 size_t fold_rec_bytes(int n_rec) { return sizeof(FoldRec) * (size_t)n_rec; }
 
 int launch_fold_pack(const int *plan, const double *col, int n_gas, int n_seg, int n_rec, FoldRec *out, hipStream_t st) {

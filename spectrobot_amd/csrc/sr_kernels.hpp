@@ -192,6 +192,14 @@ int launch_fold_pack(const int *plan, const double *col, int n_gas, int n_seg, i
 int launch_limb_adjoint_fold(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
                              int n_layers, int n_rays, const FoldRec *rec, const int *zero_off, const int *zero_row, int n_par,
                              const LimbOpts &o, int n_visits, double *rad, double *jac_layer, double *jac_par, hipStream_t st);
+// The folded recursion for up to kFoldDensePar column parameters whose masks may cover the whole path (one accumulator
+// per parameter): sr_limb_fold_dense_kernel.  plan [n_rays][n_visits][4] = layer, far segment, near segment, 0
+constexpr int kFoldDensePar = 8;
+struct FoldDense;
+size_t fold_dense_bytes(int n_rec);
+int launch_fold_dense(const int *plan, const double *col, const int *par_gas_host, int n_par, int n_seg, int n_rec, FoldDense *rec,
+                      const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, int n_visits,
+                      const LimbOpts &o, double *rad, double *jac_par, hipStream_t st);
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                     const int *seg_layer, const double *seg_col, int init_from_rad, double *rad,
                     hipStream_t st);

@@ -295,6 +295,54 @@ def test_one_pass_jacobians_vs_forward_sensitivity(eng):
     assert torch.equal(jb, jbf) and torch.equal(rb, rbf)
 
 
+def test_few_broad_parameters_folded_vs_forward(eng):
+    """sr_limb_rays_jac_dev with up to eight parameters on 1-D limb / slant rays runs the folded recursion with one
+    accumulator per parameter (sr_limb_fold_dense_kernel); the forward-sensitivity kernel (mode 1) shares nothing
+    with it but the segment's attenuation.  Broad masks (every parameter acts on every segment), two gases, both LOS
+    orders, solo absorption with a Planck background, an opaque case, slant rays (the outward half alone)."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(5)
+    nl, n = 24, 700
+    atm = _atm(nl)
+    z = atm["z"]
+    grid = syn.make_grid(2975.0, 5e-4, n)
+    t = lambda v: torch.tensor(np.ascontiguousarray(v), device="cuda")
+    vm = [np.full(nl, 1.2e-2), np.linspace(2e-3, 5e-4, nl)]
+    top = z[-1] + (z[-1] - z[-2])
+    zz = np.append(z, top)
+
+    def cmp(x, y, tol=2e-12):
+        sc = y.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+        return float(((x - y).abs() / sc).max()) < tol
+
+    for scale in (1.0, 300.0):                      # 300: line centres with tau of a few hundred per segment
+        a = [rng.uniform(0, 4e-18, (nl, n)) * scale, rng.uniform(0, 3e-17, (nl, n)) * scale]
+        e = [a[0] * rng.uniform(1e-8, 1e-7, (nl, n)), a[1] * rng.uniform(1e-8, 1e-7, (nl, n))]
+        coeffs = [(t(a[0]), t(e[0])), (t(a[1]), t(e[1]))]
+        for kind in ("limb", "slant"):
+            if kind == "limb":
+                L = syn.limb_los(z, atm["nd"] * 1e-6, vm, [z[0] + 5.0, z[6] + 3.0, z[15] + 1.0])
+            else:
+                L = syn.slant_los(z, atm["nd"] * 1e-6, vm, [0.0, 40.0, 75.0])
+            W = np.array([np.interp(L["alt"], zz, np.exp(-0.5 * ((zz - z[k]) / 250.0) ** 2)) for k in (0, 5, 11, 17, 22)] * 1
+                         + [np.interp(L["alt"], zz, np.exp(-0.5 * ((zz - z[k]) / 400.0) ** 2)) for k in (3, 14)])
+            par_gas = np.array([0, 0, 0, 0, 0, 1, 1], np.int32)
+            for opts in (dict(), dict(LOS_order="observer"), dict(solo_absorption=True, initial_temperature=200.0)):
+                los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827, 1.0], **opts)
+                g = grid if "initial_temperature" in opts else None
+                rad, jac = eng.limb_rays_jacobian(coeffs, los, par_gas, W, grid=g)
+                eng.set_jac_layer_mode(1)
+                try:
+                    rf, jf = eng.limb_rays_jacobian(coeffs, los, par_gas, W, grid=g)
+                finally:
+                    eng.set_jac_layer_mode(0)
+                assert not torch.equal(jac, jf)        # two kernels
+                assert cmp(rad, rf, 1e-13) and cmp(jac, jf), (scale, kind, opts)
+                assert cmp(rad, eng.limb_rays(coeffs, los, grid=g), 1e-13)
+                assert float(jac.abs().max()) > 0
+
+
 def test_per_level_partial_radiances_sum_to_total(eng):
     """single_rad[(gas, iso, lev)] (spect_main_module.py:2883-2887): the radiance emitted by one level and
     absorbed by the whole gas -- the level's emission share (sr_abscoeff_level_dev) with the total
