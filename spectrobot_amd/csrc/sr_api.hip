@@ -220,7 +220,8 @@ struct HostLines {
 std::atomic<int> g_variant{8};   // points per lane in the exact wings kernel
 std::atomic<int> g_far_field{2}; // 1: far wings by per-line local expansions, 2: by box pairs (multipole -> local), 0: every evaluation exact
 std::atomic<int> g_overlap{1};   // 1 (default), 2: zones kernel on a second stream beside the far-field kernel, next call's prep pipelined (2: gated behind FF+zones; measured equal)
-std::atomic<int> g_jac_layer_forward{0}; // 1: per-layer Jacobians by the forward-sensitivity kernel (sr_set_jac_layer_mode)
+// sr_set_jac_layer_mode; SR_JAC_LAYER_MODE (environment, read once at load): its initial value, for A/B runs of whole programs
+std::atomic<int> g_jac_layer_forward{[] { const char *e = getenv("SR_JAC_LAYER_MODE"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 3 ? v : 0; }()};
 std::atomic<int> g_counting{0};  // 1: counting instantiations of the far-field-mode kernels (sr_set_counting)
 std::atomic<size_t> g_table_budget{(size_t)48 << 30}; // bytes of FastRec + ColdRec tables per layer batch
 
@@ -1749,6 +1750,94 @@ LimbOpts limb_opts(const sr_los_desc *los, int n_seg) {
 
 } // namespace
 
+namespace {
+
+// The two sides of rays that walk the shells strictly inwards down to a turning shell and strictly outwards again (limb
+// rays; slant / nadir rays are the outward half, their first segment counted as the inward one): far / near
+// [n_rays][n_layers] = the segment's index in WALK order (LOS_order 'observer' reverses every ray, as stage_los lists the
+// columns) or -1, and the range of shells touched.  false: some ray is not of that shape.
+bool fold_sides(const sr_los_desc *los, int n_layers, std::vector<int> *far_out, std::vector<int> *near_out, int *l_min_out,
+                int *l_max_out) {
+  const int nr = los->n_rays;
+  std::vector<int> &far = *far_out, &near = *near_out;
+  far.assign((size_t)nr * n_layers, -1);
+  near.assign((size_t)nr * n_layers, -1);
+  int l_min = n_layers, l_max = -1;
+  bool ok = true;
+  for (int r = 0; r < nr && ok; ++r) {
+    const int a = los->seg_off[r], m = los->seg_off[r + 1] - a;
+    auto lay = [&](int q) { return los->seg_layer[los->los_order == 0 ? a + q : a + (m - 1 - q)]; };
+    int q = 0, prev = INT_MAX;
+    for (; q < m; ++q) { // far side: strictly inwards
+      const int k = lay(q);
+      if (k >= prev) break;
+      far[(size_t)r * n_layers + k] = a + q;
+      prev = k;
+      l_min = std::min(l_min, k); l_max = std::max(l_max, k);
+    }
+    prev = q < m ? lay(q) - 1 : prev;
+    if (q < m && q > 0 && lay(q) < lay(q - 1)) ok = false;
+    for (; q < m && ok; ++q) { // near side: strictly outwards (its first shell may be the far side's last)
+      const int k = lay(q);
+      if (k <= prev) { ok = false; break; }
+      near[(size_t)r * n_layers + k] = a + q;
+      prev = k;
+      l_min = std::min(l_min, k); l_max = std::max(l_max, k);
+    }
+  }
+  *l_min_out = l_min;
+  *l_max_out = l_max;
+  return ok && l_max >= l_min;
+}
+
+// The folded kernels' plan on the device: per ray and visited shell (outermost first) the layer and the ray's two
+// segments there, + room for the packed records.  n_rec = 0: some ray is not V-shaped (nothing staged).
+struct FoldStage {
+  const int *plan = nullptr;
+  FoldDense *rec = nullptr;
+  int n_vis = 0, n_rec = 0;
+  Stager *slot = nullptr;
+};
+int stage_fold(const sr_los_desc *los, int n_layers, hipStream_t st, FoldStage *out) {
+  std::vector<int> far, near;
+  int l_min = 0, l_max = -1;
+  if (!fold_sides(los, n_layers, &far, &near, &l_min, &l_max)) return SR_OK;
+  const int nr = los->n_rays;
+  std::vector<int> shells;
+  for (int k = l_max; k >= l_min; --k) {
+    bool any = false;
+    for (int r = 0; r < nr && !any; ++r) any = far[(size_t)r * n_layers + k] >= 0 || near[(size_t)r * n_layers + k] >= 0;
+    if (any) shells.push_back(k);
+  }
+  const int n_vis = (int)shells.size(), n_rec = nr * n_vis;
+  static thread_local Stager s_ring[4];
+  static thread_local unsigned s_next = 0;
+  Stager &sg = s_ring[s_next++ & 3];
+  const size_t plan_bytes = (sizeof(int) * 4 * (size_t)n_rec + 15) / 16 * 16;
+  int rc = sg.prepare(plan_bytes + fold_dense_bytes(n_rec));
+  if (rc) return rc;
+  int *pl = sg.host<int>();
+  for (int r = 0; r < nr; ++r)
+    for (int v = 0; v < n_vis; ++v) {
+      int *q = pl + ((size_t)r * n_vis + v) * 4;
+      q[0] = shells[v];
+      q[1] = far[(size_t)r * n_layers + shells[v]];
+      q[2] = near[(size_t)r * n_layers + shells[v]];
+      q[3] = 0;
+    }
+  rc = sg.push_early(plan_bytes, st);
+  if (rc) return rc;
+  char *d = sg.d.as<char>();
+  out->plan = reinterpret_cast<const int *>(d);
+  out->rec = reinterpret_cast<FoldDense *>(d + plan_bytes);
+  out->n_vis = n_vis;
+  out->n_rec = n_rec;
+  out->slot = &sg;
+  return SR_OK;
+}
+
+} // namespace
+
 extern "C" {
 
 int sr_los_columns(const sr_los_desc *los, double *col_out) {
@@ -1776,6 +1865,20 @@ int sr_limb_rays_dev(const double *abs_c, const double *emi_c, int n_layers, int
   LosDev D;
   int rc = stage_los(los, n_layers, 0, nullptr, nullptr, st, &D);
   if (rc) return rc;
+  // ray batches of a 1-D atmosphere: the folded sweep (a shell's loads and, the path being symmetric, its attenuation
+  // once for the ray's two segments); small launches keep the split kernel, whose time is a chain's latency
+  if (!limb_launch_is_small((int)n_pts, los->n_rays) && g_jac_layer_forward.load() == 0) {
+    FoldStage F;
+    rc = stage_fold(los, n_layers, st, &F);
+    if (rc) return rc;
+    if (F.n_rec > 0) {
+      LAUNCHCHK(launch_fold_fwd(F.plan, D.col, D.n_seg, F.n_rec, F.rec, abs_c, emi_c, (int)n_pts, n_layers, los->n_rays, F.n_vis,
+                                limb_opts(los, D.n_seg), rad, st));
+      rc = F.slot->mark(st);
+      if (rc) return rc;
+      return D.slot->mark(st);
+    }
+  }
   LAUNCHCHK(launch_limb(abs_c, emi_c, (int)n_pts, n_layers, los->n_rays, D.seg_off, D.seg_layer, D.col,
                         limb_opts(los, D.n_seg), rad, st));
   return D.slot->mark(st);
@@ -1868,44 +1971,6 @@ bool build_adj_plan(const sr_los_desc *los, int n_layers, const int32_t *seg_jro
     out->zero_off[r + 1] = (int)out->zero_row.size();
   }
   return true;
-}
-
-// The two sides of rays that walk the shells strictly inwards down to a turning shell and strictly outwards again (limb
-// rays; slant / nadir rays are the outward half, their first segment counted as the inward one): far / near
-// [n_rays][n_layers] = the segment's index in WALK order (LOS_order 'observer' reverses every ray, as stage_los lists the
-// columns) or -1, and the range of shells touched.  false: some ray is not of that shape.
-bool fold_sides(const sr_los_desc *los, int n_layers, std::vector<int> *far_out, std::vector<int> *near_out, int *l_min_out,
-                int *l_max_out) {
-  const int nr = los->n_rays;
-  std::vector<int> &far = *far_out, &near = *near_out;
-  far.assign((size_t)nr * n_layers, -1);
-  near.assign((size_t)nr * n_layers, -1);
-  int l_min = n_layers, l_max = -1;
-  bool ok = true;
-  for (int r = 0; r < nr && ok; ++r) {
-    const int a = los->seg_off[r], m = los->seg_off[r + 1] - a;
-    auto lay = [&](int q) { return los->seg_layer[los->los_order == 0 ? a + q : a + (m - 1 - q)]; };
-    int q = 0, prev = INT_MAX;
-    for (; q < m; ++q) { // far side: strictly inwards
-      const int k = lay(q);
-      if (k >= prev) break;
-      far[(size_t)r * n_layers + k] = a + q;
-      prev = k;
-      l_min = std::min(l_min, k); l_max = std::max(l_max, k);
-    }
-    prev = q < m ? lay(q) - 1 : prev;
-    if (q < m && q > 0 && lay(q) < lay(q - 1)) ok = false;
-    for (; q < m && ok; ++q) { // near side: strictly outwards (its first shell may be the far side's last)
-      const int k = lay(q);
-      if (k <= prev) { ok = false; break; }
-      near[(size_t)r * n_layers + k] = a + q;
-      prev = k;
-      l_min = std::min(l_min, k); l_max = std::max(l_max, k);
-    }
-  }
-  *l_min_out = l_min;
-  *l_max_out = l_max;
-  return ok && l_max >= l_min;
 }
 
 // Radiances (rad may be NULL) + per-layer Jacobian (dabs / demi / jac_layer may be NULL) + column-parameter Jacobian
@@ -2173,39 +2238,13 @@ int sr_limb_rays_jac_dev(const double *abs_c, const double *emi_c, int n_layers,
   // Few parameters, 1-D limb / slant / nadir rays: the folded recursion with an accumulator per parameter
   // (sr_limb_fold_dense_kernel) instead of the forward sensitivities (which repeat the recursion per four parameters)
   if (n_par <= kFoldDensePar && g_jac_layer_forward.load() == 0) {
-    std::vector<int> far, near;
-    int l_min = 0, l_max = -1;
-    if (fold_sides(los, n_layers, &far, &near, &l_min, &l_max)) {
-      const int nr = los->n_rays;
-      std::vector<int> shells;
-      for (int k = l_max; k >= l_min; --k) {
-        bool any = false;
-        for (int r = 0; r < nr && !any; ++r) any = far[(size_t)r * n_layers + k] >= 0 || near[(size_t)r * n_layers + k] >= 0;
-        if (any) shells.push_back(k);
-      }
-      const int n_vis = (int)shells.size(), n_rec = nr * n_vis;
-      static thread_local Stager s_ring[4];
-      static thread_local unsigned s_next = 0;
-      Stager &sg = s_ring[s_next++ & 3];
-      const size_t plan_bytes = (sizeof(int) * 4 * (size_t)n_rec + 15) / 16 * 16;
-      rc = sg.prepare(plan_bytes + fold_dense_bytes(n_rec));
-      if (rc) return rc;
-      int *pl = sg.host<int>();
-      for (int r = 0; r < nr; ++r)
-        for (int v = 0; v < n_vis; ++v) {
-          int *q = pl + ((size_t)r * n_vis + v) * 4;
-          q[0] = shells[v];
-          q[1] = far[(size_t)r * n_layers + shells[v]];
-          q[2] = near[(size_t)r * n_layers + shells[v]];
-          q[3] = 0;
-        }
-      rc = sg.push_early(plan_bytes, st);
-      if (rc) return rc;
-      char *d = sg.d.as<char>();
-      LAUNCHCHK(launch_fold_dense(reinterpret_cast<const int *>(d), D.col, par_gas, n_par, D.n_seg, n_rec,
-                                  reinterpret_cast<FoldDense *>(d + plan_bytes), abs_c, emi_c, (int)n_pts, n_layers, nr, n_vis,
-                                  limb_opts(los, D.n_seg), rad, jac, st));
-      rc = sg.mark(st);
+    FoldStage F;
+    rc = stage_fold(los, n_layers, st, &F);
+    if (rc) return rc;
+    if (F.n_rec > 0) {
+      LAUNCHCHK(launch_fold_dense(F.plan, D.col, par_gas, n_par, D.n_seg, F.n_rec, F.rec, abs_c, emi_c, (int)n_pts, n_layers,
+                                  los->n_rays, F.n_vis, limb_opts(los, D.n_seg), rad, jac, st));
+      rc = F.slot->mark(st);
       if (rc) return rc;
       return D.slot->mark(st);
     }

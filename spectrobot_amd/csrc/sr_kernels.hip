@@ -2825,8 +2825,14 @@ __global__ void sr_fold_pack_kernel(const int *__restrict__ plan, const double *
   for (int g = 0; g < 4; ++g) {
     r.u_f[g] = g < n_gas && sf >= 0 ? col[(size_t)g * n_seg + sf] : 0.0;
     r.u_n[g] = g < n_gas && sn >= 0 ? col[(size_t)g * n_seg + sn] : 0.0;
-    same = same && r.u_f[g] == r.u_n[g];
+    same = same && fabs(r.u_f[g] - r.u_n[g]) <= 2e-15 * fabs(r.u_f[g]);
   }
+  // The two segments of a shell on a symmetric path have the same column; the column integration leaves them a few
+  // ulp apart in half of the cases (<= 4.4e-16 relative on the configs[3] rays): within 2e-15 they are taken as ONE
+  // value, and the segments share their attenuation.
+  if (same)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) r.u_n[g] = r.u_f[g];
 #pragma unroll
   for (int e = 0; e < kAdjEnt; ++e) {
     r.ent_p[e] = pl[4 + e];
@@ -3063,8 +3069,14 @@ __global__ void sr_fold_dense_pack_kernel(const int *__restrict__ plan, const do
   for (int g = 0; g < 4; ++g) {
     r.u_f[g] = g < n_gas && sf >= 0 ? col[(size_t)g * n_seg + sf] : 0.0;
     r.u_n[g] = g < n_gas && sn >= 0 ? col[(size_t)g * n_seg + sn] : 0.0;
-    same = same && r.u_f[g] == r.u_n[g];
+    same = same && fabs(r.u_f[g] - r.u_n[g]) <= 2e-15 * fabs(r.u_f[g]);
   }
+  // The two segments of a shell on a symmetric path have the same column; the column integration leaves them a few
+  // ulp apart in half of the cases (<= 4.4e-16 relative on the configs[3] rays): within 2e-15 they are taken as ONE
+  // value, and the segments share their attenuation.
+  if (same)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) r.u_n[g] = r.u_f[g];
 #pragma unroll
   for (int p = 0; p < kFoldDensePar; ++p) {
     r.dc_f[p] = p < n_par && sf >= 0 ? col[(size_t)(n_gas + p) * n_seg + sf] : 0.0;
@@ -3207,6 +3219,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   rad[(size_t)ray * n_pts + j] = Iobs + Iobs_lo;
 }
 
+// The radiances alone, folded (ray batches; BASELINE configs[2]: 64 rays): one sweep over the shells, a shell's coefficients
+// loaded once for the ray's two segments and -- the path being symmetric -- ONE attenuation() for both:
+// I_obs = I_f(tangent) Tn(all) + sum E f Tn over the near side (sr_limb_adjoint_fold_kernel's sweep 1).
+template <int NG>
+__global__ __launch_bounds__(256) void sr_limb_fold_fwd_kernel(const double *__restrict__ abs_c, const double *__restrict__ emi_c,
+                                                               int n_pts, int n_layers, const FoldDense *__restrict__ rec,
+                                                               LimbOpts o, int n_visits, int n_rays, double *__restrict__ rad) {
+  int pb, ray;
+  if (!limb_block((n_pts + 255) / 256, n_rays, pb, ray)) return;
+  const int j = pb * 256 + threadIdx.x;
+  if (j >= n_pts) return;
+  const FoldDense *rc = rec + (size_t)ray * n_visits;
+  const size_t gstride = (size_t)n_layers * n_pts;
+  double If = limb_initial(o, rad, (size_t)ray * n_pts + j, j), Tn = 1.0, cs = 0.0;
+  constexpr int kB = NG == 1 ? 4 : 2; // visits whose loads are issued together
+  for (int vb = 0; vb < n_visits; vb += kB) {
+    double a[kB][NG], e[kB][NG];
+#pragma unroll
+    for (int t = 0; t < kB; ++t) {
+      const size_t ofs = (size_t)rc[min(vb + t, n_visits - 1)].layer * n_pts + j;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        a[t][g] = abs_c[g * gstride + ofs];
+        e[t][g] = emi_c[g * gstride + ofs];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kB; ++t) {
+      if (vb + t >= n_visits) break;
+      const FoldDense &R = rc[vb + t];
+      if (!R.has) continue; // wave-uniform
+      Atten A;
+      if (R.has & 1) {
+        double tau = a[t][0] * R.u_f[0], E = e[t][0] * R.u_f[0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+          tau = tau + a[t][g] * R.u_f[g];
+          E = E + e[t][g] * R.u_f[g];
+        }
+        A = attenuation(tau);
+        If = If * A.t + (o.solo_absorption ? 0.0 : E * A.f);
+        if (R.has & 4) { // the near-side segment: same columns, same tau and E
+          cs = fma(o.solo_absorption ? 0.0 : E * Tn, A.f, cs);
+          Tn *= A.t;
+        }
+      }
+      if ((R.has & 6) == 2) {
+        double tau = a[t][0] * R.u_n[0], E = e[t][0] * R.u_n[0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+          tau = tau + a[t][g] * R.u_n[g];
+          E = E + e[t][g] * R.u_n[g];
+        }
+        A = attenuation(tau);
+        cs = fma(o.solo_absorption ? 0.0 : E * Tn, A.f, cs);
+        Tn *= A.t;
+      }
+    }
+  }
+  rad[(size_t)ray * n_pts + j] = fma(If, Tn, cs);
+}
+
+int launch_fold_fwd(const int *plan, const double *col, int n_seg, int n_rec, FoldDense *rec, const double *abs_c,
+                    const double *emi_c, int n_pts, int n_layers, int n_rays, int n_visits, const LimbOpts &o, double *rad,
+                    hipStream_t st) {
+  if (n_rec <= 0 || n_pts <= 0 || n_rays <= 0) return 0;
+  hipLaunchKernelGGL(sr_fold_dense_pack_kernel, dim3((n_rec + 63) / 64), dim3(64), 0, st, plan, col, o.n_gas, 0, n_seg, n_rec, rec);
+  const dim3 grid(limb_grid((n_pts + 255) / 256, n_rays));
+#define SR_FF(NG) hipLaunchKernelGGL(sr_limb_fold_fwd_kernel<NG>, grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, rec, o, n_visits, \
+                                     n_rays, rad)
+  switch (o.n_gas) { case 1: SR_FF(1); break; case 2: SR_FF(2); break; case 3: SR_FF(3); break; default: SR_FF(4); break; }
+#undef SR_FF
+  return (int)hipGetLastError();
+}
+
 size_t fold_dense_bytes(int n_rec) { return sizeof(FoldDense) * (size_t)n_rec; }
 
 int launch_fold_dense(const int *plan, const double *col, const int *par_gas_host, int n_par, int n_seg, int n_rec, FoldDense *rec,
@@ -3292,7 +3379,7 @@ int launch_limb(const double *abs_c, const double *emi_c, int n_pts, int n_layer
                 const int *seg_layer, const double *col, const LimbOpts &o, double *rad, hipStream_t st) {
   if (n_pts <= 0 || n_rays <= 0) return 0;
   // fewer than two waves per SIMD: the latency-bound variant (a function of the launch shape only)
-  if ((long)((n_pts + 63) / 64) * n_rays < 2048) {
+  if (limb_launch_is_small(n_pts, n_rays)) {
     const dim3 gs(limb_grid((n_pts + 63) / 64, n_rays));
 #define SR_LS(NG) hipLaunchKernelGGL(sr_limb_split_kernel<NG>, gs, dim3(64 * kLimbParts), 0, st, abs_c, emi_c, n_pts, n_layers, \
                                      seg_off, seg_layer, col, o, n_rays, rad)

@@ -200,6 +200,12 @@ size_t fold_dense_bytes(int n_rec);
 int launch_fold_dense(const int *plan, const double *col, const int *par_gas_host, int n_par, int n_seg, int n_rec, FoldDense *rec,
                       const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, int n_visits,
                       const LimbOpts &o, double *rad, double *jac_par, hipStream_t st);
+// The radiances of a ray batch, folded (sr_limb_fold_fwd_kernel; the plan and records of launch_fold_dense with no parameters)
+int launch_fold_fwd(const int *plan, const double *col, int n_seg, int n_rec, FoldDense *rec, const double *abs_c,
+                    const double *emi_c, int n_pts, int n_layers, int n_rays, int n_visits, const LimbOpts &o, double *rad,
+                    hipStream_t st);
+// launch_limb takes the latency-bound split kernel below this many waves
+inline bool limb_launch_is_small(int n_pts, int n_rays) { return (long)((n_pts + 63) / 64) * n_rays < 2048; }
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,
                     const int *seg_layer, const double *seg_col, int init_from_rad, double *rad,
                     hipStream_t st);

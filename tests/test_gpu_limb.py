@@ -343,6 +343,42 @@ def test_few_broad_parameters_folded_vs_forward(eng):
                 assert float(jac.abs().max()) > 0
 
 
+def test_ray_batch_radiances_folded_vs_path_order(eng):
+    """limb_rays on a launch of more than 2048 waves (ray batches: BASELINE configs[2]) runs the folded sweep
+    (sr_limb_fold_fwd_kernel: a shell's coefficients and attenuation once for the ray's two segments); mode 2 keeps the
+    path-order kernel.  Limb rays in both LOS orders, slant rays, an opaque case, a Planck background."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(9)
+    nl, n = 24, 16384
+    atm = _atm(nl)
+    z = atm["z"]
+    grid = syn.make_grid(2975.0, 5e-4, n)
+    t = lambda v: torch.tensor(np.ascontiguousarray(v), device="cuda")
+    vm = [np.full(nl, 1.2e-2), np.linspace(2e-3, 5e-4, nl)]
+    for scale in (1.0, 300.0):
+        a = [rng.uniform(0, 4e-18, (nl, n)) * scale, rng.uniform(0, 3e-17, (nl, n)) * scale]
+        e = [a[0] * rng.uniform(1e-8, 1e-7, (nl, n)), a[1] * rng.uniform(1e-8, 1e-7, (nl, n))]
+        coeffs = [(t(a[0]), t(e[0])), (t(a[1]), t(e[1]))]
+        for L in (syn.limb_los(z, atm["nd"] * 1e-6, vm, z[0] + 5.0 + 37.0 * np.arange(9)),
+                  syn.slant_los(z, atm["nd"] * 1e-6, vm, np.linspace(0.0, 80.0, 9))):
+            for opts in (dict(), dict(LOS_order="observer"), dict(solo_absorption=True, initial_temperature=200.0),
+                         dict(initial_temperature=150.0)):
+                los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827, 1.0], **opts)
+                g = grid if "initial_temperature" in opts else None
+                rad = eng.limb_rays(coeffs, los, grid=g)
+                eng.set_jac_layer_mode(2)
+                try:
+                    ref = eng.limb_rays(coeffs, los, grid=g)
+                finally:
+                    eng.set_jac_layer_mode(0)
+                if not opts and scale == 1.0:
+                    assert not torch.equal(rad, ref)   # two kernels (slant rays walked from the observer have no near side: same operations)
+                sc = ref.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+                assert float(((rad - ref).abs() / sc).max()) < 1e-13, (scale, opts)
+                assert float(((rad - ref).abs() / ref.abs().clamp_min(1e-300)).max()) < 1e-11, (scale, opts)   # pointwise too
+
+
 def test_per_level_partial_radiances_sum_to_total(eng):
     """single_rad[(gas, iso, lev)] (spect_main_module.py:2883-2887): the radiance emitted by one level and
     absorbed by the whole gas -- the level's emission share (sr_abscoeff_level_dev) with the total
