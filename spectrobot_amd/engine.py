@@ -462,9 +462,11 @@ def limb_rays(coeffs, los, grid=None, g_lo=0, rad0=None):
     return rad
 
 
-def limb_rays_jacobian(coeffs, los, par_gas, par_w, grid=None, g_lo=0, rad0=None):
+def limb_rays_jacobian(coeffs, los, par_gas, par_w, grid=None, g_lo=0, rad0=None, joint=False):
     """Radiances and d rad / d x_p [n_rays, n_par, n_pts] for VMR-profile parameters: the VMR of gas
-    par_gas[p] at LOS sample point i is sum_p par_w[p, i] x_p (sr_limb_rays_jac_dev)."""
+    par_gas[p] at LOS sample point i is sum_p par_w[p, i] x_p (sr_limb_rays_jac_dev).
+    joint=True: both live in ONE buffer [n_rays (1 + n_par), n_pts] -- the radiances' rows first -- which is returned
+    as a third value (one hires_to_lowres call, one copy to the host, for a retrieval iteration)."""
     a, e = _gas_stack(coeffs)
     n_gas, n_layers, n_pts = a.shape
     par_gas, pg = _i(par_gas)
@@ -472,13 +474,20 @@ def limb_rays_jacobian(coeffs, los, par_gas, par_w, grid=None, g_lo=0, rad0=None
     n_par = par_gas.size
     if par_w.shape != (n_par, los.n_pt):
         raise ValueError("par_w must be [n_par, n_pt]")
-    rad = rad0 if rad0 is not None else torch.empty((los.n_rays, n_pts), dtype=torch.float64, device="cuda")
-    jac = torch.empty((los.n_rays, n_par, n_pts), dtype=torch.float64, device="cuda")
+    buf = None
+    if joint:
+        if rad0 is not None:
+            raise ValueError("joint=True allocates the radiances itself (no rad0)")
+        buf = torch.empty((los.n_rays * (1 + n_par), n_pts), dtype=torch.float64, device="cuda")
+        rad, jac = buf[:los.n_rays], buf[los.n_rays:].view(los.n_rays, n_par, n_pts)
+    else:
+        rad = rad0 if rad0 is not None else torch.empty((los.n_rays, n_pts), dtype=torch.float64, device="cuda")
+        jac = torch.empty((los.n_rays, n_par, n_pts), dtype=torch.float64, device="cuda")
     d = los.desc(grid, g_lo, rad0=rad0 is not None)
     check(lib.sr_limb_rays_jac_dev(C.c_void_p(a.data_ptr()), C.c_void_p(e.data_ptr()), n_layers, n_pts, C.byref(d),
                                    n_par, pg, pw, C.c_void_p(rad.data_ptr()), C.c_void_p(jac.data_ptr()),
                                    _stream_ptr()), "sr_limb_rays_jac_dev")
-    return rad, jac
+    return (rad, jac, buf) if joint else (rad, jac)
 
 
 def limb_rays_layer_jacobian(coeffs, dcoeffs, los, grid=None, g_lo=0):

@@ -141,11 +141,11 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
         both = low[:, None, :]
     else:
         par_gas, par_w = scene.profile_weights(bayes_set, alt)
-        rad, jac = engine.limb_rays_jacobian(coeffs, los, par_gas, par_w)
-        low = lowres(rad)
+        # radiances and derivatives in one buffer: one instrument-step launch and one copy to the host per iteration
+        _, _, buf = engine.limb_rays_jacobian(coeffs, los, par_gas, par_w, joint=True)
         n_par = len(par_gas)
-        dlow = lowres(jac.reshape(n_los * n_par, -1)).reshape(n_los, n_par, -1)
-        both = np.concatenate([low[:, None, :], dlow], axis=1)
+        lo_all = lowres(buf)
+        both = np.concatenate([lo_all[:n_los, None, :], lo_all[n_los:].reshape(n_los, n_par, -1)], axis=1)
     if shard is not None:
         # the one exchange of a sharded iteration
         import torch
@@ -156,7 +156,22 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
     low = both[:, 0, :]
     dlow = None if bayes_set is None else both[:, 1:, :]
     sims, derivs = [], []
+    grid_lo = _Grid(scene.bands_nm)              # shared by the iteration's spectra (never modified)
+
+    def spectrum_of(v):
+        sp = Spectrum.__new__(Spectrum)
+        sp.spectrum, sp.spectral_grid = v, grid_lo
+        return sp
+
     for i, pix in enumerate(pixels):
+        if pix.fov_half > 0 and fov_closed_form:
+            # the closed form is linear in the three spectra: the pixel's radiances and all its derivatives at once
+            # (FOV_integr_1D per spectrum, 8 per pixel, was a third of a configs[4] iteration's host time)
+            fov = smm.fov_closed_form(both[3 * i], both[3 * i + 1], both[3 * i + 2], pix.pixel_rot)   # [1 + n_par, n_bands]
+            sims.append(spectrum_of(np.array(fov[0])))
+            if dlow is not None:
+                derivs.append([spectrum_of(np.array(fov[1 + p])) for p in range(dlow.shape[1])])
+            continue
         three = [Spectrum(low[3 * i + q], scene.bands_nm) for q in range(3)]
         if pix.fov_half > 0:
             sims.append(smm.FOV_integr_1D(three, pix.pixel_rot, closed_form=fov_closed_form))
