@@ -1809,6 +1809,7 @@ int stage_fold(const sr_los_desc *los, int n_layers, hipStream_t st, FoldStage *
     for (int r = 0; r < nr && !any; ++r) any = far[(size_t)r * n_layers + k] >= 0 || near[(size_t)r * n_layers + k] >= 0;
     if (any) shells.push_back(k);
   }
+  if ((size_t)nr * shells.size() > ((size_t)1 << 21)) return SR_OK; // (2M records = 436 MB of plan: such batches keep the path-order kernels)
   const int n_vis = (int)shells.size(), n_rec = nr * n_vis;
   static thread_local Stager s_ring[4];
   static thread_local unsigned s_next = 0;
