@@ -1756,8 +1756,10 @@ namespace {
 // rays; slant / nadir rays are the outward half, their first segment counted as the inward one): far / near
 // [n_rays][n_layers] = the segment's index in WALK order (LOS_order 'observer' reverses every ray, as stage_los lists the
 // columns) or -1, and the range of shells touched.  false: some ray is not of that shape.
-bool fold_sides(const sr_los_desc *los, int n_layers, std::vector<int> *far_out, std::vector<int> *near_out, int *l_min_out,
-                int *l_max_out) {
+// row_of_seg (caller's segment order, or NULL: seg_layer): the SHELL of a segment where that is not its coefficient row
+// (3-D paths: seg_jac_row).
+bool fold_sides(const sr_los_desc *los, int n_layers, const int32_t *row_of_seg, std::vector<int> *far_out,
+                std::vector<int> *near_out, int *l_min_out, int *l_max_out) {
   const int nr = los->n_rays;
   std::vector<int> &far = *far_out, &near = *near_out;
   far.assign((size_t)nr * n_layers, -1);
@@ -1766,7 +1768,7 @@ bool fold_sides(const sr_los_desc *los, int n_layers, std::vector<int> *far_out,
   bool ok = true;
   for (int r = 0; r < nr && ok; ++r) {
     const int a = los->seg_off[r], m = los->seg_off[r + 1] - a;
-    auto lay = [&](int q) { return los->seg_layer[los->los_order == 0 ? a + q : a + (m - 1 - q)]; };
+    auto lay = [&](int q) { return (row_of_seg ? row_of_seg : los->seg_layer)[los->los_order == 0 ? a + q : a + (m - 1 - q)]; };
     int q = 0, prev = INT_MAX;
     for (; q < m; ++q) { // far side: strictly inwards
       const int k = lay(q);
@@ -1801,7 +1803,7 @@ struct FoldStage {
 int stage_fold(const sr_los_desc *los, int n_layers, hipStream_t st, FoldStage *out) {
   std::vector<int> far, near;
   int l_min = 0, l_max = -1;
-  if (!fold_sides(los, n_layers, &far, &near, &l_min, &l_max)) return SR_OK;
+  if (!fold_sides(los, n_layers, nullptr, &far, &near, &l_min, &l_max)) return SR_OK;
   const int nr = los->n_rays;
   std::vector<int> shells;
   for (int k = l_max; k >= l_min; --k) {
@@ -2003,11 +2005,14 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
   int n_visits = 0, n_fvis = 0, n_frec = 0;
   const int nr = los->n_rays, n_batches = (nr + kAdjSyncRays - 1) / kAdjSyncRays;
   const int jmode = g_jac_layer_forward.load();
-  if (!seg_jrow && (jmode == 0 || (jmode == 3 && nr >= 2))) {
-    // per ray: far[layer] / near[layer] = walk-order segment index or -1
+  const bool two_rows = seg_jrow != nullptr;           // 3-D paths: a coefficient row per LOS step, shells = Jacobian rows
+  const int n_sh = two_rows ? n_jrows : n_layers;      // shells
+  const int fold_rays = two_rows ? 1 : kAdjFoldRays;   // rays per thread of the folded kernel
+  if (jmode == 0 || (jmode == 3 && nr >= 2 && !two_rows)) {
+    // per ray: far[shell] / near[shell] = walk-order segment index or -1
     std::vector<int> far, near;
-    int l_min = n_layers, l_max = -1;
-    const bool ok = fold_sides(los, n_layers, &far, &near, &l_min, &l_max);
+    int l_min = n_sh, l_max = -1;
+    const bool ok = fold_sides(los, n_sh, seg_jrow, &far, &near, &l_min, &l_max);
     // The folded plan (sr_limb_adjoint_fold_kernel, the default): one visit per shell, outermost first, with every
     // ray's far-side and near-side segment there; a column parameter's touches -- read off the per-segment plan -- are
     // planned over the VISITS (a level acts on the same shells on both sides: one run, one register, one store).
@@ -2015,25 +2020,30 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
       std::vector<int> shells;
       for (int k = l_max; k >= l_min; --k) {
         bool any = false;
-        for (int r = 0; r < nr && !any; ++r) any = far[(size_t)r * n_layers + k] >= 0 || near[(size_t)r * n_layers + k] >= 0;
+        for (int r = 0; r < nr && !any; ++r) any = far[(size_t)r * n_sh + k] >= 0 || near[(size_t)r * n_sh + k] >= 0;
         if (any) shells.push_back(k);
       }
       n_fvis = (int)shells.size();
-      const int nb = (nr + kAdjFoldRays - 1) / kAdjFoldRays;
-      n_frec = nb * n_fvis * kAdjFoldRays;
-      fplan.assign((size_t)n_frec * kAdjPlanInts, 0);
+      const int nb = (nr + fold_rays - 1) / fold_rays;
+      n_frec = nb * n_fvis * fold_rays;
+      fplan.assign((size_t)n_frec * kFoldPlanInts, 0);
       bool fits = true;
       std::vector<std::vector<int>> touch(n_par);
       std::vector<int> slot_of(std::max(n_par, 1)), pos(std::max(n_par, 1));
       std::vector<char> par_seen(std::max(n_par, 1));
-      for (int rr = 0; rr < nb * kAdjFoldRays && fits; ++rr) {
-        const int bt = rr / kAdjFoldRays, i = rr % kAdjFoldRays;
-        auto rec_at = [&](int v) { return &fplan[(((size_t)bt * n_fvis + v) * kAdjFoldRays + i) * kAdjPlanInts]; };
+      for (int rr = 0; rr < nb * fold_rays && fits; ++rr) {
+        const int bt = rr / fold_rays, i = rr % fold_rays;
+        auto rec_at = [&](int v) { return &fplan[(((size_t)bt * n_fvis + v) * fold_rays + i) * kFoldPlanInts]; };
         for (int v = 0; v < n_fvis; ++v) {
           int *pl = rec_at(v);
-          pl[0] = shells[v];
-          pl[1] = rr < nr ? far[(size_t)rr * n_layers + shells[v]] : -1;
-          pl[2] = rr < nr ? near[(size_t)rr * n_layers + shells[v]] : -1;
+          pl[1] = rr < nr ? far[(size_t)rr * n_sh + shells[v]] : -1;
+          pl[2] = rr < nr ? near[(size_t)rr * n_sh + shells[v]] : -1;
+          // coefficient rows: the segments' own (a side without a segment takes the other's: its loads are not used)
+          const int row_f = pl[1] >= 0 ? plan.seg[(size_t)pl[1] * kAdjPlanInts] : -1;
+          const int row_n = pl[2] >= 0 ? plan.seg[(size_t)pl[2] * kAdjPlanInts] : -1;
+          pl[0] = two_rows ? (row_f >= 0 ? row_f : std::max(row_n, 0)) : shells[v];
+          pl[12] = two_rows ? (row_n >= 0 ? row_n : std::max(row_f, 0)) : shells[v];
+          pl[13] = shells[v];
         }
         if (rr >= nr || n_par == 0) continue;
         for (int p = 0; p < n_par; ++p) touch[p].clear();
@@ -2087,7 +2097,7 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
         n_fvis = n_frec = 0;
       }
     } else
-    if (ok && l_max >= l_min) {
+    if (ok && l_max >= l_min && !two_rows) {
       // the visits every batch walks (a batch skips nothing: a visit none of its rays takes costs one load)
       std::vector<std::pair<int, int>> visits; // (side, layer)
       for (int k = l_max; k >= l_min; --k) {
@@ -2136,7 +2146,7 @@ int limb_adjoint(const double *abs_c, const double *emi_c, const double *dabs, c
   if (n_fvis > 0) {
     FoldRec *frec = reinterpret_cast<FoldRec *>(d + in_bytes);
     LAUNCHCHK(launch_fold_pack(reinterpret_cast<const int *>(d + o_fp), D.col, los->n_gas, n_seg, n_frec, frec, st));
-    LAUNCHCHK(launch_limb_adjoint_fold(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, nr, frec,
+    LAUNCHCHK(launch_limb_adjoint_fold(abs_c, emi_c, dabs, demi, (int)n_pts, n_layers, n_jrows, two_rows ? 1 : 0, nr, frec,
                                        reinterpret_cast<const int *>(d + o_zo), reinterpret_cast<const int *>(d + o_zr), n_par,
                                        limb_opts(los, D.n_seg), n_fvis, rad, jac_layer, jac_par, st));
     rc = sg.mark(st);

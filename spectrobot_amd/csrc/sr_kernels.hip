@@ -2802,25 +2802,27 @@ int launch_limb_adjoint_sync(const double *abs_c, const double *emi_c, const dou
 #define SR_FOLD_WAVES 4 // waves per SIMD the register allocation of the folded kernel aims at
 #endif
 struct __attribute__((aligned(16))) FoldRec { // one ray in one shell
-  int layer;            // row of the coefficient tables and of the per-layer Jacobian
-  int has;              // bit 0: far-side segment, bit 1: near-side segment, bit 2: both, with the same columns
-  int n_ent, pad;
+  int layer;            // row of the coefficient tables (1-D atmospheres: of both segments; 3-D paths: of the far-side one)
+  int has;              // bit 0: far-side segment, bit 1: near-side segment, bit 2: both, with the same columns (and rows)
+  int n_ent;
+  int layer_n;          // row of the near-side segment's coefficients (3-D paths: every LOS step has its own; else = layer)
+  int jrow, pad[3];     // row of the per-layer Jacobian (the shell)
   int ent_p[kAdjEnt], ent_gf[kAdjEnt]; // as SegProg
   double u_f[4], u_n[4];               // columns of the two segments
   double dc_f[kAdjEnt], dc_n[kAdjEnt]; // d col / d x_p of the entries, per side (0: that side does not touch it)
 };
-static_assert(sizeof(FoldRec) == 176, "FoldRec layout");
+static_assert(sizeof(FoldRec) == 192, "FoldRec layout");
 
-// plan: [n_rec][kAdjPlanInts] ints: layer, far segment, near segment (-1: none), n_ent, ent_p, ent_gf
+// plan: [n_rec][kFoldPlanInts] ints: layer, far segment, near segment (-1: none), n_ent, ent_p, ent_gf, layer_n, jrow
 __global__ void sr_fold_pack_kernel(const int *__restrict__ plan, const double *__restrict__ col, int n_gas, int n_seg, int n_rec,
                                     FoldRec *__restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rec) return;
-  const int *pl = plan + (size_t)i * kAdjPlanInts;
+  const int *pl = plan + (size_t)i * kFoldPlanInts;
   const int sf = pl[1], sn = pl[2];
   FoldRec r;
-  r.layer = pl[0]; r.n_ent = pl[3]; r.pad = 0;
-  bool same = sf >= 0 && sn >= 0;
+  r.layer = pl[0]; r.n_ent = pl[3]; r.layer_n = pl[12]; r.jrow = pl[13]; r.pad[0] = r.pad[1] = r.pad[2] = 0;
+  bool same = sf >= 0 && sn >= 0 && r.layer == r.layer_n;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     r.u_f[g] = g < n_gas && sf >= 0 ? col[(size_t)g * n_seg + sf] : 0.0;
@@ -2844,12 +2846,14 @@ __global__ void sr_fold_pack_kernel(const int *__restrict__ plan, const double *
   out[i] = r;
 }
 
-template <int NG, bool LAYER, bool PAR, int NR>
+// TWO: the two segments of a shell read different coefficient rows (3-D paths: a row per LOS step; one ray per thread)
+template <int NG, bool LAYER, bool PAR, int NR, bool TWO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAVES, SR_FOLD_WAVES))) void sr_limb_adjoint_fold_kernel(
     const double *__restrict__ abs_c, const double *__restrict__ emi_c, const double *__restrict__ dabs,
-    const double *__restrict__ demi, int n_pts, int n_layers, const FoldRec *__restrict__ rec, // [n_batches][n_visits][NR]
+    const double *__restrict__ demi, int n_pts, int n_layers, int n_jrows, const FoldRec *__restrict__ rec, // [n_batches][n_visits][NR]
     const int *__restrict__ zero_off, const int *__restrict__ zero_row, int n_par, LimbOpts o, int n_visits, int n_rays,
     double *__restrict__ rad, double *__restrict__ jac_layer, double *__restrict__ jac_par) {
+  static_assert(!TWO || NR == 1, "rows per ray: one ray per thread");
 #if SR_FOLD_XCD
   int pb, batch; // all batches of a point block on one XCD, one after the other (limb_block)
   if (!limb_block((n_pts + 255) / 256, (n_rays + NR - 1) / NR, pb, batch)) return;
@@ -2867,10 +2871,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAV
     if (ray >= n_rays) continue;
     for (int q = zero_off[ray]; q < zero_off[ray + 1]; ++q) { // rows this ray never touches
       const int row = zero_row[q];
-      if (row < n_layers) {
-        if (LAYER) jac_layer[((size_t)ray * n_layers + row) * n_pts + j] = 0.0;
+      if (row < n_jrows) {
+        if (LAYER) jac_layer[((size_t)ray * n_jrows + row) * n_pts + j] = 0.0;
       } else if (PAR) {
-        jac_par[((size_t)ray * n_par + (row - n_layers)) * n_pts + j] = 0.0;
+        jac_par[((size_t)ray * n_par + (row - n_jrows)) * n_pts + j] = 0.0;
       }
     }
   }
@@ -2890,11 +2894,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAV
   for (int v = 0; v < n_visits; ++v) {
     const FoldRec *rv = rc + (size_t)v * NR;
     const size_t ofs = (size_t)rv[0].layer * n_pts + j;
-    double a[NG], e[NG];
+    double a[NG], e[NG], a2[NG], e2[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       a[g] = abs_c[g * gstride + ofs];
       e[g] = emi_c[g * gstride + ofs];
+      if (TWO) {
+        const size_t ofs2 = (size_t)rv[0].layer_n * n_pts + j;
+        a2[g] = abs_c[g * gstride + ofs2];
+        e2[g] = emi_c[g * gstride + ofs2];
+      } else {
+        a2[g] = a[g];
+        e2[g] = e[g];
+      }
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -2916,8 +2928,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAV
         double tau = 0.0, E = 0.0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          tau = g == 0 ? a[g] * R.u_n[g] : tau + a[g] * R.u_n[g];
-          E = g == 0 ? e[g] * R.u_n[g] : E + e[g] * R.u_n[g];
+          tau = g == 0 ? a2[g] * R.u_n[g] : tau + a2[g] * R.u_n[g];
+          E = g == 0 ? e2[g] * R.u_n[g] : E + e2[g] * R.u_n[g];
         }
         two_sum_add(rem[r], rem_lo[r], tau);
         if (!(R.has & 4)) A = attenuation(tau);
@@ -2944,7 +2956,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAV
   for (int v = 0; v < n_visits; ++v) {
     const FoldRec *rv = rc + (size_t)v * NR;
     const size_t ofs = (size_t)rv[0].layer * n_pts + j;
-    double a[NG], e[NG], da[NG], de[NG];
+    double a[NG], e[NG], da[NG], de[NG], a2[NG], e2[NG], da2[NG], de2[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       a[g] = abs_c[g * gstride + ofs];
@@ -2952,6 +2964,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAV
       if (LAYER) {
         da[g] = dabs[g * gstride + ofs];
         de[g] = demi[g * gstride + ofs];
+      }
+      if (TWO) {
+        const size_t ofs2 = (size_t)rv[0].layer_n * n_pts + j;
+        a2[g] = abs_c[g * gstride + ofs2];
+        e2[g] = emi_c[g * gstride + ofs2];
+        if (LAYER) {
+          da2[g] = dabs[g * gstride + ofs2];
+          de2[g] = demi[g * gstride + ofs2];
+        }
+      } else {
+        a2[g] = a[g];
+        e2[g] = e[g];
+        if (LAYER) {
+          da2[g] = da[g];
+          de2[g] = de[g];
+        }
       }
     }
 #pragma unroll
@@ -2987,11 +3015,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAV
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           const double u = R.u_n[g];
-          tau = g == 0 ? a[g] * u : tau + a[g] * u;
-          E = g == 0 ? e[g] * u : E + e[g] * u;
+          tau = g == 0 ? a2[g] * u : tau + a2[g] * u;
+          E = g == 0 ? e2[g] * u : E + e2[g] * u;
           if (LAYER) {
-            dtau = fma(da[g], u, dtau);
-            dE = fma(de[g], u, dE);
+            dtau = fma(da2[g], u, dtau);
+            dE = fma(de2[g], u, dE);
           }
         }
         if (!(R.has & 4)) {
@@ -3011,17 +3039,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAV
         if (LAYER) d += fma(wt_n, dtau, we_n * dE);
         Tn[r] *= A.t;
       }
-      if (LAYER) jac_layer[((size_t)ray * n_layers + R.layer) * n_pts + j] = d;
+      if (LAYER) jac_layer[((size_t)ray * n_jrows + R.jrow) * n_pts + j] = d;
       if (PAR) {
         for (int i = 0; i < R.n_ent; ++i) {
           const int gf = R.ent_gf[i], g = gf & 0xff, sl = (gf >> 8) & 0xff, fl = gf >> 16;
-          double ag = a[0], eg = e[0];
+          double ag = a[0], eg = e[0], ag2 = a2[0], eg2 = e2[0];
 #pragma unroll
           for (int q = 1; q < NG; ++q) {
             ag = g == q ? a[q] : ag;
             eg = g == q ? e[q] : eg;
+            ag2 = g == q ? a2[q] : ag2;
+            eg2 = g == q ? e2[q] : eg2;
           }
-          double val = fma(fma(wt_f, ag, we_f * eg), R.dc_f[i], fma(wt_n, ag, we_n * eg) * R.dc_n[i]);
+          double val = fma(fma(wt_f, ag, we_f * eg), R.dc_f[i], fma(wt_n, ag2, we_n * eg2) * R.dc_n[i]);
           if (!(fl & 1)) val += sl == 0 ? slot[r][0] : (sl == 1 ? slot[r][1] : (sl == 2 ? slot[r][2] : slot[r][3]));
           if (fl & 2) {
             double *out = jac_par + ((size_t)ray * n_par + R.ent_p[i]) * n_pts + j;
@@ -3314,22 +3344,44 @@ int launch_fold_dense(const int *plan, const double *col, const int *par_gas_hos
 size_t fold_rec_bytes(int n_rec) { return sizeof(FoldRec) * (size_t)n_rec; }
 
 int launch_fold_pack(const int *plan, const double *col, int n_gas, int n_seg, int n_rec, FoldRec *out, hipStream_t st) {
+  static_assert(kFoldPlanInts == 4 + 2 * kAdjEnt + 2, "fold plan layout");
   if (n_rec <= 0) return 0;
   hipLaunchKernelGGL(sr_fold_pack_kernel, dim3((n_rec + 63) / 64), dim3(64), 0, st, plan, col, n_gas, n_seg, n_rec, out);
   return (int)hipGetLastError();
 }
 
 int launch_limb_adjoint_fold(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
-                             int n_layers, int n_rays, const FoldRec *rec, const int *zero_off, const int *zero_row, int n_par,
-                             const LimbOpts &o, int n_visits, double *rad, double *jac_layer, double *jac_par, hipStream_t st) {
+                             int n_layers, int n_jrows, int two_rows, int n_rays, const FoldRec *rec, const int *zero_off,
+                             const int *zero_row, int n_par, const LimbOpts &o, int n_visits, double *rad, double *jac_layer,
+                             double *jac_par, hipStream_t st) {
   if (n_pts <= 0 || n_rays <= 0 || n_visits <= 0) return 0;
+  if (two_rows) { // one ray per thread, a coefficient row per segment
+#if SR_FOLD_XCD
+    const dim3 grid2(limb_grid((n_pts + 255) / 256, n_rays));
+#else
+    const dim3 grid2((n_pts + 255) / 256, n_rays);
+#endif
+#define SR_AF2(NG, L, P) hipLaunchKernelGGL((sr_limb_adjoint_fold_kernel<NG, L, P, 1, true>), grid2, dim3(256), 0, st, abs_c, emi_c, \
+                                            dabs, demi, n_pts, n_layers, n_jrows, rec, zero_off, zero_row, n_par, o, n_visits, n_rays, \
+                                            rad, jac_layer, jac_par)
+#define SR_AF23(NG)                                                    \
+  do {                                                                 \
+    if (jac_layer && jac_par) SR_AF2(NG, true, true);                  \
+    else if (jac_layer) SR_AF2(NG, true, false);                       \
+    else SR_AF2(NG, false, true);                                      \
+  } while (0)
+    switch (o.n_gas) { case 1: SR_AF23(1); break; case 2: SR_AF23(2); break; case 3: SR_AF23(3); break; default: SR_AF23(4); break; }
+#undef SR_AF23
+#undef SR_AF2
+    return (int)hipGetLastError();
+  }
 #if SR_FOLD_XCD
   const dim3 grid(limb_grid((n_pts + 255) / 256, (n_rays + kAdjFoldRays - 1) / kAdjFoldRays));
 #else
   const dim3 grid((n_pts + 255) / 256, (n_rays + kAdjFoldRays - 1) / kAdjFoldRays);
 #endif
-#define SR_AF(NG, L, P) hipLaunchKernelGGL((sr_limb_adjoint_fold_kernel<NG, L, P, kAdjFoldRays>), grid, dim3(256), 0, st, abs_c, emi_c, \
-                                           dabs, demi, n_pts, n_layers, rec, zero_off, zero_row, n_par, o, n_visits, n_rays, rad,      \
+#define SR_AF(NG, L, P) hipLaunchKernelGGL((sr_limb_adjoint_fold_kernel<NG, L, P, kAdjFoldRays, false>), grid, dim3(256), 0, st, abs_c, emi_c, \
+                                           dabs, demi, n_pts, n_layers, n_jrows, rec, zero_off, zero_row, n_par, o, n_visits, n_rays, rad, \
                                            jac_layer, jac_par)
 #define SR_AF3(NG)                                                     \
   do {                                                                 \

@@ -181,7 +181,7 @@ int launch_limb_adjoint_sync(const double *abs_c, const double *emi_c, const dou
                              const int *zero_row, int n_par, const LimbOpts &o, const int *sched, int n_visits, double *rad,
                              double *jac_layer, double *jac_par, hipStream_t st);
 // The folded variant (sr_limb_adjoint_fold_kernel): both segments of a ray in a shell together, every Jacobian value
-// stored once.  plan [n_batches][n_visits][kAdjFoldRays][kAdjPlanInts] = layer, far segment, near segment, n_ent, ent_p[4], ent_gf[4]
+// stored once.  plan [n_batches][n_visits][rays per thread][kFoldPlanInts]
 #ifndef SR_ADJ_FOLD_RAYS
 #define SR_ADJ_FOLD_RAYS 1 // rays per thread: 1: 1.28-1.39 ms per configs[3] set, 2: 1.45-1.53, 4: 2.3 (spills); path order: 2.1 (tools/adjoint_probe.py)
 #endif
@@ -189,9 +189,12 @@ constexpr int kAdjFoldRays = SR_ADJ_FOLD_RAYS;
 struct FoldRec;
 size_t fold_rec_bytes(int n_rec);
 int launch_fold_pack(const int *plan, const double *col, int n_gas, int n_seg, int n_rec, FoldRec *out, hipStream_t st);
+constexpr int kFoldPlanInts = 4 + 2 * 4 + 2; // layer, far segment, near segment, n_ent, ent_p[4], ent_gf[4], layer_n, jrow
+// two_rows: the two segments of a shell read different coefficient rows (3-D paths); one ray per thread then
 int launch_limb_adjoint_fold(const double *abs_c, const double *emi_c, const double *dabs, const double *demi, int n_pts,
-                             int n_layers, int n_rays, const FoldRec *rec, const int *zero_off, const int *zero_row, int n_par,
-                             const LimbOpts &o, int n_visits, double *rad, double *jac_layer, double *jac_par, hipStream_t st);
+                             int n_layers, int n_jrows, int two_rows, int n_rays, const FoldRec *rec, const int *zero_off,
+                             const int *zero_row, int n_par, const LimbOpts &o, int n_visits, double *rad, double *jac_layer,
+                             double *jac_par, hipStream_t st);
 // The folded recursion for up to kFoldDensePar column parameters whose masks may cover the whole path (one accumulator
 // per parameter): sr_limb_fold_dense_kernel.  plan [n_rays][n_visits][4] = layer, far segment, near segment, 0
 constexpr int kFoldDensePar = 8;
