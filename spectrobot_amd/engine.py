@@ -436,9 +436,20 @@ class LimbLOS(object):
         return out
 
 
+def gas_stack(coeffs):
+    """The gases' coefficient tables stacked once, [n_gas, n_layers, n_pts] x 2, for callers that pass the same tables to
+    many limb_rays* calls (a retrieval loop whose coefficients do not change: the stacking copies every table)."""
+    return _gas_stack(coeffs)
+
+
 def _gas_stack(coeffs):
-    """[(abs, emi)] per gas or one (abs, emi) pair -> contiguous CUDA [n_gas, n_layers, n_pts] x 2."""
+    """[(abs, emi)] per gas, one (abs, emi) pair or an already stacked pair (gas_stack) -> contiguous CUDA
+    [n_gas, n_layers, n_pts] x 2."""
     if isinstance(coeffs[0], torch.Tensor):
+        if coeffs[0].dim() == 3:
+            a, e = coeffs
+            assert a.is_cuda and a.dtype == torch.float64 and e.shape == a.shape and a.is_contiguous() and e.is_contiguous()
+            return a, e
         coeffs = [coeffs]
     a = torch.stack([c[0] for c in coeffs]).contiguous() if len(coeffs) > 1 else coeffs[0][0].contiguous()[None]
     e = torch.stack([c[1] for c in coeffs]).contiguous() if len(coeffs) > 1 else coeffs[0][1].contiguous()[None]

@@ -88,6 +88,16 @@ class LimbScene(object):
                 g.coeffs_shard = (g_lo, g_hi)
         return [g.coeffs for g in self.gases]
 
+    def coefficient_stack(self, refresh=False, g_lo=0, g_hi=None):
+        """coefficients() as the stacked pair the limb_rays* calls work on (engine.gas_stack), re-stacked only when a
+        gas's tables were recomputed: a VMR retrieval passes the same tables in every iteration."""
+        co = self.coefficients(refresh=refresh, g_lo=g_lo, g_hi=g_hi)
+        key = tuple(id(c[0]) for c in co) + tuple(id(c[1]) for c in co)
+        if getattr(self, "_stack_key", None) != key:
+            self._stack, self._stack_key = engine.gas_stack(co), key
+            self._stack_of = co          # keeps the ids alive
+        return self._stack
+
     def los(self, tangent_alts, **opts):
         """engine.LimbLOS of rays with the given tangent altitudes (photon order) + the sample altitudes."""
         L = syn.limb_los(self.z, self.nd, [g.vmr for g in self.gases], tangent_alts, R=self.R, n_sub=self.n_sub)
@@ -98,15 +108,23 @@ class LimbScene(object):
     def profile_weights(self, bayes_set, alt):
         """par_gas [n_par], par_w [n_par, n_pt]: the masks of every retrieved parameter at the LOS sample
         altitudes (masks are piecewise linear on the altitude levels, like the VMR between them)."""
+        # masks and sample altitudes do not change between the iterations of a retrieval
+        params = list(bayes_set.params())
+        key = (tuple(np.asarray(par.maskgrid.mask, dtype=float).tobytes() for par in params), tuple(par.nameset for par in params), alt.tobytes())
+        cached = getattr(self, "_weights_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1], cached[2]
         names = [g.name for g in self.gases]
         top = self.z[-1] + (self.z[-1] - self.z[-2])
         zz = np.append(self.z, top)
         par_gas, par_w = [], []
-        for par in bayes_set.params():
+        for par in params:
             par_gas.append(names.index(par.nameset))
             m = np.asarray(par.maskgrid.mask, dtype=float)
             par_w.append(np.interp(alt, zz, np.append(m, m[-1])))
-        return np.array(par_gas, np.int32), np.array(par_w)
+        out = (np.array(par_gas, np.int32), np.array(par_w))
+        self._weights_cache = (key, out[0], out[1])
+        return out
 
 
 def shard_with_halo(n_grid, g_lo, g_hi):
@@ -132,7 +150,7 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
     los, alt = scene.los(alts)
     n_grid = len(scene.grid)
     g_lo, g_hi = (0, n_grid) if shard is None else shard_with_halo(n_grid, *shard)
-    coeffs = scene.coefficients(refresh=refresh, g_lo=g_lo, g_hi=g_hi)
+    coeffs = scene.coefficient_stack(refresh=refresh, g_lo=g_lo, g_hi=g_hi)
     n_los = len(alts)
     lowres = lambda r: engine.hires_to_lowres(r, scene.grid, scene.bands_nm, scene.widths_nm, out_units=scene.out_units, g_lo=g_lo)
     if bayes_set is None:
