@@ -115,7 +115,7 @@ def serial_kernel_times_and_counts(engine, ls, step, n=5):
     return serial_kms, counts
 
 
-def coefficient_roofline(serial_kms, counts, far_field=2):
+def coefficient_roofline(serial_kms, counts, far_field=3):
     """roofline object of the dominant coefficient kernel from its stand-alone duration and executed work."""
     far_name = ("sr_farfield_kernel" if far_field == 1 else
                 "sr_farfield_kernel (level 0) + sr_s2m_kernel + sr_m2m_kernel + sr_m2l_kernel")
@@ -133,7 +133,7 @@ def coefficient_roofline(serial_kms, counts, far_field=2):
             "kernel": dom, "kernel_ms": d["ms"], "flops_per_launch": d["executed_flops"],
             "executed_counts": counts, "flop_model": FLOP, "kernels": per_kernel,
             "sr_prep_kernel_ms": float(serial_kms[0]),
-            "mode": "far-field (box pairs)" if far_field == 2 else "far-field (per line)"}
+            "mode": "far-field (box pairs)" if far_field in (2, 3) else "far-field (per line)"}
 
 
 def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total, rays, gpu=None):
@@ -218,8 +218,8 @@ def main():
     ap.add_argument("--3d", dest="three_d", action="store_true", help="--config 3 in its 3-D form: a coefficient row per LOS "
                     "step (P, T, T_vib at the local SZA along the path), Jacobians per altitude layer")
     ap.add_argument("--exact", action="store_true", help="evaluate every (line, point) exactly (no far-field expansions)")
-    ap.add_argument("--far-field", type=int, default=2, choices=(1, 2), help="2 (default): far-field expansions from box "
-                    "pairs (multipole -> local); 1: per line and box")
+    ap.add_argument("--far-field", type=int, default=3, choices=(1, 2, 3), help="3 (default): far-field expansions from box "
+                    "pairs (multipole -> local), sparse line sets per line and box; 2: box pairs always; 1: per line and box")
     args = ap.parse_args()
     args.config = args.config if args.config == "lut" else int(args.config)
 
@@ -387,7 +387,7 @@ def main():
                        "sharding": ("spectral window / %d, one all-gather per step (backend %s: nccl = RCCL over xGMI)"
                                     % (world, dist_rec["backend"]) if world > 1 else
                                     ("ONLY shard %s timed (tuning aid)" % args.shard if args.shard else "none")),
-                       "mode": "exact" if args.exact else ("far-field, box pairs" if args.far_field == 2 else "far-field, per line"), "device": info["name"],
+                       "mode": "exact" if args.exact else ("far-field, box pairs" if args.far_field in (2, 3) else "far-field, per line"), "device": info["name"],
                        "cu_count": info["cu_count"]},
             "roofline": roofline,
             "roofline_hbm": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -371,10 +371,13 @@ int sr_hires_to_lowres_shard_dev(const double *rad, int n_rays, int64_t n_pts, i
 
 /* Evaluation mode of the coefficient op.  Far region-1 wings by local Taylor expansions per box of grid
  * points (truncation <= 2.6e-13 of a line's own contribution), near field exact, with the expansions built
- * 2 (default): from box pairs -- multipole moments of the lines of a source box (sr_s2m_kernel, sr_m2m_kernel)
+ * 2: from box pairs -- multipole moments of the lines of a source box (sr_s2m_kernel, sr_m2m_kernel)
  *    translated to every well-separated target box of the level (sr_m2l_kernel), per-line expansions only for
  *    the (line, box) pairs no box pair covers;
- * 1: per line and box at every level (sr_farfield_kernel).
+ * 1: per line and box at every level (sr_farfield_kernel);
+ * 3 (default): 2 -- except for line sets with fewer than 0.35 lines per grid point (the per-level sub-linesets of the
+ *    pair tables and look-up tables), which take 1: the box pairs cost S2M / M2M / M2L over every box whatever it
+ *    holds (environment SR_SPARSE_FF1: the threshold);
  * 0: every (line, point) evaluated exactly (sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel). */
 int sr_set_far_field(int on);
 /* Far-field mode only.  1, 2: sr_abscoeff_near_zones_kernel runs on a second, internal stream beside

@@ -218,7 +218,7 @@ struct HostLines {
 // Process-wide mode switches (sr_set_*).  Atomic: a call reads each ONCE at entry and works with that
 // snapshot, so flipping a switch from another thread never changes a call half way.
 std::atomic<int> g_variant{8};   // points per lane in the exact wings kernel
-std::atomic<int> g_far_field{2}; // 1: far wings by per-line local expansions, 2: by box pairs (multipole -> local), 0: every evaluation exact
+std::atomic<int> g_far_field{3}; // 1: far wings by per-line local expansions, 2: by box pairs (multipole -> local), 3 (default): 2, but sparse line sets by 1, 0: every evaluation exact
 std::atomic<int> g_overlap{1};   // 1 (default), 2: zones kernel on a second stream beside the far-field kernel, next call's prep pipelined (2: gated behind FF+zones; measured equal)
 // sr_set_jac_layer_mode; SR_JAC_LAYER_MODE (environment, read once at load): its initial value, for A/B runs of whole programs
 std::atomic<int> g_jac_layer_forward{[] { const char *e = getenv("SR_JAC_LAYER_MODE"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 3 ? v : 0; }()};
@@ -397,7 +397,7 @@ int sr_set_table_budget(int64_t bytes) {
 }
 
 int sr_set_far_field(int on) {
-  g_far_field.store(on < 0 ? 0 : (on > 2 ? 2 : on));
+  g_far_field.store(on < 0 ? 0 : (on > 3 ? 3 : on));
   return SR_OK;
 }
 
@@ -728,7 +728,15 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   for (int k = 0; k < nl; ++k)
     if (!(atm->temps[k] > 0.0) || !(atm->press[k] >= 0.0)) return SR_ERR_ARG;
   // one snapshot of the mode switches per call
-  const int far_field = g_far_field.load(), overlap = g_overlap.load(), variant = g_variant.load();
+  const int overlap = g_overlap.load(), variant = g_variant.load();
+  // Sparse line sets (the per-level sub-linesets of the pair tables: 9-15 % of a hot-band list): the box-pair far field
+  // has a fixed cost per box and layer -- S2M, M2M, M2L over every box whatever it holds -- that the per-line
+  // expansions at every level (mode 1) do not have: below ~0.37 lines per grid point they are the faster route
+  // (tools/ff_mode_crossover.py: 0.3: 2.54 vs 2.61 ms, 0.4: 3.07 vs 3.03, 1.0: 6.74 vs 5.62; the 12 pair tables of the
+  // configs[1] list 19.1 vs 21.5 ms).  Mode 3 (the default) switches; SR_SPARSE_FF1 = the threshold (0: always box pairs).
+  static const double sparse_thr = [] { const char *e = getenv("SR_SPARSE_FF1"); return e ? atof(e) : 0.35; }();
+  const int far_mode = g_far_field.load();
+  const int far_field = far_mode == 3 ? ((double)ls->n_lines < sparse_thr * (double)ls->gp.n_grid ? 1 : 2) : far_mode;
   const bool counting = g_counting.load() != 0 && far_field;
   const size_t table_budget = g_table_budget.load();
 

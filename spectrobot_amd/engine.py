@@ -734,12 +734,13 @@ def set_jac_layer_mode(forward):
     check(lib.sr_set_jac_layer_mode(int(forward)), "sr_set_jac_layer_mode")
 
 
-FAR_FIELD_DEFAULT = 2  # the library's default far-field mode (sr_set_far_field)
+FAR_FIELD_DEFAULT = 3  # the library's default far-field mode (sr_set_far_field)
 
 
 def set_far_field(on):
     """1: far wings by per-line local expansions; 2: by box pairs (multipole moments of the lines of a source
-    box, translated to the local expansions of the well-separated target boxes); 0: every evaluation exact."""
+    box, translated to the local expansions of the well-separated target boxes); 3 (default): box pairs, sparse line
+    sets (< 0.35 lines per grid point: per-level sub-linesets) by per-line expansions; 0: every evaluation exact."""
     check(lib.sr_set_far_field(int(on)), "sr_set_far_field")
 
 
