@@ -216,8 +216,11 @@ def config3_3d(args, rank, world, info, base):
         return engine.limb_rays_jacobians(co, Lr["los"], dcoeffs=dco, par_gas=pg, par_w=Lr["W"], seg_jac_row=Lr["seg_alt_layer"],
                                           n_jac_rows=args.layers)
 
+    state = {}
+
     def step_factored():
-        lf = engine.LevelFactored(ls, T_rows, P_rows, dT=DT_FACTORED)
+        # the tables are REBUILT every step (a retrieval iteration moves the temperatures), in place
+        lf = state["lf"].rebuild(T_rows, P_rows) if "lf" in state else state.setdefault("lf", engine.LevelFactored(ls, T_rows, P_rows, dT=DT_FACTORED))
         # ONE combine for the steps of all sets: the tables are read once (per set: once per set)
         (ca, ce), (da, de) = lf.steps(step_row, tvib=tv_all, derivative=True)
         res, at = None, 0
@@ -408,8 +411,11 @@ def main(args):
         tv_all = np.concatenate([a["tvib"] for a in atms], axis=1)
         timing = {}
 
+        state = {}
+
         def step_factored():
-            lf = engine.LevelFactored(ls, T_rows, P_rows, dT=DT_FACTORED)
+            # the tables are REBUILT every step (a retrieval iteration moves the temperatures), in place
+            lf = state["lf"].rebuild(T_rows, P_rows) if "lf" in state else state.setdefault("lf", engine.LevelFactored(ls, T_rows, P_rows, dT=DT_FACTORED))
             (ca, ce), (da, de) = lf.steps(row0, tvib=tv_all, derivative=True)     # all sets' layers in one combine
             res = None
             for i in range(len(my)):

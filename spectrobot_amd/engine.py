@@ -325,17 +325,27 @@ class LevelFactored(object):
         1.5e-4 of truncation where the exact-weight quotient needed 0.002 K and sat on the reference's
         single-precision staircase (1e-7 |c| / dT = 1e-3 of the derivative)."""
         self.ls = ls
+        self.dT = dT
+        self._shard, self._linear = (g_lo, g_hi), linear_weights
+        self.tab = self.tab_dT = None
+        self.rebuild(temps_rows, press_rows)
+
+    def rebuild(self, temps_rows, press_rows):
+        """New (P, T) rows (a retrieval iteration that moved the temperatures): the tables are rebuilt IN PLACE when the
+        number of rows is the same -- 6 GB per build at configs[3] size stay out of the allocator."""
+        ls, (g_lo, g_hi) = self.ls, self._shard
         self.temps = np.ascontiguousarray(temps_rows, dtype=np.float64)
         self.press = np.ascontiguousarray(press_rows, dtype=np.float64)
-        self.dT = dT
-        self.tab = ls.glevel_pairs(self.temps, self.press, g_lo=g_lo, g_hi=g_hi)
-        self.tab_dT = None
-        if dT:
-            ls.set_bounds_temps(self.temps, linear_weights=linear_weights)
+        keep = self.tab is not None and self.tab.shape[2] == self.temps.size
+        self.tab = ls.glevel_pairs(self.temps, self.press, g_lo=g_lo, g_hi=g_hi, out=self.tab if keep else None)
+        if self.dT:
+            ls.set_bounds_temps(self.temps, linear_weights=self._linear)
             try:
-                self.tab_dT = ls.glevel_pairs(self.temps + dT, self.press, g_lo=g_lo, g_hi=g_hi)
+                self.tab_dT = ls.glevel_pairs(self.temps + self.dT, self.press, g_lo=g_lo, g_hi=g_hi,
+                                              out=self.tab_dT if keep and self.tab_dT is not None else None)
             finally:
                 ls.set_bounds_temps(None)
+        return self
 
     @staticmethod
     def unique_rows(temps, press):
