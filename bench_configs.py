@@ -98,7 +98,7 @@ def los_3d_set(atm, vm, tz, sza, az):
 
 
 ROUTE = _os.environ.get("SR_CONFIG3_ROUTE", "factored")     # "direct": a folded coefficient op per set (rounds 1-3)
-DT_FACTORED = 0.05     # K, difference of the pair tables' SHAPES (line weights linearised about T: engine.LevelFactored)
+DT_FACTORED = float(os.environ.get("SR_DT_FACTORED", "0.02"))   # K: the T + dT tables of the level-factored route (linearised weights): error of the radiance Jacobian against central differences 5.8e-4 / 3.5e-4 / 8.0e-4 / 1.5e-3 at 0.01 / 0.02 / 0.05 / 0.1 K
 
 
 def layer_vmr_weights(z, alt):
