@@ -736,7 +736,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   // configs[1] list 19.1 vs 21.5 ms).  Mode 3 (the default) switches; SR_SPARSE_FF1 = the threshold (0: always box pairs).
   static const double sparse_thr = [] { const char *e = getenv("SR_SPARSE_FF1"); return e ? atof(e) : 0.35; }();
   const int far_mode = g_far_field.load();
-  const int far_field = far_mode == 3 ? ((double)ls->n_lines < sparse_thr * (double)ls->gp.n_grid ? 1 : 2) : far_mode;
+  const bool sparse_set = far_mode == 3 && (double)ls->n_lines < sparse_thr * (double)ls->gp.n_grid;
+  const int far_field = far_mode == 3 ? (sparse_set ? 1 : 2) : far_mode;
   const bool counting = g_counting.load() != 0 && far_field;
   const size_t table_budget = g_table_budget.load();
 
@@ -1081,6 +1082,9 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     fp.pm = d_pm;
     fp.coef = w.d_coef[b].as<double>();
     fp.m2l = far_field == 2 ? 1 : 0;
+    // SR_SPARSE_ROWS=0 (tuning): the sparse sets through sr_farfield_kernel (a layer per wave) as the explicit mode 1
+    static const int rows_env = [] { const char *e = getenv("SR_SPARSE_ROWS"); return e ? atoi(e) : 1; }();
+    fp.rows = sparse_set && rows_env ? 1 : 0;
     fp.pm_src = d_pm + nl;
     fp.disp_lo_end = (int)std::min<int64_t>(std::max<int64_t>(ls->n_disp_lo - line_lo, 0), n_sub);
     fp.disp_hi_begin = (int)std::min<int64_t>(std::max<int64_t>(ls->n_lines - ls->n_disp_hi - line_lo, 0), n_sub);

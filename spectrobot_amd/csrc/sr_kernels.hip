@@ -850,6 +850,165 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
   if (COUNT) count_add(cnt, kCntExpansions, n_exp, lane);
 }
 
+// The per-line scheme for SPARSE line sets (the per-level passes of the pair tables: 0.09-0.16 lines per grid point):
+// sr_farfield_kernel gives a (box, level, layer) a wave whatever the box holds -- five or six lines in one chunk body
+// of ~230 instructions at a tenth of its lanes, behind ~450 of range searches, reduction and indexing: 0.34 of the pass's
+// 0.53 ms were that.  Here a wave takes a box for kFarRows LAYERS: lane = (line of the chunk, layer), eight lines x
+// eight layers per chunk body; the candidate ranges are the union over the wave's layers (the exact admissibility tests
+// run per lane with its layer's margins), the 2 kFC sums are reduced over the eight lanes of a layer (three exchange
+// steps instead of six).  Same expansions, same owner of every (line, box): the coefficients differ from
+// sr_farfield_kernel<., false>'s by the summation order.
+constexpr int kFarRows = 8;
+template <int N, int M>
+__device__ inline void lane_reduce_slots(int lane, int *idx) { // which of the N values v[i] holds after lane_reduce<N, M>
+  if constexpr (M >= 1) {
+    constexpr int half = N / 2;
+    const bool up = (lane & M) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) idx[i] = up ? idx[i + half] : idx[i];
+    if constexpr (N & 1) idx[half] = idx[2 * half];
+    lane_reduce_slots<half + (N & 1), M / 2>(lane, idx);
+  }
+}
+template <int N, int M>
+constexpr int lane_reduce_left() { // values per lane after lane_reduce<N, M>
+  if constexpr (M >= 1) return lane_reduce_left<N / 2 + (N & 1), M / 2>(); else return N;
+}
+template <bool COUNT>
+__global__ __launch_bounds__(64) void sr_farfield_rows_kernel(const FastRec *__restrict__ fast, IcIndex ix,
+                                                              const int *__restrict__ zmax, int n_sub, int g_lo, FarParams fp,
+                                                              unsigned long long *__restrict__ cnt) {
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int grp = wid / fp.n_boxes_total; // group of kFarRows layers
+  int idx = wid - grp * fp.n_boxes_total, level = fp.n_levels - 1;
+  while (level > 0 && idx >= fp.box_count[level]) { // widest level first
+    idx -= fp.box_count[level];
+    --level;
+  }
+  const int b = idx;
+  const int lane = threadIdx.x, sub = lane & 7, layer = grp * kFarRows + (lane >> 3);
+  const bool live = layer < fp.n_layers;
+  const int lc = min(layer, fp.n_layers - 1);
+  const int W = 64 << level, h = W >> 1;
+  const int blo = g_lo + b * W, bhi = blo + W - 1;
+  const int pm = fp.pm[lc];
+  const int zm = min(zmax[lc], kHalf - 1);
+  const int thr2 = ff_thr2(level, pm);
+  const bool top = level == fp.n_levels - 1;
+  const int W2 = 2 * W, plo = g_lo + (b >> 1) * W2, phi = plo + W2 - 1, thr2p = ff_thr2(level + 1, pm);
+  // margins of the wave's layers: the candidate ranges must hold every layer's candidates
+  int pm_min = pm, pm_max = pm, zm_max = zm;
+#pragma unroll
+  for (int m = 8; m < 64; m <<= 1) {
+    pm_min = min(pm_min, __shfl_xor(pm_min, m));
+    pm_max = max(pm_max, __shfl_xor(pm_max, m));
+    zm_max = max(zm_max, __shfl_xor(zm_max, m));
+  }
+  pm_min = __builtin_amdgcn_readfirstlane(pm_min);
+  pm_max = __builtin_amdgcn_readfirstlane(pm_max);
+  zm_max = __builtin_amdgcn_readfirstlane(zm_max);
+  int clo[4], chi[4], nr;
+  const int mid = blo + h, near_in = kTheta * h + pm_min;
+  if (top) {
+    clo[0] = blo - kHalf - 1; chi[0] = mid - near_in + 1;
+    clo[1] = mid + near_in - 2; chi[1] = bhi + kHalf + 1;
+    nr = 2;
+  } else {
+    const int bn = max(2 * kTheta * h + h + pm_max, zm_max + 3 * h) + 2;
+    clo[0] = plo - kHalf; chi[0] = phi - (kHalf - 1) + 1;       // window end inside the parent
+    clo[1] = mid - bn - 1; chi[1] = mid - near_in + 1;           // left near band
+    clo[2] = mid + near_in - 2; chi[2] = mid + bn + 1;           // right near band
+    clo[3] = plo + kHalf - 1; chi[3] = phi + kHalf + 1;          // window start inside the parent
+    nr = 4;
+  }
+  int rs[4], re[4];
+  for (int i = 0; i < nr; ++i) {
+    rs[i] = lower_bound_ic(ix, clo[i]);
+    re[i] = lower_bound_ic(ix, chi[i] + 1);
+  }
+  for (int i = 1; i < nr; ++i) // sort by start
+    for (int k = i; k > 0 && rs[k] < rs[k - 1]; --k) {
+      int t0 = rs[k]; rs[k] = rs[k - 1]; rs[k - 1] = t0;
+      t0 = re[k]; re[k] = re[k - 1]; re[k - 1] = t0;
+    }
+  int done = 0; // make disjoint
+  for (int i = 0; i < nr; ++i) {
+    rs[i] = max(rs[i], done);
+    re[i] = max(re[i], rs[i]);
+    done = re[i];
+  }
+  // Adjacent ranges merge; the chunks are aligned on multiples of eight LINE INDICES, lane sub takes the lines with
+  // l = sub (mod 8) in increasing order: which lane adds which line, and in which order, then depends on the layer's
+  // own admissible lines alone -- not on the other layers of the wave, whose margins widen the ranges -- and a layer
+  // stack processed in batches (sr_set_table_budget) gives the bits of the unbatched call.
+  int nm = 0;
+  for (int i = 0; i < nr; ++i) {
+    if (re[i] <= rs[i]) continue;
+    if (nm > 0 && rs[i] <= ((re[nm - 1] + 7) & ~7)) {
+      re[nm - 1] = re[i]; // (the lines between the two ranges are no candidates of any layer: the exact tests reject them)
+    } else {
+      rs[nm] = rs[i]; re[nm] = re[i]; ++nm;
+    }
+  }
+
+  double v[2 * kFC];
+#pragma unroll
+  for (int n = 0; n < 2 * kFC; ++n) v[n] = 0.;
+  const FastRec *frow = fast + (size_t)lc * n_sub;
+  const double hw = (double)h;
+  unsigned n_exp = 0;
+  for (int i = 0; i < nm; ++i)
+  for (int l0 = rs[i] & ~7; l0 < re[i]; l0 += 8) {
+    const int l = l0 + sub;
+    if (l < rs[i] || l >= re[i] || !live) continue;
+    const FastRec r = frow[l];
+    const int j1 = r.j1, il = r.il(), ir = r.ir();
+    if (!ff_admissible(j1, il, ir, blo, bhi, thr2)) continue;
+    if (!top && ff_admissible(j1, il, ir, plo, phi, thr2p)) continue; // owned by a wider box
+    const int cls = classify(j1, il, ir, blo, bhi);
+    if (COUNT) ++n_exp;
+    const double xc = cls == 1 ? fma(0.5 * (double)(2 * (blo - j1) + W - 1), r.xstep, -r.xl)
+                               : fma(0.5 * (double)(2 * (blo - (j1 + ir - 1)) + W - 1), r.xstep, r.xr);
+    const double e = hw * r.xstep;
+    const double u0 = xc * xc, u1 = 2. * xc * e, u2 = e * e;
+    const double n0 = fma(r.b, u0, r.a), n1 = r.b * u1, n2 = r.b * u2;
+    const double d0 = fma(u0, fma(4., u0, r.d), r.c);
+    const double d1 = u1 * fma(8., u0, r.d);
+    const double d2 = fma(u2, r.d, 4. * fma(u1, u1, 2. * u0 * u2));
+    const double d3 = 8. * u1 * u2, d4 = 4. * u2 * u2;
+    const double r0 = fast_rcp<2>(d0);
+    const double D1 = d1 * r0, D2 = d2 * r0, D3 = d3 * r0, D4 = d4 * r0;
+    double f0 = n0 * r0;
+    double f1 = fma(-D1, f0, n1 * r0);
+    double f2 = fma(-D1, f1, fma(-D2, f0, n2 * r0));
+    double f3 = -fma(D1, f2, fma(D2, f1, D3 * f0));
+    v[0] = fma(r.wabs, f0, v[0]); v[kFC + 0] = fma(r.wemi, f0, v[kFC + 0]);
+    v[1] = fma(r.wabs, f1, v[1]); v[kFC + 1] = fma(r.wemi, f1, v[kFC + 1]);
+    v[2] = fma(r.wabs, f2, v[2]); v[kFC + 2] = fma(r.wemi, f2, v[kFC + 2]);
+    v[3] = fma(r.wabs, f3, v[3]); v[kFC + 3] = fma(r.wemi, f3, v[kFC + 3]);
+#pragma unroll
+    for (int n = 4; n < kFC; ++n) {
+      const double fn = -fma(D1, f3, fma(D2, f2, fma(D3, f1, D4 * f0)));
+      v[n] = fma(r.wabs, fn, v[n]);
+      v[kFC + n] = fma(r.wemi, fn, v[kFC + n]);
+      f0 = f1; f1 = f2; f2 = f3; f3 = fn;
+    }
+  }
+  // sums over the eight lanes of a layer (lane bits 4, 2, 1); every lane is left with kLeft finished values
+  lane_reduce<2 * kFC, 4>(v, lane);
+  constexpr int kLeft = lane_reduce_left<2 * kFC, 4>();
+  int slot[2 * kFC];
+#pragma unroll
+  for (int n = 0; n < 2 * kFC; ++n) slot[n] = n;
+  lane_reduce_slots<2 * kFC, 4>(lane, slot);
+  if (live) {
+    double *out = fp.coef + ((size_t)layer * fp.n_boxes_total + fp.box_off[level] + b) * (2 * kFC);
+#pragma unroll
+    for (int n = 0; n < kLeft; ++n) out[slot[n]] = v[n]; // (an unpaired value is held by two lanes: the same sum twice)
+  }
+  if (COUNT) count_add(cnt, kCntExpansions, n_exp, lane);
+}
+
 // ------------------------------------------------------------------------
 // Box-pair far field (FarParams::m2l): multipole moments, upward pass, translations.
 //
@@ -1864,6 +2023,14 @@ int launch_add2(double *a, const double *za, double *e, const double *ze, size_t
 int launch_farfield(const FastRec *fast, const IcIndex &ix, const int *zmax, int n_sub, int n_layers, int g_lo,
                     int g_hi, const FarParams &fp, unsigned long long *cnt, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
+  if (!fp.m2l && fp.rows) { // sparse line set: a box for kFarRows layers per wave
+    const dim3 gr((unsigned)(fp.n_boxes_total * ((n_layers + kFarRows - 1) / kFarRows)));
+    if (cnt)
+      hipLaunchKernelGGL(sr_farfield_rows_kernel<true>, gr, dim3(64), 0, st, fast, ix, zmax, n_sub, g_lo, fp, cnt);
+    else
+      hipLaunchKernelGGL(sr_farfield_rows_kernel<false>, gr, dim3(64), 0, st, fast, ix, zmax, n_sub, g_lo, fp, cnt);
+    return (int)hipGetLastError();
+  }
   const dim3 grid((unsigned)((fp.m2l ? fp.box_count[0] : fp.n_boxes_total) * n_layers));
 #define SR_FAR(C, M) hipLaunchKernelGGL((sr_farfield_kernel<C, M>), grid, dim3(64), 0, st, fast, ix, zmax, n_sub, g_lo, g_hi, fp, cnt)
   if (fp.m2l) {

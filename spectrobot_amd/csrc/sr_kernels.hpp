@@ -94,6 +94,7 @@ struct FarParams {
   double *coef;  // [n_layers][n_boxes_total][2][kFC]
   // box-pair mode (m2l != 0)
   int m2l;
+  int rows; // per-line mode (m2l == 0) for a SPARSE line set: sr_farfield_rows_kernel (eight layers of a box per wave)
   int n_src[kMaxFarLevels], src_off[kMaxFarLevels]; // source boxes per level (storage index = box + (kSrcPad >> level))
   // Lines beyond the grid ends have their window on the first / last grid point (closest_grid, spect_classes.py:1941)
   // and their centre up to kHalf points outside it: they are sorted first / last (indices of the shard's line
