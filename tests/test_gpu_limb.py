@@ -339,6 +339,10 @@ def test_few_broad_parameters_folded_vs_forward(eng):
                     eng.set_jac_layer_mode(0)
                 assert not torch.equal(jac, jf)        # two kernels
                 assert cmp(rad, rf, 1e-13) and cmp(jac, jf), (scale, kind, opts)
+                # joint=True: the same values in ONE buffer, radiances' rows first (one instrument-step call per iteration)
+                r2, j2, buf = eng.limb_rays_jacobian(coeffs, los, par_gas, W, grid=g, joint=True)
+                assert torch.equal(r2, rad) and torch.equal(j2, jac) and buf.shape == (los.n_rays * (1 + len(par_gas)), n)
+                assert buf.data_ptr() == r2.data_ptr() and torch.equal(buf[los.n_rays:].view_as(jac), jac)
                 assert cmp(rad, eng.limb_rays(coeffs, los, grid=g), 1e-13)
                 assert float(jac.abs().max()) > 0
 

@@ -59,11 +59,12 @@ def test_humliv_shim_golden(eng, golden):
         assert relerr(out, y) < 1e-13
 
 
-@pytest.mark.parametrize("ppl,far", [(8, 2), (8, 1), (8, 0), (4, 0)])
+@pytest.mark.parametrize("ppl,far", [(8, 3), (8, 2), (8, 1), (8, 0), (4, 0)])
 def test_e2e_ch4_levels_golden(eng, golden, ppl, far):
     """A2-A8 against the reference Python run: non-LTE levels, clipped windows,
     dropped (unidentified / same-level) lines, an A=0 line.  far=2: far wings by local expansions built
-    from box pairs (default mode); far=1: built per line; far=0: every evaluation exact."""
+    from box pairs; far=1: built per line; far=3 (the default): box pairs, sparse line sets (this one) per line with a
+    box for eight layers per wave (sr_farfield_rows_kernel); far=0: every evaluation exact."""
     g = golden("e2e_ch4_levels")
     eng.set_points_per_lane(ppl)
     eng.set_far_field(far)
@@ -265,7 +266,7 @@ def test_full_size_linearity_property(eng):
     assert float(((em0 - em).abs() / em0.abs()).max()) < 2e-11
 
 
-@pytest.mark.parametrize("far", [2, 1])
+@pytest.mark.parametrize("far", [3, 2, 1])
 def test_far_field_vs_exact_mode(eng, oracle, far):
     """The far-field modes of the coefficient op against the exact mode and the oracle on a
     case where every far-field level is populated (3e4-point grid, dense lines, 4 layers from
@@ -315,7 +316,7 @@ def test_hires_to_lowres_golden(eng, golden):
         hi.hires_to_lowres(obs, spectral_widths=[1.0, 2.0])
 
 
-@pytest.mark.parametrize("far", [2, 1])
+@pytest.mark.parametrize("far", [3, 2, 1])
 @pytest.mark.parametrize("seed", range(16))
 def test_randomized_configs_far_vs_exact_vs_oracle(eng, oracle, seed, far):
     """Random grids (step, length not a multiple of 64, shard offsets), molar masses, pressures from
@@ -764,7 +765,7 @@ def test_many_layers_unaligned_shard(eng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("far", [2, 1, 0])
+@pytest.mark.parametrize("far", [3, 2, 1, 0])
 def test_outer_lines_golden_and_oracle(eng, oracle, golden, far):
     """Lines whose centre lies outside their own window (3.3 - 25 cm-1 outside the grid): the coarse op
     adds their far wings like the reference (humliv_bb's outer branches), in both evaluation modes;

@@ -719,3 +719,24 @@ def test_partition_sum_derivative_and_level_rows():
     Tr, Pr, row = engine.LevelFactored.unique_rows(T, P)
     assert len(Tr) == 3 and np.array_equal(Tr[row], T) and np.array_equal(Pr[row], P) and row.dtype == np.int32
     assert row[0] == row[3] and row[1] == row[4] and len(set(row)) == 3
+
+
+def test_fov_closed_form_on_stacks():
+    """smm.fov_closed_form (the retrieval loop integrates a pixel's radiances and all its derivatives at once) is
+    FOV_integr_1D(closed_form=True) element by element, linear in the three spectra, and the integral the reference's
+    quadrature approximates (2.5e-4 at its default tolerances, FOV_integr_1D's docstring)."""
+    from spectrobot_amd import spect_main_module as smm
+    from spectrobot_amd.retrieval import Spectrum
+    rng = np.random.default_rng(3)
+    stack = rng.uniform(1e-7, 3e-6, (3, 5, 14))        # three LOS x (1 + 4 derivatives) x 14 bands
+    for rot in (0.0, 7.5, 20.0, 45.0):
+        got = smm.fov_closed_form(stack[0], stack[1], stack[2], rot)
+        assert got.shape == (5, 14)
+        for p in range(5):
+            one = smm.FOV_integr_1D([Spectrum(stack[q, p]) for q in range(3)], rot, closed_form=True)
+            assert np.array_equal(one.spectrum, got[p])
+        lin = smm.fov_closed_form(2.0 * stack[0] + stack[1], 2.0 * stack[1] + stack[2], 2.0 * stack[2] + stack[0], rot)
+        ref = 2.0 * got + smm.fov_closed_form(stack[1], stack[2], stack[0], rot)
+        assert np.max(np.abs(lin - ref) / np.abs(ref)) < 1e-14
+    quad = smm.FOV_integr_1D([Spectrum(stack[q, 0]) for q in range(3)], 20.0, closed_form=False)
+    assert np.max(np.abs(quad.spectrum / smm.fov_closed_form(stack[0, 0], stack[1, 0], stack[2, 0], 20.0) - 1)) < 1e-3
