@@ -858,7 +858,11 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
 // run per lane with its layer's margins), the 2 kFC sums are reduced over the eight lanes of a layer (three exchange
 // steps instead of six).  Same expansions, same owner of every (line, box): the coefficients differ from
 // sr_farfield_kernel<., false>'s by the summation order.
-constexpr int kFarRows = 8;
+#ifndef SR_FAR_ROWS
+#define SR_FAR_ROWS 8 // layers per wave (8 x 8 lines; 16 x 4 and 4 x 16: tools/r04_ab.sh with variant builds)
+#endif
+constexpr int kFarRows = SR_FAR_ROWS, kFarLines = 64 / kFarRows; // lanes: kFarRows layers x kFarLines lines of a chunk
+static_assert(kFarRows == 4 || kFarRows == 8 || kFarRows == 16, "SR_FAR_ROWS");
 template <int N, int M>
 __device__ inline void lane_reduce_slots(int lane, int *idx) { // which of the N values v[i] holds after lane_reduce<N, M>
   if constexpr (M >= 1) {
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(64) void sr_farfield_rows_kernel(const FastRec *__r
     --level;
   }
   const int b = idx;
-  const int lane = threadIdx.x, sub = lane & 7, layer = grp * kFarRows + (lane >> 3);
+  const int lane = threadIdx.x, sub = lane % kFarLines, layer = grp * kFarRows + lane / kFarLines;
   const bool live = layer < fp.n_layers;
   const int lc = min(layer, fp.n_layers - 1);
   const int W = 64 << level, h = W >> 1;
@@ -899,7 +903,7 @@ __global__ __launch_bounds__(64) void sr_farfield_rows_kernel(const FastRec *__r
   // margins of the wave's layers: the candidate ranges must hold every layer's candidates
   int pm_min = pm, pm_max = pm, zm_max = zm;
 #pragma unroll
-  for (int m = 8; m < 64; m <<= 1) {
+  for (int m = kFarLines; m < 64; m <<= 1) {
     pm_min = min(pm_min, __shfl_xor(pm_min, m));
     pm_max = max(pm_max, __shfl_xor(pm_max, m));
     zm_max = max(zm_max, __shfl_xor(zm_max, m));
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(64) void sr_farfield_rows_kernel(const FastRec *__r
   int nm = 0;
   for (int i = 0; i < nr; ++i) {
     if (re[i] <= rs[i]) continue;
-    if (nm > 0 && rs[i] <= ((re[nm - 1] + 7) & ~7)) {
+    if (nm > 0 && rs[i] <= ((re[nm - 1] + kFarLines - 1) & ~(kFarLines - 1))) {
       re[nm - 1] = re[i]; // (the lines between the two ranges are no candidates of any layer: the exact tests reject them)
     } else {
       rs[nm] = rs[i]; re[nm] = re[i]; ++nm;
@@ -958,7 +962,7 @@ __global__ __launch_bounds__(64) void sr_farfield_rows_kernel(const FastRec *__r
   const double hw = (double)h;
   unsigned n_exp = 0;
   for (int i = 0; i < nm; ++i)
-  for (int l0 = rs[i] & ~7; l0 < re[i]; l0 += 8) {
+  for (int l0 = rs[i] & ~(kFarLines - 1); l0 < re[i]; l0 += kFarLines) {
     const int l = l0 + sub;
     if (l < rs[i] || l >= re[i] || !live) continue;
     const FastRec r = frow[l];
@@ -995,12 +999,12 @@ __global__ __launch_bounds__(64) void sr_farfield_rows_kernel(const FastRec *__r
     }
   }
   // sums over the eight lanes of a layer (lane bits 4, 2, 1); every lane is left with kLeft finished values
-  lane_reduce<2 * kFC, 4>(v, lane);
-  constexpr int kLeft = lane_reduce_left<2 * kFC, 4>();
+  lane_reduce<2 * kFC, kFarLines / 2>(v, lane);
+  constexpr int kLeft = lane_reduce_left<2 * kFC, kFarLines / 2>();
   int slot[2 * kFC];
 #pragma unroll
   for (int n = 0; n < 2 * kFC; ++n) slot[n] = n;
-  lane_reduce_slots<2 * kFC, 4>(lane, slot);
+  lane_reduce_slots<2 * kFC, kFarLines / 2>(lane, slot);
   if (live) {
     double *out = fp.coef + ((size_t)layer * fp.n_boxes_total + fp.box_off[level] + b) * (2 * kFC);
 #pragma unroll
