@@ -1727,6 +1727,9 @@ __device__ inline void core_eval4(const CorePend &P, bool on, const GridParams &
 #ifndef SR_R2_SPLIT
 #define SR_R2_SPLIT 1 // region 2: the left and the right run of a line in two loops
 #endif
+#ifndef SR_R2_XRUN
+#define SR_R2_XRUN 1 // region 2: x by a running sum (see the row walk): 5.38 vs 5.42 ms per headline step
+#endif
 #if SR_RMAX
 #define SR_RMAX_OR(lds_value, row_value) __builtin_amdgcn_readfirstlane(lds_value)
 #else
@@ -1910,10 +1913,21 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
         // for ~5 % more steps)
         auto run = [&](const int n, const int n_max, const double c, const int i0) {
           const int n_steps = (n_max + kRowLanes - 1) / kRowLanes; // wave-uniform: a scalar loop counter
+#if SR_R2_XRUN
+          // x of the lane's point by a running sum, eight steps of xstep at a time (one add instead of a conversion
+          // and an fma per point; <= 20 steps of a run: <= 20 ulp of x, 1e-14 of the value at most)
+          double xt = fma((double)col, xstep, c);
+          const double xs8 = (double)kRowLanes * xstep;
+#endif
           for (int st = 0; st < n_steps; ++st) {
             const int t = col + kRowLanes * st;
             if (t < n) {
+#if SR_R2_XRUN
+              const double y = region2_val(q2, xt);
+              xt += xs8;
+#else
               const double y = region2_val(q2, fma((double)t, xstep, c));
+#endif
               if (COUNT) ++n_r2;
               atomicAdd(&s_a[t + i0], wa * y); // return-less LDS adds: no wait for a read, runs of different lines overlap
               atomicAdd(&s_e[t + i0], we * y);
