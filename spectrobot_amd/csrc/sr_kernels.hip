@@ -1919,20 +1919,30 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
           double xt = fma((double)col, xstep, c);
           const double xs8 = (double)kRowLanes * xstep;
 #endif
+#if SR_R2_XRUN
+          // ... and ONE counter per lane: the byte offset of its point in the image, which is the loop's predicate too
+          int ab = (col + i0) * 8;
+          const int ab_end = (n + i0) * 8;
+          for (int st = 0; st < n_steps; ++st, ab += 8 * kRowLanes) {
+            if (ab < ab_end) {
+              const double y = region2_val(q2, xt);
+              xt += xs8;
+              if (COUNT) ++n_r2;
+              atomicAdd(reinterpret_cast<double *>(reinterpret_cast<char *>(s_a) + ab), wa * y); // return-less LDS adds: no wait for a read, runs of different lines overlap
+              atomicAdd(reinterpret_cast<double *>(reinterpret_cast<char *>(s_e) + ab), we * y);
+            }
+          }
+#else
           for (int st = 0; st < n_steps; ++st) {
             const int t = col + kRowLanes * st;
             if (t < n) {
-#if SR_R2_XRUN
-              const double y = region2_val(q2, xt);
-              xt += xs8;
-#else
               const double y = region2_val(q2, fma((double)t, xstep, c));
-#endif
               if (COUNT) ++n_r2;
               atomicAdd(&s_a[t + i0], wa * y); // return-less LDS adds: no wait for a read, runs of different lines overlap
               atomicAdd(&s_e[t + i0], we * y);
             }
           }
+#endif
         };
 #if SR_R2_SPLIT
         run(live ? na : 0, SR_RMAX_OR(s_rmax[wave][0][g >> 3], live ? na : 0),
