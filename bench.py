@@ -7,8 +7,8 @@ recursion of the ray batch and, for N > 1, the all-gather of the spectral shards
 Default workload = BASELINE.json configs[1]: CH4 Titan limb, 1e5 lines x 1e5 nu-grid
 x 80 layers, 1 ray, fp64.  Inputs are uploaded before the timed region (HBM resident).
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W     N > 1 without WORLD_SIZE: starts its own N ranks (launch_ranks)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the same ranks, from torchrun)
   python bench.py --config 2|3|4|lut  extra lines for BASELINE configs[2..4] and the look-up-table build (bench_configs.py;
                                       not the headline)
 
@@ -199,6 +199,58 @@ def cpu_columns(L, scale):
                      for a, b in zip(L["pt_off"][:-1], L["pt_off"][1:])])
 
 
+def launch_ranks(n, argv=None, build=True):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as fresh child processes of
+    this script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torchrun would) and return the job's exit
+    code.  The reference fans out in-process too (spect_main_module.py:2746-2767: one Process per LOS; :1619-1630,
+    2814-2818: spectral splits) -- its callers never wrap it in a launcher.  This process has not imported torch nor
+    touched the GPU and never does: it only builds the library (hipcc), waits, forwards rank 0's JSON line (the children
+    inherit stdout; only rank 0 prints) and, when a rank dies, ends the others -- by their own PIDs.
+    argv: the child's command line after the interpreter (default: this script with this process's arguments)."""
+    import signal
+    import socket
+    import subprocess
+    import __graft_entry__
+    if build:
+        __graft_entry__.ensure_built(builder=True)       # once, before any rank starts
+    argv = [os.path.abspath(__file__)] + sys.argv[1:] if argv is None else list(argv)
+    with socket.socket() as s:                           # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SR_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.05)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:                # one rank failed: the others would wait in a collective for ever
+                    rc = code if code > 0 else 1
+                    for q in live:
+                        q.terminate()
+                    t_end = time.time() + 10.0
+                    while any(q.poll() is None for q in live) and time.time() < t_end:
+                        time.sleep(0.05)
+                    for q in live:
+                        if q.poll() is None:
+                            q.kill()
+    except BaseException:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        raise
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +274,8 @@ def main():
                     "pairs (multipole -> local), sparse line sets per line and box; 2: box pairs always; 1: per line and box")
     args = ap.parse_args()
     args.config = args.config if args.config == "lut" else int(args.config)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # the driver's form: python bench.py --gpus N
+        sys.exit(launch_ranks(args.gpus))
 
     import __graft_entry__
     __graft_entry__.ensure_built(builder=int(os.environ.get("LOCAL_RANK", "0")) == 0)  # fresh checkouts carry no library

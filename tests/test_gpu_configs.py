@@ -255,6 +255,29 @@ print("rank", rank, "ok")
     assert all("ok" in o for o in outs)
 
 
+def test_bench_gpus2_launches_itself(eng):
+    """The driver's own form, `python bench.py --gpus 2 ...` with no WORLD_SIZE: bench.py starts its two ranks as fresh
+    child processes before it touches the GPU (launch_ranks), here both on the one GPU (SR_DIST_BACKEND=gloo: RCCL
+    needs a device per rank); exactly one JSON line comes back, with the `dist` record of a two-rank group, a gathered
+    spectrum equal to a blocking gather, and exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--lines", "20000", "--grid", "40000", "--layers", "16"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dist"]["world_size"] == 2 and rec["dist"]["backend"] == "gloo"
+    assert rec["dist"]["async_equals_blocking"] is True
+    assert rec["value"] > 0 and rec["steps"] == 5 and rec["scaling"] == "strong"
+
+
 def test_rccl_async_gather_branch_one_rank(eng, tmp_path):
     """The RCCL branch of the bench's step on hardware: backend "nccl" with a ONE-rank process group on the one GPU
     (RCCL needs a device per rank, so more ranks cannot be rehearsed here).  Nine steps of coefficient op + limb

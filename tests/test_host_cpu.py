@@ -1,5 +1,6 @@
 """Host-side logic and the C-ABI surface, no GPU needed (no kernel is launched)."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -119,6 +120,43 @@ def test_all_gather_spectrum_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_bench_launches_its_own_ranks(tmp_path, capfd):
+    """`python bench.py --gpus N` without WORLD_SIZE (the driver's form) starts its N ranks itself: bench.launch_ranks
+    with a stand-in child (gloo, two CPU ranks; the bench's own child needs a GPU: tests/test_gpu_configs.py) -- the
+    ranks rendezvous on the loopback port the launcher chose, only rank 0's line reaches stdout, the exit code is 0;
+    a rank that fails takes the job down with its code and the launcher ends the rank left waiting."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    ok = tmp_path / "ok.py"
+    ok.write_text(
+        "import os, sys, json, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from spectrobot_amd import distributed as sd\n"
+        "assert os.environ['SR_BENCH_CHILD'] == '1' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "rank, local, world = sd.init_from_env(backend='gloo')\n"
+        "t = torch.tensor([float(rank + 1)], dtype=torch.float64)\n"
+        "torch.distributed.all_reduce(t)\n"
+        "if rank == 0:\n"
+        "    print(json.dumps({'dist': sd.dist_info(), 'sum': float(t.item()), 'argv': sys.argv[1:]}))\n"
+        "torch.distributed.barrier()\n" % ROOT)
+    capfd.readouterr()
+    assert bench.launch_ranks(2, argv=[str(ok), "--steps", "5"], build=False) == 0
+    lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["dist"] == {"backend": "gloo", "world_size": 2, "rank": 0} and rec["sum"] == 3.0
+    assert rec["argv"] == ["--steps", "5"]
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys, time\n"
+                   "if os.environ['RANK'] == '1':\n"
+                   "    sys.exit(3)\n"
+                   "time.sleep(600)\n")
+    t0 = time.time()
+    assert bench.launch_ranks(2, argv=[str(bad)], build=False) == 3
+    assert time.time() - t0 < 30.0
 
 
 def test_async_gather_branch_bookkeeping(monkeypatch):
