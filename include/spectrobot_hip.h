@@ -404,6 +404,10 @@ int sr_set_table_budget(int64_t bytes);
  * of 16) -- kept as the check of the others.  2: one pass per ray in path order, one ray per thread, always.
  * 3: path order, two rays per thread sharing a shell's coefficient loads (sr_limb_adjoint_sync_kernel; the bits of 2). */
 int sr_set_jac_layer_mode(int forward);
+/* Which recursion kernel the most recent sr_limb_rays_dev call on this thread launched: 1 the path-order kernels
+ * (sr_limb_kernel / sr_limb_split_kernel), 2 the folded sweep (sr_limb_fold_fwd_kernel: ray batches that share their
+ * shells), 0 none yet.  Diagnostic (tests pin the choice: a 3-D batch with a coefficient row per LOS step must not fold). */
+int sr_last_limb_route(void);
 /* Tuning knob of the exact wings kernel: grid points per lane (4 or 8; default 8). */
 int sr_set_points_per_lane(int p);
 

@@ -107,6 +107,7 @@ SYMBOLS = {
                                                C.c_int, C.c_double, C.c_int, dp, C.c_void_p]),
     "sr_set_points_per_lane": (C.c_int, [C.c_int]),
     "sr_set_jac_layer_mode": (C.c_int, [C.c_int]),
+    "sr_last_limb_route": (C.c_int, []),
     "sr_set_far_field": (C.c_int, [C.c_int]),
     "sr_set_overlap": (C.c_int, [C.c_int]),
     "sr_set_table_budget": (C.c_int, [C.c_int64]),

@@ -1824,6 +1824,17 @@ int stage_fold(const sr_los_desc *los, int n_layers, hipStream_t st, FoldStage *
     if (any) shells.push_back(k);
   }
   if ((size_t)nr * shells.size() > ((size_t)1 << 21)) return SR_OK; // (2M records = 436 MB of plan: such batches keep the path-order kernels)
+  // The fold pays when the rays SHARE shells.  A 3-D batch lists a row per LOS step (seg_layer = arange): every ray then
+  // looks like a slant ray through rows of its own, the union of the shells is the steps of ALL rays and a ray's plan is
+  // mostly empty visits (n_rays x n_seg_total records).  Such batches keep the path-order kernel: the union may be at
+  // most twice the shells of the longest ray.
+  size_t longest = 0;
+  for (int r = 0; r < nr; ++r) {
+    size_t n_real = 0;
+    for (int k : shells) n_real += far[(size_t)r * n_layers + k] >= 0 || near[(size_t)r * n_layers + k] >= 0;
+    longest = std::max(longest, n_real);
+  }
+  if (shells.size() > 2 * longest) return SR_OK;
   const int n_vis = (int)shells.size(), n_rec = nr * n_vis;
   static thread_local Stager s_ring[4];
   static thread_local unsigned s_next = 0;
@@ -1872,6 +1883,9 @@ int sr_los_columns(const sr_los_desc *los, double *col_out) {
   return SR_OK;
 }
 
+static thread_local int g_last_limb_route = 0;
+int sr_last_limb_route(void) { return g_last_limb_route; }
+
 int sr_limb_rays_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, const sr_los_desc *los,
                      double *rad, void *stream) {
   if (!abs_c || !emi_c || !rad || n_layers <= 0 || n_pts <= 0) return SR_ERR_ARG;
@@ -1889,6 +1903,7 @@ int sr_limb_rays_dev(const double *abs_c, const double *emi_c, int n_layers, int
     if (F.n_rec > 0) {
       LAUNCHCHK(launch_fold_fwd(F.plan, D.col, D.n_seg, F.n_rec, F.rec, abs_c, emi_c, (int)n_pts, n_layers, los->n_rays, F.n_vis,
                                 limb_opts(los, D.n_seg), rad, st));
+      g_last_limb_route = 2;
       rc = F.slot->mark(st);
       if (rc) return rc;
       return D.slot->mark(st);
@@ -1896,6 +1911,7 @@ int sr_limb_rays_dev(const double *abs_c, const double *emi_c, int n_layers, int
   }
   LAUNCHCHK(launch_limb(abs_c, emi_c, (int)n_pts, n_layers, los->n_rays, D.seg_off, D.seg_layer, D.col,
                         limb_opts(los, D.n_seg), rad, st));
+  g_last_limb_route = 1;
   return D.slot->mark(st);
 }
 

@@ -589,7 +589,12 @@ __device__ inline double humliv_point(int k, const FastRec &r, const ColdFull &z
     const double a = fabs(xf(k) - z.x0);
     double rx = a * z.inv_dwp;
     rx = fma(fma(-z.dwp, rx, a), z.inv_dwp, rx);
-    return core_point(rx, z.ry, z.ryf);
+    // region 3 / 4 by the record's interval, as the zones kernel does: make_cold found it with the reference's own
+    // per-point test (:528), so it IS that test -- and with frozen boundaries (sr_lineset_set_bounds_temps) it is the
+    // interval of the boundary temperature in every mode (a per-point test here made the exact mode differ from the
+    // far-field modes by a region seam, 1e-5..1e-4, at the one or two points where the interval moves)
+    const double b = (double)(float)(-rx);
+    return (k >= z.k3lo() && k <= z.k3hi()) ? core_region3(z.ryf, b) : core_region4(z.ryf, b);
   }
   if (il < il2 && k >= il && k <= il2) // :503-512
     return region2_val(z.q2, fma(-(double)(k - il), r.xstep, z.xs2l));

@@ -3463,11 +3463,13 @@ __global__ __launch_bounds__(256) void sr_limb_fold_fwd_kernel(const double *__r
     double a[kB][NG], e[kB][NG];
 #pragma unroll
     for (int t = 0; t < kB; ++t) {
-      const size_t ofs = (size_t)rc[min(vb + t, n_visits - 1)].layer * n_pts + j;
+      const FoldDense &Rl = rc[min(vb + t, n_visits - 1)];
+      const bool on = Rl.has != 0; // wave-uniform: a shell this ray does not cross costs no loads
+      const size_t ofs = (size_t)Rl.layer * n_pts + j;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        a[t][g] = abs_c[g * gstride + ofs];
-        e[t][g] = emi_c[g * gstride + ofs];
+        a[t][g] = on ? abs_c[g * gstride + ofs] : 0.0;
+        e[t][g] = on ? emi_c[g * gstride + ofs] : 0.0;
       }
     }
 #pragma unroll

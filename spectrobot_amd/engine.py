@@ -744,6 +744,12 @@ def set_jac_layer_mode(forward):
     check(lib.sr_set_jac_layer_mode(int(forward)), "sr_set_jac_layer_mode")
 
 
+def last_limb_route():
+    """Which recursion kernel the last limb_rays call of this thread launched: 1 path order, 2 the folded sweep
+    (sr_last_limb_route; diagnostic)."""
+    return int(lib.sr_last_limb_route())
+
+
 FAR_FIELD_DEFAULT = 3  # the library's default far-field mode (sr_set_far_field)
 
 

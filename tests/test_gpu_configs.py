@@ -476,34 +476,58 @@ def test_temperature_derivative_schemes(eng):
 
 
 def test_frozen_boundaries_at_other_temperatures_lose_nothing(eng):
-    """sr_lineset_set_bounds_temps with boundary temperatures several K away from the call's own: the
-    zone of a line is then placed with the widths of Tb while the kernels' candidate bound (widest zone of the layer)
-    came from T alone -- for Tb > T a line's outermost region-2 points were never visited.  Sparse lines (one per 200
-    points: in its own outer zone a line is most of the sum), so a dropped contribution is an O(1) deviation from the
-    unfrozen call, while what freezing legitimately changes is where the Humlicek regions hand over: up to ~1e-2 when
-    region 2 (which has no Gaussian part) reaches inside |x| + y = 5.5 at Tb = T - 8 K and y -> 0, 1e-3 otherwise.
-    Both far-field modes and the exact mode."""
+    """sr_lineset_set_bounds_temps with boundary temperatures several K away from the call's own (ADVICE rounds 3, 4):
+    the zone of a line is then placed with the widths of Tb while the kernels' candidate bound (widest zone of the
+    layer) came from T alone -- for Tb > T a line's outermost region-2 points were never visited.
+    (a) With the SAME boundary temperatures every far-field mode (3 = the default, 2, 1) must reproduce the exact mode
+    (0: every (line, point) evaluated, the regions placed by the same frozen boundaries) at working precision: a
+    dropped outer zone is a 1e-5..1 error there, the far-field truncation 1e-12.  A sparse set (one line per 200
+    points: per-line expansions in mode 3) and a dense one (0.4 lines per point: box pairs), the folded op, the
+    per-level pair tables (sub-linesets with their own boundary slices) and linearised weights.
+    (b) Sanity against the UNFROZEN call of the same mode: what freezing legitimately changes is where the Humlicek
+    regions hand over, up to ~1e-2 (region 2 has no Gaussian part and reaches inside |x| + y = 5.5 at Tb = T - 8 K
+    and y -> 0); a dropped contribution of a sparse line is O(1)."""
     import torch
+    import torch.nn.functional as F
     from spectrobot_amd import synthetic as syn
     grid = syn.make_grid(2990.0, 5e-4, 30000)
-    L = syn.make_lines(150, grid, seed=11, n_levels=12, config_id=2)
     atm = syn.make_atmosphere(6, 12)
-    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
     T, P, tv = atm["temps"], atm["press"], atm["tvib"]
+
+    def env_rel(x, y):
+        # relative to the local envelope of |y| (+-64 points): under non-LTE populations abs crosses zero
+        sc = F.max_pool1d(y.abs().reshape(1, -1, y.shape[-1]), 129, stride=1, padding=64).reshape(y.shape)
+        return float(((x - y).abs() / sc.clamp_min(1e-300)).max())
+
     try:
-        for mode in (2, 1, 0):
-            eng.set_far_field(mode)
-            a0, e0 = ls.abscoeff_layers(T, P, tvib=tv)
+        for n_lines, seed in ((150, 11), (12000, 12)):
+            L = syn.make_lines(n_lines, grid, seed=seed, n_levels=12, config_id=2)
+            ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
             for dTb in (8.0, -8.0, 25.0):
-                ls.set_bounds_temps(T + dTb)
-                try:
-                    a1, e1 = ls.abscoeff_layers(T, P, tvib=tv)
-                finally:
-                    ls.set_bounds_temps(None)
-                ra = float(((a1 - a0).abs() / a0.abs()).max())
-                re = float(((e1 - e0).abs() / e0.abs()).max())
-                print("far-field mode %d, boundaries at T%+.0f K: max rel deviation from the unfrozen call %.1e %.1e" % (mode, dTb, ra, re))
-                assert 0.0 < ra < 5e-2 and 0.0 < re < 5e-2
+                for linear in (False, True):
+                    if linear and dTb != 8.0:
+                        continue
+                    res = {}
+                    for mode in (0, 3, 2, 1):
+                        eng.set_far_field(mode)
+                        ls.set_bounds_temps(T + dTb, linear_weights=linear)
+                        try:
+                            res[mode] = ls.abscoeff_layers(T, P, tvib=tv) + (ls.glevel_pairs(T, P),)
+                        finally:
+                            ls.set_bounds_temps(None)
+                    for mode in (3, 2, 1):
+                        ra, re = env_rel(res[mode][0], res[0][0]), env_rel(res[mode][1], res[0][1])
+                        rp = env_rel(res[mode][2], res[0][2])
+                        print("%d lines, boundaries at T%+.0f K%s: far-field mode %d vs exact mode, same boundaries: abs %.1e emi "
+                              "%.1e pair tables %.1e" % (n_lines, dTb, ", linear weights" if linear else "", mode, ra, re, rp))
+                        assert ra < 1e-11 and re < 1e-11 and rp < 1e-11, (n_lines, dTb, linear, mode)
+                    if not linear:
+                        for mode in (0, 3):
+                            eng.set_far_field(mode)
+                            a0, e0 = ls.abscoeff_layers(T, P, tvib=tv)
+                            ra, re = env_rel(res[mode][0], a0), env_rel(res[mode][1], e0)
+                            assert 0.0 < ra < 5e-2 and 0.0 < re < 5e-2, (n_lines, dTb, mode, ra, re)
+            ls.close()
     finally:
         eng.set_far_field(eng.FAR_FIELD_DEFAULT)
 
@@ -637,6 +661,33 @@ def test_config3_3d_level_factored_route(eng, oracle):
     sc = lambda y: y.abs().reshape(y.shape[0], -1).amax(dim=1).clamp_min(1e-300).reshape((-1,) + (1,) * (y.dim() - 1))
     assert float(((r1 - r2).abs() / sc(r2)).max()) < 1e-11 and float(((jt1 - jt2).abs() / sc(jt2)).max()) < 1e-10
     assert float(((jv1 - jv2).abs() / sc(jv2)).max()) < 1e-10
+
+
+def test_parsed_hitran_file_through_the_hip_path(eng, oracle):
+    """N3 end to end: read_line_database (spect_classes.py:1532-1601, HITRAN-2012 160-column records) ->
+    lines_to_soa -> LineSet.abscoeff_layers against the oracle on the same parsed lines.  The fixture (written by the
+    reference's own Print_hitran) holds a CH4 line with air broadening 0.000: the reader's default of 0.05
+    (spect_classes.py:1578-1581) is what both sides must see; a zero Lorentz width would put ry = 0 into humliv_bb."""
+    from spectrobot_amd import spect_classes as spcl, synthetic as syn
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", "hitran_sample.par")
+    raw = [float(ln[35:40]) for ln in open(path) if ln[:3] == " 61"]
+    lines = spcl.read_line_database(path, mol=6, iso=1)
+    assert len(lines) == len(raw) and min(raw) == 0.0                 # the file holds a zero air-broadening record ...
+    soa = spcl.lines_to_soa(lines)
+    assert soa["air_broad"].min() > 0.0 and np.any((np.array(raw) == 0.0) & (soa["air_broad"] == 0.05))   # ... the reader's default replaces it
+    grid = syn.make_grid(2900.0, 1e-3, 201000)
+    atm = syn.make_atmosphere(5, 0)
+    T, P = atm["temps"], atm["press"] * np.array([30.0, 3.0, 1.0, 1.0, 1.0])
+    ls = eng.LineSet(soa, grid, 6, 1, syn.CH4_MM, [])
+    ab, em = ls.abscoeff_layers(T, P)
+    abo, emo = oracle.abscoeff_layers(soa, syn.CH4_MM, np.zeros(0), T, P, _q(T), None, grid, mode=1, n_threads=4)
+    assert abo.max() > 0 and relerr(ab.cpu().numpy(), abo) < 1e-10 and relerr(em.cpu().numpy(), emo) < 1e-10
+    # the default matters: with the file's literal zero the widest-pressure layer differs at the 1e-2 level at that line
+    k = int(np.argmax(np.array(raw) == 0.0))
+    soa0 = dict(soa, air_broad=np.where(np.arange(len(raw)) == k, 1e-6, soa["air_broad"]))
+    ab0, _ = eng.LineSet(soa0, grid, 6, 1, syn.CH4_MM, []).abscoeff_layers(T, P)
+    assert relerr(ab0[0].cpu().numpy(), abo[0]) > 1e-3
 
 
 def test_config0_co_nadir_and_slant_radiance(eng, oracle):

@@ -383,6 +383,40 @@ def test_ray_batch_radiances_folded_vs_path_order(eng):
                 assert float(((rad - ref).abs() / ref.abs().clamp_min(1e-300)).max()) < 1e-11, (scale, opts)   # pointwise too
 
 
+def test_per_step_batches_keep_the_path_order_kernel(eng):
+    """A 3-D batch lists a coefficient row per LOS step (seg_layer = arange(n_seg_total)): every ray then looks like a
+    slant ray through rows of its own, and folded it would walk the steps of ALL rays (n_rays x the traffic, n_rays x
+    n_seg_total plan records).  Such batches must take the path-order kernel (sr_last_limb_route == 1) while the same
+    rays on shared shells fold (== 2); both give the same radiances."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(10)
+    nl, n = 24, 16384
+    atm = _atm(nl)
+    z = atm["z"]
+    vm = [np.full(nl, 1.2e-2)]
+    L = syn.limb_los(z, atm["nd"] * 1e-6, vm, z[0] + 5.0 + 23.0 * np.arange(8))
+    a = rng.uniform(0, 4e-18, (nl, n))
+    e = a * rng.uniform(1e-8, 1e-7, (nl, n))
+    t = lambda v: torch.tensor(np.ascontiguousarray(v), device="cuda")
+    los1 = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827])
+    r1 = eng.limb_rays((t(a), t(e)), los1)
+    assert eng.last_limb_route() == 2
+    steps = np.arange(len(L["seg_layer"]), dtype=np.int32)         # a row per LOS step, as geometry.limb_los_3d lists them
+    los3 = eng.LimbLOS(L["seg_off"], steps, L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827])
+    r3 = eng.limb_rays((t(a[L["seg_layer"]]), t(e[L["seg_layer"]])), los3)
+    assert eng.last_limb_route() == 1
+    sc = r1.abs().amax(dim=-1, keepdim=True)
+    assert float(((r3 - r1).abs() / sc).max()) < 1e-13
+    # two rays of a 3-D batch: the union of their steps is twice the longer ray's -- still folded, empty visits cost no loads
+    two = np.array([0, L["seg_off"][1], L["seg_off"][2]], dtype=np.int32)
+    k = int(two[-1])
+    los2 = eng.LimbLOS(two, steps[:k], L["pt_off"][:k + 1], L["x"][:L["pt_off"][k]], L["nd"][:L["pt_off"][k]],
+                       [v[:L["pt_off"][k]] for v in L["vmr"]], col_scale=[0.98827])
+    r2 = eng.limb_rays((t(a[L["seg_layer"][:k]]), t(e[L["seg_layer"][:k]])), los2)
+    assert float(((r2 - r1[:2]).abs() / sc[:2]).max()) < 1e-13
+
+
 def test_per_level_partial_radiances_sum_to_total(eng):
     """single_rad[(gas, iso, lev)] (spect_main_module.py:2883-2887): the radiance emitted by one level and
     absorbed by the whole gas -- the level's emission share (sr_abscoeff_level_dev) with the total
