@@ -377,16 +377,17 @@ int sr_hires_to_lowres_shard_dev(const double *rad, int n_rays, int64_t n_pts, i
  * 1: per line and box at every level (sr_farfield_kernel);
  * 3 (default): 2 -- except for line sets with fewer than 0.35 lines per grid point (the per-level sub-linesets of the
  *    pair tables and look-up tables), which take 1: the box pairs cost S2M / M2M / M2L over every box whatever it
- *    holds (environment SR_SPARSE_FF1: the threshold);
+ *    holds;
  * 0: every (line, point) evaluated exactly (sr_abscoeff_wings_kernel + sr_abscoeff_cores_kernel). */
 int sr_set_far_field(int on);
-/* Far-field mode only.  1, 2: sr_abscoeff_near_zones_kernel runs on a second, internal stream beside
- * sr_farfield_kernel (it needs the record tables only) and the wings kernel joins both; the NEXT call's
- * record tables are prepared on a third internal stream while this call computes -- with 1 (default) as soon
- * as the tables of the call before are free, with 2 only beside this call's wings kernel (keeps the
- * HBM-write-bound prep kernel away from the two VALU-bound kernels; measured equal on config 2: 8.63 vs
- * 8.60 ms per step).  The caller's stream sees the op complete in order as before.  0: the four kernels one
- * after the other on the caller's stream (per-kernel times for sr_last_kernel_ms). */
+/* Far-field mode only: how the kernels of a call share the chip.  1 (default): the decoupled, phased pipeline -- the
+ * table preparation, the far-field chain (level-0 pass | S2M -> M2M -> M2L) and the zones kernel run on internal
+ * streams on scratch of the call's parity, each as soon as what it reads is ready (the preparation of call c + 1
+ * while call c computes), the zones kernel gated behind the level-0 pass and S2M of its own call; only the wings
+ * kernel, which writes abs_out / emi_out, is on the caller's stream.  2: round 3's order (zones forked off the
+ * caller's stream beside the far-field chain on it; the A/B partner, and what counting passes run).  0: the kernels
+ * one after the other on the caller's stream (per-kernel times for sr_last_kernel_ms).  The caller's stream sees the
+ * op complete in order in every mode. */
 int sr_set_overlap(int on);
 /* Memory knob: the per-(line, layer) record tables (128 B each, plus the far-field scratch of a layer) of one launch are kept
  * under this many bytes (default 48 GiB of the 288 GB); a longer layer stack (the reference

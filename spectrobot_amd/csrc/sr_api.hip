@@ -219,7 +219,7 @@ struct HostLines {
 // snapshot, so flipping a switch from another thread never changes a call half way.
 std::atomic<int> g_variant{8};   // points per lane in the exact wings kernel
 std::atomic<int> g_far_field{3}; // 1: far wings by per-line local expansions, 2: by box pairs (multipole -> local), 3 (default): 2, but sparse line sets by 1, 0: every evaluation exact
-std::atomic<int> g_overlap{1};   // 1 (default), 2: zones kernel on a second stream beside the far-field kernel, next call's prep pipelined (2: gated behind FF+zones; measured equal)
+std::atomic<int> g_overlap{1};   // 1 (default): the decoupled, phased pipeline; 2: round 3's order (zones forked off the caller's stream beside the far-field chain; the A/B partner); 0: kernels one after the other
 // sr_set_jac_layer_mode; SR_JAC_LAYER_MODE (environment, read once at load): its initial value, for A/B runs of whole programs
 std::atomic<int> g_jac_layer_forward{[] { const char *e = getenv("SR_JAC_LAYER_MODE"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 3 ? v : 0; }()};
 std::atomic<int> g_counting{0};  // 1: counting instantiations of the far-field-mode kernels (sr_set_counting)
@@ -243,29 +243,11 @@ struct CoefWork {
   hipEvent_t ev_far_done[2] = {nullptr, nullptr}, ev_zones_done[2] = {nullptr, nullptr};
   hipStream_t chain_st = nullptr, chain2_st = nullptr; // the far-field chain (decoupled pipeline): level-0 pass | moments, translations
   hipEvent_t ev_l0_done[2] = {nullptr, nullptr}, ev_s2m_done[2] = {nullptr, nullptr};
-  hipEvent_t ev_wings_done[2] = {nullptr, nullptr};
-  bool wings_recorded[2] = {false, false};
-  // hipGraph of everything a call issues on the internal streams (staging copy, preparation, far-field chain, zones
-  // kernel and the events between them), per parity and call shape: replayed by ONE hipGraphLaunch on graph_st[b]
-  struct GraphEntry {
-    std::vector<uintptr_t> key;
-    hipGraphExec_t exec = nullptr;
-    unsigned long long last_use = 0;
-  };
-  std::vector<GraphEntry> graphs[2];
-  hipStream_t graph_st[2] = {nullptr, nullptr};
-  hipEvent_t ev_pre_done[2] = {nullptr, nullptr};
-  unsigned long long graph_clock = 0;
-  bool graphs_broken = false; // a capture failed once: direct launches from then on
   bool free_recorded[2] = {false, false};
   int parity = 0;
   bool overlapped = false;       // last call ran that way (timing hook)
   bool pipelined = false;        // last call prepared its tables on prep_st
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  // overlap mode 2: the NEXT call's table preparation may start only when this call's far-field and zones
-  // kernels are done, i.e. beside the wings kernel (see sr_set_overlap)
-  hipEvent_t ev_tail = nullptr;
-  bool tail_recorded = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int n_timed = 0; // kernels timed in the last call
   bool timed = false;
@@ -292,12 +274,6 @@ struct CoefWork {
       if (ev_zones_done[b]) (void)hipEventDestroy(ev_zones_done[b]);
       if (ev_l0_done[b]) (void)hipEventDestroy(ev_l0_done[b]);
       if (ev_s2m_done[b]) (void)hipEventDestroy(ev_s2m_done[b]);
-      if (ev_wings_done[b]) (void)hipEventDestroy(ev_wings_done[b]);
-      for (auto &g : graphs[b])
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-      graphs[b].clear();
-      if (graph_st[b]) (void)hipStreamDestroy(graph_st[b]);
-      if (ev_pre_done[b]) (void)hipEventDestroy(ev_pre_done[b]);
       d_zone2[b].release();
       d_coef[b].release();
       d_mom[b].release();
@@ -312,7 +288,6 @@ struct CoefWork {
     d_zone.release();
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
-    if (ev_tail) (void)hipEventDestroy(ev_tail);
     if (aux) (void)hipStreamDestroy(aux);
     for (auto &e : ev)
       if (e) (void)hipEventDestroy(e);
@@ -402,7 +377,7 @@ int sr_set_far_field(int on) {
 }
 
 int sr_set_overlap(int on) {
-  g_overlap.store(on < 0 ? 0 : (on > 2 ? 2 : on));
+  g_overlap.store(on < 0 ? 0 : (on > 2 ? 2 : on)); // see spectrobot_hip.h
   return SR_OK;
 }
 
@@ -733,8 +708,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   // has a fixed cost per box and layer -- S2M, M2M, M2L over every box whatever it holds -- that the per-line
   // expansions at every level (mode 1) do not have: below ~0.37 lines per grid point they are the faster route
   // (tools/ff_mode_crossover.py: 0.3: 2.54 vs 2.61 ms, 0.4: 3.07 vs 3.03, 1.0: 6.74 vs 5.62; the 12 pair tables of the
-  // configs[1] list 19.1 vs 21.5 ms).  Mode 3 (the default) switches; SR_SPARSE_FF1 = the threshold (0: always box pairs).
-  static const double sparse_thr = [] { const char *e = getenv("SR_SPARSE_FF1"); return e ? atof(e) : 0.35; }();
+  // configs[1] list 19.1 vs 21.5 ms).  Mode 3 (the default) switches at 0.35.
+  constexpr double sparse_thr = 0.35;
   const int far_mode = g_far_field.load();
   const bool sparse_set = far_mode == 3 && (double)ls->n_lines < sparse_thr * (double)ls->gp.n_grid;
   const int far_field = far_mode == 3 ? (sparse_set ? 1 : 2) : far_mode;
@@ -819,23 +794,9 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     }
     pst = w.prep_st;
   }
-  // Round 4: the decoupled pipeline (see the far-field branch below) and its hipGraph
-  static const int pipe_env = [] { const char *e = getenv("SR_PIPELINE"); return e ? atoi(e) : 2; }();
-  // SR_GRAPH=1: hipGraph of the internal-stream part of a call (below).  Built, tested (the whole -m gpu suite passes
-  // with it) and MEASURED SLOWER on ROCm 7.2 / gfx950: hipGraphLaunch of the 11-kernel, 4-branch graph costs the host
-  // 406 us per step against 322 us for the direct launches it replaces (tools/host_overhead.py), and the device runs
-  // the graph's branches less concurrently than the streams did: 5.78 vs 5.48 ms per step on the whole grid, 0.883 vs
-  // 0.805 ms on a 1/8 shard.  Off by default.
-  static const int graph_env = [] { const char *e = getenv("SR_GRAPH"); return e ? atoi(e) : 0; }();
-  const bool decoupled = overlap && far_field && !counting && pipe_env != 0;
-  bool want_graph = decoupled && graph_env != 0 && !w.graphs_broken;
-  if (want_graph) {
-    if (!w.graph_st[b]) {
-      HIPCHK(hipStreamCreateWithFlags(&w.graph_st[b], hipStreamNonBlocking));
-      HIPCHK(hipEventCreateWithFlags(&w.ev_pre_done[b], hipEventDisableTiming));
-    }
-    pst = w.graph_st[b];
-  }
+  // overlap 1: the decoupled, phased pipeline (see the far-field branch below); counting passes and overlap 2 keep
+  // round 3's order (the counters are zeroed on the caller's stream)
+  const bool decoupled = overlap == 1 && far_field && !counting;
   Stager &SL = w.s_layers[b];
   DevBuf &d_fast = w.d_fast[b], &d_cold = w.d_cold[b];
   int rc = SL.prepare(hl_bytes);
@@ -896,96 +857,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   }
   // set b was last read by the kernels of the call before the previous one
   if (overlap && w.free_recorded[b]) HIPCHK(hipStreamWaitEvent(pst, w.ev_tables_free[b], 0));
-  if (overlap == 2 && w.tail_recorded) HIPCHK(hipStreamWaitEvent(pst, w.ev_tail, 0));
-  // hipGraph (SR_GRAPH=1; off by default, see graph_env above): every launch between here and the wings kernel goes to internal streams and
-  // scratch of parity b -- staging copy, sr_prep_kernel, level-0 pass, S2M, M2M x 4, M2L, zones kernel, ~20 event
-  // operations: ~30 API calls of ~9 us each on the host.  They are captured once per call shape (the key below: every
-  // value and pointer a node bakes in) and replayed with one hipGraphLaunch; the host then only fills the pinned
-  // staging buffer.  A per-call graph of the WHOLE op would serialise consecutive calls on one stream; this one
-  // covers exactly the part that never touches the caller's buffers, on a stream of the call's parity, so the
-  // pipeline across calls stays what it is.  All allocations happen before the capture begins (pre-flight).
-  hipGraphExec_t g_exec = nullptr;
-  bool capturing = false;
-  std::vector<uintptr_t> g_key;
-  struct CaptureGuard { // an early return inside the captured span must not leave the stream capturing
-    hipStream_t s = nullptr;
-    bool active = false;
-    ~CaptureGuard() {
-      if (!active) return;
-      hipGraph_t g = nullptr;
-      (void)hipStreamEndCapture(s, &g);
-      if (g) (void)hipGraphDestroy(g);
-    }
-  } cap_guard;
-  if (want_graph) {
-    const auto lo_p = std::lower_bound(ls->ic.begin(), ls->ic.end(), (int)g_lo - (kHalf - 1));
-    const auto hi_p = std::upper_bound(ls->ic.begin(), ls->ic.end(), (int)g_hi - 1 + kHalf);
-    const int n_sub_p = (int)(hi_p - lo_p);
-    const size_t n_pts_p = (size_t)(g_hi - g_lo);
-    if (n_sub_p <= 0) {
-      want_graph = false;
-    } else {
-      rc = d_fast.ensure(sizeof(FastRec) * ((size_t)n_sub_p * nl + 1));
-      if (!rc) rc = d_cold.ensure(sizeof(ColdRec) * ((size_t)n_sub_p * nl + 1));
-      size_t boxes = 0;
-      for (int lv = 0; lv < kMaxFarLevels; ++lv) boxes += (n_pts_p + (64u << lv) - 1) / (64u << lv);
-      if (!rc) rc = w.d_coef[b].ensure(sizeof(double) * (size_t)nl * boxes * 2 * kFC);
-      if (!rc && far_field == 2) {
-        const size_t top_boxes = (((size_t)kSrcPad * 64 + n_pts_p + kHalf + 64) >> (6 + kMaxFarLevels - 1)) + 1;
-        rc = w.d_mom[b].ensure(sizeof(double) * (top_boxes * ((1u << kMaxFarLevels) - 1)) * nl * kMomPerBox);
-        const double *tab_p = nullptr;
-        if (!rc) rc = m2l_table_dev(&tab_p);
-      }
-      if (!rc) rc = w.d_zone2[b].ensure(sizeof(double) * 2 * n_pts_p * nl);
-      if (rc) return rc;
-      if (!w.aux) {
-        HIPCHK(hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
-      }
-      if (!w.chain_st) {
-        HIPCHK(hipStreamCreateWithFlags(&w.chain_st, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&w.chain2_st, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-          HIPCHK(hipEventCreateWithFlags(&w.ev_l0_done[i], hipEventDisableTiming));
-          HIPCHK(hipEventCreateWithFlags(&w.ev_s2m_done[i], hipEventDisableTiming));
-          HIPCHK(hipEventCreateWithFlags(&w.ev_wings_done[i], hipEventDisableTiming));
-        }
-      }
-      g_key = {(uintptr_t)ls, (uintptr_t)g_lo, (uintptr_t)g_hi, (uintptr_t)nl, (uintptr_t)W.mode, (uintptr_t)(W.level + 1),
-               (uintptr_t)far_field, (uintptr_t)(frozen ? 1 : 0), (uintptr_t)(frozen && bown->linear_weights ? 1 : 0),
-               (uintptr_t)pipe_env, (uintptr_t)n_sub_p, (uintptr_t)(lo_p - ls->ic.begin()), (uintptr_t)d_fast.p,
-               (uintptr_t)d_cold.p, (uintptr_t)w.d_coef[b].p, (uintptr_t)w.d_mom[b].p, (uintptr_t)w.d_zone2[b].p,
-               (uintptr_t)SL.d.p, (uintptr_t)SL.h, (uintptr_t)hl_bytes, (uintptr_t)ls->d_lines.p, (uintptr_t)ls->d_first.p,
-               (uintptr_t)ls->n_disp_lo, (uintptr_t)ls->n_disp_hi};
-      for (auto &g : w.graphs[b])
-        if (g.key == g_key) {
-          g_exec = g.exec;
-          g.last_use = ++w.graph_clock;
-          break;
-        }
-      if (!g_exec) {
-        if (hipStreamBeginCapture(pst, hipStreamCaptureModeRelaxed) == hipSuccess) {
-          capturing = true;
-          cap_guard.s = pst;
-          cap_guard.active = true;
-        } else {
-          (void)hipGetLastError();
-          w.graphs_broken = true;
-          want_graph = false;
-        }
-      }
-    }
-  }
-  const bool emit = g_exec == nullptr; // false: the launches below are in the graph that will be replayed
-  if (emit) {
-    if (want_graph) { // the copy alone: its completion event is recorded behind the graph launch
-      if (hl_bytes) HIPCHK(hipMemcpyAsync(SL.d.p, SL.h, hl_bytes, hipMemcpyHostToDevice, pst));
-    } else {
-      rc = SL.push(hl_bytes, pst);
-      if (rc) return rc;
-    }
-  }
+  rc = SL.push(hl_bytes, pst);
+  if (rc) return rc;
   LayersDev A;
   const double *dl = SL.d.as<double>();
   A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.ltrat = dl + 4 * nl;
@@ -1052,17 +925,14 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   if (rc) return rc;
 
 
-  if (emit) {
-    // (timing events stay out of a capture: ev[0] / ev[1] then bracket the whole graph, see below)
-    if (!want_graph) HIPCHK(hipEventRecord(w.ev[0], pst));
-    // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
-    LAUNCHCHK(launch_prep(ls->L, A, ls->gp, W, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
-                          far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), pst));
-    if (!want_graph) HIPCHK(hipEventRecord(w.ev[1], pst));
-    if (overlap) HIPCHK(hipEventRecord(w.ev_prep_done[b], pst));
-  }
-  if (overlap) { // the caller's stream takes over once the tables are ready (graph: it waits for the whole graph below)
-    if (!want_graph) HIPCHK(hipStreamWaitEvent(st, w.ev_prep_done[b], 0));
+  HIPCHK(hipEventRecord(w.ev[0], pst));
+  // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
+  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, W, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
+                        far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), pst));
+  HIPCHK(hipEventRecord(w.ev[1], pst));
+  if (overlap) { // the caller's stream takes over once the tables are ready
+    HIPCHK(hipEventRecord(w.ev_prep_done[b], pst));
+    HIPCHK(hipStreamWaitEvent(st, w.ev_prep_done[b], 0));
     HIPCHK(hipEventRecord(w.ev_op0, st));
   }
   if (far_field) {
@@ -1082,9 +952,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     fp.pm = d_pm;
     fp.coef = w.d_coef[b].as<double>();
     fp.m2l = far_field == 2 ? 1 : 0;
-    // SR_SPARSE_ROWS=0 (tuning): the sparse sets through sr_farfield_kernel (a layer per wave) as the explicit mode 1
-    static const int rows_env = [] { const char *e = getenv("SR_SPARSE_ROWS"); return e ? atoi(e) : 1; }();
-    fp.rows = sparse_set && rows_env ? 1 : 0;
+    fp.rows = sparse_set ? 1 : 0; // the sparse sets' own kernel (sr_farfield_rows_kernel: a box for eight layers per wave)
     fp.pm_src = d_pm + nl;
     fp.disp_lo_end = (int)std::min<int64_t>(std::max<int64_t>(ls->n_disp_lo - line_lo, 0), n_sub);
     fp.disp_hi_begin = (int)std::min<int64_t>(std::max<int64_t>(ls->n_lines - ls->n_disp_hi - line_lo, 0), n_sub);
@@ -1130,7 +998,6 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     // phases: B = [wings(c) | level-0 pass(c + 1) | S2M(c + 1)] -- short waves that share the chip fairly --, then
     // A = [zones(c + 1) | M2M, M2L(c + 1) | prep(c + 2)]; the zones kernel is GATED behind the level-0 pass and S2M of
     // its own call (it needs neither), which is what keeps it from flooding the chip before they are through.
-    // Counting passes keep the round-3 order (their counters are zeroed on the caller's stream).
     if (decoupled) {
       if (!w.aux) {
         HIPCHK(hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
@@ -1138,16 +1005,11 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         HIPCHK(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
       }
       if (!w.chain_st) {
-        // SR_CHAIN_PRIO=1 (tuning): the chain's streams at the highest priority the device offers
-        static const int prio_env = [] { const char *e = getenv("SR_CHAIN_PRIO"); return e ? atoi(e) : 0; }();
-        int p_lo = 0, p_hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&p_lo, &p_hi));
-        HIPCHK(hipStreamCreateWithPriority(&w.chain_st, hipStreamNonBlocking, prio_env ? p_hi : 0));
-        HIPCHK(hipStreamCreateWithPriority(&w.chain2_st, hipStreamNonBlocking, prio_env ? p_hi : 0));
+        HIPCHK(hipStreamCreateWithFlags(&w.chain_st, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&w.chain2_st, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
           HIPCHK(hipEventCreateWithFlags(&w.ev_l0_done[i], hipEventDisableTiming));
           HIPCHK(hipEventCreateWithFlags(&w.ev_s2m_done[i], hipEventDisableTiming));
-          HIPCHK(hipEventCreateWithFlags(&w.ev_wings_done[i], hipEventDisableTiming));
         }
       }
       rc = w.d_zone2[b].ensure(sizeof(double) * 2 * n_pts * nl);
@@ -1155,19 +1017,12 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       double *z_abs = w.d_zone2[b].as<double>(), *z_emi = z_abs + n_pts * nl;
       // (the buffers of parity b were last read by the wings kernel two calls ago: the preparation waited for that)
       // far-field chain: level-0 pass on one stream, moments + upward pass on another, translations behind both
-      // SR_CHAIN_AFTER_WINGS (tuning): 1: S2M, 2: S2M and the level-0 pass start only when the PREVIOUS call's wings
-      // kernel is through (beside it S2M's 154-VGPR waves lose every slot race: 1.45 instead of 0.38 ms)
-      static const int after_env = [] { const char *e = getenv("SR_CHAIN_AFTER_WINGS"); return e ? atoi(e) : 0; }();
-      const bool prev_wings = w.wings_recorded[b ^ 1] && !want_graph; // (an event from outside cannot be waited on inside a capture)
-      if (emit) {
       HIPCHK(hipStreamWaitEvent(w.chain_st, w.ev_prep_done[b], 0));
-      if (after_env >= 2 && prev_wings) HIPCHK(hipStreamWaitEvent(w.chain_st, w.ev_wings_done[b ^ 1], 0));
       LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, w.chain_st));
       HIPCHK(hipEventRecord(w.ev_l0_done[b], w.chain_st));
       hipStream_t last = w.chain_st;
       if (fp.m2l) {
         HIPCHK(hipStreamWaitEvent(w.chain2_st, w.ev_prep_done[b], 0));
-        if (after_env >= 1 && prev_wings) HIPCHK(hipStreamWaitEvent(w.chain2_st, w.ev_wings_done[b ^ 1], 0));
         LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, w.chain2_st, 1));
         HIPCHK(hipEventRecord(w.ev_s2m_done[b], w.chain2_st));
         HIPCHK(hipStreamWaitEvent(w.chain2_st, w.ev_l0_done[b], 0));
@@ -1175,64 +1030,18 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         last = w.chain2_st;
       }
       HIPCHK(hipEventRecord(w.ev_far_done[b], last));
-      // zones: needs the tables only; gated (SR_PIPELINE=2, default) behind the kernels that cannot run beside it
+      // zones: needs the tables only; gated behind the kernels that cannot run beside it
       HIPCHK(hipStreamWaitEvent(w.aux, w.ev_prep_done[b], 0));
-      if (pipe_env >= 2) {
-        HIPCHK(hipStreamWaitEvent(w.aux, w.ev_l0_done[b], 0));
-        if (fp.m2l) HIPCHK(hipStreamWaitEvent(w.aux, w.ev_s2m_done[b], 0));
-      }
+      HIPCHK(hipStreamWaitEvent(w.aux, w.ev_l0_done[b], 0));
+      if (fp.m2l) HIPCHK(hipStreamWaitEvent(w.aux, w.ev_s2m_done[b], 0));
       LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo,
                             (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, w.aux));
       HIPCHK(hipEventRecord(w.ev_zones_done[b], w.aux));
-      } // emit
-      if (capturing) { // join the forked streams, close the capture, instantiate
-        HIPCHK(hipStreamWaitEvent(pst, w.ev_far_done[b], 0));
-        HIPCHK(hipStreamWaitEvent(pst, w.ev_zones_done[b], 0));
-        hipGraph_t graph = nullptr;
-        cap_guard.active = false;
-        hipError_t ge = hipStreamEndCapture(pst, &graph);
-        if (ge == hipSuccess && graph) ge = hipGraphInstantiate(&g_exec, graph, nullptr, nullptr, 0);
-        if (graph) (void)hipGraphDestroy(graph);
-        if (ge != hipSuccess || !g_exec) {
-          (void)hipGetLastError();
-          w.graphs_broken = true;
-          g_err = std::string("hipGraph capture of the coefficient op failed: ") + hipGetErrorString(ge);
-          return SR_ERR_HIP;
-        }
-        auto &cache = w.graphs[b];
-        if (cache.size() >= 32) { // evict the least recently used shape
-          size_t victim = 0;
-          for (size_t i = 1; i < cache.size(); ++i)
-            if (cache[i].last_use < cache[victim].last_use) victim = i;
-          (void)hipGraphExecDestroy(cache[victim].exec);
-          cache.erase(cache.begin() + (long)victim);
-        }
-        CoefWork::GraphEntry ge_new;
-        ge_new.key = g_key;
-        ge_new.exec = g_exec;
-        ge_new.last_use = ++w.graph_clock;
-        cache.push_back(ge_new);
-      }
-      if (want_graph) {
-        HIPCHK(hipEventRecord(w.ev[0], pst));
-        HIPCHK(hipGraphLaunch(g_exec, pst));
-        HIPCHK(hipEventRecord(w.ev[1], pst));
-        // the graph's copy node reads the pinned staging buffer: the slot is free again when the graph is through (an
-        // event record node inside the graph is not relied upon for host-side synchronisation)
-        HIPCHK(hipEventRecord(SL.done, pst));
-        SL.pending = true;
-        HIPCHK(hipEventRecord(w.ev_pre_done[b], pst));
-        HIPCHK(hipStreamWaitEvent(st, w.ev_pre_done[b], 0));
-        HIPCHK(hipEventRecord(w.ev[2], st));
-      } else {
-        HIPCHK(hipStreamWaitEvent(st, w.ev_far_done[b], 0));
-        HIPCHK(hipEventRecord(w.ev[2], st));
-        HIPCHK(hipStreamWaitEvent(st, w.ev_zones_done[b], 0));
-      }
+      HIPCHK(hipStreamWaitEvent(st, w.ev_far_done[b], 0));
+      HIPCHK(hipEventRecord(w.ev[2], st));
+      HIPCHK(hipStreamWaitEvent(st, w.ev_zones_done[b], 0));
       LAUNCHCHK(launch_near(1, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo,
                             (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st, z_abs, z_emi));
-      HIPCHK(hipEventRecord(w.ev_wings_done[b], st));
-      w.wings_recorded[b] = true;
       HIPCHK(hipEventRecord(w.ev[3], st));
       HIPCHK(hipEventRecord(w.ev[4], st));
       w.overlapped = true;
@@ -1252,8 +1061,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       // Small shards do not fill the chip: there the wings kernel need not wait for the zones kernel
       // either -- zones writes a private buffer, one pass adds it at the end (on the full grid the
       // VALU is saturated and this variant measured slower: 9.26 vs 9.06 ms).
-      static const size_t small_limit = [] { const char *e = getenv("SR_SMALL_LIMIT"); return e ? (size_t)atoll(e) : (size_t)3000000; }();
-      const bool small = n_pts * (size_t)nl <= small_limit; // SR_SMALL_LIMIT: tuning override (point-layers)
+      const bool small = n_pts * (size_t)nl <= (size_t)3000000; // point-layers
       double *z_abs = abs_out, *z_emi = emi_out;
       if (small) {
         rc = w.d_zone.ensure(sizeof(double) * 2 * n_pts * nl);
@@ -1268,9 +1076,6 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       if (rc) return rc;
       HIPCHK(hipEventRecord(w.ev[2], st));
       if (!small) HIPCHK(hipStreamWaitEvent(st, w.ev_join, 0));
-      if (!w.ev_tail) HIPCHK(hipEventCreateWithFlags(&w.ev_tail, hipEventDisableTiming));
-      HIPCHK(hipEventRecord(w.ev_tail, st));
-      w.tail_recorded = true;
       LAUNCHCHK(launch_near(1, small ? 0 : 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st));
       HIPCHK(hipEventRecord(w.ev[3], st));
@@ -1340,10 +1145,7 @@ static int level_set(sr_lineset *ls, int level, sr_lineset **out, bool up_only =
     c->mm = ls->mm;
     c->n_levels = ls->n_levels;
     c->e_lev = ls->e_lev;
-    // scratch, streams and events of the parent (SR_LEVEL_OWN_WORK=1, tuning: a CoefWork of its own per level, so that
-    // the internal kernels of ALL levels of a pair-table build can run ahead of the one caller's stream)
-    static const int own_env = [] { const char *e = getenv("SR_LEVEL_OWN_WORK"); return e ? atoi(e) : 0; }();
-    if (!own_env) c->work = ls->work;
+    c->work = ls->work; // scratch, streams and events of the parent (see CoefWork)
     c->parent = ls;
     for (int which = 0; which < 2; ++which) {
       const HostLines &H = which ? ls->host_outer : ls->host;

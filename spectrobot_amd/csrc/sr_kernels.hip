@@ -2122,20 +2122,10 @@ constexpr int kZoneImage = SR_ZONES_WT; // grid points per LDS image of sr_absco
 template <int NW, bool COUNT>
 static void launch_zones(dim3 gz, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
                          int n_sub, int n_t, int g_lo, int g_hi, const GridParams &gp, int add, double *abs_out,
-                         double *emi_out, unsigned long long *cnt, hipStream_t st, int n_layers, int n_chunks) {
-  // Layer chunks (one launch each, same stream): a single dispatch of 15 680 one-millisecond waves keeps every wave
-  // slot it is given -- the dispatcher serves the OLDER dispatch first whenever its next workgroup fits, so kernels of
-  // the other streams (the far-field chain, the next call's preparation) sat in their queues until it drained
-  // (tools/r03_timeline.sh).  Between two chunks they are the older ones and get in; the next chunk fills what they
-  // leave.  (gz.x = n_t * n_layers on entry.)
-  n_chunks = n_chunks < 1 ? 1 : (n_chunks > n_layers ? n_layers : n_chunks);
-  for (int c = 0; c < n_chunks; ++c) {
-    const int l0 = (int)((long)n_layers * c / n_chunks), l1 = (int)((long)n_layers * (c + 1) / n_chunks);
-    if (l1 <= l0) continue;
-    hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<kZoneImage, NW, COUNT>), dim3((unsigned)(n_t * (l1 - l0))), dim3(64 * NW), 0,
-                       st, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, l0);
-  }
-  (void)gz;
+                         double *emi_out, unsigned long long *cnt, hipStream_t st) {
+  // (layer chunks, one launch each, were measured and lost: profiles/r04_timeline_zones_chunks8.txt)
+  hipLaunchKernelGGL((sr_abscoeff_near_zones_kernel<kZoneImage, NW, COUNT>), gz, dim3(64 * NW), 0, st, fast, cold, ix, zmax, n_sub,
+                     n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, 0);
 }
 
 int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, const IcIndex &ix, const int *zmax,
@@ -2148,16 +2138,11 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
   if (part == 1) {
     // slots per wave: 4 (256-point groups) measured 2.53 ms on config 2, 2: 2.31 ms, 1: see DESIGN.md
     const int n_g1 = (g_hi - g_lo + 63) / 64;
-    // SR_WINGS_LDS (bytes, tuning): dynamic LDS requested per block to CAP this kernel's occupancy (it uses none): 80 VGPRs
-    // pack six waves per SIMD and leave 32 registers -- no wave of S2M (168) or of the level-0 pass (140) of the next call
-    // ever fits beside it; 10240 B holds it to four waves per SIMD (16 blocks per CU) and leaves 192 registers free.
-    static const unsigned wings_lds = [] { const char *e = getenv("SR_WINGS_LDS"); return e ? (unsigned)atoi(e) : 0u; }();
-    const unsigned w_lds = z_abs ? wings_lds : 0u; // decoupled pipeline only
     if (cnt)
       hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<true>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
                          fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, z_abs, z_emi, abs_out, emi_out, cnt);
     else
-      hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<false>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), w_lds, st,
+      hipLaunchKernelGGL(sr_abscoeff_near_wings_kernel<false>, dim3((unsigned)(n_g1 * n_layers)), dim3(64), 0, st,
                          fast, ix, zmax, n_sub, n_g1, g_lo, g_hi, fp, add, z_abs, z_emi, abs_out, emi_out, cnt);
   } else {
     // Image width: wider images cut fewer zones in two (fewer (line, group) pairs: 7.1 -> 6.7 ms on
@@ -2166,16 +2151,10 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
     const long waves512 = (long)((g_hi - g_lo + kZoneImage - 1) / kZoneImage) * n_layers;
     const int n_t = (g_hi - g_lo + kZoneImage - 1) / kZoneImage;
     const dim3 gz((unsigned)(n_t * n_layers));
-    static const int chunks_env = [] { const char *e = getenv("SR_ZONES_CHUNKS"); return e ? atoi(e) : 1; }();
-    const int n_chunks = waves512 >= 3 * 4096 ? chunks_env : 1; // whole grids only: a small shard's launch is short as it is
 #define SR_ZONES(NW)                                                                                         \
-  (cnt ? launch_zones<NW, true>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st, n_layers, n_chunks) \
-       : launch_zones<NW, false>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st, n_layers, n_chunks))
-    // SR_ZONES_NW=1|2|4|8 (environment, read once): tuning override of the waves per image
-    static const int nw_env = [] { const char *e = getenv("SR_ZONES_NW"); return e ? atoi(e) : 0; }();
-    if (nw_env == 1 || nw_env == 2 || nw_env == 4 || nw_env == 8) {
-      switch (nw_env) { case 1: SR_ZONES(1); break; case 2: SR_ZONES(2); break; case 4: SR_ZONES(4); break; default: SR_ZONES(8); }
-    } else if (waves512 >= 3 * 4096)
+  (cnt ? launch_zones<NW, true>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st) \
+       : launch_zones<NW, false>(gz, fast, cold, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, add, abs_out, emi_out, cnt, st))
+    if (waves512 >= 3 * 4096)
       SR_ZONES(1);
     else if (waves512 >= 3 * 2048)
       SR_ZONES(2);
