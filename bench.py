@@ -315,9 +315,11 @@ def main():
     full = torch.empty((args.rays, args.grid), dtype=torch.float64, device="cuda") if world > 1 else None
 
     def step():
-        ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"], q_part=q_part, g_lo=g_lo, g_hi=g_hi,
-                           out=(ab, em))
-        rad = engine.limb_rays((ab, em), los)      # columns (curgod_fort_2) + recursion on the device
+        # coefficient op + recursion of the resident LOS batch in one library call (sr_limb_step_dev); the columns
+        # (curgod_fort_2) of the batch were integrated on the device when it was made resident, outside the loop, as
+        # the reference computes a line of sight's steps once (spect_main_module.py:2746-2767)
+        _, _, rad = ls.limb_step(atm["temps"], atm["press"], los, tvib=atm["tvib"], q_part=q_part, g_lo=g_lo, g_hi=g_hi,
+                                 out=(ab, em))
         if args.shard:
             return rad
         # async: the next step's kernels need not wait for this step's (latency-bound) gather; barrier() below
@@ -340,11 +342,15 @@ def main():
     gc.collect()
     gc.freeze()
     kms = np.zeros(5)
+    engine.set_timing(0)          # no per-kernel timing events in the timed steps (diagnostics: the pass below has them)
+    step()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):   # no host synchronisation inside: consecutive steps pipeline on the GPU
         spec = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    engine.set_timing(1)
     for _ in range(args.steps):   # HIP-event times of this rank's kernels (each query synchronises that step)
         step()
         kms += np.array(ls.last_kernel_ms())
@@ -358,7 +364,7 @@ def main():
         # what the collective really was, and the asynchronous gather of the last timed step against a blocking one
         # of the same shard (outside the timed region)
         dist_rec = dict(sd.dist_info(), async_gather=bool(ASYNC_GATHER), gathers=dict(sd.stats))
-        rad_chk = engine.limb_rays((ab, em), los)
+        rad_chk = engine.limb_rays((ab, em), los, resident=False)   # (the per-call staging route: a second opinion)
         blocking = sd.all_gather_spectrum(rad_chk, args.grid, world, rank, async_op=False)
         torch.cuda.synchronize()
         dist_rec["async_equals_blocking"] = bool(torch.equal(blocking, spec))

@@ -295,6 +295,26 @@ int sr_los_columns(const sr_los_desc *los, double *col_out);
 int sr_limb_rays_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, const sr_los_desc *los,
                      double *rad, void *stream);
 
+/* A LOS batch resident on the device: the description staged, the Curtis-Godson columns of its segments integrated
+ * (curgod_fort_2) and, where the rays share their shells, the folded sweep's records packed -- ONCE, as the reference
+ * computes a line of sight's steps once (los.calc_radtran_steps, spect_main_module.py:2746-2767, 3147) and runs
+ * radtran / radtran_fast on them for every call of the forward model (:2838, 3214).  The description's arrays are
+ * copied; init_mode / t_init / w0 / step / los_order / solo_absorption are taken as given (g_lo per call).  n_layers:
+ * rows of the coefficient tables the handle will be used with (seg_layer is checked against it).  Synchronises. */
+typedef struct sr_los sr_los;
+int sr_los_create(const sr_los_desc *los, int n_layers, sr_los **out);
+int sr_los_destroy(sr_los *h);
+/* sr_limb_rays_dev on a resident LOS: kernel launches only (no staging copy, no column kernel, no host plan).
+ * g_lo: grid index of abs_c's first point (Planck initial intensity, init_mode 2). */
+int sr_limb_rays_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
+                         double *rad, void *stream);
+/* One forward-model step of one gas in ONE call: sr_abscoeff_layers_dev into abs_out / emi_out, then the recursion of
+ * the resident LOS (n_gas = 1) through them into rad [n_rays][g_hi - g_lo] -- what a caller of make_abscoeff_isomolec
+ * + radtran_fast does per spectrum (spect_main_module.py:1979-1990, 2838).  A 1/8 spectral shard of BASELINE
+ * configs[1] is 0.8 ms of device time: the host's enqueue time per step is what eight ranks must stay under. */
+int sr_limb_step_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *abs_out,
+                     double *emi_out, sr_los *h, double *rad, void *stream);
+
 /* + Jacobian w.r.t. n_par VMR-profile parameters: the VMR of gas par_gas[p] at LOS sample point i is
  * sum_p par_w[p][i] x_p (mask values of RetParam / LinearProfile at the point, spect_main_module.py:319-375), so
  * d col_g[s] / d x_p = col_scale[g] curgod_fort_2(nd, par_w[p], x).  par_gas: HOST [n_par]; par_w: HOST
@@ -432,6 +452,9 @@ int sr_last_eval_counts(sr_lineset *ls, uint64_t *counts10);
  * sr_abscoeff_near_zones_kernel.  Exact mode: ms5[1] sr_abscoeff_wings_kernel,
  * ms5[2] sr_abscoeff_cores_kernel.  Unused entries 0.  Synchronises. */
 int sr_last_kernel_ms(sr_lineset *ls, float *ms5);
+/* 0: the coefficient op records no timing events (seven hipEventRecord fewer per call: a 1/8 spectral shard's step is
+ * bound by the host's enqueue time before anything else); sr_last_kernel_ms then returns SR_ERR_ARG.  1 (default). */
+int sr_set_timing(int on);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,12 @@ SYMBOLS = {
     "sr_los_columns": (C.c_int, [C.POINTER(LosDesc), dp]),
     "sr_limb_rays_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(LosDesc), C.c_void_p,
                                    C.c_void_p]),
+    "sr_los_create": (C.c_int, [C.POINTER(LosDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "sr_los_destroy": (C.c_int, [C.c_void_p]),
+    "sr_limb_rays_los_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                       C.c_void_p]),
+    "sr_limb_step_dev": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_limb_rays_jac_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(LosDesc), C.c_int, ip, dp,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_limb_rays_jacobians_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
@@ -113,6 +119,7 @@ SYMBOLS = {
     "sr_set_table_budget": (C.c_int, [C.c_int64]),
     "sr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sr_set_counting": (C.c_int, [C.c_int]),
+    "sr_set_timing": (C.c_int, [C.c_int]),
     "sr_lineset_set_bounds_temps": (C.c_int, [C.c_void_p, dp, C.c_int]),
     "sr_lineset_set_linear_weights": (C.c_int, [C.c_void_p, C.c_int]),
     "sr_last_eval_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

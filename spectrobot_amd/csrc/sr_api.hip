@@ -222,6 +222,7 @@ std::atomic<int> g_far_field{3}; // 1: far wings by per-line local expansions, 2
 std::atomic<int> g_overlap{1};   // 1 (default): the decoupled, phased pipeline; 2: round 3's order (zones forked off the caller's stream beside the far-field chain; the A/B partner); 0: kernels one after the other
 // sr_set_jac_layer_mode; SR_JAC_LAYER_MODE (environment, read once at load): its initial value, for A/B runs of whole programs
 std::atomic<int> g_jac_layer_forward{[] { const char *e = getenv("SR_JAC_LAYER_MODE"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 3 ? v : 0; }()};
+std::atomic<int> g_timing{1};    // 0: no timing events in the coefficient op (sr_set_timing: seven hipEventRecord fewer per call)
 std::atomic<int> g_counting{0};  // 1: counting instantiations of the far-field-mode kernels (sr_set_counting)
 std::atomic<size_t> g_table_budget{(size_t)48 << 30}; // bytes of FastRec + ColdRec tables per layer batch
 
@@ -378,6 +379,11 @@ int sr_set_far_field(int on) {
 
 int sr_set_overlap(int on) {
   g_overlap.store(on < 0 ? 0 : (on > 2 ? 2 : on)); // see spectrobot_hip.h
+  return SR_OK;
+}
+
+int sr_set_timing(int on) {
+  g_timing.store(on ? 1 : 0);
   return SR_OK;
 }
 
@@ -704,6 +710,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     if (!(atm->temps[k] > 0.0) || !(atm->press[k] >= 0.0)) return SR_ERR_ARG;
   // one snapshot of the mode switches per call
   const int overlap = g_overlap.load(), variant = g_variant.load();
+  const bool timing = g_timing.load() != 0;
   // Sparse line sets (the per-level sub-linesets of the pair tables: 9-15 % of a hot-band list): the box-pair far field
   // has a fixed cost per box and layer -- S2M, M2M, M2L over every box whatever it holds -- that the per-line
   // expansions at every level (mode 1) do not have: below ~0.37 lines per grid point they are the faster route
@@ -925,15 +932,15 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   if (rc) return rc;
 
 
-  HIPCHK(hipEventRecord(w.ev[0], pst));
+  if (timing) HIPCHK(hipEventRecord(w.ev[0], pst));
   // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
   LAUNCHCHK(launch_prep(ls->L, A, ls->gp, W, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
                         far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), pst));
-  HIPCHK(hipEventRecord(w.ev[1], pst));
+  if (timing) HIPCHK(hipEventRecord(w.ev[1], pst));
   if (overlap) { // the caller's stream takes over once the tables are ready
     HIPCHK(hipEventRecord(w.ev_prep_done[b], pst));
     HIPCHK(hipStreamWaitEvent(st, w.ev_prep_done[b], 0));
-    HIPCHK(hipEventRecord(w.ev_op0, st));
+    if (timing) HIPCHK(hipEventRecord(w.ev_op0, st));
   }
   if (far_field) {
     FarParams fp;
@@ -1038,12 +1045,12 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
                             (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, w.aux));
       HIPCHK(hipEventRecord(w.ev_zones_done[b], w.aux));
       HIPCHK(hipStreamWaitEvent(st, w.ev_far_done[b], 0));
-      HIPCHK(hipEventRecord(w.ev[2], st));
+      if (timing) HIPCHK(hipEventRecord(w.ev[2], st));
       HIPCHK(hipStreamWaitEvent(st, w.ev_zones_done[b], 0));
       LAUNCHCHK(launch_near(1, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo,
                             (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st, z_abs, z_emi));
-      HIPCHK(hipEventRecord(w.ev[3], st));
-      HIPCHK(hipEventRecord(w.ev[4], st));
+      if (timing) HIPCHK(hipEventRecord(w.ev[3], st));
+      if (timing) HIPCHK(hipEventRecord(w.ev[4], st));
       w.overlapped = true;
     } else
     if (overlap) {
@@ -1074,27 +1081,27 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       HIPCHK(hipEventRecord(w.ev_join, w.aux));
       rc = far_pass(st);
       if (rc) return rc;
-      HIPCHK(hipEventRecord(w.ev[2], st));
+      if (timing) HIPCHK(hipEventRecord(w.ev[2], st));
       if (!small) HIPCHK(hipStreamWaitEvent(st, w.ev_join, 0));
       LAUNCHCHK(launch_near(1, small ? 0 : 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub,
                             nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st));
-      HIPCHK(hipEventRecord(w.ev[3], st));
+      if (timing) HIPCHK(hipEventRecord(w.ev[3], st));
       if (small) {
         HIPCHK(hipStreamWaitEvent(st, w.ev_join, 0));
         LAUNCHCHK(launch_add2(abs_out, z_abs, emi_out, z_emi, n_pts * nl, st));
       }
-      HIPCHK(hipEventRecord(w.ev[4], st));
+      if (timing) HIPCHK(hipEventRecord(w.ev[4], st));
       w.overlapped = true;
     } else {
       w.overlapped = false;
       rc = far_pass(st);
       if (rc) return rc;
-      HIPCHK(hipEventRecord(w.ev[2], st));
+      if (timing) HIPCHK(hipEventRecord(w.ev[2], st));
       for (int part = 1; part <= 2; ++part) {
         LAUNCHCHK(launch_near(part, part == 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix,
                               zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out,
                               d_cnt, st));
-        HIPCHK(hipEventRecord(w.ev[2 + part], st));
+        if (timing) HIPCHK(hipEventRecord(w.ev[2 + part], st));
       }
     }
     w.n_timed = 4;
@@ -1104,7 +1111,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       LAUNCHCHK(launch_abscoeff(variant, which, d_fast.as<FastRec>(), d_cold.as<ColdRec>(),
                                 ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp,
                                 abs_out, emi_out, st));
-      HIPCHK(hipEventRecord(w.ev[2 + which], st));
+      if (timing) HIPCHK(hipEventRecord(w.ev[2 + which], st));
     }
   }
   rc = add_outer(); // after the timing events: not part of the per-kernel times
@@ -1116,7 +1123,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   HIPCHK(hipEventRecord(w.ev_last_done, st));
   w.last_done_recorded = true;
   w.pipelined = overlap != 0;
-  w.timed = true;
+  w.timed = timing;
   w.counted = counting;
   return SR_OK;
 }
@@ -1463,8 +1470,9 @@ int check_los(const sr_los_desc *los, int n_layers, int *n_seg_out, int *n_pt_ou
 }
 
 // Stage the LOS on `st` and evaluate the columns of the gases and of n_par profile parameters.
+// own: the staging slot of a device-resident LOS (sr_los_create) instead of the per-call ring.
 int stage_los(const sr_los_desc *los, int n_layers, int n_par, const int32_t *par_gas, const double *par_w,
-              hipStream_t st, LosDev *out) {
+              hipStream_t st, LosDev *out, Stager *own = nullptr) {
   int n_seg = 0, n_pt = 0;
   int rc = check_los(los, n_layers, &n_seg, &n_pt);
   if (rc) return rc;
@@ -1473,7 +1481,7 @@ int stage_los(const sr_los_desc *los, int n_layers, int n_par, const int32_t *pa
     if (par_gas[p] < 0 || par_gas[p] >= los->n_gas) return SR_ERR_ARG;
   static thread_local Stager s_ring[4];
   static thread_local unsigned s_next = 0;
-  Stager &sg = s_ring[s_next++ & 3];
+  Stager &sg = own ? *own : s_ring[s_next++ & 3];
   const int n_prof = los->n_gas + n_par, nr = los->n_rays;
   auto al = [](size_t v) { return (v + 15) / 16 * 16; };
   const size_t o_x = 0, o_nd = o_x + sizeof(double) * n_pt, o_prof = o_nd + sizeof(double) * n_pt;
@@ -1614,7 +1622,7 @@ struct FoldStage {
   int n_vis = 0, n_rec = 0;
   Stager *slot = nullptr;
 };
-int stage_fold(const sr_los_desc *los, int n_layers, hipStream_t st, FoldStage *out) {
+int stage_fold(const sr_los_desc *los, int n_layers, hipStream_t st, FoldStage *out, Stager *own = nullptr) {
   std::vector<int> far, near;
   int l_min = 0, l_max = -1;
   if (!fold_sides(los, n_layers, nullptr, &far, &near, &l_min, &l_max)) return SR_OK;
@@ -1640,7 +1648,7 @@ int stage_fold(const sr_los_desc *los, int n_layers, hipStream_t st, FoldStage *
   const int n_vis = (int)shells.size(), n_rec = nr * n_vis;
   static thread_local Stager s_ring[4];
   static thread_local unsigned s_next = 0;
-  Stager &sg = s_ring[s_next++ & 3];
+  Stager &sg = own ? *own : s_ring[s_next++ & 3];
   const size_t plan_bytes = (sizeof(int) * 4 * (size_t)n_rec + 15) / 16 * 16;
   int rc = sg.prepare(plan_bytes + fold_dense_bytes(n_rec));
   if (rc) return rc;
@@ -1687,6 +1695,88 @@ int sr_los_columns(const sr_los_desc *los, double *col_out) {
 
 static thread_local int g_last_limb_route = 0;
 int sr_last_limb_route(void) { return g_last_limb_route; }
+
+} // extern "C"
+
+// A LOS batch resident on the device (sr_los_create): the staged description, its Curtis-Godson columns and -- where
+// the rays share their shells -- the folded sweep's packed records, all made ONCE.  The reference computes a LOS's
+// steps once too (los.calc_radtran_steps, spect_main_module.py:2746-2767) and runs radtran on them many times.
+struct sr_los {
+  Stager s_los, s_fold;
+  LosDev D{};
+  FoldStage F{};
+  sr_los_desc opt{}; // the scalar options; its pointers are not kept
+  int n_layers = 0, dev = -1;
+};
+
+// the recursion of a resident LOS on `st`: launches only
+static int limb_rays_los(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
+                         double *rad, hipStream_t st) {
+  sr_los_desc o = h->opt;
+  o.g_lo = g_lo;
+  if (h->F.n_rec > 0 && !limb_launch_is_small((int)n_pts, o.n_rays) && g_jac_layer_forward.load() == 0) {
+    LAUNCHCHK(launch_fold_fwd(h->F.plan, h->D.col, h->D.n_seg, h->F.n_rec, h->F.rec, abs_c, emi_c, (int)n_pts, n_layers, o.n_rays,
+                              h->F.n_vis, limb_opts(&o, h->D.n_seg), rad, st, /*pack=*/false));
+    g_last_limb_route = 2;
+    return SR_OK;
+  }
+  LAUNCHCHK(launch_limb(abs_c, emi_c, (int)n_pts, n_layers, o.n_rays, h->D.seg_off, h->D.seg_layer, h->D.col,
+                        limb_opts(&o, h->D.n_seg), rad, st));
+  g_last_limb_route = 1;
+  return SR_OK;
+}
+
+extern "C" {
+
+int sr_los_create(const sr_los_desc *los, int n_layers, sr_los **out) {
+  if (!out || n_layers <= 0) return SR_ERR_ARG;
+  *out = nullptr;
+  sr_los *h = new sr_los();
+  int rc = stage_los(los, n_layers, 0, nullptr, nullptr, nullptr, &h->D, &h->s_los);
+  if (!rc) rc = stage_fold(los, n_layers, nullptr, &h->F, &h->s_fold);
+  if (!rc && h->F.n_rec > 0) {
+    LimbOpts o = limb_opts(los, h->D.n_seg);
+    rc = launch_fold_fwd(h->F.plan, h->D.col, h->D.n_seg, h->F.n_rec, h->F.rec, nullptr, nullptr, 0, n_layers, los->n_rays,
+                         h->F.n_vis, o, nullptr, nullptr) ? SR_ERR_HIP : SR_OK;
+  }
+  if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = SR_ERR_HIP; // (the null stream waited for the copy stream's work)
+  if (rc) {
+    h->s_los.release();
+    h->s_fold.release();
+    delete h;
+    return rc;
+  }
+  h->opt = *los;
+  h->opt.seg_off = h->opt.seg_layer = h->opt.pt_off = nullptr;
+  h->opt.x = h->opt.nd = h->opt.vmr = h->opt.col_scale = nullptr;
+  h->n_layers = n_layers;
+  (void)hipGetDevice(&h->dev);
+  *out = h;
+  return SR_OK;
+}
+
+int sr_los_destroy(sr_los *h) {
+  if (!h) return SR_OK;
+  h->s_los.release();
+  h->s_fold.release();
+  delete h;
+  return SR_OK;
+}
+
+int sr_limb_rays_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
+                         double *rad, void *stream) {
+  if (!abs_c || !emi_c || !rad || !h || n_layers != h->n_layers || n_pts <= 0) return SR_ERR_ARG;
+  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  return limb_rays_los(abs_c, emi_c, n_layers, n_pts, h, g_lo, rad, static_cast<hipStream_t>(stream));
+}
+
+int sr_limb_step_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *abs_out, double *emi_out,
+                     sr_los *h, double *rad, void *stream) {
+  if (!h || !rad || !atm || h->opt.n_gas != 1 || atm->n_layers != h->n_layers) return SR_ERR_ARG;
+  const int rc = coef_op(ls, atm, g_lo, g_hi, abs_out, emi_out, stream, WeightMode{kWeightFolded, 0});
+  if (rc) return rc;
+  return limb_rays_los(abs_out, emi_out, atm->n_layers, g_hi - g_lo, h, g_lo, rad, static_cast<hipStream_t>(stream));
+}
 
 int sr_limb_rays_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, const sr_los_desc *los,
                      double *rad, void *stream) {

@@ -3489,9 +3489,11 @@ __global__ __launch_bounds__(256) void sr_limb_fold_fwd_kernel(const double *__r
 
 int launch_fold_fwd(const int *plan, const double *col, int n_seg, int n_rec, FoldDense *rec, const double *abs_c,
                     const double *emi_c, int n_pts, int n_layers, int n_rays, int n_visits, const LimbOpts &o, double *rad,
-                    hipStream_t st) {
-  if (n_rec <= 0 || n_pts <= 0 || n_rays <= 0) return 0;
-  hipLaunchKernelGGL(sr_fold_dense_pack_kernel, dim3((n_rec + 63) / 64), dim3(64), 0, st, plan, col, o.n_gas, 0, n_seg, n_rec, rec);
+                    hipStream_t st, bool pack) {
+  if (n_rec <= 0 || n_rays <= 0) return 0;
+  if (pack)
+    hipLaunchKernelGGL(sr_fold_dense_pack_kernel, dim3((n_rec + 63) / 64), dim3(64), 0, st, plan, col, o.n_gas, 0, n_seg, n_rec, rec);
+  if (n_pts <= 0) return (int)hipGetLastError(); // (packing only)
   const dim3 grid(limb_grid((n_pts + 255) / 256, n_rays));
 #define SR_FF(NG) hipLaunchKernelGGL(sr_limb_fold_fwd_kernel<NG>, grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, rec, o, n_visits, \
                                      n_rays, rad)

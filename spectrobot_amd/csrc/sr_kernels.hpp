@@ -205,9 +205,10 @@ int launch_fold_dense(const int *plan, const double *col, const int *par_gas_hos
                       const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, int n_visits,
                       const LimbOpts &o, double *rad, double *jac_par, hipStream_t st);
 // The radiances of a ray batch, folded (sr_limb_fold_fwd_kernel; the plan and records of launch_fold_dense with no parameters)
+// pack = false: `rec` was packed by an earlier call with the same plan and columns (a device-resident LOS, sr_los_create)
 int launch_fold_fwd(const int *plan, const double *col, int n_seg, int n_rec, FoldDense *rec, const double *abs_c,
                     const double *emi_c, int n_pts, int n_layers, int n_rays, int n_visits, const LimbOpts &o, double *rad,
-                    hipStream_t st);
+                    hipStream_t st, bool pack = true);
 // launch_limb takes the latency-bound split kernel below this many waves
 inline bool limb_launch_is_small(int n_pts, int n_rays) { return (long)((n_pts + 63) / 64) * n_rays < 2048; }
 int launch_radiance(const double *abs_c, const double *emi_c, int n_pts, int n_rays, const int *seg_off,

@@ -84,6 +84,7 @@ class LineSet(object):
               "sr_lineset_create")
         self._h = h
         self.n_kept = kept.value
+        self._step_cache = None
 
     def close(self):
         if getattr(self, "_h", None) and lib is not None:
@@ -129,6 +130,38 @@ class LineSet(object):
         check(lib.sr_abscoeff_layers_dev(self._h, C.byref(desc), int(g_lo), g_hi, C.c_void_p(ab.data_ptr()),
                                          C.c_void_p(em.data_ptr()), _stream_ptr()), "sr_abscoeff_layers_dev")
         return ab, em
+
+    def limb_step(self, temps, press, los, tvib=None, q_part=None, g_lo=0, g_hi=None, out=None, rad=None, grid=None):
+        """One forward-model step in ONE library call (sr_limb_step_dev): the coefficient spectra of this gas over
+        [g_lo, g_hi) into `out` (as abscoeff_layers) and the radiances of the resident LOS batch `los` (LimbLOS, one
+        gas) through them -- make_abscoeff_isomolec + radtran_fast per spectrum (spect_main_module.py:1979-1990, 2838).
+        The layer descriptor is cached on the arrays' identity: a loop over the same atmosphere objects pays for
+        neither conversions nor staging.  Returns (abs, emi, rad)."""
+        g_hi = self.n_grid if g_hi is None else int(g_hi)
+        key = (id(temps), id(press), id(tvib), id(q_part))
+        c = self._step_cache
+        if c is None or c[0] != key:
+            desc, keep, n = self._layers(temps, press, tvib, q_part)
+            c = (key, desc, keep, n)
+            # cached only when the descriptor points into the caller's own arrays (contiguous float64: no copies were
+            # made), so that values changed in place are seen; the arrays are referenced, their ids stay theirs
+            given = [a for a in (temps, press, tvib, q_part) if a is not None]
+            self._step_cache = c if all(any(k is a for k in keep) for a in given) else None
+        _, desc, _, n = c
+        npts = g_hi - int(g_lo)
+        if npts <= 0:
+            raise ValueError("empty shard")
+        if out is None:
+            out = (torch.empty((n, npts), dtype=torch.float64, device="cuda"), torch.empty((n, npts), dtype=torch.float64, device="cuda"))
+        ab, em = out
+        if rad is None:
+            rad = torch.empty((los.n_rays, npts), dtype=torch.float64, device="cuda")
+        assert ab.shape == (n, npts) and em.shape == (n, npts) and rad.shape == (los.n_rays, npts)
+        assert ab.is_contiguous() and em.is_contiguous() and rad.is_contiguous()
+        h = los.handle(n, grid)
+        check(lib.sr_limb_step_dev(self._h, C.byref(desc), int(g_lo), g_hi, ab.data_ptr(), em.data_ptr(), h, rad.data_ptr(),
+                                   _stream_ptr()), "sr_limb_step_dev")
+        return ab, em, rad
 
     def set_bounds_temps(self, temps=None, linear_weights=False):
         """Place the Humlicek region boundaries of the next coefficient calls as at `temps` [n_layers] (None: at each
@@ -367,6 +400,11 @@ class LevelFactored(object):
         return glevel_combine(self.tab, step_row, pop, tab_dT=self.tab_dT, dpop=dpop, dT=self.dT, out=out)
 
 
+def set_timing(on):
+    """0: no timing events in the coefficient op (host-bound loops: small shards); last_kernel_ms is then unavailable."""
+    check(lib.sr_set_timing(int(on)), "sr_set_timing")
+
+
 def set_counting(on):
     """1: the next coefficient ops run the counting instantiations (executed-work accounting, untimed)."""
     check(lib.sr_set_counting(int(bool(on))), "sr_set_counting")
@@ -406,12 +444,13 @@ class LimbLOS(object):
 
     def __init__(self, seg_off, seg_layer, pt_off, x, nd, vmr, col_scale=None, LOS_order='photon',
                  solo_absorption=False, initial_temperature=None):
-        self.seg_off, self._so = _i(seg_off)
-        self.seg_layer, self._sl = _i(seg_layer)
-        self.pt_off, self._po = _i(pt_off)
-        self.x, self._x = _d(x)
-        self.nd, self._nd = _d(nd)
-        self.vmr, self._v = _d(np.atleast_2d(vmr))
+        # (copies: the object is the geometry as given -- its device-resident form is built once, see handle())
+        self.seg_off, self._so = _i(np.array(seg_off))
+        self.seg_layer, self._sl = _i(np.array(seg_layer))
+        self.pt_off, self._po = _i(np.array(pt_off))
+        self.x, self._x = _d(np.array(x))
+        self.nd, self._nd = _d(np.array(nd))
+        self.vmr, self._v = _d(np.atleast_2d(np.array(vmr)))
         self.n_rays, self.n_gas = self.seg_off.size - 1, self.vmr.shape[0]
         self.n_seg, self.n_pt = self.seg_layer.size, self.x.size
         if self.vmr.shape[1] != self.n_pt or self.nd.size != self.n_pt or self.pt_off.size != self.n_seg + 1:
@@ -420,6 +459,30 @@ class LimbLOS(object):
         if LOS_order not in ('photon', 'observer'):
             raise ValueError("LOS_order must be 'photon' or 'observer'")
         self.LOS_order, self.solo_absorption, self.initial_temperature = LOS_order, bool(solo_absorption), initial_temperature
+        self._handles = {}
+
+    def handle(self, n_layers, grid=None, rad0=False):
+        """The batch resident on the device (sr_los_create): staged, its columns integrated and the folded sweep's
+        records packed once per (n_layers, grid, rad0); limb_rays and LineSet.limb_step then only launch.  The
+        object IS the geometry it was built from: its arrays were copied at construction, build a new LimbLOS for
+        other VMRs or paths."""
+        gp = None if (grid is None or self.initial_temperature is None or rad0) else grid_params(grid)[:2]
+        key = (int(n_layers), gp, bool(rad0))
+        h = self._handles.get(key)
+        if h is None:
+            d = self.desc(grid, 0, rad0=rad0)
+            h = C.c_void_p()
+            check(lib.sr_los_create(C.byref(d), int(n_layers), C.byref(h)), "sr_los_create")
+            self._handles[key] = h
+        return h
+
+    def close(self):
+        for h in getattr(self, "_handles", {}).values():
+            if lib is not None:
+                lib.sr_los_destroy(h)
+        self._handles = {}
+
+    __del__ = close
 
     def desc(self, grid=None, g_lo=0, rad0=False):
         d = _lib.LosDesc()
@@ -467,16 +530,22 @@ def _gas_stack(coeffs):
     return a, e
 
 
-def limb_rays(coeffs, los, grid=None, g_lo=0, rad0=None):
-    """Radiances [n_rays, n_pts] of a LimbLOS batch through the gases' coefficients (sr_limb_rays_dev):
-    columns per segment on the device, then the recursion.  coeffs: (abs, emi) or [(abs, emi)] per gas,
-    CUDA [n_layers, n_pts] each.  rad0: CUDA [n_rays, n_pts] initial intensity (overwritten)."""
+def limb_rays(coeffs, los, grid=None, g_lo=0, rad0=None, resident=True):
+    """Radiances [n_rays, n_pts] of a LimbLOS batch through the gases' coefficients: columns per segment on the device,
+    then the recursion.  coeffs: (abs, emi) or [(abs, emi)] per gas, CUDA [n_layers, n_pts] each.  rad0: CUDA
+    [n_rays, n_pts] initial intensity (overwritten).  resident (default): through the batch's device-resident form
+    (LimbLOS.handle -> sr_limb_rays_los_dev); False: staged per call (sr_limb_rays_dev)."""
     a, e = _gas_stack(coeffs)
     n_gas, n_layers, n_pts = a.shape
     if n_gas != los.n_gas:
         raise ValueError("%d coefficient sets for %d gases" % (n_gas, los.n_gas))
     rad = rad0 if rad0 is not None else torch.empty((los.n_rays, n_pts), dtype=torch.float64, device="cuda")
     assert rad.shape == (los.n_rays, n_pts) and rad.is_contiguous()
+    if resident:   # the LOS staged, its columns and plan made once (sr_los_create); this call only launches
+        h = los.handle(n_layers, grid, rad0=rad0 is not None)
+        check(lib.sr_limb_rays_los_dev(a.data_ptr(), e.data_ptr(), n_layers, n_pts, h, int(g_lo), rad.data_ptr(), _stream_ptr()),
+              "sr_limb_rays_los_dev")
+        return rad
     d = los.desc(grid, g_lo, rad0=rad0 is not None)
     check(lib.sr_limb_rays_dev(C.c_void_p(a.data_ptr()), C.c_void_p(e.data_ptr()), n_layers, n_pts, C.byref(d),
                                C.c_void_p(rad.data_ptr()), _stream_ptr()), "sr_limb_rays_dev")

@@ -417,6 +417,59 @@ def test_per_step_batches_keep_the_path_order_kernel(eng):
     assert float(((r2 - r1[:2]).abs() / sc[:2]).max()) < 1e-13
 
 
+def test_resident_los_equals_per_call_staging(eng):
+    """A LOS batch made resident once (sr_los_create: staged, columns integrated, folded records packed) gives the
+    radiances of the per-call route (sr_limb_rays_dev: all of that on every call) bit for bit -- the same kernels on
+    the same columns -- for one ray (split kernel), a ray batch (folded sweep), both LOS orders, a Planck background on
+    a shard (g_lo per call), two gases and a given initial intensity; and one sr_limb_step_dev call equals the
+    coefficient op followed by the recursion."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(21)
+    nl, n = 24, 16384
+    atm = _atm(nl)
+    z = atm["z"]
+    grid = syn.make_grid(2975.0, 5e-4, 2 * n)
+    t = lambda v: torch.tensor(np.ascontiguousarray(v), device="cuda")
+    vm = [np.full(nl, 1.2e-2), np.linspace(2e-3, 5e-4, nl)]
+    a = [rng.uniform(0, 4e-17, (nl, n)), rng.uniform(0, 3e-17, (nl, n))]
+    e = [a[0] * rng.uniform(1e-8, 1e-7, (nl, n)), a[1] * rng.uniform(1e-8, 1e-7, (nl, n))]
+    two = [(t(a[0]), t(e[0])), (t(a[1]), t(e[1]))]
+    for zt in (z[0] + 5.0 + 37.0 * np.arange(9), [z[3] + 2.0]):
+        L = syn.limb_los(z, atm["nd"] * 1e-6, vm, zt)
+        for opts in (dict(), dict(LOS_order="observer"), dict(solo_absorption=True, initial_temperature=200.0), dict(initial_temperature=150.0)):
+            los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827, 1.0], **opts)
+            g = grid if "initial_temperature" in opts else None
+            for g_lo in (0, 5000):
+                ref = eng.limb_rays(two, los, grid=g, g_lo=g_lo, resident=False)
+                got = [eng.limb_rays(two, los, grid=g, g_lo=g_lo) for _ in range(2)]     # made resident, then reused
+                assert torch.equal(got[0], ref) and torch.equal(got[1], ref), (len(zt), opts, g_lo)
+            assert len(los._handles) == 1
+        r0 = t(rng.uniform(1e-9, 1e-8, (len(zt), n)))
+        los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"])
+        assert torch.equal(eng.limb_rays(two, los, rad0=r0.clone()), eng.limb_rays(two, los, rad0=r0.clone(), resident=False))
+    # the whole step in one call
+    grid = syn.make_grid(2990.0, 5e-4, 30000)
+    Lns = syn.make_lines(3000, grid, seed=4, n_levels=12)
+    am = syn.make_atmosphere(16, 12)
+    ls = eng.LineSet(Lns, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    Lr = syn.limb_los(am["z"], syn.number_density(am["press"], am["temps"]), [np.full(16, 0.0148)], [am["z"][0] + 4.0, am["z"][8] + 4.0])
+    los = eng.LimbLOS(Lr["seg_off"], Lr["seg_layer"], Lr["pt_off"], Lr["x"], Lr["nd"], Lr["vmr"], col_scale=[syn.CH4_ISO_RATIO])
+    T = np.ascontiguousarray(am["temps"])
+    for lo, hi in ((0, 30000), (7000, 19000)):
+        ab, em = ls.abscoeff_layers(T, am["press"], tvib=am["tvib"], g_lo=lo, g_hi=hi)
+        rad = eng.limb_rays((ab, em), los, resident=False)
+        for rep in range(2):
+            ab2, em2, rad2 = ls.limb_step(T, am["press"], los, tvib=am["tvib"], g_lo=lo, g_hi=hi)
+            assert torch.equal(ab2, ab) and torch.equal(em2, em) and torch.equal(rad2, rad), (lo, rep)
+    T += 2.0          # values changed in place are seen (the layer descriptor is cached on the arrays, not on their values)
+    ab, em = ls.abscoeff_layers(T, am["press"], tvib=am["tvib"])
+    ab2, _, rad2 = ls.limb_step(T, am["press"], los, tvib=am["tvib"])
+    assert torch.equal(ab2, ab) and torch.equal(rad2, eng.limb_rays((ab, em), los))
+    with pytest.raises(RuntimeError):
+        ls.limb_step(T[:5], am["press"][:5], los, tvib=am["tvib"][:, :5])     # 5 layers against a LOS through 16
+
+
 def test_per_level_partial_radiances_sum_to_total(eng):
     """single_rad[(gas, iso, lev)] (spect_main_module.py:2883-2887): the radiance emitted by one level and
     absorbed by the whole gas -- the level's emission share (sr_abscoeff_level_dev) with the total

@@ -74,6 +74,20 @@ def test_argument_checks_return_before_any_launch(L):
                                    C.byref(h), None) == L.SR_ERR_ARG
     assert L.lib.sr_lineset_create(C.byref(ld), C.byref(iso), C.byref(L.GridDesc(3000.0, 5e-4, 2000001)),
                                    C.byref(h), None) == L.SR_ERR_LIMIT
+    # a resident LOS: bad descriptions are refused before anything is staged
+    hl = C.c_void_p()
+    d = L.LosDesc()
+    assert L.lib.sr_los_create(C.byref(d), 0, C.byref(hl)) == L.SR_ERR_ARG            # no layers
+    assert L.lib.sr_los_create(C.byref(d), 4, C.byref(hl)) == L.SR_ERR_ARG            # empty description
+    so, sl, po = np.array([0, 1], np.int32), np.array([7], np.int32), np.array([0, 2], np.int32)
+    xx = np.array([0.0, 1.0])
+    d.n_rays, d.n_gas = 1, 1
+    d.seg_off, d.seg_layer, d.pt_off = (a.ctypes.data_as(ip) for a in (so, sl, po))
+    d.x = d.nd = d.vmr = xx.ctypes.data_as(dp)
+    assert L.lib.sr_los_create(C.byref(d), 4, C.byref(hl)) == L.SR_ERR_ARG and not hl.value   # seg_layer 7 of 4 layers
+    assert L.lib.sr_los_destroy(None) == L.SR_OK
+    assert L.lib.sr_limb_rays_los_dev(None, None, 4, 10, None, 0, None, None) == L.SR_ERR_ARG
+    assert L.lib.sr_limb_step_dev(None, None, 0, 10, None, None, None, None, None) == L.SR_ERR_ARG
     with pytest.raises(L.SpectRobotHipError):
         L.check(L.SR_ERR_ARG, "x")
 

@@ -16,24 +16,34 @@ los, Lr = B.build_rays(syn, engine, atm, 1)
 g_lo, g_hi = 0, 100000 // 64
 ab = torch.empty((80, g_hi - g_lo), dtype=torch.float64, device="cuda"); em = torch.empty_like(ab)
 q = np.atleast_1d(spcl.CalcPartitionSum(6, 1, atm["temps"]))
+RES = True
 def step(t):
     t0 = time.perf_counter()
     ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"], q_part=q, g_lo=g_lo, g_hi=g_hi, out=(ab, em))
     t1 = time.perf_counter()
-    engine.limb_rays((ab, em), los)
+    engine.limb_rays((ab, em), los, resident=RES)
     t2 = time.perf_counter()
     t[0] += t1 - t0; t[1] += t2 - t1
-for _ in range(20): step([0, 0])
-torch.cuda.synchronize()
+def one_call(t):
+    t0 = time.perf_counter()
+    ls.limb_step(atm["temps"], atm["press"], los, tvib=atm["tvib"], q_part=q, g_lo=g_lo, g_hi=g_hi, out=(ab, em))
+    t[0] += time.perf_counter() - t0
 n = 300
-t = [0.0, 0.0]
-w0 = time.perf_counter()
-for _ in range(n): step(t)
-w1 = time.perf_counter()
-torch.cuda.synchronize()
-w2 = time.perf_counter()
-print("host per step: abscoeff_layers %.1f us, limb_rays %.1f us, loop %.1f us; drain after the loop %.1f us/step" % (
-    t[0] / n * 1e6, t[1] / n * 1e6, (w1 - w0) / n * 1e6, (w2 - w1) / n * 1e6))
+for name, fn, res, timing in (("two calls, LOS staged per call (round 4)", step, False, 1), ("two calls, resident LOS", step, True, 1),
+                              ("one call (sr_limb_step_dev)", one_call, True, 1), ("one call, no timing events", one_call, True, 0)):
+    RES = res
+    engine.set_timing(timing)
+    for _ in range(20): fn([0, 0])
+    torch.cuda.synchronize()
+    t = [0.0, 0.0]
+    w0 = time.perf_counter()
+    for _ in range(n): fn(t)
+    w1 = time.perf_counter()
+    torch.cuda.synchronize()
+    w2 = time.perf_counter()
+    print("%-42s host per step: coefficient op (or whole step) %.1f us, limb_rays %.1f us, loop %.1f us; drain after the loop %.1f us/step" % (
+        name, t[0] / n * 1e6, t[1] / n * 1e6, (w1 - w0) / n * 1e6, (w2 - w1) / n * 1e6))
+engine.set_timing(1)
 if len(sys.argv) > 1:
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable()
