@@ -29,6 +29,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# six streams per coefficient op: give them hardware queues of their own (see spectrobot_amd/__init__.py; set before
+# anything initialises HIP)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (= fp64 matrix) dense peak, SURVEY 8-d / AMD datasheet
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)

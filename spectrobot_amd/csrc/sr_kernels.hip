@@ -1432,32 +1432,47 @@ __device__ inline void wing_series6(double xc, double e, const FastRec &r, doubl
 // of 64 lines.  ends: line of lane i is valid at points p <= pos_i; starts: at p >= pos_i; pos is
 // non-decreasing over the lanes (lines sorted by window centre); lanes without such a line carry
 // zero coefficients.  c: [0, kWE) abs, [kWE, 2 kWE) emi series coefficients of the lane's line.
-__device__ inline void window_end_sum(bool ends, int pos, double c[2 * kWE], int lane, double &out_a, double &out_e) {
-  // inclusive suffix (ends) or prefix (starts) sums over the lanes: inside each row of 16 lanes by DPP
-  // row shifts (plain VALU moves, zero shifted in at the row end), then the totals of the other rows
-  const int row = lane >> 4;
+//
+// Round 5: the twelve suffix (prefix) sums over the lanes run TRANSPOSED through LDS.  As DPP row scans they were
+// 29 (23) VALU instructions per coefficient -- 8 row-shift moves, 4 adds, 6 v_readlane and the nested selects of the
+// row totals -- 348 + 276 per slot, a quarter of the kernel's instructions.  Now every lane stores its line's twelve
+// coefficients (s_c[n][lane]), lanes (block b of 16 lines, coefficient n) scan their 16 entries serially in place --
+// 16 adds for all twelve sums at once --, the block totals become per-block offsets (s_o[n][b]), and a point reads
+// its cut-off column s_c[n][src] + s_o[n][src / 16].  Column 64 / block 4 hold zeros: "no line" needs no select.
+constexpr int kWECols = 66; // 64 lines, the zero column, one of padding (rows 2 banks apart)
+template <bool ENDS>
+__device__ inline void window_end_scan(int lane, double (*s_c)[kWECols], double (*s_o)[5]) {
+  const int b = lane / (2 * kWE), n = lane - (2 * kWE) * b; // lanes 0..47
+  if (lane < 4 * 2 * kWE) {
+    double *cell = &s_c[n][16 * b];
+    double acc = 0.;
 #pragma unroll
-  for (int n = 0; n < 2 * kWE; ++n) {
-    double v = c[n];
-    if (ends) {
-      v += dpp_move<0x101>(v); // row_shl:1  lane i <- lane i + 1
-      v += dpp_move<0x102>(v);
-      v += dpp_move<0x104>(v);
-      v += dpp_move<0x108>(v);
-      const double t1 = lane_value(v, 16), t2 = lane_value(v, 32), t3 = lane_value(v, 48); // row totals
-      const double t23 = t2 + t3;
-      v += row == 0 ? t1 + t23 : (row == 1 ? t23 : (row == 2 ? t3 : 0.0));
-    } else {
-      v += dpp_move<0x111>(v); // row_shr:1  lane i <- lane i - 1
-      v += dpp_move<0x112>(v);
-      v += dpp_move<0x114>(v);
-      v += dpp_move<0x118>(v);
-      const double t0 = lane_value(v, 15), t1 = lane_value(v, 31), t2 = lane_value(v, 47);
-      const double t01 = t0 + t1;
-      v += row == 3 ? t01 + t2 : (row == 2 ? t01 : (row == 1 ? t0 : 0.0));
+    for (int k = 0; k < 16; ++k) {
+      const int kk = ENDS ? 15 - k : k;
+      acc += cell[kk];
+      cell[kk] = acc;
     }
-    c[n] = v;
   }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 4 * 2 * kWE) {
+    double o = 0.;
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const double tv = s_c[n][ENDS ? 16 * bb : 16 * bb + 15]; // the block's total
+      o += (ENDS ? bb > b : bb < b) ? tv : 0.0;
+    }
+    s_o[n][b] = o;
+  }
+}
+__device__ inline void window_end_sum(bool ends, int pos, const double c[2 * kWE], int lane, double (*s_c)[kWECols],
+                                      double (*s_o)[5], double &out_a, double &out_e) {
+  __builtin_amdgcn_wave_barrier(); // (the previous call's reads are through: one wave, LDS in order)
+#pragma unroll
+  for (int n = 0; n < 2 * kWE; ++n) s_c[n][lane] = c[n];
+  __builtin_amdgcn_wave_barrier();
+  if (ends) window_end_scan<true>(lane, s_c, s_o);
+  else window_end_scan<false>(lane, s_c, s_o);
+  __builtin_amdgcn_wave_barrier();
   // this lane as a POINT p = lane: ends: first line with pos >= p; starts: last line with pos <= p
   int lo = 0, hi = 64; // 65 possible answers: 7 halvings
 #pragma unroll
@@ -1469,15 +1484,15 @@ __device__ inline void window_end_sum(bool ends, int pos, double c[2 * kWE], int
     lo = right ? mid + 1 : lo;
     hi = left ? mid : hi;
   }
-  const int src = ends ? lo : lo - 1; // lo = number of lines with pos < p (ends) / pos <= p (starts)
-  const bool any = ends ? src < 64 : src >= 0;
+  // lo = number of lines with pos < p (ends) / pos <= p (starts); 64: no line (the zero column, the zero offset)
+  const int src = ends ? lo : (lo == 0 ? 64 : lo - 1);
+  const int bs = src >> 4;
   const double t = (double)(2 * lane - 63) * (1.0 / 64);
   double pa = 0., pe = 0.;
 #pragma unroll
   for (int n = kWE - 1; n >= 0; --n) {
-    const double ca = __shfl(c[n], src & 63), ce = __shfl(c[kWE + n], src & 63);
-    pa = fma(pa, t, any ? ca : 0.0);
-    pe = fma(pe, t, any ? ce : 0.0);
+    pa = fma(pa, t, s_c[n][src] + s_o[n][bs]);
+    pe = fma(pe, t, s_c[kWE + n][src] + s_o[kWE + n][bs]);
   }
   out_a += pa;
   out_e += pe;
@@ -1490,7 +1505,7 @@ __device__ inline void window_end_sum(bool ends, int pos, double c[2 * kWE], int
 // by per-lane loads.  Before, every such line cost a scalar record fetch, a ballot walk and four specialised masked
 // loops: the walk took 0.87 of the kernel's 1.34 ms for 0.27 ms worth of vector work.
 template <bool COUNT>
-__global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr_abscoeff_near_wings_kernel( // 80 VGPRs: six waves per SIMD (81 would be five)
     const FastRec *__restrict__ fast, IcIndex ix, const int *__restrict__ zmax, int n_sub,
     int n_tiles, int g_lo, int g_hi, FarParams fp, int add, const double *__restrict__ z_abs,
     const double *__restrict__ z_emi, double *__restrict__ abs_out, double *__restrict__ emi_out,
@@ -1507,7 +1522,34 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
 
   constexpr int kRowLanes = 8, kRows = 8;
   const int row = lane / kRowLanes, col = lane % kRowLanes;
+  __shared__ double s_c[2 * kWE][kWECols]; // window_end_sum: the lines' series coefficients, scanned in place
+  __shared__ double s_o[2 * kWE][5];
   double sum_a = 0., sum_e = 0.; // this lane's point wlo + lane: window ends, polynomials, and the rows' total
+  // The polynomials come FIRST: their coefficients are wave-uniform and must arrive by scalar loads.  The pointer comes
+  // out of a by-value kernel argument (a flat pointer to the compiler), and after the first LDS store of the kernel a
+  // flat load counts as clobbered: placed behind the window-end scans these became 24 vector loads per level
+  // (SQ_INSTS_VMEM_RD 1.6e7 -> 3.1e7, SQ_INSTS_SMEM 1.1e7 -> 3e6, the kernel 1.05 -> 1.16 ms).
+  // far field: one polynomial per level
+  const double *cl = fp.coef + (size_t)layer * fp.n_boxes_total * (2 * kFC);
+  for (int lv = 0; lv < fp.n_levels; ++lv) {
+    const int W = 64 << lv;
+    const int b = (wlo - g_lo) >> (6 + lv);
+    const int blo = g_lo + b * W;
+    const double t = (double)(2 * (wlo + lane - blo) - (W - 1)) * (1.0 / 64 / (double)(1 << lv)); // exact: W = 2^(6+lv)
+    const double *c = cl + (size_t)(fp.box_off[lv] + b) * (2 * kFC);
+    double pa = c[kFC - 1], pe = c[2 * kFC - 1];
+#pragma unroll
+    for (int n = kFC - 2; n >= 0; --n) {
+      pa = fma3s(pa, t, c[n]);
+      pe = fma3s(pe, t, c[kFC + n]);
+    }
+    sum_a += pa;
+    sum_e += pe;
+  }
+  if (lane < 2 * kWE) {
+    s_c[lane][64] = 0.;
+    s_o[lane][4] = 0.;
+  }
   double ra[kRows], rb[kRows];    // rows: partial sums (abs, emi) of point wlo + col + 8 s over the lines of this lane's row
 #pragma unroll
   for (int q = 0; q < kRows; ++q) ra[q] = rb[q] = 0.;
@@ -1563,7 +1605,7 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
             }
             need = false; // done here
           }
-          window_end_sum(ends, pos, c, lane, sum_a, sum_e);
+          window_end_sum(ends, pos, c, lane, s_c, s_o, sum_a, sum_e);
           if (__ballot(need) == 0) continue;
         }
       }
@@ -1630,18 +1672,22 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
       }
     }
   }
-  // totals of the rows: point wlo + lane is (col, step) = (lane % 8, lane / 8): sum over the eight rows of that step
+  // totals of the rows: point wlo + lane is (col, step) = (lane % 8, lane / 8): sum over the eight rows of that step.
+  // Through LDS (round 5; as xor-shuffles: 96 ds_bpermute and 111 VALU instructions per wave): every lane stores its
+  // eight partial sums, step-major with 72 doubles per step (reads two banks apart), and reads the eight rows of its own.
+  {
+    static_assert(2 * kWE * kWECols >= kRows * 72, "the window-end scratch holds the row totals");
+    double *s_t = &s_c[0][0];
 #pragma unroll
-  for (int q = 0; q < kRows; ++q) {
-    double ta = ra[q], te = rb[q];
+    for (int ch = 0; ch < 2; ++ch) {
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int m = kRowLanes; m < 64; m <<= 1) {
-      ta += __shfl_xor(ta, m);
-      te += __shfl_xor(te, m);
-    }
-    if (row == q) {
-      sum_a += ta;
-      sum_e += te;
+      for (int q = 0; q < kRows; ++q) s_t[q * 72 + lane] = ch == 0 ? ra[q] : rb[q];
+          __builtin_amdgcn_wave_barrier();
+      double tot = 0.;
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) tot += s_t[row * 72 + r * kRowLanes + col];
+      if (ch == 0) sum_a += tot; else sum_e += tot;
     }
   }
   if (COUNT) {
@@ -1652,23 +1698,6 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
 #else
     count_add(cnt, kCntPolyPoints, (wlo + lane <= whi) ? (unsigned)fp.n_levels : 0u, lane);
 #endif
-  }
-  // far field: one polynomial per level
-  const double *cl = fp.coef + (size_t)layer * fp.n_boxes_total * (2 * kFC);
-  for (int lv = 0; lv < fp.n_levels; ++lv) {
-    const int W = 64 << lv;
-    const int b = (wlo - g_lo) >> (6 + lv);
-    const int blo = g_lo + b * W;
-    const double t = (double)(2 * (wlo + lane - blo) - (W - 1)) * (1.0 / 64 / (double)(1 << lv)); // exact: W = 2^(6+lv)
-    const double *c = cl + (size_t)(fp.box_off[lv] + b) * (2 * kFC);
-    double pa = c[kFC - 1], pe = c[2 * kFC - 1];
-#pragma unroll
-    for (int n = kFC - 2; n >= 0; --n) {
-      pa = fma3s(pa, t, c[n]);
-      pe = fma3s(pe, t, c[kFC + n]);
-    }
-    sum_a += pa;
-    sum_e += pe;
   }
   const size_t orow = (size_t)layer * (size_t)(g_hi - g_lo);
   const int j = wlo + lane;
