@@ -2273,8 +2273,11 @@ int sr_hires_to_lowres_shard_dev(const double *rad, int n_rays, int64_t n_pts, i
   if (rc) return rc;
   rc = d_out.ensure(sizeof(double) * nb * n_rays);
   if (rc) return rc;
+  static thread_local DevBuf d_weights; // the bands' weight table [n_bands][n_pts] + point ranges, rebuilt by every call
+  rc = d_weights.ensure(lowres_scratch_bytes((int)n_pts, n_bands, n_rays));
+  if (rc) return rc;
   LAUNCHCHK(launch_lowres(rad, (int)n_pts, (int)g_lo, n_rays, w0, step, s_bands.d.as<double>(), s_bands.d.as<double>() + nb,
-                          n_bands, n_sigma, out_units, d_out.as<double>(), st));
+                          n_bands, n_sigma, out_units, d_out.as<double>(), d_weights.p, st));
   HIPCHK(hipMemcpyAsync(out_host, d_out.p, sizeof(double) * nb * n_rays, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return SR_OK;

@@ -4072,18 +4072,26 @@ __global__ void sr_curgod_kernel(int which, const double *__restrict__ nd, const
 // ------------------------------------------------------------------------
 // g_lo: grid index of rad's first point (a spectral shard's PARTIAL band integrals: the trapezoids between the
 // shard's own points, grid values exactly those of the whole grid; the partial sums of the shards add up).
-__global__ __launch_bounds__(256) void sr_lowres_kernel(const double *__restrict__ rad, int n_pts, int g_lo, double w0,
-                                                        double gstep, const double *__restrict__ cen,
-                                                        const double *__restrict__ wid, int n_bands,
-                                                        double n_sigma, int out_units,
-                                                        double *__restrict__ out) {
-  const int b = blockIdx.x, ray = blockIdx.y;
+//
+// Round 5: two kernels.  The trapezoid sum of a band, sum_i (x_(i+1) - x_i) (y_(i+1) + y_i) / 2 with y_i = s_i u_i, is
+// sum_i s_i W_i with W_i = u_i c_i, c_i = (x_(i+1) - x_(i-1)) / 2 inside the window and the half interval at its two
+// ends -- and W depends on the band and the grid alone, not on the spectrum.  A retrieval iteration degrades 144 spectra
+// (18 LOS x (radiance + 7 derivatives)) with the same 14 bands: one block per (band, spectrum) re-evaluated the
+// Gaussian, four IEEE divisions and two exp per trapezoid 144 times over (0.19 ms of a 1.26 ms configs[4] iteration).
+// sr_lowres_weights_kernel makes W [n_bands][n_pts] (cm-1 index order) and the bands' point ranges once per call,
+// sr_lowres_apply_kernel is the banded product: a block per (spectrum, chunk of 4096 points, group of 16 bands), the
+// chunks' partial sums added in chunk order by sr_lowres_sum_kernel.
+__global__ __launch_bounds__(256) void sr_lowres_weights_kernel(int n_pts, int g_lo, double w0, double gstep,
+                                                                const double *__restrict__ cen, const double *__restrict__ wid,
+                                                                double n_sigma, double *__restrict__ W, // [n_bands][n_pts]
+                                                                int *__restrict__ range) {               // [n_bands][2]: j_lo, j_hi (exclusive)
+  const int b = blockIdx.y;
   const double f = cen[b], w = wid[b];
   const double lo = f - n_sigma * w, hi = f + n_sigma * w;
   const double fac = 1 / (w * sqrt(2. * kPi));
-  const double *sp = rad + (size_t)ray * n_pts;
-  auto xnm = [&](int i) { return 1.e7 / (w0 + (double)(g_lo + n_pts - 1 - i) * gstep); };
-  // first i with x >= lo, first i with x > hi (x ascending in i)
+  auto gcm = [&](int i) { return w0 + (double)(g_lo + n_pts - 1 - i) * gstep; }; // nm index i <-> cm-1 index n-1-i
+  auto xnm = [&](int i) { return 1.e7 / gcm(i); };
+  // first i with x >= lo, first i with x > hi (x ascending in i): every thread the same two searches (17 steps)
   int i0, i1;
   {
     int a = 0, c = n_pts;
@@ -4091,37 +4099,96 @@ __global__ __launch_bounds__(256) void sr_lowres_kernel(const double *__restrict
     i0 = a;
     a = 0; c = n_pts;
     while (a < c) { int m = (a + c) >> 1; if (xnm(m) <= hi) a = m + 1; else c = m; }
-    i1 = a; // selected: i0 .. i1-1
+    i1 = a; // selected: i0 .. i1-1; fewer than two points: no trapezoid
   }
-  double acc = 0.0;
-  for (int i = i0 + threadIdx.x; i + 1 < i1; i += blockDim.x) {
-    const int j0 = n_pts - 1 - i, j1 = j0 - 1;
-    const double g0 = w0 + (double)(g_lo + j0) * gstep, g1 = w0 + (double)(g_lo + j1) * gstep;
-    const double x0 = 1.e7 / g0, x1 = 1.e7 / g1;
-    const double t0 = (x0 - f) / w, t1 = (x1 - f) / w;
-    const double y0 = (sp[j0] * (g0 * g0) * 1.e-7) * (fac * exp(-0.5 * (t0 * t0)));
-    const double y1 = (sp[j1] * (g1 * g1) * 1.e-7) * (fac * exp(-0.5 * (t1 * t1)));
-    acc += (x1 - x0) * (y1 + y0) / 2.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const bool any = i1 - i0 >= 2;
+    range[2 * b] = any ? n_pts - i1 : 0;       // cm-1 indices j = n_pts - 1 - i, i in [i0, i1)
+    range[2 * b + 1] = any ? n_pts - i0 : 0;
   }
-  __shared__ double red[4];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_pts) return;
+  const int i = n_pts - 1 - j;
+  double wgt = 0.0;
+  if (i >= i0 && i < i1 && i1 - i0 >= 2) {
+    const double g = gcm(i), x = 1.e7 / g, t = (x - f) / w;
+    const double u = ((g * g) * 1.e-7) * (fac * exp(-0.5 * (t * t))); // y = s u (spcl:779-783 the cm-1 -> nm factor, :1926-1934 the Gaussian)
+    const double xl = i > i0 ? xnm(i - 1) : x, xr = i + 1 < i1 ? xnm(i + 1) : x;
+    wgt = u * ((xr - xl) / 2.0);
+  }
+  W[(size_t)b * n_pts + j] = wgt;
+}
+
+constexpr int kLowresBands = 16;   // bands per block of the apply kernel
+constexpr int kLowresChunk = 4096; // points per block: 144 spectra x 15 chunks fill the chip (a block per spectrum walked
+                                   // its 60 000 points alone: 117 dependent rounds of 15 loads, 0.21 ms)
+__global__ __launch_bounds__(256) void sr_lowres_apply_kernel(const double *__restrict__ rad, int n_pts,
+                                                              const double *__restrict__ W, const int *__restrict__ range,
+                                                              int n_bands, int n_chunks,
+                                                              double *__restrict__ part) { // [n_rays][n_chunks][n_bands]
+  const int ray = blockIdx.x, chunk = blockIdx.y, b0 = blockIdx.z * kLowresBands, nb = min(kLowresBands, n_bands - b0);
+  const double *sp = rad + (size_t)ray * n_pts;
+  const int c_lo = chunk * kLowresChunk, c_hi = min(c_lo + kLowresChunk, n_pts);
+  double acc[kLowresBands];
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double v = (red[0] + red[1]) + (red[2] + red[3]);
-    v = v * 1.e-3;                  // 'ergscm2' -> 'Wm2', spcl:1215-1218
-    if (out_units == 1) v = v * 1.e3; // -> 'ergscm2', spcl:1224-1228
-    if (out_units == 2) v = v * 1.e5; // -> 'nWcm2',   spcl:1230-1234
-    out[(size_t)ray * n_bands + b] = v;
+  for (int q = 0; q < kLowresBands; ++q) acc[q] = 0.0;
+  // W is zero outside a band's window: no per-point range test, only whole bands that miss the chunk are skipped
+  // (block-uniform); the loads of a point's bands are independent of each other
+  bool use[kLowresBands];
+#pragma unroll
+  for (int q = 0; q < kLowresBands; ++q) use[q] = q < nb && range[2 * (b0 + q)] < c_hi && range[2 * (b0 + q) + 1] > c_lo;
+  for (int j = c_lo + (int)threadIdx.x; j < c_hi; j += (int)blockDim.x) {
+    const double sv = sp[j];
+#pragma unroll
+    for (int q = 0; q < kLowresBands; ++q)
+      if (use[q]) acc[q] = fma(sv, W[(size_t)(b0 + q) * n_pts + j], acc[q]);
   }
+  __shared__ double red[kLowresBands][4];
+#pragma unroll
+  for (int q = 0; q < kLowresBands; ++q) {
+    double v = acc[q];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nb) {
+    const int q = threadIdx.x;
+    part[((size_t)ray * n_chunks + chunk) * n_bands + b0 + q] = (red[q][0] + red[q][1]) + (red[q][2] + red[q][3]);
+  }
+}
+__global__ void sr_lowres_sum_kernel(const double *__restrict__ part, int n_rays, int n_chunks, int n_bands, int out_units,
+                                     double *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_rays * n_bands) return;
+  const int ray = t / n_bands, b = t - ray * n_bands;
+  double v = 0.0;
+  for (int c = 0; c < n_chunks; ++c) v += part[((size_t)ray * n_chunks + c) * n_bands + b]; // in chunk order: deterministic
+  v = v * 1.e-3;                    // 'ergscm2' -> 'Wm2', spcl:1215-1218
+  if (out_units == 1) v = v * 1.e3; // -> 'ergscm2', spcl:1224-1228
+  if (out_units == 2) v = v * 1.e5; // -> 'nWcm2',   spcl:1230-1234
+  out[t] = v;
+}
+
+static int lowres_chunks(int n_pts) { return (n_pts + kLowresChunk - 1) / kLowresChunk; }
+size_t lowres_scratch_bytes(int n_pts, int n_bands, int n_rays) {
+  return sizeof(double) * (size_t)n_bands * n_pts + sizeof(double) * (size_t)n_rays * lowres_chunks(n_pts) * n_bands +
+         sizeof(int) * 2 * (size_t)n_bands;
 }
 
 int launch_lowres(const double *rad, int n_pts, int g_lo, int n_rays, double w0, double gstep, const double *cen,
-                  const double *wid, int n_bands, double n_sigma, int out_units, double *out, hipStream_t st) {
+                  const double *wid, int n_bands, double n_sigma, int out_units, double *out, void *scratch, hipStream_t st) {
   if (n_bands <= 0 || n_rays <= 0) return 0;
-  hipLaunchKernelGGL(sr_lowres_kernel, dim3(n_bands, n_rays), dim3(256), 0, st, rad, n_pts, g_lo, w0, gstep, cen, wid,
-                     n_bands, n_sigma, out_units, out);
+  const int n_chunks = lowres_chunks(n_pts);
+  double *W = static_cast<double *>(scratch);
+  double *part = W + (size_t)n_bands * n_pts;
+  int *range = reinterpret_cast<int *>(part + (size_t)n_rays * n_chunks * n_bands);
+  hipLaunchKernelGGL(sr_lowres_weights_kernel, dim3((n_pts + 255) / 256, n_bands), dim3(256), 0, st, n_pts, g_lo, w0, gstep, cen, wid,
+                     n_sigma, W, range);
+  hipLaunchKernelGGL(sr_lowres_apply_kernel, dim3(n_rays, n_chunks, (n_bands + kLowresBands - 1) / kLowresBands), dim3(256), 0, st,
+                     rad, n_pts, W, range, n_bands, n_chunks, part);
+  hipLaunchKernelGGL(sr_lowres_sum_kernel, dim3((n_rays * n_bands + 255) / 256), dim3(256), 0, st, part, n_rays, n_chunks, n_bands,
+                     out_units, out);
   return (int)hipGetLastError();
 }
 

@@ -21,17 +21,28 @@ def _i(a):
     return a, a.ctypes.data_as(ip)
 
 
+_GRID_CACHE = []   # [(grid array, (w0, step, n))], the last few grids checked: a retrieval loop passes the same array in every iteration
+
+
 def grid_params(grid):
     """(w0, step, n) of an equally spaced numpy-arange grid (spect_main_module.py:1267);
-    raises if the grid is not exactly w0 + j*step."""
-    grid = np.asarray(grid, dtype=np.float64)
-    if grid.ndim != 1 or grid.size < 2:
+    raises if the grid is not exactly w0 + j*step.  The check walks the whole grid (1e5..2e6 points): the result is
+    remembered for the array OBJECT it was made for (grids are not modified in place anywhere in this package)."""
+    for g, res in _GRID_CACHE:
+        if g is grid:
+            return res
+    arr = np.asarray(grid, dtype=np.float64)
+    if arr.ndim != 1 or arr.size < 2:
         raise ValueError("spectral grid must be 1-D with at least 2 points")
-    w0, step = float(grid[0]), float(grid[1] - grid[0])
-    if not np.array_equal(grid, w0 + np.arange(grid.size) * step):
+    w0, step = float(arr[0]), float(arr[1] - arr[0])
+    if not np.array_equal(arr, w0 + np.arange(arr.size) * step):
         raise ValueError("spectral grid is not an np.arange grid (w0 + j*step); the reference assumes "
                          "equal spacing (SpectralGrid.step, spect_classes.py:366)")
-    return w0, step, grid.size
+    res = (w0, step, arr.size)
+    if isinstance(grid, np.ndarray):
+        _GRID_CACHE.append((grid, res))
+        del _GRID_CACHE[:-8]
+    return res
 
 
 def set_device(index):

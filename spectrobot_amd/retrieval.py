@@ -99,9 +99,19 @@ class LimbScene(object):
         return self._stack
 
     def los(self, tangent_alts, **opts):
-        """engine.LimbLOS of rays with the given tangent altitudes (photon order) + the sample altitudes."""
-        L = syn.limb_los(self.z, self.nd, [g.vmr for g in self.gases], tangent_alts, R=self.R, n_sub=self.n_sub)
-        los = engine.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"],
+        """engine.LimbLOS of rays with the given tangent altitudes (photon order) + the sample altitudes.  The geometry
+        (paths, sample points, densities) depends on the altitudes alone and is kept; between the iterations of a
+        retrieval only the VMRs at the sample points change."""
+        key = tuple(float(a) for a in tangent_alts)
+        geo = getattr(self, "_los_geo", None)
+        if geo is None or geo[0] != key:
+            L = syn.limb_los(self.z, self.nd, [g.vmr for g in self.gases], tangent_alts, R=self.R, n_sub=self.n_sub)
+            top = self.z[-1] + (self.z[-1] - self.z[-2])
+            geo = self._los_geo = (key, L, np.append(self.z, top))
+        _, L, zz = geo
+        # (geometry._profiles: every VMR linear in altitude between the levels, constant above the last one)
+        vmr = np.array([np.interp(L["alt"], zz, np.append(g.vmr, g.vmr[-1])) for g in self.gases])
+        los = engine.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], vmr,
                              col_scale=[g.iso_ratio for g in self.gases], **opts)
         return los, L["alt"]
 
