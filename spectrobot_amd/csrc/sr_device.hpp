@@ -58,19 +58,29 @@ struct ArrX {
 
 // Per (layer, line) record read by every workgroup whose tile the line's window
 // touches; staged through LDS in the main kernel.  80 bytes = 5 x 16 B.
+#ifndef SR_FASTREC64
+#define SR_FASTREC64 1 // 64-byte records: the four region-1 coefficients are rebuilt from ry at every use (0: stored, 80 bytes)
+#endif
 struct __attribute__((aligned(16))) FastRec {
   double xl;    // (x0 - x(1))/dw          region-1 left running x at k = 1
   double xr;    // (x(ir) - x0)/dw         region-1 right running x at k = ir
   double xstep; // (x(2) - x(1))/dw
+#if SR_FASTREC64
+  double ry;         // lw/dw': a, b, c, d are functions of it alone (region1_coef)
+#else
   double a, b, c, d; // region-1 rational (lineshape.f:456-459), e = 4
+#endif
   double wabs, wemi; // level-population weighted G coefficients / fac
   int32_t j1;        // grid index of window point k = 1 (ic - 6505; may be < 0)
   uint32_t ilir;     // region-1 boundaries il | ir << 16 (1-based window indices);
                      // one dword so that the whole record is scalar-loadable
+#if SR_FASTREC64
+  double pad_;
+#endif
   __host__ __device__ inline int il() const { return (int)(ilir & 0xffffu); }
   __host__ __device__ inline int ir() const { return (int)(ilir >> 16); }
 };
-static_assert(sizeof(FastRec) == 80, "FastRec must be 80 bytes");
+static_assert(sizeof(FastRec) == (SR_FASTREC64 ? 64 : 80), "FastRec must be 80 (64) bytes");
 
 // What regions 2-4 of one (line, layer) need beyond the FastRec, as stored: 48 bytes.  The eight region-2
 // coefficients, (double)(float)ry and 1/dw' are functions of ry and dw' alone and are rebuilt where a line's
@@ -141,6 +151,26 @@ __device__ inline void region1_coef(double ry, double &a, double &b, double &c, 
   b = 2.2567584 * ry;
   c = (1. + 2. * ry2) * (1. + 2. * ry2);
   d = -4. + 8. * ry2;
+}
+
+// The region-1 coefficients of a record: its fields, or (SR_FASTREC64) rebuilt from ry.
+struct R1Coef { double a, b, c, d; };
+__device__ inline R1Coef r1_of(const FastRec &r) {
+  R1Coef q;
+#if SR_FASTREC64
+  region1_coef(r.ry, q.a, q.b, q.c, q.d);
+#else
+  q.a = r.a; q.b = r.b; q.c = r.c; q.d = r.d;
+#endif
+  return q;
+}
+__device__ inline void r1_set(FastRec &r, double ry) {
+#if SR_FASTREC64
+  r.ry = ry;
+  r.pad_ = 0.0;
+#else
+  region1_coef(ry, r.a, r.b, r.c, r.d);
+#endif
 }
 
 // ---- region 2: lineshape.f:492-521 ----
@@ -603,7 +633,8 @@ __device__ inline double humliv_point(int k, const FastRec &r, const ColdFull &z
   const double x = (k <= il) ? fma(-(double)(k - 1), r.xstep, r.xl)  // :461-468
                              : fma((double)(k - ir), r.xstep, r.xr); // :470-477
   const double x2 = x * x;
-  return fma(x2, r.b, r.a) * fast_rcp<2>(fma(x2, fma(x2, 4.0, r.d), r.c));
+  const R1Coef q = r1_of(r);
+  return fma(x2, q.b, q.a) * fast_rcp<2>(fma(x2, fma(x2, 4.0, q.d), q.c));
 }
 
 } // namespace sr

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kPrepBlock) void sr_prep_kernel(LinesDev L, LayersD
   r.xl = B.xl;
   r.xr = B.xr;
   r.xstep = B.xstep;
-  region1_coef(B.ry, r.a, r.b, r.c, r.d);
+  r1_set(r, B.ry);
   r.wabs = ph.wabs;
   r.wemi = ph.wemi;
   r.j1 = ic - kHalf;
@@ -436,7 +436,8 @@ __global__ __launch_bounds__(64) void sr_abscoeff_wings_kernel(
       const int cls = glo <= whi ? classify(r.j1, r.il(), r.ir(), glo, ghi) : 0;
       if (cls == 0) continue; // left to sr_abscoeff_cores_kernel (or outside the window)
       const double xb = wing_x_at(r, cls, r.j1, glo);
-      wing_eval4(xb, r.xstep, r.a, r.b, r.c, r.d, r.wabs, r.wemi, fl, acc_a + 4 * g, acc_e + 4 * g);
+      const R1Coef rq = r1_of(r);
+      wing_eval4(xb, r.xstep, rq.a, rq.b, rq.c, rq.d, r.wabs, r.wemi, fl, acc_a + 4 * g, acc_e + 4 * g);
     }
   }
   const size_t row = (size_t)layer * (size_t)(g_hi - g_lo);
@@ -509,7 +510,8 @@ __global__ __launch_bounds__(64) void sr_abscoeff_cores_kernel(
         if (scls != 0) { // the whole slot in one wing
           const double x = fma(fl[p], r.xstep, wing_x_at(r, scls, j1, wlo));
           const double x2 = x * x;
-          y = fma(x2, r.b, r.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, r.d), r.c));
+          const R1Coef rq = r1_of(r);
+          y = fma(x2, rq.b, rq.a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, rq.d), rq.c));
         } else {
           const int k = slo + lane - j1 + 1; // 1-based window index
           y = (k >= 1 && k <= kImxsig && slo + lane <= shi) ? humliv_point(k, r, cr, xf) : 0.0;
@@ -798,10 +800,11 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
                                  : fma(0.5 * (double)(2 * (blo - (j1 + ir - 1)) + W - 1), r.xstep, r.xr);
       const double e = hw * r.xstep;
       const double u0 = xc * xc, u1 = 2. * xc * e, u2 = e * e;
-      const double n0 = fma(r.b, u0, r.a), n1 = r.b * u1, n2 = r.b * u2;
-      const double d0 = fma(u0, fma(4., u0, r.d), r.c);
-      const double d1 = u1 * fma(8., u0, r.d);
-      const double d2 = fma(u2, r.d, 4. * fma(u1, u1, 2. * u0 * u2));
+      const R1Coef rq = r1_of(r);
+      const double n0 = fma(rq.b, u0, rq.a), n1 = rq.b * u1, n2 = rq.b * u2;
+      const double d0 = fma(u0, fma(4., u0, rq.d), rq.c);
+      const double d1 = u1 * fma(8., u0, rq.d);
+      const double d2 = fma(u2, rq.d, 4. * fma(u1, u1, 2. * u0 * u2));
       const double d3 = 8. * u1 * u2, d4 = 4. * u2 * u2;
       const double r0 = fast_rcp<2>(d0);
       const double D1 = d1 * r0, D2 = d2 * r0, D3 = d3 * r0, D4 = d4 * r0;
@@ -975,10 +978,11 @@ __global__ __launch_bounds__(64) void sr_farfield_rows_kernel(const FastRec *__r
                                : fma(0.5 * (double)(2 * (blo - (j1 + ir - 1)) + W - 1), r.xstep, r.xr);
     const double e = hw * r.xstep;
     const double u0 = xc * xc, u1 = 2. * xc * e, u2 = e * e;
-    const double n0 = fma(r.b, u0, r.a), n1 = r.b * u1, n2 = r.b * u2;
-    const double d0 = fma(u0, fma(4., u0, r.d), r.c);
-    const double d1 = u1 * fma(8., u0, r.d);
-    const double d2 = fma(u2, r.d, 4. * fma(u1, u1, 2. * u0 * u2));
+    const R1Coef rq = r1_of(r);
+    const double n0 = fma(rq.b, u0, rq.a), n1 = rq.b * u1, n2 = rq.b * u2;
+    const double d0 = fma(u0, fma(4., u0, rq.d), rq.c);
+    const double d1 = u1 * fma(8., u0, rq.d);
+    const double d2 = fma(u2, rq.d, 4. * fma(u1, u1, 2. * u0 * u2));
     const double d3 = 8. * u1 * u2, d4 = 4. * u2 * u2;
     const double r0 = fast_rcp<2>(d0);
     const double D1 = d1 * r0, D2 = d2 * r0, D3 = d3 * r0, D4 = d4 * r0;
@@ -1094,9 +1098,10 @@ __global__ __launch_bounds__(64) SR_S2M_ATTR void sr_s2m_kernel(const FastRec *_
     const double V = fast_rcp<2>(sh * sh);
     double E[NE]; // e_(n-1) (xstep h)^(-2n) / (2n-1)!
     {
-      const double dV = 0.25 * r.d * V, cV = 0.25 * r.c * (V * V);
-      E[0] = 0.25 * r.b * V;
-      E[1] = fma(0.25 * r.a * V, V, -dV * E[0]);
+      const R1Coef rq = r1_of(r);
+      const double dV = 0.25 * rq.d * V, cV = 0.25 * rq.c * (V * V);
+      E[0] = 0.25 * rq.b * V;
+      E[1] = fma(0.25 * rq.a * V, V, -dV * E[0]);
 #pragma unroll
       for (int k = 2; k < NE; ++k) E[k] = -fma(dV, E[k - 1], cV * E[k - 2]);
 #pragma unroll
@@ -1181,9 +1186,10 @@ __global__ __launch_bounds__(64) SR_S2M_ATTR void sr_s2m_kernel(const FastRec *_
     const double V = fast_rcp<2>(sh * sh);
     double E[NE]; // e_(n-1) (xstep h)^(-2n) / (2n-1)!
     {
-      const double dV = 0.25 * r.d * V, cV = 0.25 * r.c * (V * V);
-      E[0] = 0.25 * r.b * V;
-      E[1] = fma(0.25 * r.a * V, V, -dV * E[0]);
+      const R1Coef rq = r1_of(r);
+      const double dV = 0.25 * rq.d * V, cV = 0.25 * rq.c * (V * V);
+      E[0] = 0.25 * rq.b * V;
+      E[1] = fma(0.25 * rq.a * V, V, -dV * E[0]);
 #pragma unroll
       for (int k = 2; k < NE; ++k) E[k] = -fma(dV, E[k - 1], cV * E[k - 2]);
 #pragma unroll
@@ -1414,10 +1420,11 @@ __device__ inline double lane_value(double v, int src_lane) { // wave-uniform: t
 constexpr int kWE = 6; // series coefficients of the window-end expansions
 __device__ inline void wing_series6(double xc, double e, const FastRec &r, double f[kWE]) {
   const double u0 = xc * xc, u1 = 2. * xc * e, u2 = e * e;
-  const double n0 = fma(r.b, u0, r.a), n1 = r.b * u1, n2 = r.b * u2;
-  const double d0 = fma(u0, fma(4., u0, r.d), r.c);
-  const double d1 = u1 * fma(8., u0, r.d);
-  const double d2 = fma(u2, r.d, 4. * fma(u1, u1, 2. * u0 * u2));
+  const R1Coef rq = r1_of(r);
+  const double n0 = fma(rq.b, u0, rq.a), n1 = rq.b * u1, n2 = rq.b * u2;
+  const double d0 = fma(u0, fma(4., u0, rq.d), rq.c);
+  const double d1 = u1 * fma(8., u0, rq.d);
+  const double d2 = fma(u2, rq.d, 4. * fma(u1, u1, 2. * u0 * u2));
   const double d3 = 8. * u1 * u2, d4 = 4. * u2 * u2;
   const double r0 = fast_rcp<2>(d0);
   const double D1 = d1 * r0, D2 = d2 * r0, D3 = d3 * r0, D4 = d4 * r0;
@@ -1637,7 +1644,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
 #endif
         const bool live = code >= 0, rw = live && (code & 64);
         const FastRec &r = frow[base + (live ? (code & 63) : 0)];
-        const double xstep = r.xstep, a = r.a, b = r.b, c = r.c, d = r.d, wa = r.wabs, we = r.wemi;
+        const R1Coef rq = r1_of(r);
+        const double xstep = r.xstep, a = rq.a, b = rq.b, c = rq.c, d = rq.d, wa = r.wabs, we = r.wemi;
         const int j1 = r.j1, il = r.il(), ir = r.ir();
         const int kb0 = wlo - j1 + 1 + col;              // window index of this lane's point at step 0
         const int k_last = min(kImxsig, whi - j1 + 1);  // last window index inside the slot, the grid and the window
@@ -3733,7 +3741,7 @@ __global__ __launch_bounds__(256) void sr_humliv_kernel(const double *__restrict
   const Bounds B = humliv_bounds(xf, n, x0, lw, dwp); // cheap; every thread recomputes
   FastRec r;
   r.xl = B.xl; r.xr = B.xr; r.xstep = B.xstep;
-  region1_coef(B.ry, r.a, r.b, r.c, r.d);
+  r1_set(r, B.ry);
   r.wabs = r.wemi = 1.0; r.j1 = 0;
   r.ilir = (uint32_t)B.il | ((uint32_t)B.ir << 16);
   const ColdFull c = expand_cold(make_cold(B, dwp, x0, xf));
