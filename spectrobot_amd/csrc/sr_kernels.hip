@@ -1565,8 +1565,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
 #ifdef SR_DIAG_WINGS
   unsigned n_diag = 0;
 #endif
-  for (int rg = 0; rg < 3; ++rg) {
-    for (int base = rs[rg]; base < re[rg]; base += 64) {
+  // The chunks of the three candidate ranges as ONE sequence, with the next chunk's (j1, il | ir) words requested before
+  // the current chunk is worked on (round 5): every chunk began with a dependent per-lane load of them.
+  auto chunk = [&](const int rg, const int base, const int j1_c, const unsigned ilir_c) {
       const int lv = base + lane;
       // lane = line: does the line have region-1 points in this slot that no far-field level owns, and are they
       // cut by the window end / start only (then it can join the expansion + scan below)
@@ -1574,8 +1575,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
       bool has_l = false, has_r = false; // region-1 points of the lane's line in this slot: left wing (k < il), right wing (k > ir)
       int pos = 64; // lanes without a line: never selected by the scan
       if (lv < re[rg]) {
-        const int j1 = frow[lv].j1;
-        const unsigned ilir = frow[lv].ilir;
+        const int j1 = j1_c;
+        const unsigned ilir = ilir_c;
         const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
         // cut-off position of the scan: every line of the range takes part in it (the positions are
         // non-decreasing over the lanes), lines handled elsewhere with zero coefficients
@@ -1588,7 +1589,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
             fastl = rg == 0 ? (has_r && !has_l && j1 + ir <= wlo) : (has_l && !has_r && j1 + il - 2 >= wlo + 63);
         }
       }
-      if (__ballot(need) == 0) continue;
+      if (__ballot(need) == 0) return;
       // window ends (range 0) / starts (range 2) of this slot, when there are enough of them
       if (rg != 1) {
         const bool ends = rg == 0;
@@ -1613,7 +1614,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
             need = false; // done here
           }
           window_end_sum(ends, pos, c, lane, s_c, s_o, sum_a, sum_e);
-          if (__ballot(need) == 0) continue;
+          if (__ballot(need) == 0) return;
         }
       }
       // rows: region 1 is k < il (running x from k = 1: x = (k - 1) xstep - xl, i.e. -x) or k > ir
@@ -1678,6 +1679,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
         }
 #endif
       }
+  };
+  {
+    int rg = 0, base = rs[0];
+    while (rg < 3 && base >= re[rg]) { ++rg; if (rg < 3) base = rs[rg]; }
+    int j1_n = 0;
+    unsigned ilir_n = 0;
+    auto fetch = [&](int rg_, int base_) {
+      if (rg_ < 3 && base_ + lane < re[rg_]) {
+        j1_n = frow[base_ + lane].j1;
+        ilir_n = frow[base_ + lane].ilir;
+      }
+    };
+    fetch(rg, base);
+    while (rg < 3) {
+      const int j1_c = j1_n;
+      const unsigned ilir_c = ilir_n;
+      int rg2 = rg, base2 = base + 64;
+      while (rg2 < 3 && base2 >= re[rg2]) { ++rg2; if (rg2 < 3) base2 = rs[rg2]; }
+      fetch(rg2, base2);
+      chunk(rg, base, j1_c, ilir_c);
+      rg = rg2;
+      base = base2;
     }
   }
   // totals of the rows: point wlo + lane is (col, step) = (lane % 8, lane / 8): sum over the eight rows of that step.
