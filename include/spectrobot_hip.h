@@ -304,6 +304,16 @@ int sr_limb_rays_dev(const double *abs_c, const double *emi_c, int n_layers, int
 typedef struct sr_los sr_los;
 int sr_los_create(const sr_los_desc *los, int n_layers, sr_los **out);
 int sr_los_destroy(sr_los *h);
+/* The same with n_par column (VMR-profile) parameters staged alongside (par_gas, par_w as for sr_limb_rays_jac_dev): the
+ * batch of a retrieval, whose paths, densities and parameter masks stay while the VMRs change every iteration.
+ * sr_los_set_vmr: new VMRs [n_gas][n_pt] (HOST) at the batch's sample points -- one copy and the column kernel on
+ * `stream` (photon-order batches only).  sr_limb_rays_jac_los_dev: radiances and d rad / d x_p through the resident
+ * batch, launches only (the folded kernel for <= 8 parameters on shared shells, else the forward sensitivities). */
+int sr_los_create_par(const sr_los_desc *los, int n_layers, int n_par, const int32_t *par_gas, const double *par_w,
+                      sr_los **out);
+int sr_los_set_vmr(sr_los *h, const double *vmr, void *stream);
+int sr_limb_rays_jac_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
+                             double *rad, double *jac, void *stream);
 /* sr_limb_rays_dev on a resident LOS: kernel launches only (no staging copy, no column kernel, no host plan).
  * g_lo: grid index of abs_c's first point (Planck initial intensity, init_mode 2). */
 int sr_limb_rays_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,

@@ -1702,11 +1702,13 @@ int sr_last_limb_route(void) { return g_last_limb_route; }
 // the rays share their shells -- the folded sweep's packed records, all made ONCE.  The reference computes a LOS's
 // steps once too (los.calc_radtran_steps, spect_main_module.py:2746-2767) and runs radtran on them many times.
 struct sr_los {
-  Stager s_los, s_fold;
+  Stager s_los, s_fold, s_vmr;
   LosDev D{};
   FoldStage F{};
   sr_los_desc opt{}; // the scalar options; its pointers are not kept
   int n_layers = 0, dev = -1;
+  int n_par = 0;                 // column parameters staged with the batch (sr_los_create_par)
+  std::vector<int32_t> par_gas;  // their gases (host copy: a kernel argument of the folded kernel)
 };
 
 // the recursion of a resident LOS on `st`: launches only
@@ -1728,13 +1730,14 @@ static int limb_rays_los(const double *abs_c, const double *emi_c, int n_layers,
 
 extern "C" {
 
-int sr_los_create(const sr_los_desc *los, int n_layers, sr_los **out) {
-  if (!out || n_layers <= 0) return SR_ERR_ARG;
+int sr_los_create_par(const sr_los_desc *los, int n_layers, int n_par, const int32_t *par_gas, const double *par_w,
+                      sr_los **out) {
+  if (!out || n_layers <= 0 || n_par < 0) return SR_ERR_ARG;
   *out = nullptr;
   sr_los *h = new sr_los();
-  int rc = stage_los(los, n_layers, 0, nullptr, nullptr, nullptr, &h->D, &h->s_los);
+  int rc = stage_los(los, n_layers, n_par, par_gas, par_w, nullptr, &h->D, &h->s_los);
   if (!rc) rc = stage_fold(los, n_layers, nullptr, &h->F, &h->s_fold);
-  if (!rc && h->F.n_rec > 0) {
+  if (!rc && n_par == 0 && h->F.n_rec > 0) { // (with parameters the records are packed per call: the columns change with the VMRs)
     LimbOpts o = limb_opts(los, h->D.n_seg);
     rc = launch_fold_fwd(h->F.plan, h->D.col, h->D.n_seg, h->F.n_rec, h->F.rec, nullptr, nullptr, 0, n_layers, los->n_rays,
                          h->F.n_vis, o, nullptr, nullptr) ? SR_ERR_HIP : SR_OK;
@@ -1750,16 +1753,68 @@ int sr_los_create(const sr_los_desc *los, int n_layers, sr_los **out) {
   h->opt.seg_off = h->opt.seg_layer = h->opt.pt_off = nullptr;
   h->opt.x = h->opt.nd = h->opt.vmr = h->opt.col_scale = nullptr;
   h->n_layers = n_layers;
+  h->n_par = n_par;
+  if (n_par > 0) h->par_gas.assign(par_gas, par_gas + n_par);
   (void)hipGetDevice(&h->dev);
   *out = h;
   return SR_OK;
+}
+
+int sr_los_create(const sr_los_desc *los, int n_layers, sr_los **out) {
+  return sr_los_create_par(los, n_layers, 0, nullptr, nullptr, out);
 }
 
 int sr_los_destroy(sr_los *h) {
   if (!h) return SR_OK;
   h->s_los.release();
   h->s_fold.release();
+  h->s_vmr.release();
   delete h;
+  return SR_OK;
+}
+
+// New VMRs at the sample points of a resident batch (a retrieval iteration: paths, densities and parameter weights
+// stay): one small copy and the column integration of the gases' profiles, on `stream`.
+int sr_los_set_vmr(sr_los *h, const double *vmr, void *stream) {
+  if (!h || !vmr) return SR_ERR_ARG;
+  if (h->opt.los_order != 0) {
+    g_err = "sr_los_set_vmr: batches in observer order re-list their sample points; build a new handle";
+    return SR_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t bytes = sizeof(double) * (size_t)h->opt.n_gas * h->D.n_pt;
+  int rc = h->s_vmr.prepare(bytes); // (waits for the previous update's copy: the one pinned buffer is being refilled)
+  if (rc) return rc;
+  std::memcpy(h->s_vmr.host<char>(), vmr, bytes);
+  // straight into the batch's profile table: [n_gas + n_par][n_pt], the gases first
+  HIPCHK(hipMemcpyAsync(const_cast<double *>(h->D.prof), h->s_vmr.h, bytes, hipMemcpyHostToDevice, st));
+  rc = h->s_vmr.mark(st);
+  if (rc) return rc;
+  LAUNCHCHK(launch_los_columns(h->D.nd, h->D.x, h->D.prof, h->D.scale, h->D.pt_off, h->D.n_seg, h->D.n_pt, h->opt.n_gas, h->D.col, st));
+  if (h->n_par == 0 && h->F.n_rec > 0) { // the radiance route keeps packed records: repack them with the new columns
+    LimbOpts o = limb_opts(&h->opt, h->D.n_seg);
+    LAUNCHCHK(launch_fold_fwd(h->F.plan, h->D.col, h->D.n_seg, h->F.n_rec, h->F.rec, nullptr, nullptr, 0, h->n_layers, h->opt.n_rays,
+                              h->F.n_vis, o, nullptr, st));
+  }
+  return SR_OK;
+}
+
+// sr_limb_rays_jac_dev on a resident batch made with its column parameters (sr_los_create_par): launches only.
+int sr_limb_rays_jac_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
+                             double *rad, double *jac, void *stream) {
+  if (!abs_c || !emi_c || !rad || !jac || !h || n_layers != h->n_layers || n_pts <= 0 || h->n_par <= 0) return SR_ERR_ARG;
+  if (n_pts > 2000000) return SR_ERR_LIMIT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  sr_los_desc o = h->opt;
+  o.g_lo = g_lo;
+  if (h->n_par <= kFoldDensePar && h->F.n_rec > 0 && g_jac_layer_forward.load() == 0) {
+    LAUNCHCHK(launch_fold_dense(h->F.plan, h->D.col, h->par_gas.data(), h->n_par, h->D.n_seg, h->F.n_rec, h->F.rec, abs_c, emi_c,
+                                (int)n_pts, n_layers, o.n_rays, h->F.n_vis, limb_opts(&o, h->D.n_seg), rad, jac, st));
+    return SR_OK;
+  }
+  LAUNCHCHK(launch_limb_jac(abs_c, emi_c, (int)n_pts, n_layers, o.n_rays, h->D.seg_off, h->D.seg_layer, h->D.col,
+                            h->D.col + (size_t)o.n_gas * h->D.n_seg, h->D.par_gas, h->n_par, limb_opts(&o, h->D.n_seg), rad,
+                            jac, st));
   return SR_OK;
 }
 

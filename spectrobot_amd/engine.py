@@ -444,6 +444,11 @@ def radiance_rays(abs_c, emi_c, seg_off, seg_layer, seg_col, rad0=None):
     return rad
 
 
+class _ParHandle(object):
+    def __init__(self, h, keep):
+        self.h, self.keep = h, keep
+
+
 class LimbLOS(object):
     """A batch of lines of sight for the device LOS pipeline (sr_los_desc): per ray the segments it crosses,
     per segment the layer whose coefficients apply and the LOS sample points (path coordinate x [cm], number
@@ -487,10 +492,37 @@ class LimbLOS(object):
             self._handles[key] = h
         return h
 
+    def handle_par(self, n_layers, par_gas, par_w, grid=None, rad0=False):
+        """handle() with the column parameters (par_gas [n_par], par_w [n_par, n_pt]) staged alongside
+        (sr_los_create_par): the batch of a retrieval.  Keyed on the two arrays' identity."""
+        gp = None if (grid is None or self.initial_temperature is None or rad0) else grid_params(grid)[:2]
+        key = (int(n_layers), gp, bool(rad0), id(par_gas), id(par_w))
+        ent = self._handles.get(key)
+        if ent is None:
+            pg_a, pg = _i(par_gas)
+            pw_a, pw = _d(par_w)
+            if pw_a.shape != (pg_a.size, self.n_pt):
+                raise ValueError("par_w must be [n_par, n_pt]")
+            d = self.desc(grid, 0, rad0=rad0)
+            h = C.c_void_p()
+            check(lib.sr_los_create_par(C.byref(d), int(n_layers), pg_a.size, pg, pw, C.byref(h)), "sr_los_create_par")
+            ent = self._handles[key] = _ParHandle(h, (par_gas, par_w))     # (the arrays referenced: their ids stay theirs)
+        return ent.h
+
+    def set_vmr(self, vmr):
+        """New VMRs [n_gas, n_pt] at the sample points (the next iteration of a retrieval): the host copy and every
+        resident form of the batch (sr_los_set_vmr: one small copy + the column kernel; nothing else is re-staged)."""
+        v = np.ascontiguousarray(np.atleast_2d(vmr), dtype=np.float64)
+        if v.shape != self.vmr.shape:
+            raise ValueError("vmr must be [n_gas, n_pt]")
+        self.vmr[...] = v
+        for h in self._handles.values():
+            check(lib.sr_los_set_vmr(getattr(h, "h", h), self._v, _stream_ptr()), "sr_los_set_vmr")
+
     def close(self):
         for h in getattr(self, "_handles", {}).values():
             if lib is not None:
-                lib.sr_los_destroy(h)
+                lib.sr_los_destroy(getattr(h, "h", h))
         self._handles = {}
 
     __del__ = close
@@ -563,13 +595,16 @@ def limb_rays(coeffs, los, grid=None, g_lo=0, rad0=None, resident=True):
     return rad
 
 
-def limb_rays_jacobian(coeffs, los, par_gas, par_w, grid=None, g_lo=0, rad0=None, joint=False):
+def limb_rays_jacobian(coeffs, los, par_gas, par_w, grid=None, g_lo=0, rad0=None, joint=False, resident=False):
     """Radiances and d rad / d x_p [n_rays, n_par, n_pts] for VMR-profile parameters: the VMR of gas
     par_gas[p] at LOS sample point i is sum_p par_w[p, i] x_p (sr_limb_rays_jac_dev).
     joint=True: both live in ONE buffer [n_rays (1 + n_par), n_pts] -- the radiances' rows first -- which is returned
-    as a third value (one hires_to_lowres call, one copy to the host, for a retrieval iteration)."""
+    as a third value (one hires_to_lowres call, one copy to the host, for a retrieval iteration).
+    resident=True: through the batch's device-resident form with these parameter arrays (LimbLOS.handle_par, keyed on
+    the arrays' identity) -- a retrieval loop that keeps its LimbLOS and calls los.set_vmr between iterations."""
     a, e = _gas_stack(coeffs)
     n_gas, n_layers, n_pts = a.shape
+    par_gas_in, par_w_in = par_gas, par_w
     par_gas, pg = _i(par_gas)
     par_w, pw = _d(par_w)
     n_par = par_gas.size
@@ -584,6 +619,11 @@ def limb_rays_jacobian(coeffs, los, par_gas, par_w, grid=None, g_lo=0, rad0=None
     else:
         rad = rad0 if rad0 is not None else torch.empty((los.n_rays, n_pts), dtype=torch.float64, device="cuda")
         jac = torch.empty((los.n_rays, n_par, n_pts), dtype=torch.float64, device="cuda")
+    if resident:   # the batch with its parameters staged once (sr_los_create_par); VMR updates through los.set_vmr
+        h = los.handle_par(n_layers, par_gas_in, par_w_in, grid, rad0=rad0 is not None)
+        check(lib.sr_limb_rays_jac_los_dev(a.data_ptr(), e.data_ptr(), n_layers, n_pts, h, int(g_lo), rad.data_ptr(), jac.data_ptr(),
+                                           _stream_ptr()), "sr_limb_rays_jac_los_dev")
+        return (rad, jac, buf) if joint else (rad, jac)
     d = los.desc(grid, g_lo, rad0=rad0 is not None)
     check(lib.sr_limb_rays_jac_dev(C.c_void_p(a.data_ptr()), C.c_void_p(e.data_ptr()), n_layers, n_pts, C.byref(d),
                                    n_par, pg, pw, C.c_void_p(rad.data_ptr()), C.c_void_p(jac.data_ptr()),

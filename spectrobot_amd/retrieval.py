@@ -111,8 +111,16 @@ class LimbScene(object):
         _, L, zz = geo
         # (geometry._profiles: every VMR linear in altitude between the levels, constant above the last one)
         vmr = np.array([np.interp(L["alt"], zz, np.append(g.vmr, g.vmr[-1])) for g in self.gases])
+        # the batch itself is kept too (photon order, no options): its device-resident form (engine.LimbLOS.handle_par)
+        # then needs only the new VMRs (LimbLOS.set_vmr: one small copy + the column kernel)
+        kept = getattr(self, "_los_obj", None)
+        if not opts and kept is not None and kept[0] == key:
+            kept[1].set_vmr(vmr)
+            return kept[1], L["alt"]
         los = engine.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], vmr,
                              col_scale=[g.iso_ratio for g in self.gases], **opts)
+        if not opts:
+            self._los_obj = (key, los)
         return los, L["alt"]
 
     def profile_weights(self, bayes_set, alt):
@@ -170,7 +178,7 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
     else:
         par_gas, par_w = scene.profile_weights(bayes_set, alt)
         # radiances and derivatives in one buffer: one instrument-step launch and one copy to the host per iteration
-        _, _, buf = engine.limb_rays_jacobian(coeffs, los, par_gas, par_w, joint=True)
+        _, _, buf = engine.limb_rays_jacobian(coeffs, los, par_gas, par_w, joint=True, resident=True)
         n_par = len(par_gas)
         lo_all = lowres(buf)
         both = np.concatenate([lo_all[:n_los, None, :], lo_all[n_los:].reshape(n_los, n_par, -1)], axis=1)

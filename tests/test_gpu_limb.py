@@ -470,6 +470,46 @@ def test_resident_los_equals_per_call_staging(eng):
         ls.limb_step(T[:5], am["press"][:5], los, tvib=am["tvib"][:, :5])     # 5 layers against a LOS through 16
 
 
+def test_resident_los_with_parameters_and_vmr_updates(eng):
+    """The batch of a retrieval: made resident once with its column parameters (sr_los_create_par), new VMRs every
+    iteration through LimbLOS.set_vmr (one small copy + the column kernel).  Radiances and parameter Jacobians equal
+    the per-call route's (everything staged on every call) bit for bit, before and after VMR updates, for the folded
+    kernel (7 broad parameters) and the forward-sensitivity fallback (12 parameters); the radiance handle of the same
+    object follows the update too; observer-order batches refuse the update."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(33)
+    nl, n = 24, 8192
+    atm = _atm(nl)
+    z = atm["z"]
+    top = z[-1] + (z[-1] - z[-2])
+    zz = np.append(z, top)
+    t = lambda v: torch.tensor(np.ascontiguousarray(v), device="cuda")
+    a = [rng.uniform(0, 4e-17, (nl, n)), rng.uniform(0, 3e-17, (nl, n))]
+    e = [a[0] * rng.uniform(1e-8, 1e-7, (nl, n)), a[1] * rng.uniform(1e-8, 1e-7, (nl, n))]
+    two = [(t(a[0]), t(e[0])), (t(a[1]), t(e[1]))]
+    vm = [np.full(nl, 1.2e-2), np.linspace(2e-3, 5e-4, nl)]
+    L = syn.limb_los(z, atm["nd"] * 1e-6, vm, z[0] + 5.0 + 31.0 * np.arange(6))
+    for n_par in (7, 12):
+        centres = np.linspace(zz[0], zz[-1], n_par)
+        W = np.array([np.interp(L["alt"], zz, np.exp(-0.5 * ((zz - c) / 150.0) ** 2)) for c in centres])
+        pg = (np.arange(n_par) % 2).astype(np.int32)
+        los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827, 1.0])
+        for it in range(3):
+            if it:
+                los.set_vmr(L["vmr"] * (1.0 + 0.3 * it) + 1e-5 * it)
+            fresh = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], los.vmr, col_scale=[0.98827, 1.0])
+            r_ref, j_ref = eng.limb_rays_jacobian(two, fresh, pg, W)
+            r, j = eng.limb_rays_jacobian(two, los, pg, W, resident=True)
+            assert torch.equal(r, r_ref) and torch.equal(j, j_ref), (n_par, it)
+            assert torch.equal(eng.limb_rays(two, los), eng.limb_rays(two, fresh, resident=False)), (n_par, it)
+        assert len(los._handles) == 2 and float(j.abs().max()) > 0
+    obs = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], LOS_order="observer")
+    eng.limb_rays(two, obs)
+    with pytest.raises(RuntimeError):
+        obs.set_vmr(L["vmr"] * 2.0)
+
+
 def test_per_level_partial_radiances_sum_to_total(eng):
     """single_rad[(gas, iso, lev)] (spect_main_module.py:2883-2887): the radiance emitted by one level and
     absorbed by the whole gas -- the level's emission share (sr_abscoeff_level_dev) with the total
