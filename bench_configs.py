@@ -167,9 +167,14 @@ def retrieval_problem(scene, n_pix=6, seed=1, noise_frac=0.004):
 
 def _sync_time(fn, steps, warmup):
     import torch
+    import gc
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    # as bench.py: a full collection of Python's garbage collector walks ~1e6 objects (40 ms) -- inside 20 timed steps
+    # that is 2 ms per step (it hit --config 2 this round: 8.1 instead of 5.9 ms); collect now, freeze what exists
+    gc.collect()
+    gc.freeze()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = fn()
@@ -517,10 +522,13 @@ def main(args):
         # iteration, the algebra replicated (retrieval.simulate; spect_main_module.py:2814-2853)
         shard = sd.shard_bounds(len(scene.grid), world, rank) if world > 1 else None
         import copy
+        import gc
         bs0 = copy.deepcopy(bs)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
+        gc.collect()
+        gc.freeze()      # (see _sync_time)
         t0 = time.perf_counter()
         chi, obs, sims, bs = retrieval.inversion_fast_limb(scene, bs, pixels, max_it=20, shard=shard)
         torch.cuda.synchronize()

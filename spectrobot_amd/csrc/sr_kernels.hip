@@ -1053,10 +1053,8 @@ __device__ constexpr double inv_factorial(int n) {
 #else
 #define SR_S2M_ATTR
 #endif
-#ifndef SR_S2M_ONE_SET
-#define SR_S2M_ONE_SET 1 // 1 (round 4): one convolution per line about the MEAN of its two anchors + first-order corrections; 0: one per side
-#endif
-#if SR_S2M_ONE_SET
+// (one convolution per line about the MEAN of its two anchors + first-order corrections; round 3's one-per-side
+// variant is in the history: S2M 0.375 vs 0.31 ms)
 // Round 4: one moment set per line instead of one per side.  The two wings of a line use different anchors (the zero of
 // the reference's running x: xl from x(1), xr from x(ir): lineshape.f:462, 471), eps ~ 1e-9 grid points apart (the
 // rounding of the grid).  The moments are analytic in the anchor: M_q(delta +- eps / 2) = M_q(delta) +- (eps / 2) d M_q /
@@ -1156,82 +1154,6 @@ __global__ __launch_bounds__(64) SR_S2M_ATTR void sr_s2m_kernel(const FastRec *_
   }
   if (COUNT) count_add(cnt, kCntS2M, n_lines, lane);
 }
-#else
-template <bool COUNT>
-__global__ __launch_bounds__(64) SR_S2M_ATTR void sr_s2m_kernel(const FastRec *__restrict__ fast, IcIndex ix, int n_sub, int g_lo,
-                                                    FarParams fp, unsigned long long *__restrict__ cnt) {
-  const int wid = xcd_remap(blockIdx.x, gridDim.x);
-  const int layer = wid / fp.n_src[0], sb = wid - layer * fp.n_src[0];
-  const int lane = threadIdx.x;
-  const int s_lo = g_lo + (sb - kSrcPad) * 64; // first centre position of the box
-  // A box wholly LEFT of the shard only ever serves targets to its right (side 0), one wholly right of it targets to
-  // its left (side 1) -- and so do all its ancestors: half of a 1/8 shard's source boxes are such halo boxes.  They
-  // take 64 lines of the one side per step; the side nobody reads is written as zeros (sr_m2m_kernel sums both).
-  const int only = s_lo + 64 <= g_lo ? 0 : (s_lo >= g_lo + fp.box_count[0] * 64 ? 1 : -1);
-  const int side = only >= 0 ? only : lane >> 5, sub = only >= 0 ? lane : lane & 31, per_step = only >= 0 ? 64 : 32;
-  const int l0 = lower_bound_ic(ix, s_lo), l1 = lower_bound_ic(ix, s_lo + 64);
-  constexpr int NE = kFD / 2; // terms of the Laurent series
-  double v[2 * kMQ];          // [0, kMQ): abs, [kMQ, 2 kMQ): emi
-#pragma unroll
-  for (int n = 0; n < 2 * kMQ; ++n) v[n] = 0.;
-  const FastRec *frow = fast + (size_t)layer * n_sub;
-  unsigned n_lines = 0;
-  for (int base = l0; base < l1; base += per_step) {
-    const int l = base + sub;
-    if (l >= l1 || l < fp.disp_lo_end || l >= fp.disp_hi_begin) continue;
-    const FastRec r = frow[l];
-    if (COUNT) ++n_lines;
-    constexpr double h = 32.0;
-    const double sh = r.xstep * h;
-    const double V = fast_rcp<2>(sh * sh);
-    double E[NE]; // e_(n-1) (xstep h)^(-2n) / (2n-1)!
-    {
-      const R1Coef rq = r1_of(r);
-      const double dV = 0.25 * rq.d * V, cV = 0.25 * rq.c * (V * V);
-      E[0] = 0.25 * rq.b * V;
-      E[1] = fma(0.25 * rq.a * V, V, -dV * E[0]);
-#pragma unroll
-      for (int k = 2; k < NE; ++k) E[k] = -fma(dV, E[k - 1], cV * E[k - 2]);
-#pragma unroll
-      for (int k = 1; k < NE; ++k) E[k] *= inv_factorial(2 * k + 1);
-    }
-    // delta / h: zero of the running x of this wing, relative to the box centre s_lo + 31.5
-    const double off = side == 0 ? (double)(r.j1 + r.ir() - 1 - s_lo - 32) + (0.5 - r.xr / r.xstep)
-                                 : (double)(r.j1 - s_lo - 32) + (0.5 + r.xl / r.xstep);
-    const double dt = off * (1.0 / h);
-    double D[kMQ]; // (delta/h)^m / m!, m = 0..kFD-2
-    D[0] = 1.0;
-#pragma unroll
-    for (int m = 1; m < kMQ; ++m) D[m] = D[m - 1] * (dt * (1.0 / (double)m));
-#pragma unroll
-    for (int q = 2; q <= kFD; ++q) {
-      double mq = 0.;
-#pragma unroll
-      for (int n = 1; 2 * n <= q; ++n) mq = fma(E[n - 1], D[q - 2 * n], mq);
-      v[q - 2] = fma(r.wabs, mq, v[q - 2]);
-      v[kMQ + q - 2] = fma(r.wemi, mq, v[kMQ + q - 2]);
-    }
-  }
-  // sums within each half-wave, one weight at a time (kMQ values over 32 lanes leave one per lane)
-  lane_reduce<kMQ, 16>(v, lane);
-  lane_reduce<kMQ, 16>(v + kMQ, lane);
-  if (only >= 0) { // the two half-waves hold partial sums of the same side
-    v[0] += __shfl_xor(v[0], 32);
-    v[kMQ] += __shfl_xor(v[kMQ], 32);
-  }
-  bool primary = true;
-  const int n_out = lane_reduce_index<kMQ, 16>(lane & 31, primary);
-  if (primary) {
-    const int wside = only >= 0 ? (lane < 32 ? only : 1 - only) : side;
-    const bool zero = only >= 0 && lane >= 32;
-    double *mo = fp.mom + ((size_t)(fp.src_off[0] + sb) * fp.n_layers + layer) * kMomPerBox + wside * (2 * kMQ) + n_out;
-    mo[0] = zero ? 0.0 : v[0];
-    mo[kMQ] = zero ? 0.0 : v[kMQ];
-  }
-  if (COUNT) count_add(cnt, kCntS2M, n_lines, lane);
-}
-
-#endif // SR_S2M_ONE_SET
 
 // One thread per (parent box of level l, layer, side, weight); one launch per level, narrow to wide (round 3: one
 // thread per widest-level subtree walked all its 15 boxes in sequence -- 500 waves with 15 dependent rounds of loads:
@@ -1439,47 +1361,32 @@ __device__ inline void wing_series6(double xc, double e, const FastRec &r, doubl
 // of 64 lines.  ends: line of lane i is valid at points p <= pos_i; starts: at p >= pos_i; pos is
 // non-decreasing over the lanes (lines sorted by window centre); lanes without such a line carry
 // zero coefficients.  c: [0, kWE) abs, [kWE, 2 kWE) emi series coefficients of the lane's line.
-//
-// Round 5: the twelve suffix (prefix) sums over the lanes run TRANSPOSED through LDS.  As DPP row scans they were
-// 29 (23) VALU instructions per coefficient -- 8 row-shift moves, 4 adds, 6 v_readlane and the nested selects of the
-// row totals -- 348 + 276 per slot, a quarter of the kernel's instructions.  Now every lane stores its line's twelve
-// coefficients (s_c[n][lane]), lanes (block b of 16 lines, coefficient n) scan their 16 entries serially in place --
-// 16 adds for all twelve sums at once --, the block totals become per-block offsets (s_o[n][b]), and a point reads
-// its cut-off column s_c[n][src] + s_o[n][src / 16].  Column 64 / block 4 hold zeros: "no line" needs no select.
-constexpr int kWECols = 66; // 64 lines, the zero column, one of padding (rows 2 banks apart)
-template <bool ENDS>
-__device__ inline void window_end_scan(int lane, double (*s_c)[kWECols], double (*s_o)[5]) {
-  const int b = lane / (2 * kWE), n = lane - (2 * kWE) * b; // lanes 0..47
-  if (lane < 4 * 2 * kWE) {
-    double *cell = &s_c[n][16 * b];
-    double acc = 0.;
+__device__ inline void window_end_sum(bool ends, int pos, double c[2 * kWE], int lane, double &out_a, double &out_e) {
+  // inclusive suffix (ends) or prefix (starts) sums over the lanes: inside each row of 16 lanes by DPP
+  // row shifts (plain VALU moves, zero shifted in at the row end), then the totals of the other rows
+  const int row = lane >> 4;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int kk = ENDS ? 15 - k : k;
-      acc += cell[kk];
-      cell[kk] = acc;
+  for (int n = 0; n < 2 * kWE; ++n) {
+    double v = c[n];
+    if (ends) {
+      v += dpp_move<0x101>(v); // row_shl:1  lane i <- lane i + 1
+      v += dpp_move<0x102>(v);
+      v += dpp_move<0x104>(v);
+      v += dpp_move<0x108>(v);
+      const double t1 = lane_value(v, 16), t2 = lane_value(v, 32), t3 = lane_value(v, 48); // row totals
+      const double t23 = t2 + t3;
+      v += row == 0 ? t1 + t23 : (row == 1 ? t23 : (row == 2 ? t3 : 0.0));
+    } else {
+      v += dpp_move<0x111>(v); // row_shr:1  lane i <- lane i - 1
+      v += dpp_move<0x112>(v);
+      v += dpp_move<0x114>(v);
+      v += dpp_move<0x118>(v);
+      const double t0 = lane_value(v, 15), t1 = lane_value(v, 31), t2 = lane_value(v, 47);
+      const double t01 = t0 + t1;
+      v += row == 3 ? t01 + t2 : (row == 2 ? t01 : (row == 1 ? t0 : 0.0));
     }
+    c[n] = v;
   }
-  __builtin_amdgcn_wave_barrier();
-  if (lane < 4 * 2 * kWE) {
-    double o = 0.;
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-      const double tv = s_c[n][ENDS ? 16 * bb : 16 * bb + 15]; // the block's total
-      o += (ENDS ? bb > b : bb < b) ? tv : 0.0;
-    }
-    s_o[n][b] = o;
-  }
-}
-__device__ inline void window_end_sum(bool ends, int pos, const double c[2 * kWE], int lane, double (*s_c)[kWECols],
-                                      double (*s_o)[5], double &out_a, double &out_e) {
-  __builtin_amdgcn_wave_barrier(); // (the previous call's reads are through: one wave, LDS in order)
-#pragma unroll
-  for (int n = 0; n < 2 * kWE; ++n) s_c[n][lane] = c[n];
-  __builtin_amdgcn_wave_barrier();
-  if (ends) window_end_scan<true>(lane, s_c, s_o);
-  else window_end_scan<false>(lane, s_c, s_o);
-  __builtin_amdgcn_wave_barrier();
   // this lane as a POINT p = lane: ends: first line with pos >= p; starts: last line with pos <= p
   int lo = 0, hi = 64; // 65 possible answers: 7 halvings
 #pragma unroll
@@ -1491,15 +1398,15 @@ __device__ inline void window_end_sum(bool ends, int pos, const double c[2 * kWE
     lo = right ? mid + 1 : lo;
     hi = left ? mid : hi;
   }
-  // lo = number of lines with pos < p (ends) / pos <= p (starts); 64: no line (the zero column, the zero offset)
-  const int src = ends ? lo : (lo == 0 ? 64 : lo - 1);
-  const int bs = src >> 4;
+  const int src = ends ? lo : lo - 1; // lo = number of lines with pos < p (ends) / pos <= p (starts)
+  const bool any = ends ? src < 64 : src >= 0;
   const double t = (double)(2 * lane - 63) * (1.0 / 64);
   double pa = 0., pe = 0.;
 #pragma unroll
   for (int n = kWE - 1; n >= 0; --n) {
-    pa = fma(pa, t, s_c[n][src] + s_o[n][bs]);
-    pe = fma(pe, t, s_c[kWE + n][src] + s_o[kWE + n][bs]);
+    const double ca = __shfl(c[n], src & 63), ce = __shfl(c[kWE + n], src & 63);
+    pa = fma(pa, t, any ? ca : 0.0);
+    pe = fma(pe, t, any ? ce : 0.0);
   }
   out_a += pa;
   out_e += pe;
@@ -1512,7 +1419,7 @@ __device__ inline void window_end_sum(bool ends, int pos, const double c[2 * kWE
 // by per-lane loads.  Before, every such line cost a scalar record fetch, a ballot walk and four specialised masked
 // loops: the walk took 0.87 of the kernel's 1.34 ms for 0.27 ms worth of vector work.
 template <bool COUNT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr_abscoeff_near_wings_kernel( // 80 VGPRs: six waves per SIMD (81 would be five)
+__global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
     const FastRec *__restrict__ fast, IcIndex ix, const int *__restrict__ zmax, int n_sub,
     int n_tiles, int g_lo, int g_hi, FarParams fp, int add, const double *__restrict__ z_abs,
     const double *__restrict__ z_emi, double *__restrict__ abs_out, double *__restrict__ emi_out,
@@ -1529,34 +1436,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
 
   constexpr int kRowLanes = 8, kRows = 8;
   const int row = lane / kRowLanes, col = lane % kRowLanes;
-  __shared__ double s_c[2 * kWE][kWECols]; // window_end_sum: the lines' series coefficients, scanned in place
-  __shared__ double s_o[2 * kWE][5];
   double sum_a = 0., sum_e = 0.; // this lane's point wlo + lane: window ends, polynomials, and the rows' total
-  // The polynomials come FIRST: their coefficients are wave-uniform and must arrive by scalar loads.  The pointer comes
-  // out of a by-value kernel argument (a flat pointer to the compiler), and after the first LDS store of the kernel a
-  // flat load counts as clobbered: placed behind the window-end scans these became 24 vector loads per level
-  // (SQ_INSTS_VMEM_RD 1.6e7 -> 3.1e7, SQ_INSTS_SMEM 1.1e7 -> 3e6, the kernel 1.05 -> 1.16 ms).
-  // far field: one polynomial per level
-  const double *cl = fp.coef + (size_t)layer * fp.n_boxes_total * (2 * kFC);
-  for (int lv = 0; lv < fp.n_levels; ++lv) {
-    const int W = 64 << lv;
-    const int b = (wlo - g_lo) >> (6 + lv);
-    const int blo = g_lo + b * W;
-    const double t = (double)(2 * (wlo + lane - blo) - (W - 1)) * (1.0 / 64 / (double)(1 << lv)); // exact: W = 2^(6+lv)
-    const double *c = cl + (size_t)(fp.box_off[lv] + b) * (2 * kFC);
-    double pa = c[kFC - 1], pe = c[2 * kFC - 1];
-#pragma unroll
-    for (int n = kFC - 2; n >= 0; --n) {
-      pa = fma3s(pa, t, c[n]);
-      pe = fma3s(pe, t, c[kFC + n]);
-    }
-    sum_a += pa;
-    sum_e += pe;
-  }
-  if (lane < 2 * kWE) {
-    s_c[lane][64] = 0.;
-    s_o[lane][4] = 0.;
-  }
   double ra[kRows], rb[kRows];    // rows: partial sums (abs, emi) of point wlo + col + 8 s over the lines of this lane's row
 #pragma unroll
   for (int q = 0; q < kRows; ++q) ra[q] = rb[q] = 0.;
@@ -1565,9 +1445,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
 #ifdef SR_DIAG_WINGS
   unsigned n_diag = 0;
 #endif
-  // The chunks of the three candidate ranges as ONE sequence, with the next chunk's (j1, il | ir) words requested before
-  // the current chunk is worked on (round 5): every chunk began with a dependent per-lane load of them.
-  auto chunk = [&](const int rg, const int base, const int j1_c, const unsigned ilir_c) {
+  for (int rg = 0; rg < 3; ++rg) {
+    for (int base = rs[rg]; base < re[rg]; base += 64) {
       const int lv = base + lane;
       // lane = line: does the line have region-1 points in this slot that no far-field level owns, and are they
       // cut by the window end / start only (then it can join the expansion + scan below)
@@ -1575,8 +1454,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
       bool has_l = false, has_r = false; // region-1 points of the lane's line in this slot: left wing (k < il), right wing (k > ir)
       int pos = 64; // lanes without a line: never selected by the scan
       if (lv < re[rg]) {
-        const int j1 = j1_c;
-        const unsigned ilir = ilir_c;
+        const int j1 = frow[lv].j1;
+        const unsigned ilir = frow[lv].ilir;
         const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
         // cut-off position of the scan: every line of the range takes part in it (the positions are
         // non-decreasing over the lanes), lines handled elsewhere with zero coefficients
@@ -1589,7 +1468,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
             fastl = rg == 0 ? (has_r && !has_l && j1 + ir <= wlo) : (has_l && !has_r && j1 + il - 2 >= wlo + 63);
         }
       }
-      if (__ballot(need) == 0) return;
+      if (__ballot(need) == 0) continue;
       // window ends (range 0) / starts (range 2) of this slot, when there are enough of them
       if (rg != 1) {
         const bool ends = rg == 0;
@@ -1613,8 +1492,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
             }
             need = false; // done here
           }
-          window_end_sum(ends, pos, c, lane, s_c, s_o, sum_a, sum_e);
-          if (__ballot(need) == 0) return;
+          window_end_sum(ends, pos, c, lane, sum_a, sum_e);
+          if (__ballot(need) == 0) continue;
         }
       }
       // rows: region 1 is k < il (running x from k = 1: x = (k - 1) xstep - xl, i.e. -x) or k > ir
@@ -1679,46 +1558,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
         }
 #endif
       }
-  };
-  {
-    int rg = 0, base = rs[0];
-    while (rg < 3 && base >= re[rg]) { ++rg; if (rg < 3) base = rs[rg]; }
-    int j1_n = 0;
-    unsigned ilir_n = 0;
-    auto fetch = [&](int rg_, int base_) {
-      if (rg_ < 3 && base_ + lane < re[rg_]) {
-        j1_n = frow[base_ + lane].j1;
-        ilir_n = frow[base_ + lane].ilir;
-      }
-    };
-    fetch(rg, base);
-    while (rg < 3) {
-      const int j1_c = j1_n;
-      const unsigned ilir_c = ilir_n;
-      int rg2 = rg, base2 = base + 64;
-      while (rg2 < 3 && base2 >= re[rg2]) { ++rg2; if (rg2 < 3) base2 = rs[rg2]; }
-      fetch(rg2, base2);
-      chunk(rg, base, j1_c, ilir_c);
-      rg = rg2;
-      base = base2;
     }
   }
-  // totals of the rows: point wlo + lane is (col, step) = (lane % 8, lane / 8): sum over the eight rows of that step.
-  // Through LDS (round 5; as xor-shuffles: 96 ds_bpermute and 111 VALU instructions per wave): every lane stores its
-  // eight partial sums, step-major with 72 doubles per step (reads two banks apart), and reads the eight rows of its own.
-  {
-    static_assert(2 * kWE * kWECols >= kRows * 72, "the window-end scratch holds the row totals");
-    double *s_t = &s_c[0][0];
+  // totals of the rows: point wlo + lane is (col, step) = (lane % 8, lane / 8): sum over the eight rows of that step
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      __builtin_amdgcn_wave_barrier();
+  for (int q = 0; q < kRows; ++q) {
+    double ta = ra[q], te = rb[q];
 #pragma unroll
-      for (int q = 0; q < kRows; ++q) s_t[q * 72 + lane] = ch == 0 ? ra[q] : rb[q];
-          __builtin_amdgcn_wave_barrier();
-      double tot = 0.;
-#pragma unroll
-      for (int r = 0; r < kRows; ++r) tot += s_t[row * 72 + r * kRowLanes + col];
-      if (ch == 0) sum_a += tot; else sum_e += tot;
+    for (int m = kRowLanes; m < 64; m <<= 1) {
+      ta += __shfl_xor(ta, m);
+      te += __shfl_xor(te, m);
+    }
+    if (row == q) {
+      sum_a += ta;
+      sum_e += te;
     }
   }
   if (COUNT) {
@@ -1729,6 +1582,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void sr
 #else
     count_add(cnt, kCntPolyPoints, (wlo + lane <= whi) ? (unsigned)fp.n_levels : 0u, lane);
 #endif
+  }
+  // far field: one polynomial per level
+  const double *cl = fp.coef + (size_t)layer * fp.n_boxes_total * (2 * kFC);
+  for (int lv = 0; lv < fp.n_levels; ++lv) {
+    const int W = 64 << lv;
+    const int b = (wlo - g_lo) >> (6 + lv);
+    const int blo = g_lo + b * W;
+    const double t = (double)(2 * (wlo + lane - blo) - (W - 1)) * (1.0 / 64 / (double)(1 << lv)); // exact: W = 2^(6+lv)
+    const double *c = cl + (size_t)(fp.box_off[lv] + b) * (2 * kFC);
+    double pa = c[kFC - 1], pe = c[2 * kFC - 1];
+#pragma unroll
+    for (int n = kFC - 2; n >= 0; --n) {
+      pa = fma3s(pa, t, c[n]);
+      pe = fma3s(pe, t, c[kFC + n]);
+    }
+    sum_a += pa;
+    sum_e += pe;
   }
   const size_t orow = (size_t)layer * (size_t)(g_hi - g_lo);
   const int j = wlo + lane;
