@@ -1512,10 +1512,11 @@ __global__ __launch_bounds__(64) void sr_abscoeff_near_wings_kernel(
           int c_ = -1; // wave-uniform
           if (m_l) {
             c_ = __builtin_ctzll(m_l);
-            m_l &= m_l - 1;
+            asm("s_bitset0_b64 %0, %1" : "+s"(m_l) : "s"(c_)); // m_l &= m_l - 1 in one scalar instruction instead of three
           } else if (m_r) {
-            c_ = __builtin_ctzll(m_r) | 64;
-            m_r &= m_r - 1;
+            const int cr = __builtin_ctzll(m_r);
+            asm("s_bitset0_b64 %0, %1" : "+s"(m_r) : "s"(cr));
+            c_ = cr | 64;
           }
           code = row == q ? c_ : code;
         }
