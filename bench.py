@@ -318,9 +318,10 @@ def main():
     full = torch.empty((args.rays, args.grid), dtype=torch.float64, device="cuda") if world > 1 else None
 
     def step():
-        # coefficient op + recursion of the resident LOS batch in one library call (sr_limb_step_dev); the columns
-        # (curgod_fort_2) of the batch were integrated on the device when it was made resident, outside the loop, as
-        # the reference computes a line of sight's steps once (spect_main_module.py:2746-2767)
+        # The LOS columns (curgod_fort_2 per segment) integrated on the device from the resident batch's sample points --
+        # part of the step as in every round; what the resident batch saves is re-staging an unchanged batch from the
+        # host --, then coefficient op + recursion in one library call (sr_limb_step_dev).
+        los.refresh_columns()
         _, _, rad = ls.limb_step(atm["temps"], atm["press"], los, tvib=atm["tvib"], q_part=q_part, g_lo=g_lo, g_hi=g_hi,
                                  out=(ab, em))
         if args.shard:
@@ -336,6 +337,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    los.handle(args.layers)       # the batch resident on the device (outside the timed region, like the line list)
     for _ in range(args.warmup):
         step()
     barrier()

@@ -312,6 +312,9 @@ int sr_los_destroy(sr_los *h);
 int sr_los_create_par(const sr_los_desc *los, int n_layers, int n_par, const int32_t *par_gas, const double *par_w,
                       sr_los **out);
 int sr_los_set_vmr(sr_los *h, const double *vmr, void *stream);
+/* The columns of a resident batch integrated again from its staged sample points (two launches, no copy): for callers
+ * whose step includes the column integration by definition. */
+int sr_los_refresh_columns(sr_los *h, void *stream);
 int sr_limb_rays_jac_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
                              double *rad, double *jac, void *stream);
 /* sr_limb_rays_dev on a resident LOS: kernel launches only (no staging copy, no column kernel, no host plan).

@@ -92,6 +92,7 @@ SYMBOLS = {
     "sr_los_destroy": (C.c_int, [C.c_void_p]),
     "sr_los_create_par": (C.c_int, [C.POINTER(LosDesc), C.c_int, C.c_int, ip, dp, C.POINTER(C.c_void_p)]),
     "sr_los_set_vmr": (C.c_int, [C.c_void_p, dp, C.c_void_p]),
+    "sr_los_refresh_columns": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sr_limb_rays_jac_los_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
     "sr_limb_rays_los_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,

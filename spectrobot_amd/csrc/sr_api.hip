@@ -1799,6 +1799,22 @@ int sr_los_set_vmr(sr_los *h, const double *vmr, void *stream) {
   return SR_OK;
 }
 
+// The Curtis-Godson columns of a resident batch integrated again from its staged sample points (and the folded
+// records repacked): two launches on `stream`, nothing copied.  For callers whose step is "columns + recursion" by
+// definition (bench.py: the timed step keeps the column integration on the device, it only no longer re-stages a
+// batch that has not changed).
+int sr_los_refresh_columns(sr_los *h, void *stream) {
+  if (!h) return SR_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LAUNCHCHK(launch_los_columns(h->D.nd, h->D.x, h->D.prof, h->D.scale, h->D.pt_off, h->D.n_seg, h->D.n_pt, h->D.n_prof, h->D.col, st));
+  if (h->n_par == 0 && h->F.n_rec > 0) {
+    LimbOpts o = limb_opts(&h->opt, h->D.n_seg);
+    LAUNCHCHK(launch_fold_fwd(h->F.plan, h->D.col, h->D.n_seg, h->F.n_rec, h->F.rec, nullptr, nullptr, 0, h->n_layers, h->opt.n_rays,
+                              h->F.n_vis, o, nullptr, st));
+  }
+  return SR_OK;
+}
+
 // sr_limb_rays_jac_dev on a resident batch made with its column parameters (sr_los_create_par): launches only.
 int sr_limb_rays_jac_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
                              double *rad, double *jac, void *stream) {

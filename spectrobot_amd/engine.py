@@ -509,6 +509,12 @@ class LimbLOS(object):
             ent = self._handles[key] = _ParHandle(h, (par_gas, par_w))     # (the arrays referenced: their ids stay theirs)
         return ent.h
 
+    def refresh_columns(self):
+        """Integrate the Curtis-Godson columns of every resident form of the batch again, on the device, from the staged
+        sample points (sr_los_refresh_columns: launches only)."""
+        for h in self._handles.values():
+            check(lib.sr_los_refresh_columns(getattr(h, "h", h), _stream_ptr()), "sr_los_refresh_columns")
+
     def set_vmr(self, vmr):
         """New VMRs [n_gas, n_pt] at the sample points (the next iteration of a retrieval): the host copy and every
         resident form of the batch (sr_los_set_vmr: one small copy + the column kernel; nothing else is re-staged)."""

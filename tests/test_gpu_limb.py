@@ -445,6 +445,8 @@ def test_resident_los_equals_per_call_staging(eng):
                 got = [eng.limb_rays(two, los, grid=g, g_lo=g_lo) for _ in range(2)]     # made resident, then reused
                 assert torch.equal(got[0], ref) and torch.equal(got[1], ref), (len(zt), opts, g_lo)
             assert len(los._handles) == 1
+            los.refresh_columns()                     # the columns integrated again on the device: the same bits
+            assert torch.equal(eng.limb_rays(two, los, grid=g, g_lo=5000), ref)
         r0 = t(rng.uniform(1e-9, 1e-8, (len(zt), n)))
         los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"])
         assert torch.equal(eng.limb_rays(two, los, rad0=r0.clone()), eng.limb_rays(two, los, rad0=r0.clone(), resident=False))

@@ -968,6 +968,30 @@ def test_per_line_dropin_route(eng, golden):
 
 
 @pytest.mark.gpu
+def test_timing_events_can_be_switched_off(eng):
+    """sr_set_timing(0): the coefficient op records no timing events (host-bound loops); same results, and
+    last_kernel_ms then refuses instead of returning stale times."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2980.0, 5e-4, 20000)
+    L = syn.make_lines(3000, grid, seed=8, n_levels=12)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    atm = syn.make_atmosphere(6, 12)
+    a1, e1 = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
+    assert len(ls.last_kernel_ms()) == 5
+    try:
+        eng.set_timing(0)
+        a0, e0 = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
+        with pytest.raises(RuntimeError):
+            ls.last_kernel_ms()
+    finally:
+        eng.set_timing(1)
+    assert torch.equal(a0, a1) and torch.equal(e0, e1)
+    ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
+    assert ls.last_kernel_ms()[0] > 0.0
+
+
+@pytest.mark.gpu
 def test_schedules_agree_over_changing_shapes(eng):
     """The three schedules of the coefficient op (sr_set_overlap: 1 the decoupled, phased pipeline on internal streams and
     parity scratch, 2 round 3's order, 0 serial) over changing inputs, shard bounds, layer counts and weight modes --

@@ -173,6 +173,18 @@ def test_bench_launches_its_own_ranks(tmp_path, capfd):
     assert time.time() - t0 < 30.0
 
 
+def test_hardware_queues_default_is_set_before_hip_and_respects_the_caller():
+    """The coefficient op runs on six HIP streams; the package asks ROCm for eight hardware queues (GPU_MAX_HW_QUEUES) at
+    import -- the runtime reads it at its first HIP call -- unless the caller has set the variable (spectrobot_amd/__init__.py)."""
+    code = "import os, sys; sys.path.insert(0, %r); import spectrobot_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0 and out.stdout.decode().strip() == "8", out.stderr.decode()[-500:]
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="4"), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0 and out.stdout.decode().strip() == "4"
+
+
 def test_async_gather_branch_bookkeeping(monkeypatch):
     """The asynchronous branch of all_gather_spectrum (taken for the RCCL backend only) with the collective
     replaced by a recorder: every Work handle is waited on exactly once -- on eviction (at most 4 in flight) or

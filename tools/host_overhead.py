@@ -26,11 +26,12 @@ def step(t):
     t[0] += t1 - t0; t[1] += t2 - t1
 def one_call(t):
     t0 = time.perf_counter()
+    los.refresh_columns()      # (bench.py's step: the column integration stays in it, two launches)
     ls.limb_step(atm["temps"], atm["press"], los, tvib=atm["tvib"], q_part=q, g_lo=g_lo, g_hi=g_hi, out=(ab, em))
     t[0] += time.perf_counter() - t0
 n = 300
 for name, fn, res, timing in (("two calls, LOS staged per call (round 4)", step, False, 1), ("two calls, resident LOS", step, True, 1),
-                              ("one call (sr_limb_step_dev)", one_call, True, 1), ("one call, no timing events", one_call, True, 0)):
+                              ("columns + one call (bench.py's step)", one_call, True, 1), ("columns + one call, no timing events", one_call, True, 0)):
     RES = res
     engine.set_timing(timing)
     for _ in range(20): fn([0, 0])
