@@ -1837,13 +1837,14 @@ int sr_limb_rays_jac_los_dev(const double *abs_c, const double *emi_c, int n_lay
 int sr_limb_rays_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
                          double *rad, void *stream) {
   if (!abs_c || !emi_c || !rad || !h || n_layers != h->n_layers || n_pts <= 0) return SR_ERR_ARG;
+  if (h->n_par != 0) return SR_ERR_ARG; // a batch made with parameters keeps no packed radiance records: sr_limb_rays_jac_los_dev
   if (n_pts > 2000000) return SR_ERR_LIMIT;
   return limb_rays_los(abs_c, emi_c, n_layers, n_pts, h, g_lo, rad, static_cast<hipStream_t>(stream));
 }
 
 int sr_limb_step_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *abs_out, double *emi_out,
                      sr_los *h, double *rad, void *stream) {
-  if (!h || !rad || !atm || h->opt.n_gas != 1 || atm->n_layers != h->n_layers) return SR_ERR_ARG;
+  if (!h || !rad || !atm || h->opt.n_gas != 1 || h->n_par != 0 || atm->n_layers != h->n_layers) return SR_ERR_ARG;
   const int rc = coef_op(ls, atm, g_lo, g_hi, abs_out, emi_out, stream, WeightMode{kWeightFolded, 0});
   if (rc) return rc;
   return limb_rays_los(abs_out, emi_out, atm->n_layers, g_hi - g_lo, h, g_lo, rad, static_cast<hipStream_t>(stream));

@@ -480,8 +480,8 @@ class LimbLOS(object):
     def handle(self, n_layers, grid=None, rad0=False):
         """The batch resident on the device (sr_los_create): staged, its columns integrated and the folded sweep's
         records packed once per (n_layers, grid, rad0); limb_rays and LineSet.limb_step then only launch.  The
-        object IS the geometry it was built from: its arrays were copied at construction, build a new LimbLOS for
-        other VMRs or paths."""
+        object IS the geometry it was built from: its arrays were copied at construction.  New VMRs go through
+        set_vmr() (which updates the resident forms); other paths need a new LimbLOS."""
         gp = None if (grid is None or self.initial_temperature is None or rad0) else grid_params(grid)[:2]
         key = (int(n_layers), gp, bool(rad0))
         h = self._handles.get(key)
