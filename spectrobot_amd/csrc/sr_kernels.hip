@@ -3354,6 +3354,115 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   rad[(size_t)ray * n_pts + j] = Iobs + Iobs_lo;
 }
 
+// The same Jacobians in ONE sweep (round 5): forward sensitivities in fold order.  The far side carries dI_f / dx_p through
+// the recursion (dI_f' = dI_f t + (w_tau a_g + w_E e_g) dc_far,p); the near side is visited from the observer inwards, so
+// the transmission T_n between a segment and the observer is known when the segment is reached, and its logarithmic
+// derivative D_p = sum a_g dc_near,p over the segments already passed is carried beside it:
+//   d cs_p += T_n (f e_g + E f' a_g) dc_near,p - E f T_n D_p,   D_p += a_g dc_near,p,
+//   d I_obs / d x_p = T_n (dI_f,p - I_f D_p) + d cs_p           (I_obs = I_f T_n + cs).
+// No second sweep (the two-sweep kernel above spent 10 023 VALU instructions per wave on configs[4]: one attenuation() per
+// shell and sweep more, the exponential of the remaining optical depth, four error-free sums), three accumulators per
+// parameter instead of one, and no difference of nearly equal sums anywhere: every term is a product of the quantities
+// the radiance itself is made of.  A parameter's gas is wave-uniform: the choice between the gases' weights is a scalar
+// branch (the asm statements keep the compiler from turning it into per-lane selects, two v_cndmask per double).
+#ifndef SR_FOLD_ONE_SWEEP
+#define SR_FOLD_ONE_SWEEP 1
+#endif
+template <int NG>
+__global__ __launch_bounds__(256) void sr_limb_fold_sens_kernel(
+    const double *__restrict__ abs_c, const double *__restrict__ emi_c, int n_pts, int n_layers,
+    const FoldDense *__restrict__ rec, // [n_rays][n_visits]
+    int n_par, ParGas pg, LimbOpts o, int n_visits, int n_rays, double *__restrict__ rad, double *__restrict__ jac_par) {
+  int pb, ray; // all rays of a point block on one XCD, one after the other
+  if (!limb_block((n_pts + 255) / 256, n_rays, pb, ray)) return;
+  const int j = pb * 256 + threadIdx.x;
+  if (j >= n_pts) return;
+  const FoldDense *rc = rec + (size_t)ray * n_visits;
+  const size_t gstride = (size_t)n_layers * n_pts;
+  double If = limb_initial(o, rad, (size_t)ray * n_pts + j, j), Tn = 1.0, cs = 0.0;
+  double dIf[kFoldDensePar], dcs[kFoldDensePar], Dn[kFoldDensePar];
+  int gmask = 0;
+#pragma unroll
+  for (int p = 0; p < kFoldDensePar; ++p) {
+    dIf[p] = dcs[p] = Dn[p] = 0.0;
+    gmask |= (pg.g[p] & 3) << (2 * p);
+  }
+  for (int v = 0; v < n_visits; ++v) {
+    const FoldDense &R = rc[v];
+    if (!R.has) continue;
+    const size_t ofs = (size_t)R.layer * n_pts + j;
+    double a[NG], e[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      a[g] = abs_c[g * gstride + ofs];
+      e[g] = emi_c[g * gstride + ofs];
+    }
+    // one pass for a shell whose two segments have the same columns (has & 4: every shell of a 1-D limb path) or one
+    // segment; otherwise the far segment, then the near one
+    const int n_pass = (R.has & 7) == 3 ? 2 : 1;
+    for (int k = 0; k < n_pass; ++k) {
+      const bool far = (R.has & 1) && k == 0, near = (R.has & 2) && (k == 1 || n_pass == 1);
+      const double *u = far ? R.u_f : R.u_n;
+      double cf[kFoldDensePar], cn[kFoldDensePar]; // (wave-uniform: scalar loads, issued together here)
+#pragma unroll
+      for (int p = 0; p < kFoldDensePar; ++p) {
+        cf[p] = far ? R.dc_f[p] : 0.0;
+        cn[p] = near ? R.dc_n[p] : 0.0;
+      }
+      double tau = a[0] * u[0], E = e[0] * u[0];
+#pragma unroll
+      for (int g = 1; g < NG; ++g) {
+        tau = tau + a[g] * u[g];
+        E = E + e[g] * u[g];
+      }
+      if (o.solo_absorption) E = 0.0;
+      const Atten A = attenuation(tau);
+      const double fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
+      const double Ef = E * A.f, we = o.solo_absorption ? 0.0 : A.f;
+      double t_f = 1.0, nEfTn = 0.0, bf[NG], wn[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) bf[g] = wn[g] = 0.0;
+      if (far) {
+        const double wt = fma(E, fp, -If * A.t);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) bf[g] = fma(wt, a[g], we * e[g]);
+        If = If * A.t + Ef;
+        t_f = A.t;
+      }
+      if (near) {
+        const double wtn = (E * Tn) * fp, wen = we * Tn;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) wn[g] = fma(wtn, a[g], wen * e[g]);
+        cs = fma(E * Tn, A.f, cs); // (sr_limb_fold_fwd_kernel's operations: the two kernels' radiances are the same doubles)
+        nEfTn = -(Ef * Tn);
+        Tn *= A.t;
+      }
+      // (the parameters' gases as a bit field, made opaque per pass: hoisted out of the loop as 16 compare results they
+      // cost 32 SGPRs and spill.  Gas by gas, so that every (gas, parameter) step is its own block behind a scalar
+      // branch: one chain over the gases per parameter was tail-merged into moves of the chosen weights, 3-6 v_mov_b64.)
+      int gm = gmask, np = n_par;
+      asm volatile("" : "+s"(gm), "+s"(np));
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+#pragma unroll
+        for (int p = 0; p < kFoldDensePar; ++p) {
+          if (p < np && (NG == 1 || ((gm >> (2 * p)) & 3) == q)) {
+            asm volatile("");
+            dIf[p] = fma3(dIf[p], t_f, bf[q] * cf[p]);
+            dcs[p] = fma(wn[q], cn[p], dcs[p]);
+            dcs[p] = fma(nEfTn, Dn[p], dcs[p]);
+            Dn[p] = fma(a[q], cn[p], Dn[p]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < kFoldDensePar; ++p)
+    if (p < n_par) jac_par[((size_t)ray * n_par + p) * n_pts + j] = fma(Tn, fma(-If, Dn[p], dIf[p]), dcs[p]);
+  rad[(size_t)ray * n_pts + j] = fma(If, Tn, cs);
+}
+
 // The radiances alone, folded (ray batches; BASELINE configs[2]: 64 rays): one sweep over the shells, a shell's coefficients
 // loaded once for the ray's two segments and -- the path being symmetric -- ONE attenuation() for both:
 // I_obs = I_f(tangent) Tn(all) + sum E f Tn over the near side (sr_limb_adjoint_fold_kernel's sweep 1).
@@ -3443,7 +3552,12 @@ int launch_fold_dense(const int *plan, const double *col, const int *par_gas_hos
   ParGas pg;
   for (int p = 0; p < kFoldDensePar; ++p) pg.g[p] = p < n_par ? par_gas_host[p] : 0;
   const dim3 grid(limb_grid((n_pts + 255) / 256, n_rays));
-#define SR_FD(NG) hipLaunchKernelGGL(sr_limb_fold_dense_kernel<NG>, grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, rec, n_par, pg, \
+#if SR_FOLD_ONE_SWEEP
+#define SR_FD_KERNEL sr_limb_fold_sens_kernel
+#else
+#define SR_FD_KERNEL sr_limb_fold_dense_kernel
+#endif
+#define SR_FD(NG) hipLaunchKernelGGL(SR_FD_KERNEL<NG>, grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, rec, n_par, pg, \
                                      o, n_visits, n_rays, rad, jac_par)
   switch (o.n_gas) { case 1: SR_FD(1); break; case 2: SR_FD(2); break; case 3: SR_FD(3); break; default: SR_FD(4); break; }
 #undef SR_FD
