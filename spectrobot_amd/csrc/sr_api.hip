@@ -2336,20 +2336,42 @@ int sr_hires_to_lowres_shard_dev(const double *rad, int n_rays, int64_t n_pts, i
   hipStream_t st = static_cast<hipStream_t>(stream);
   static thread_local Stager s_bands;
   static thread_local DevBuf d_out;
+  static thread_local DevBuf d_weights; // the bands' weight table [n_bands][n_pts] + point ranges, then the partial sums
+  // The table depends on the grid window and the bands alone: kept while they (and the buffer) stay the same -- the
+  // instrument step of a retrieval iteration is then two launches and no upload (the weights kernel was 19 us of it)
+  struct WeightKey {
+    int64_t n_pts = -1, g_lo = 0;
+    double w0 = 0, step = 0, n_sigma = 0;
+    void *buf = nullptr;
+    std::vector<double> bands;
+  };
+  static thread_local WeightKey s_key;
   const size_t nb = (size_t)n_bands;
-  int rc = s_bands.prepare(sizeof(double) * 2 * nb);
+  int rc = d_out.ensure(sizeof(double) * nb * n_rays);
   if (rc) return rc;
-  std::memcpy(s_bands.host<double>(), centers_nm, sizeof(double) * nb);
-  std::memcpy(s_bands.host<double>() + nb, widths_nm, sizeof(double) * nb);
-  rc = s_bands.push(sizeof(double) * 2 * nb, st);
-  if (rc) return rc;
-  rc = d_out.ensure(sizeof(double) * nb * n_rays);
-  if (rc) return rc;
-  static thread_local DevBuf d_weights; // the bands' weight table [n_bands][n_pts] + point ranges, rebuilt by every call
   rc = d_weights.ensure(lowres_scratch_bytes((int)n_pts, n_bands, n_rays));
   if (rc) return rc;
+  const bool same = s_key.buf == d_weights.p && s_key.n_pts == n_pts && s_key.g_lo == g_lo && s_key.w0 == w0 && s_key.step == step &&
+                    s_key.n_sigma == n_sigma && s_key.bands.size() == 2 * nb &&
+                    std::memcmp(s_key.bands.data(), centers_nm, sizeof(double) * nb) == 0 &&
+                    std::memcmp(s_key.bands.data() + nb, widths_nm, sizeof(double) * nb) == 0;
+  if (!same) {
+    s_key.buf = nullptr; // (until the launch below has been issued)
+    rc = s_bands.prepare(sizeof(double) * 2 * nb);
+    if (rc) return rc;
+    std::memcpy(s_bands.host<double>(), centers_nm, sizeof(double) * nb);
+    std::memcpy(s_bands.host<double>() + nb, widths_nm, sizeof(double) * nb);
+    rc = s_bands.push(sizeof(double) * 2 * nb, st);
+    if (rc) return rc;
+  }
   LAUNCHCHK(launch_lowres(rad, (int)n_pts, (int)g_lo, n_rays, w0, step, s_bands.d.as<double>(), s_bands.d.as<double>() + nb,
-                          n_bands, n_sigma, out_units, d_out.as<double>(), d_weights.p, st));
+                          n_bands, n_sigma, out_units, d_out.as<double>(), d_weights.p, st, !same));
+  if (!same) {
+    s_key.n_pts = n_pts; s_key.g_lo = g_lo; s_key.w0 = w0; s_key.step = step; s_key.n_sigma = n_sigma;
+    s_key.bands.assign(centers_nm, centers_nm + nb);
+    s_key.bands.insert(s_key.bands.end(), widths_nm, widths_nm + nb);
+    s_key.buf = d_weights.p; // (this call synchronises its stream below: the table is complete before any later call)
+  }
   HIPCHK(hipMemcpyAsync(out_host, d_out.p, sizeof(double) * nb * n_rays, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return SR_OK;

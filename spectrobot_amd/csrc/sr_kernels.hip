@@ -3463,6 +3463,178 @@ __global__ __launch_bounds__(256) void sr_limb_fold_sens_kernel(
   rad[(size_t)ray * n_pts + j] = fma(If, Tn, cs);
 }
 
+// attenuation() with the polynomial's coefficients in SGPRs (the same operations, bit for bit): for a kernel whose
+// registers are its accumulators (20 VGPRs of constants otherwise)
+__device__ inline Atten attenuation_sc(double tau) {
+  const double x = -tau;
+  const double n = rint(x * 0x1.71547652b82fep+0);
+  double r = fma(-n, 0x1.62e42fefa39efp-1, x);
+  r = fma(-n, 0x1.abc9e3b39803fp-56, r);
+  double p = fma3vs(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+  p = fma3s(r, p, 0x1.71dee623fde64p-19);
+  p = fma3s(r, p, 0x1.a01997c89e6b0p-16);
+  p = fma3s(r, p, 0x1.a01a014761f6ep-13);
+  p = fma3s(r, p, 0x1.6c16c1852b7b0p-10);
+  p = fma3s(r, p, 0x1.1111111122322p-7);
+  p = fma3s(r, p, 0x1.55555555502a1p-5);
+  p = fma3s(r, p, 0x1.5555555555511p-3);
+  p = fma3s(r, p, 0x1.000000000000bp-1);
+  const double pm1 = r * fma(r, p, 1.0);
+  const double s = ldexp(1.0, (int)fmin(fmax(n, -1100.0), 1100.0));
+  Atten A;
+  A.t = fma(s, pm1, s);
+  A.em1 = fma(-s, pm1, 1.0 - s);
+  A.thin = !(fabs(tau) > 1e-12);
+  A.rtau = fast_rcp<2>(tau);
+  A.f = A.thin ? 1.0 : A.em1 * A.rtau;
+  return A;
+}
+
+// The one-sweep kernel with the ray's records in LDS.  With the records read by scalar loads (sr_limb_fold_sens_kernel)
+// a wave waits for its 208-byte record (the scalar cache holds 16 KB, the rays resident on a CU stream 50 KB through
+// it), THEN for the coefficients whose address the record gives, then computes: 46 % issue-busy at four waves per SIMD.
+// Here a block copies its ray's records to LDS in chunks of kSensChunk shells; headers are read one shell ahead, so
+// the next shell's coefficients are in flight during this shell's arithmetic, and the column derivatives arrive
+// as LDS broadcasts under the attenuation.
+constexpr int kSensChunk = 64;
+constexpr int kSensRecD = 26; // doubles per FoldDense
+static_assert(sizeof(FoldDense) == kSensRecD * 8, "FoldDense in doubles");
+template <int NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG <= 2 ? 4 : 3, NG <= 2 ? 4 : 3))) void sr_limb_fold_sens_lds_kernel(
+    const double *__restrict__ abs_c, const double *__restrict__ emi_c, int n_pts, int n_layers,
+    const FoldDense *__restrict__ rec, // [n_rays][n_visits]
+    int n_par, ParGas pg, LimbOpts o, int n_visits, int n_rays, double *__restrict__ rad, double *__restrict__ jac_par) {
+  __shared__ double lrec[kSensChunk * kSensRecD + kFoldDensePar]; // + a row of zeros
+  int pb, ray; // all rays of a point block on one XCD, one after the other
+  if (!limb_block((n_pts + 255) / 256, n_rays, pb, ray)) return; // (block-uniform)
+  const int j0 = pb * 256 + threadIdx.x;
+  const bool live = j0 < n_pts;
+  const int j = live ? j0 : n_pts - 1; // (the block's barriers need every thread)
+  const double *src = reinterpret_cast<const double *>(rec + (size_t)ray * n_visits);
+  const size_t gstride = (size_t)n_layers * n_pts;
+  double If = limb_initial(o, rad, (size_t)ray * n_pts + j, j), Tn = 1.0, cs = 0.0;
+  double dIf[kFoldDensePar], dcs[kFoldDensePar], Dn[kFoldDensePar];
+  int gmask = 0;
+#pragma unroll
+  for (int p = 0; p < kFoldDensePar; ++p) {
+    dIf[p] = dcs[p] = Dn[p] = 0.0;
+    gmask |= (pg.g[p] & 3) << (2 * p);
+  }
+  const bool solo = o.solo_absorption != 0;
+  for (int v0 = 0; v0 < n_visits; v0 += kSensChunk) {
+    const int nv = min(kSensChunk, n_visits - v0);
+    __syncthreads(); // (the previous chunk has been consumed)
+    for (int i = threadIdx.x; i < nv * kSensRecD; i += 256) lrec[i] = src[(size_t)v0 * kSensRecD + i];
+    if (threadIdx.x < kFoldDensePar) lrec[kSensChunk * kSensRecD + threadIdx.x] = 0.0;
+    __syncthreads();
+    double an[NG], en[NG];
+    int has_n;
+    auto fetch = [&](int v) { // header of shell v of the chunk; its coefficients requested
+      has_n = 0;
+      if (v < nv) {
+        const int2 hd = *reinterpret_cast<const int2 *>(lrec + v * kSensRecD);
+        has_n = __builtin_amdgcn_readfirstlane(hd.y);
+        const int layer = __builtin_amdgcn_readfirstlane(hd.x);
+        if (has_n) {
+          const size_t ofs = (size_t)layer * n_pts + j;
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            an[g] = abs_c[g * gstride + ofs];
+            en[g] = emi_c[g * gstride + ofs];
+          }
+        }
+      }
+    };
+    fetch(0);
+    for (int v = 0; v < nv; ++v) {
+      const int has = has_n;
+      double a[NG], e[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        a[g] = an[g];
+        e[g] = en[g];
+      }
+      fetch(v + 1);
+      if (!has) continue;
+      const double *lr = lrec + v * kSensRecD;
+      // one pass for a shell whose two segments have the same columns (has & 4: every shell of a 1-D limb path) or one
+      // segment; otherwise the far segment, then the near one
+      const int n_pass = (has & 7) == 3 ? 2 : 1;
+      for (int k = 0; k < n_pass; ++k) {
+        const bool far = (has & 1) && k == 0, near = (has & 2) && (k == 1 || n_pass == 1);
+        const double *u = lr + (far ? 2 : 6);
+        const double *lcf = lr + 10, *lcn = near ? lr + 18 : lrec + kSensChunk * kSensRecD; // (no near segment: zeros)
+        // (LDS broadcasts: the first half of the parameters in flight under the attenuation, the second half under the
+        // first half's steps -- all sixteen doubles at the top were 140 VGPRs, three waves per SIMD)
+        constexpr int kH = kFoldDensePar / 2;
+        double cf[kFoldDensePar], cn[kFoldDensePar];
+#pragma unroll
+        for (int p = 0; p < kH; ++p) {
+          cf[p] = lcf[p];
+          cn[p] = lcn[p];
+        }
+        double tau = a[0] * u[0], E = e[0] * u[0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+          tau = tau + a[g] * u[g];
+          E = E + e[g] * u[g];
+        }
+        if (solo) E = 0.0;
+        const Atten A = attenuation_sc(tau);
+        const double fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
+        const double Ef = E * A.f, we = solo ? 0.0 : A.f;
+        double t_f = 1.0, nEfTn = 0.0, bf[NG], wn[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) bf[g] = wn[g] = 0.0;
+        if (far) {
+          const double wt = fma(E, fp, -If * A.t);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) bf[g] = fma(wt, a[g], we * e[g]);
+          If = If * A.t + Ef;
+          t_f = A.t;
+        }
+        if (near) {
+          const double wtn = (E * Tn) * fp, wen = we * Tn;
+#pragma unroll
+          for (int g = 0; g < NG; ++g) wn[g] = fma(wtn, a[g], wen * e[g]);
+          cs = fma(E * Tn, A.f, cs); // (sr_limb_fold_fwd_kernel's operations: the two kernels' radiances are the same doubles)
+          nEfTn = -(Ef * Tn);
+          Tn *= A.t;
+        }
+        // (see sr_limb_fold_sens_kernel)
+        int gm = gmask, np = n_par;
+        asm volatile("" : "+s"(gm), "+s"(np) : : "memory");
+#pragma unroll
+        for (int p = kH; p < kFoldDensePar; ++p) {
+          cf[p] = lcf[p];
+          cn[p] = lcn[p];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int q = 0; q < NG; ++q) {
+#pragma unroll
+            for (int p = h * kH; p < (h + 1) * kH; ++p) {
+              if (p < np && (NG == 1 || ((gm >> (2 * p)) & 3) == q)) {
+                asm volatile("");
+                dIf[p] = fma3(dIf[p], t_f, bf[q] * cf[p]);
+                dcs[p] = fma(wn[q], cn[p], dcs[p]);
+                dcs[p] = fma(nEfTn, Dn[p], dcs[p]);
+                Dn[p] = fma(a[q], cn[p], Dn[p]);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int p = 0; p < kFoldDensePar; ++p)
+    if (p < n_par) jac_par[((size_t)ray * n_par + p) * n_pts + j] = fma(Tn, fma(-If, Dn[p], dIf[p]), dcs[p]);
+  rad[(size_t)ray * n_pts + j] = fma(If, Tn, cs);
+}
+
 // The radiances alone, folded (ray batches; BASELINE configs[2]: 64 rays): one sweep over the shells, a shell's coefficients
 // loaded once for the ray's two segments and -- the path being symmetric -- ONE attenuation() for both:
 // I_obs = I_f(tangent) Tn(all) + sum E f Tn over the near side (sr_limb_adjoint_fold_kernel's sweep 1).
@@ -3552,7 +3724,12 @@ int launch_fold_dense(const int *plan, const double *col, const int *par_gas_hos
   ParGas pg;
   for (int p = 0; p < kFoldDensePar; ++p) pg.g[p] = p < n_par ? par_gas_host[p] : 0;
   const dim3 grid(limb_grid((n_pts + 255) / 256, n_rays));
-#if SR_FOLD_ONE_SWEEP
+#ifndef SR_FOLD_SENS_LDS
+#define SR_FOLD_SENS_LDS 1
+#endif
+#if SR_FOLD_ONE_SWEEP && SR_FOLD_SENS_LDS
+#define SR_FD_KERNEL sr_limb_fold_sens_lds_kernel
+#elif SR_FOLD_ONE_SWEEP
 #define SR_FD_KERNEL sr_limb_fold_sens_kernel
 #else
 #define SR_FD_KERNEL sr_limb_fold_dense_kernel
@@ -4189,18 +4366,20 @@ __global__ void sr_lowres_sum_kernel(const double *__restrict__ part, int n_rays
 static int lowres_chunks(int n_pts) { return (n_pts + kLowresChunk - 1) / kLowresChunk; }
 size_t lowres_scratch_bytes(int n_pts, int n_bands, int n_rays) {
   return sizeof(double) * (size_t)n_bands * n_pts + sizeof(double) * (size_t)n_rays * lowres_chunks(n_pts) * n_bands +
-         sizeof(int) * 2 * (size_t)n_bands;
+         sizeof(int) * (2 * (size_t)n_bands + 2);
 }
 
 int launch_lowres(const double *rad, int n_pts, int g_lo, int n_rays, double w0, double gstep, const double *cen,
-                  const double *wid, int n_bands, double n_sigma, int out_units, double *out, void *scratch, hipStream_t st) {
+                  const double *wid, int n_bands, double n_sigma, int out_units, double *out, void *scratch, hipStream_t st,
+                  bool weights) {
   if (n_bands <= 0 || n_rays <= 0) return 0;
   const int n_chunks = lowres_chunks(n_pts);
   double *W = static_cast<double *>(scratch);
-  double *part = W + (size_t)n_bands * n_pts;
-  int *range = reinterpret_cast<int *>(part + (size_t)n_rays * n_chunks * n_bands);
-  hipLaunchKernelGGL(sr_lowres_weights_kernel, dim3((n_pts + 255) / 256, n_bands), dim3(256), 0, st, n_pts, g_lo, w0, gstep, cen, wid,
-                     n_sigma, W, range);
+  int *range = reinterpret_cast<int *>(W + (size_t)n_bands * n_pts); // (before the partial sums: their size follows n_rays)
+  double *part = reinterpret_cast<double *>(range + 2 * (size_t)n_bands + 2);
+  if (weights)
+    hipLaunchKernelGGL(sr_lowres_weights_kernel, dim3((n_pts + 255) / 256, n_bands), dim3(256), 0, st, n_pts, g_lo, w0, gstep, cen,
+                       wid, n_sigma, W, range);
   hipLaunchKernelGGL(sr_lowres_apply_kernel, dim3(n_rays, n_chunks, (n_bands + kLowresBands - 1) / kLowresBands), dim3(256), 0, st,
                      rad, n_pts, W, range, n_bands, n_chunks, part);
   hipLaunchKernelGGL(sr_lowres_sum_kernel, dim3((n_rays * n_bands + 255) / 256), dim3(256), 0, st, part, n_rays, n_chunks, n_bands,

@@ -225,10 +225,13 @@ int launch_humliv(const double *x, int i1, int i2, double x0, double lw, double 
                   hipStream_t st);
 int launch_sum_lines(double *spe, long n_spe, const double *rows, const int *init, const int *fin,
                      int n_lines, int row_len, hipStream_t st);
-// scratch: lowres_scratch_bytes(...) of device memory (the bands' weight table, the chunks' partial sums, point ranges)
+// scratch: lowres_scratch_bytes(...) of device memory (the bands' weight table and point ranges, then the chunks' partial
+// sums).  weights = false: the table and ranges at the head of `scratch` are those of an earlier call with the same
+// grid window and bands (a retrieval's instrument step: every iteration the same bands)
 size_t lowres_scratch_bytes(int n_pts, int n_bands, int n_rays);
 int launch_lowres(const double *rad, int n_pts, int g_lo, int n_rays, double w0, double gstep, const double *cen,
-                  const double *wid, int n_bands, double n_sigma, int out_units, double *out, void *scratch, hipStream_t st);
+                  const double *wid, int n_bands, double n_sigma, int out_units, double *out, void *scratch, hipStream_t st,
+                  bool weights = true);
 int launch_lut(int combine, const double *tab, int n_pt, int n_pts, int n_steps, const int *idx, const double *wgt,
                const double *pop, double *out_a, double *out_e, hipStream_t st);
 // Level-factored combine (sr_glevel_combine_dev): rows_used [n_used] table rows that have steps, row_off [n_used + 1]

@@ -199,11 +199,17 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
         sp.spectrum, sp.spectral_grid = v, grid_lo
         return sp
 
+    # pixels with a field of view and one rotation (the usual case): the closed form for all of them in one pass -- the same
+    # elementwise operations on [n_pix, 1 + n_par, n_bands] stacks (it was 45 us of a 640 us configs[4] iteration)
+    fov_all = None
+    if fov_closed_form and pixels and all(pix.fov_half > 0 and pix.pixel_rot == pixels[0].pixel_rot for pix in pixels):
+        fov_all = smm.fov_closed_form(both[0::3], both[1::3], both[2::3], pixels[0].pixel_rot)
     for i, pix in enumerate(pixels):
         if pix.fov_half > 0 and fov_closed_form:
             # the closed form is linear in the three spectra: the pixel's radiances and all its derivatives at once
             # (FOV_integr_1D per spectrum, 8 per pixel, was a third of a configs[4] iteration's host time)
-            fov = smm.fov_closed_form(both[3 * i], both[3 * i + 1], both[3 * i + 2], pix.pixel_rot)   # [1 + n_par, n_bands]
+            fov = fov_all[i] if fov_all is not None else \
+                smm.fov_closed_form(both[3 * i], both[3 * i + 1], both[3 * i + 2], pix.pixel_rot)   # [1 + n_par, n_bands]
             sims.append(spectrum_of(np.array(fov[0])))
             if dlow is not None:
                 derivs.append([spectrum_of(np.array(fov[1 + p])) for p in range(dlow.shape[1])])
