@@ -152,7 +152,7 @@ def shard_with_halo(n_grid, g_lo, g_hi):
     return int(g_lo), int(min(g_hi + 1, n_grid))
 
 
-def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, refresh=False):
+def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, refresh=False, arrays=False):
     """One forward-model pass for all pixels (the body of the reference's iteration,
     spect_main_module.py:2736-2940): returns (sims, derivs) with sims[i] the FOV-integrated low-resolution
     spectrum of pixel i (Spectrum) and derivs[i][p] its derivative w.r.t. parameter p of bayes_set.
@@ -162,7 +162,11 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
     put together before the instrument step).  The rank computes radiances and Jacobians on its shard only and its
     PARTIAL instrument-band integrals; one all-reduce (sum) of [n_los x (1 + n_par) x n_bands] doubles over the
     ranks completes them (distributed.all_reduce_sum; a no-op without a process group), then every rank holds the
-    same low-resolution spectra and runs the same n_par x n_par algebra."""
+    same low-resolution spectra and runs the same n_par x n_par algebra.
+
+    arrays=True (every pixel with a field of view and the closed form -- or none with a field of view): returns
+    (low [n_pix, n_bands], dlow [n_pix, n_par, n_bands]) instead of the spectrum objects (the retrieval loop: the
+    objects of an iteration were ~0.1 ms of its 0.65)."""
     from . import distributed as sd
     alts = [a for pix in pixels for a in pix.los_alts()]
     los, alt = scene.los(alts)
@@ -199,11 +203,17 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
         sp.spectrum, sp.spectral_grid = v, grid_lo
         return sp
 
-    # pixels with a field of view and one rotation (the usual case): the closed form for all of them in one pass -- the same
-    # elementwise operations on [n_pix, 1 + n_par, n_bands] stacks (it was 45 us of a 640 us configs[4] iteration)
+    # pixels with a field of view: the closed form for all of them in one pass -- the same elementwise operations on
+    # [n_pix, 1 + n_par, n_bands] stacks, a rotation per pixel (it was 45 us of a 640 us configs[4] iteration)
     fov_all = None
-    if fov_closed_form and pixels and all(pix.fov_half > 0 and pix.pixel_rot == pixels[0].pixel_rot for pix in pixels):
-        fov_all = smm.fov_closed_form(both[0::3], both[1::3], both[2::3], pixels[0].pixel_rot)
+    if fov_closed_form and pixels and all(pix.fov_half > 0 for pix in pixels):
+        fov_all = smm.fov_closed_form(both[0::3], both[1::3], both[2::3], [pix.pixel_rot for pix in pixels])
+    if arrays:
+        if fov_all is None:
+            if any(pix.fov_half > 0 for pix in pixels):
+                raise ValueError("simulate(arrays=True) needs the closed-form field of view for every pixel, or for none")
+            fov_all = both[1::3]
+        return fov_all[:, 0, :], fov_all[:, 1:, :]
     for i, pix in enumerate(pixels):
         if pix.fov_half > 0 and fov_closed_form:
             # the closed form is linear in the three spectra: the pixel's radiances and all its derivatives at once
@@ -243,27 +253,64 @@ def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10,
     noise = [pix.noise for pix in pixels]
     bayes_set.history, bayes_set.stop = [], 'max_it'
     chi_old, chi, sims = None, None, []
+    # The loop on arrays: when every pixel has the closed-form field of view (or none has one) an
+    # iteration's spectra stay [n_pix, (n_par,) n_bands] arrays -- the same numbers in the same operations as the
+    # object path (genvec / build_jacobian concatenate and mask exactly these rows) -- and become spectrum objects
+    # once, when the loop ends; otherwise the objects of the reference's loop, iteration by iteration.
+    with_fov = sum(pix.fov_half > 0 for pix in pixels)
+    fast = not solo_simulation and ((with_fov == len(pixels) and fov_closed_form) or with_fov == 0)
+    if fast:
+        obs_vec, _, noi_vec = smm.genvec(obs, obs, noise, masks=masks)
+        masktot = None if masks is None else np.concatenate([np.asarray(m, dtype=bool) for m in masks])
+        Sa_inv = np.linalg.inv(np.asarray(bayes_set.VCM_apriori(), dtype=float))
+        grid_lo = _Grid(scene.bands_nm)
+
+        def wrap(v):
+            sp = Spectrum.__new__(Spectrum)
+            sp.spectrum, sp.spectral_grid = np.array(v), grid_lo
+            return sp
+
+        def finish(low, dlow):
+            for num in range(len(pixels)):
+                for ip, par in enumerate(bayes_set.params()):
+                    par.store_deriv(wrap(dlow[num, ip]), num=num)              # :2929, 2940 (of the last iteration)
+            return [wrap(v) for v in low]
     for num_it in range(max_it):
-        sims, derivs = simulate(scene, pixels, bayes_set, fov_closed_form=fov_closed_form, shard=shard, refresh=refresh)
-        if solo_simulation:
-            return None
-        for num, row in enumerate(derivs):
-            for par, der in zip(bayes_set.params(), row):
-                par.store_deriv(der, num=num)                                  # :2929, 2940
+        if fast:
+            low, dlow = simulate(scene, pixels, bayes_set, fov_closed_form=fov_closed_form, shard=shard, refresh=refresh, arrays=True)
+            for par in bayes_set.params():
                 par.set_used()
-        chi = smm.chicalc(obs, sims, noise, masks, bayes_set.n_used_par())      # :2949
+            sim_vec = low.reshape(-1) if masktot is None else low.reshape(-1)[masktot]
+            chi = np.sum(((obs_vec - sim_vec) / noi_vec) ** 2) / (len(obs_vec) - bayes_set.n_used_par())   # chicalc, :2949
+        else:
+            sims, derivs = simulate(scene, pixels, bayes_set, fov_closed_form=fov_closed_form, shard=shard, refresh=refresh)
+            if solo_simulation:
+                return None
+            for num, row in enumerate(derivs):
+                for par, der in zip(bayes_set.params(), row):
+                    par.store_deriv(der, num=num)                              # :2929, 2940
+                    par.set_used()
+            chi = smm.chicalc(obs, sims, noise, masks, bayes_set.n_used_par())  # :2949
         bayes_set.history.append(chi)
         if check_log is not None:
             check_log.write('Iteration {:2d}: chi is {:8.3f}\n'.format(num_it, chi))
         why = smm.retrieval_converged(chi, chi_old, chi_threshold)             # :2963-2973
         if why:
             bayes_set.stop = why
-            return chi, obs, sims, bayes_set
+            return chi, obs, (finish(low, dlow) if fast else sims), bayes_set
         chi_old = chi
-        smm.inversion_algebra(obs, sims, noise, bayes_set, lambda_LM=lambda_LM, L1_reg=L1_reg, masks=masks)  # :2977
+        if fast:
+            n_par = dlow.shape[1]
+            jac = np.transpose(dlow, (1, 0, 2)).reshape(n_par, -1)             # build_jacobian's rows
+            jac = (jac if masktot is None else jac[:, masktot]).T
+            bayes_set.jacobian = jac
+            smm.inversion_algebra_arrays(jac, obs_vec, sim_vec, noi_vec, bayes_set, lambda_LM=lambda_LM, L1_reg=L1_reg,
+                                         Sa_inv=Sa_inv)                        # :2977
+        else:
+            smm.inversion_algebra(obs, sims, noise, bayes_set, lambda_LM=lambda_LM, L1_reg=L1_reg, masks=masks)  # :2977
         for name in bayes_set.sets.keys():                                     # :2984-2985
             scene.gas(name).add_clim(bayes_set.sets[name].profile())
-    return chi, obs, sims, bayes_set
+    return chi, obs, (finish(low, dlow) if fast else sims), bayes_set
 
 
 def lut_coefficients(scene, temp_step=5.0, pres_step_log=1.0, refresh=False, **_unused):

@@ -564,13 +564,21 @@ def inversion_algebra(obs, sims, noise, bayes_set, lambda_LM=0.1, L1_reg=False, 
     host side as in the reference; S_y is diagonal, so it is applied as a row scaling instead of
     inverting an n_obs x n_obs matrix."""
     jac = np.asarray(bayes_set.build_jacobian(masks=masks), dtype=float)
-    xi = np.asarray(bayes_set.param_vector(), dtype=float)
     obs_vec, sim_vec, noi_vec = genvec(obs, sims, noise, masks=masks)
-    S_ap = np.asarray(bayes_set.VCM_apriori(), dtype=float)
+    inversion_algebra_arrays(jac, obs_vec, sim_vec, noi_vec, bayes_set, lambda_LM=lambda_LM, L1_reg=L1_reg)
+
+
+def inversion_algebra_arrays(jac, obs_vec, sim_vec, noi_vec, bayes_set, lambda_LM=0.1, L1_reg=False, Sa_inv=None):
+    """inversion_algebra on the vectors themselves (jac [n_obs, n_par] as build_jacobian returns it, the vectors as
+    genvec does): the retrieval loop keeps its spectra as arrays and wraps them into spectrum objects once, at the
+    end (retrieval.inversion_fast_limb).  Sa_inv: the inverse a-priori covariance when the caller kept it (it
+    does not change between iterations)."""
+    xi = np.asarray(bayes_set.param_vector(), dtype=float)
     x_ap = np.asarray(bayes_set.apriori_vector(), dtype=float)
+    if Sa_inv is None:
+        Sa_inv = np.linalg.inv(np.asarray(bayes_set.VCM_apriori(), dtype=float))
     KtSy = jac.T / noi_vec ** 2.0
     G_inv = KtSy @ jac
-    Sa_inv = np.linalg.inv(S_ap)
     S_inv = G_inv + Sa_inv
     LM = np.diag(np.diag(S_inv))
     S_x = np.linalg.inv(S_inv)
@@ -883,6 +891,20 @@ def _clone_spectrum(obj, spectrum=None):
 def fov_closed_form(s0, s1, s2, pixel_rot=0.0):
     """The closed form of FOV_integr_1D on arrays of any (common) shape: the spectra of the three lines of sight -- or
     stacks of them, e.g. a pixel's radiances and all its parameter derivatives at once (the integral is linear in them)."""
+    if np.ndim(pixel_rot) > 0:
+        # one rotation per leading index of the stacks (pixels with different rotations in one pass): the same elementwise
+        # operations with the geometry factors as [n_pix, 1, ...] columns, the edge term where there is an edge
+        rot = np.abs(np.deg2rad(np.asarray(pixel_rot, dtype=float))).reshape((-1,) + (1,) * (np.ndim(s1) - 1))
+        dmax = np.sqrt(2.0) / 2.0 * np.cos(np.pi / 4 - rot)
+        delta = dmax - np.sin(rot)
+        esse = 1.0 / np.cos(rot)
+        c = (s0 + s2 - 2.0 * s1) / (2.0 * dmax ** 2)
+        edge = dmax - delta
+        total = 2.0 * (s1 * delta + c * delta ** 3 / 3.0)
+        has_edge = edge > 1e-14 * dmax
+        m2 = dmax * (dmax ** 3 - delta ** 3) / 3.0 - (dmax ** 4 - delta ** 4) / 4.0
+        with_edge = total + s1 * edge + 2.0 * c * m2 / np.where(has_edge, edge, 1.0)
+        return esse * np.where(has_edge, with_edge, total)
     rot = abs(np.deg2rad(pixel_rot))
     dmax = np.sqrt(2.0) / 2.0 * np.cos(np.pi / 4 - rot)
     delta = dmax - np.sin(rot)
