@@ -2239,7 +2239,7 @@ int sr_limb_rays_jac_dev(const double *abs_c, const double *emi_c, int n_layers,
   int rc = stage_los(los, n_layers, n_par, par_gas, par_w, st, &D);
   if (rc) return rc;
   // Few parameters, 1-D limb / slant / nadir rays: the folded recursion with an accumulator per parameter
-  // (sr_limb_fold_dense_kernel) instead of the forward sensitivities (which repeat the recursion per four parameters)
+  // (sr_limb_fold_sens_lds_kernel) instead of the path-order forward sensitivities (which repeat the recursion per four parameters)
   if (n_par <= kFoldDensePar && g_jac_layer_forward.load() == 0) {
     FoldStage F;
     rc = stage_fold(los, n_layers, st, &F);

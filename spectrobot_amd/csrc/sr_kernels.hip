@@ -3176,11 +3176,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAV
 }
 
 // ------------------------------------------------------------------------
-// The folded recursion for FEW, BROAD column parameters (round 4; the retrieval loop of configs[4]: 7 profile parameters
-// whose masks cover the whole path): the forward-sensitivity kernel carries four derivatives through the recursion and
-// repeats it per block of four; here the recursion runs once (two sweeps over the shells, sr_limb_adjoint_fold_kernel's
-// quantities) and every parameter has an accumulator, acc_p += (w_tau a_g + w_E e_g)(far) dc_far,p + (..)(near) dc_near,p,
-// stored once at the end.  Up to kFoldDensePar parameters.
+// The folded recursion for FEW, BROAD column parameters (the retrieval loop of configs[4]: 7 profile parameters whose
+// masks cover the whole path): the path-order forward-sensitivity kernel carries four derivatives through the recursion
+// and repeats it per block of four, segment by segment; here a shell's coefficients are loaded once for its two
+// segments and every parameter (up to kFoldDensePar) is carried along in ONE sweep: sr_limb_fold_sens_lds_kernel below.
 // ------------------------------------------------------------------------
 struct __attribute__((aligned(16))) FoldDense { // one ray in one shell
   int layer, has, pad0, pad1;                // has: as FoldRec
@@ -3221,247 +3220,18 @@ __global__ void sr_fold_dense_pack_kernel(const int *__restrict__ plan, const do
   out[i] = r;
 }
 
-template <int NG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void sr_limb_fold_dense_kernel(
-    const double *__restrict__ abs_c, const double *__restrict__ emi_c, int n_pts, int n_layers,
-    const FoldDense *__restrict__ rec, // [n_rays][n_visits]
-    int n_par, ParGas pg, LimbOpts o, int n_visits, int n_rays, double *__restrict__ rad, double *__restrict__ jac_par) {
-  int pb, ray; // all rays of a point block on one XCD, one after the other
-  if (!limb_block((n_pts + 255) / 256, n_rays, pb, ray)) return;
-  const int j = pb * 256 + threadIdx.x;
-  if (j >= n_pts) return;
-  const FoldDense *rc = rec + (size_t)ray * n_visits;
-  const size_t gstride = (size_t)n_layers * n_pts;
-  auto two_sum_add = [](double &hi, double &lo, double x) {
-    const double sm = hi + x, bb = sm - hi;
-    lo += (hi - (sm - bb)) + (x - bb);
-    hi = sm;
-  };
-  double If = limb_initial(o, rad, (size_t)ray * n_pts + j, j), rem = 0.0, rem_lo = 0.0, Tn = 1.0, cs = 0.0, cs_lo = 0.0;
-  // sweep 1: the observed radiance and the path's optical depth (see sr_limb_adjoint_fold_kernel)
-  for (int v = 0; v < n_visits; ++v) {
-    const FoldDense &R = rc[v];
-    if (!R.has) continue;
-    const size_t ofs = (size_t)R.layer * n_pts + j;
-    double a[NG], e[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      a[g] = abs_c[g * gstride + ofs];
-      e[g] = emi_c[g * gstride + ofs];
-    }
-    Atten A;
-    if (R.has & 1) {
-      double tau = 0.0, E = 0.0;
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        tau = g == 0 ? a[g] * R.u_f[g] : tau + a[g] * R.u_f[g];
-        E = g == 0 ? e[g] * R.u_f[g] : E + e[g] * R.u_f[g];
-      }
-      two_sum_add(rem, rem_lo, tau);
-      A = attenuation(tau);
-      If = If * A.t + (o.solo_absorption ? 0.0 : E * A.f);
-    }
-    if (R.has & 2) {
-      double tau = 0.0, E = 0.0;
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        tau = g == 0 ? a[g] * R.u_n[g] : tau + a[g] * R.u_n[g];
-        E = g == 0 ? e[g] * R.u_n[g] : E + e[g] * R.u_n[g];
-      }
-      two_sum_add(rem, rem_lo, tau);
-      if (!(R.has & 4)) A = attenuation(tau);
-      two_sum_add(cs, cs_lo, (o.solo_absorption ? 0.0 : E * Tn) * A.f);
-      Tn *= A.t;
-    }
-  }
-  const double p_hi = If * Tn, p_lo = fma(If, Tn, -p_hi);
-  double Iobs = cs, Iobs_lo = cs_lo + p_lo;
-  two_sum_add(Iobs, Iobs_lo, p_hi);
-  If = limb_initial(o, rad, (size_t)ray * n_pts + j, j); // (rad is written at the very end)
-  cs = cs_lo = 0.0;
-  Tn = 1.0;
-  double acc[kFoldDensePar];
-#pragma unroll
-  for (int p = 0; p < kFoldDensePar; ++p) acc[p] = 0.0;
-  // sweep 2: the weights, shell by shell
-  for (int v = 0; v < n_visits; ++v) {
-    const FoldDense &R = rc[v];
-    if (!R.has) continue;
-    const size_t ofs = (size_t)R.layer * n_pts + j;
-    double a[NG], e[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      a[g] = abs_c[g * gstride + ofs];
-      e[g] = emi_c[g * gstride + ofs];
-    }
-    Atten A;
-    double fp = 0.0, wt_f = 0.0, we_f = 0.0, wt_n = 0.0, we_n = 0.0;
-    if (R.has & 1) {
-      double tau = 0.0, E = 0.0;
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        tau = g == 0 ? a[g] * R.u_f[g] : tau + a[g] * R.u_f[g];
-        E = g == 0 ? e[g] * R.u_f[g] : E + e[g] * R.u_f[g];
-      }
-      A = attenuation(tau);
-      fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
-      two_sum_add(rem, rem_lo, -tau);
-      const double Ta = exp_bounded(fmin(fmax(-(rem + rem_lo), -700.0), 700.0));
-      wt_f = (o.solo_absorption ? -If * A.t : fma(E, fp, -If * A.t)) * Ta;
-      we_f = o.solo_absorption ? 0.0 : A.f * Ta;
-      If = If * A.t + (o.solo_absorption ? 0.0 : E * A.f);
-    }
-    if (R.has & 2) {
-      double tau = 0.0, E = 0.0;
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        tau = g == 0 ? a[g] * R.u_n[g] : tau + a[g] * R.u_n[g];
-        E = g == 0 ? e[g] * R.u_n[g] : E + e[g] * R.u_n[g];
-      }
-      if (!(R.has & 4)) {
-        A = attenuation(tau);
-        fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
-      }
-      const double ETn = o.solo_absorption ? 0.0 : E * Tn;
-      two_sum_add(cs, cs_lo, ETn * A.f);
-      const double X = (Iobs - cs) + (Iobs_lo - cs_lo); // I_in t Tn (sr_limb_adjoint_fold_kernel)
-      wt_n = fma(ETn, fp, -X);
-      we_n = o.solo_absorption ? 0.0 : A.f * Tn;
-      Tn *= A.t;
-    }
-    double bf[NG], bn[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      bf[g] = fma(wt_f, a[g], we_f * e[g]);
-      bn[g] = fma(wt_n, a[g], we_n * e[g]);
-    }
-#pragma unroll
-    for (int p = 0; p < kFoldDensePar; ++p) {
-      if (p >= n_par) break;
-      const int g = pg.g[p];
-      double vf = bf[0], vn = bn[0];
-#pragma unroll
-      for (int q = 1; q < NG; ++q) {
-        vf = g == q ? bf[q] : vf;
-        vn = g == q ? bn[q] : vn;
-      }
-      acc[p] = fma(vf, R.dc_f[p], fma(vn, R.dc_n[p], acc[p]));
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < kFoldDensePar; ++p)
-    if (p < n_par) jac_par[((size_t)ray * n_par + p) * n_pts + j] = acc[p];
-  rad[(size_t)ray * n_pts + j] = Iobs + Iobs_lo;
-}
-
-// The same Jacobians in ONE sweep (round 5): forward sensitivities in fold order.  The far side carries dI_f / dx_p through
-// the recursion (dI_f' = dI_f t + (w_tau a_g + w_E e_g) dc_far,p); the near side is visited from the observer inwards, so
-// the transmission T_n between a segment and the observer is known when the segment is reached, and its logarithmic
+// ONE sweep (round 5): forward sensitivities in fold order.  The far side carries dI_f / dx_p through the recursion
+// (dI_f' = dI_f t + (w_tau a_g + w_E e_g) dc_far,p); the near side is visited from the observer inwards, so the
+// transmission T_n between a segment and the observer is known when the segment is reached, and its logarithmic
 // derivative D_p = sum a_g dc_near,p over the segments already passed is carried beside it:
 //   d cs_p += T_n (f e_g + E f' a_g) dc_near,p - E f T_n D_p,   D_p += a_g dc_near,p,
 //   d I_obs / d x_p = T_n (dI_f,p - I_f D_p) + d cs_p           (I_obs = I_f T_n + cs).
-// No second sweep (the two-sweep kernel above spent 10 023 VALU instructions per wave on configs[4]: one attenuation() per
-// shell and sweep more, the exponential of the remaining optical depth, four error-free sums), three accumulators per
-// parameter instead of one, and no difference of nearly equal sums anywhere: every term is a product of the quantities
-// the radiance itself is made of.  A parameter's gas is wave-uniform: the choice between the gases' weights is a scalar
-// branch (the asm statements keep the compiler from turning it into per-lane selects, two v_cndmask per double).
-#ifndef SR_FOLD_ONE_SWEEP
-#define SR_FOLD_ONE_SWEEP 1
-#endif
-template <int NG>
-__global__ __launch_bounds__(256) void sr_limb_fold_sens_kernel(
-    const double *__restrict__ abs_c, const double *__restrict__ emi_c, int n_pts, int n_layers,
-    const FoldDense *__restrict__ rec, // [n_rays][n_visits]
-    int n_par, ParGas pg, LimbOpts o, int n_visits, int n_rays, double *__restrict__ rad, double *__restrict__ jac_par) {
-  int pb, ray; // all rays of a point block on one XCD, one after the other
-  if (!limb_block((n_pts + 255) / 256, n_rays, pb, ray)) return;
-  const int j = pb * 256 + threadIdx.x;
-  if (j >= n_pts) return;
-  const FoldDense *rc = rec + (size_t)ray * n_visits;
-  const size_t gstride = (size_t)n_layers * n_pts;
-  double If = limb_initial(o, rad, (size_t)ray * n_pts + j, j), Tn = 1.0, cs = 0.0;
-  double dIf[kFoldDensePar], dcs[kFoldDensePar], Dn[kFoldDensePar];
-  int gmask = 0;
-#pragma unroll
-  for (int p = 0; p < kFoldDensePar; ++p) {
-    dIf[p] = dcs[p] = Dn[p] = 0.0;
-    gmask |= (pg.g[p] & 3) << (2 * p);
-  }
-  for (int v = 0; v < n_visits; ++v) {
-    const FoldDense &R = rc[v];
-    if (!R.has) continue;
-    const size_t ofs = (size_t)R.layer * n_pts + j;
-    double a[NG], e[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      a[g] = abs_c[g * gstride + ofs];
-      e[g] = emi_c[g * gstride + ofs];
-    }
-    // one pass for a shell whose two segments have the same columns (has & 4: every shell of a 1-D limb path) or one
-    // segment; otherwise the far segment, then the near one
-    const int n_pass = (R.has & 7) == 3 ? 2 : 1;
-    for (int k = 0; k < n_pass; ++k) {
-      const bool far = (R.has & 1) && k == 0, near = (R.has & 2) && (k == 1 || n_pass == 1);
-      const double *u = far ? R.u_f : R.u_n;
-      double cf[kFoldDensePar], cn[kFoldDensePar]; // (wave-uniform: scalar loads, issued together here)
-#pragma unroll
-      for (int p = 0; p < kFoldDensePar; ++p) {
-        cf[p] = far ? R.dc_f[p] : 0.0;
-        cn[p] = near ? R.dc_n[p] : 0.0;
-      }
-      double tau = a[0] * u[0], E = e[0] * u[0];
-#pragma unroll
-      for (int g = 1; g < NG; ++g) {
-        tau = tau + a[g] * u[g];
-        E = E + e[g] * u[g];
-      }
-      if (o.solo_absorption) E = 0.0;
-      const Atten A = attenuation(tau);
-      const double fp = A.thin ? -0.5 : (tau * A.t - A.em1) * (A.rtau * A.rtau);
-      const double Ef = E * A.f, we = o.solo_absorption ? 0.0 : A.f;
-      double t_f = 1.0, nEfTn = 0.0, bf[NG], wn[NG];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) bf[g] = wn[g] = 0.0;
-      if (far) {
-        const double wt = fma(E, fp, -If * A.t);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) bf[g] = fma(wt, a[g], we * e[g]);
-        If = If * A.t + Ef;
-        t_f = A.t;
-      }
-      if (near) {
-        const double wtn = (E * Tn) * fp, wen = we * Tn;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) wn[g] = fma(wtn, a[g], wen * e[g]);
-        cs = fma(E * Tn, A.f, cs); // (sr_limb_fold_fwd_kernel's operations: the two kernels' radiances are the same doubles)
-        nEfTn = -(Ef * Tn);
-        Tn *= A.t;
-      }
-      // (the parameters' gases as a bit field, made opaque per pass: hoisted out of the loop as 16 compare results they
-      // cost 32 SGPRs and spill.  Gas by gas, so that every (gas, parameter) step is its own block behind a scalar
-      // branch: one chain over the gases per parameter was tail-merged into moves of the chosen weights, 3-6 v_mov_b64.)
-      int gm = gmask, np = n_par;
-      asm volatile("" : "+s"(gm), "+s"(np));
-#pragma unroll
-      for (int q = 0; q < NG; ++q) {
-#pragma unroll
-        for (int p = 0; p < kFoldDensePar; ++p) {
-          if (p < np && (NG == 1 || ((gm >> (2 * p)) & 3) == q)) {
-            asm volatile("");
-            dIf[p] = fma3(dIf[p], t_f, bf[q] * cf[p]);
-            dcs[p] = fma(wn[q], cn[p], dcs[p]);
-            dcs[p] = fma(nEfTn, Dn[p], dcs[p]);
-            Dn[p] = fma(a[q], cn[p], Dn[p]);
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < kFoldDensePar; ++p)
-    if (p < n_par) jac_par[((size_t)ray * n_par + p) * n_pts + j] = fma(Tn, fma(-If, Dn[p], dIf[p]), dcs[p]);
-  rad[(size_t)ray * n_pts + j] = fma(If, Tn, cs);
-}
+// Round 4's kernel ran two sweeps with one accumulator per parameter (sr_limb_adjoint_fold_kernel's quantities: 10 023
+// VALU instructions per wave on configs[4] -- an attenuation() per shell and sweep, the exponential of the remaining
+// optical depth, four error-free sums); here three accumulators per parameter, 4 300-5 000 instructions, and no
+// difference of nearly equal sums anywhere: every term is a product of the quantities the radiance itself is made of.
+// A parameter's gas is wave-uniform: the choice between the gases' weights is a scalar branch (the asm statements keep
+// the compiler from turning it into per-lane selects, two v_cndmask per double).  profiles/r05_fold_sens_ab.txt.
 
 // attenuation() with the polynomial's coefficients in SGPRs (the same operations, bit for bit): for a kernel whose
 // registers are its accumulators (20 VGPRs of constants otherwise)
@@ -3490,7 +3260,7 @@ __device__ inline Atten attenuation_sc(double tau) {
   return A;
 }
 
-// The one-sweep kernel with the ray's records in LDS.  With the records read by scalar loads (sr_limb_fold_sens_kernel)
+// The one-sweep kernel with the ray's records in LDS.  With the records read by scalar loads (the first one-sweep version)
 // a wave waits for its 208-byte record (the scalar cache holds 16 KB, the rays resident on a CU stream 50 KB through
 // it), THEN for the coefficients whose address the record gives, then computes: 46 % issue-busy at four waves per SIMD.
 // Here a block copies its ray's records to LDS in chunks of kSensChunk shells; headers are read one shell ahead, so
@@ -3601,7 +3371,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG <= 2 ? 4
           nEfTn = -(Ef * Tn);
           Tn *= A.t;
         }
-        // (see sr_limb_fold_sens_kernel)
+        // The parameters' gases as a bit field, made opaque per pass (hoisted out of the loop as 16 compare results they
+        // cost 32 SGPRs and spill), and gas by gas, so that every (gas, parameter) step is its own block behind a scalar
+        // branch (one chain over the gases per parameter was tail-merged into moves of the chosen weights)
         int gm = gmask, np = n_par;
         asm volatile("" : "+s"(gm), "+s"(np) : : "memory");
 #pragma unroll
@@ -3724,17 +3496,7 @@ int launch_fold_dense(const int *plan, const double *col, const int *par_gas_hos
   ParGas pg;
   for (int p = 0; p < kFoldDensePar; ++p) pg.g[p] = p < n_par ? par_gas_host[p] : 0;
   const dim3 grid(limb_grid((n_pts + 255) / 256, n_rays));
-#ifndef SR_FOLD_SENS_LDS
-#define SR_FOLD_SENS_LDS 1
-#endif
-#if SR_FOLD_ONE_SWEEP && SR_FOLD_SENS_LDS
-#define SR_FD_KERNEL sr_limb_fold_sens_lds_kernel
-#elif SR_FOLD_ONE_SWEEP
-#define SR_FD_KERNEL sr_limb_fold_sens_kernel
-#else
-#define SR_FD_KERNEL sr_limb_fold_dense_kernel
-#endif
-#define SR_FD(NG) hipLaunchKernelGGL(SR_FD_KERNEL<NG>, grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, rec, n_par, pg, \
+#define SR_FD(NG) hipLaunchKernelGGL(sr_limb_fold_sens_lds_kernel<NG>, grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, rec, n_par, pg, \
                                      o, n_visits, n_rays, rad, jac_par)
   switch (o.n_gas) { case 1: SR_FD(1); break; case 2: SR_FD(2); break; case 3: SR_FD(3); break; default: SR_FD(4); break; }
 #undef SR_FD

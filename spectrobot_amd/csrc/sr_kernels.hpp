@@ -196,8 +196,8 @@ int launch_limb_adjoint_fold(const double *abs_c, const double *emi_c, const dou
                              int n_layers, int n_jrows, int two_rows, int n_rays, const FoldRec *rec, const int *zero_off,
                              const int *zero_row, int n_par, const LimbOpts &o, int n_visits, double *rad, double *jac_layer,
                              double *jac_par, hipStream_t st);
-// The folded recursion for up to kFoldDensePar column parameters whose masks may cover the whole path (one accumulator
-// per parameter): sr_limb_fold_dense_kernel.  plan [n_rays][n_visits][4] = layer, far segment, near segment, 0
+// The folded recursion for up to kFoldDensePar column parameters whose masks may cover the whole path (one sweep, three
+// accumulators per parameter): sr_limb_fold_sens_lds_kernel.  plan [n_rays][n_visits][4] = layer, far segment, near segment, 0
 constexpr int kFoldDensePar = 8;
 struct FoldDense;
 size_t fold_dense_bytes(int n_rec);

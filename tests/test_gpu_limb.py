@@ -296,9 +296,9 @@ def test_one_pass_jacobians_vs_forward_sensitivity(eng):
 
 
 def test_few_broad_parameters_folded_vs_forward(eng):
-    """sr_limb_rays_jac_dev with up to eight parameters on 1-D limb / slant rays runs the folded recursion with one
-    accumulator per parameter (sr_limb_fold_dense_kernel); the forward-sensitivity kernel (mode 1) shares nothing
-    with it but the segment's attenuation.  Broad masks (every parameter acts on every segment), two gases, both LOS
+    """sr_limb_rays_jac_dev with up to eight parameters on 1-D limb / slant rays runs the folded recursion in one
+    sweep (sr_limb_fold_sens_lds_kernel: forward sensitivities in fold order); the path-order forward-sensitivity kernel
+    (mode 1) shares nothing with it but the segment's attenuation.  Broad masks (every parameter acts on every segment), two gases, both LOS
     orders, solo absorption with a Planck background, an opaque case, slant rays (the outward half alone)."""
     import torch
     from spectrobot_amd import synthetic as syn

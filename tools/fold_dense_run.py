@@ -1,5 +1,5 @@
 """The forward model of one configs[4] retrieval iteration (18 LOS x (radiance + 7 parameter Jacobians), two gases) a
-few times: the target of tools/pmc_cmd.sh for the counters of sr_limb_fold_dense_kernel, and its HIP-event time."""
+few times: the target of tools/pmc_cmd.sh for the counters of sr_limb_fold_sens_lds_kernel, and its HIP-event time."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
