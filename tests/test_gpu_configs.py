@@ -278,6 +278,32 @@ def test_bench_gpus2_launches_itself(eng):
     assert rec["value"] > 0 and rec["steps"] == 5 and rec["scaling"] == "strong"
 
 
+def test_bench_gpus2_under_torchrun(eng):
+    """The driver's launch form for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...` -- WORLD_SIZE is set by the launcher, so bench.py does NOT start
+    ranks of its own; both ranks on the one GPU (SR_DIST_BACKEND=gloo), one JSON line from rank 0, exit code 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(SR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5",
+                        "--warmup", "2", "--lines", "20000", "--grid", "40000", "--layers", "16"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dist"]["world_size"] == 2 and rec["dist"]["async_equals_blocking"] is True
+    assert rec["value"] > 0 and rec["steps"] == 5
+
+
 def test_rccl_async_gather_branch_one_rank(eng, tmp_path):
     """The RCCL branch of the bench's step on hardware: backend "nccl" with a ONE-rank process group on the one GPU
     (RCCL needs a device per rank, so more ranks cannot be rehearsed here).  Nine steps of coefficient op + limb
