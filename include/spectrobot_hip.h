@@ -317,6 +317,21 @@ int sr_los_set_vmr(sr_los *h, const double *vmr, void *stream);
 int sr_los_refresh_columns(sr_los *h, void *stream);
 int sr_limb_rays_jac_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
                              double *rad, double *jac, void *stream);
+/* The forward model of ONE retrieval iteration on such a batch in one call -- what spect_main_module.py:2736-2940 does
+ * between `add_clim` of the new profiles and `chicalc`: x [n_par] (HOST, the parameter vector in the batch's parameter
+ * order) -> VMRs of the retrieved gases at the sample points (sum_p x_p w_p: a profile that is sum_p mask_p x_p on the
+ * levels, spect_main_module.py:256-283, interpolated like its masks) -> columns -> radiances and parameter Jacobians ->
+ * instrument bands (sr_hires_to_lowres_shard_dev's arguments) -> the closed-form field-of-view integral of every pixel
+ * (FOV_integr_1D, :3342-3374; three rays per pixel in the batch's order).
+ * fov: [n_rays / 3][7] = delta, delta^3, 2 dmax^2, edge, m2, esse, has_edge per pixel (the geometry factors of the
+ * rotated square pixel), or NULL: the rays themselves.  buf: DEVICE scratch [n_rays (1 + n_par)][n_pts].
+ * out (HOST): [n_rays / 3 or n_rays][1 + n_par][n_bands], row 0 the radiance, row 1 + p the derivative to x_p.  A
+ * spectral shard (g_lo, n_pts) returns its partial band integrals (the integral is linear: all-reduce `out`).
+ * Synchronises `stream`. */
+int sr_retrieval_forward_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
+                             const double *x, double w0, double step, const double *centers_nm, const double *widths_nm,
+                             int n_bands, double n_sigma, int out_units, const double *fov, double *buf, double *out,
+                             void *stream);
 /* sr_limb_rays_dev on a resident LOS: kernel launches only (no staging copy, no column kernel, no host plan).
  * g_lo: grid index of abs_c's first point (Planck initial intensity, init_mode 2). */
 int sr_limb_rays_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,

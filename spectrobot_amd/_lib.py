@@ -97,6 +97,8 @@ SYMBOLS = {
                                            C.c_void_p, C.c_void_p]),
     "sr_limb_rays_los_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                        C.c_void_p]),
+    "sr_retrieval_forward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, dp, C.c_double,
+                                           C.c_double, dp, dp, C.c_int, C.c_double, C.c_int, dp, C.c_void_p, dp, C.c_void_p]),
     "sr_limb_step_dev": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_limb_rays_jac_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(LosDesc), C.c_int, ip, dp,

@@ -1702,7 +1702,7 @@ int sr_last_limb_route(void) { return g_last_limb_route; }
 // the rays share their shells -- the folded sweep's packed records, all made ONCE.  The reference computes a LOS's
 // steps once too (los.calc_radtran_steps, spect_main_module.py:2746-2767) and runs radtran on them many times.
 struct sr_los {
-  Stager s_los, s_fold, s_vmr;
+  Stager s_los, s_fold, s_vmr, s_x;
   LosDev D{};
   FoldStage F{};
   sr_los_desc opt{}; // the scalar options; its pointers are not kept
@@ -1769,6 +1769,7 @@ int sr_los_destroy(sr_los *h) {
   h->s_los.release();
   h->s_fold.release();
   h->s_vmr.release();
+  h->s_x.release();
   delete h;
   return SR_OK;
 }
@@ -1831,6 +1832,64 @@ int sr_limb_rays_jac_los_dev(const double *abs_c, const double *emi_c, int n_lay
   LAUNCHCHK(launch_limb_jac(abs_c, emi_c, (int)n_pts, n_layers, o.n_rays, h->D.seg_off, h->D.seg_layer, h->D.col,
                             h->D.col + (size_t)o.n_gas * h->D.n_seg, h->D.par_gas, h->n_par, limb_opts(&o, h->D.n_seg), rad,
                             jac, st));
+  return SR_OK;
+}
+
+// The forward model of ONE retrieval iteration on a resident batch made with its parameters, in one call: parameter
+// vector -> VMRs of the retrieved gases at the sample points (sr_los_vmr_from_params_kernel) -> Curtis-Godson columns
+// -> radiances and parameter Jacobians of every ray (one launch) -> instrument bands (sr_hires_to_lowres_shard_dev's
+// kernels, its cached band weights) -> one copy to the host -> the closed-form field-of-view integral of every pixel
+// (three rays each; spect_main_module.py:3342-3374 in the closed form of the mirror's fov_closed_form, geometry factors
+// from the caller).  What spect_main_module.py:2736-2940 does per iteration between add_clim and chicalc.
+//   buf: device scratch [n_rays (1 + n_par)][n_pts] (radiances' rows first)
+//   fov: [n_pix][7] = delta, delta^3, 2 dmax^2, edge, m2, esse, has_edge (0 / 1) per pixel, n_pix = n_rays / 3; or null: no
+//        field of view, `out` then holds the rays themselves
+//   out: host [n_pix or n_rays][1 + n_par][n_bands]
+int sr_retrieval_forward_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
+                             const double *x, double w0, double step, const double *centers_nm, const double *widths_nm,
+                             int n_bands, double n_sigma, int out_units, const double *fov, double *buf, double *out,
+                             void *stream) {
+  if (!h || !x || !buf || !out || h->n_par <= 0 || n_bands <= 0) return SR_ERR_ARG;
+  const int n_rays = h->opt.n_rays, n_par = h->n_par, n_row = 1 + n_par;
+  if (fov && n_rays % 3 != 0) return SR_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = h->s_x.prepare(sizeof(double) * (size_t)n_par);
+  if (rc) return rc;
+  std::memcpy(h->s_x.host<double>(), x, sizeof(double) * (size_t)n_par);
+  rc = h->s_x.push(sizeof(double) * (size_t)n_par, st);
+  if (rc) return rc;
+  LAUNCHCHK(launch_los_vmr_from_params(const_cast<double *>(h->D.prof), h->opt.n_gas, n_par, h->D.n_pt, h->D.par_gas,
+                                       h->s_x.d.as<double>(), st));
+  LAUNCHCHK(launch_los_columns(h->D.nd, h->D.x, h->D.prof, h->D.scale, h->D.pt_off, h->D.n_seg, h->D.n_pt, h->opt.n_gas, h->D.col, st));
+  rc = sr_limb_rays_jac_los_dev(abs_c, emi_c, n_layers, n_pts, h, g_lo, buf, buf + (size_t)n_rays * n_pts, stream);
+  if (rc) return rc;
+  static thread_local std::vector<double> low; // [n_rays + n_rays n_par][n_bands]
+  low.resize((size_t)n_rays * n_row * n_bands);
+  rc = sr_hires_to_lowres_shard_dev(buf, n_rays * n_row, n_pts, g_lo, w0, step, centers_nm, widths_nm, n_bands, n_sigma, out_units,
+                                    low.data(), stream);
+  if (rc) return rc;
+  // row of (ray r, quantity q): q = 0 the radiance, q = 1 + p the derivative to parameter p
+  auto row = [&](int r, int q) { return low.data() + (size_t)(q == 0 ? r : n_rays + r * n_par + (q - 1)) * n_bands; };
+  if (!fov) {
+    for (int r = 0; r < n_rays; ++r)
+      for (int q = 0; q < n_row; ++q) std::memcpy(out + ((size_t)r * n_row + q) * n_bands, row(r, q), sizeof(double) * n_bands);
+    return SR_OK;
+  }
+  for (int px = 0; px < n_rays / 3; ++px) {
+    const double *f = fov + 7 * px;
+    const double delta = f[0], delta3 = f[1], two_dmax2 = f[2], edge = f[3], m2 = f[4], esse = f[5];
+    const bool has_edge = f[6] != 0.0;
+    for (int q = 0; q < n_row; ++q) {
+      const double *s0 = row(3 * px, q), *s1 = row(3 * px + 1, q), *s2 = row(3 * px + 2, q);
+      double *o = out + ((size_t)px * n_row + q) * n_bands;
+      for (int b = 0; b < n_bands; ++b) { // (the operations of fov_closed_form, in its order)
+        const double c = (s0[b] + s2[b] - 2.0 * s1[b]) / two_dmax2;
+        double total = 2.0 * (s1[b] * delta + c * delta3 / 3.0);
+        if (has_edge) total = total + s1[b] * edge + 2.0 * c * m2 / edge;
+        o[b] = esse * total;
+      }
+    }
+  }
   return SR_OK;
 }
 

@@ -2311,6 +2311,31 @@ __global__ void sr_los_columns_kernel(const double *__restrict__ nd, const doubl
   col[(size_t)q * n_seg + s] = scale[q] * acc;
 }
 
+// The VMRs of the retrieved gases at a resident batch's sample points from the parameter vector of a retrieval:
+// prof[g][i] = sum over the parameters p of gas g of x_p w_p[i], w_p = prof[n_gas + p] the parameter's mask at the
+// sample points.  (A profile that is sum_p mask_p x_p on the altitude levels, interpolated linearly to the sample
+// points, is the same sum of the interpolated masks: spect_main_module.py LinearProfile_1D.profile.)  Gases without
+// parameters keep their row.
+__global__ void sr_los_vmr_from_params_kernel(double *__restrict__ prof, int n_gas, int n_par, int n_pt,
+                                              const int *__restrict__ par_gas, const double *__restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+  if (i >= n_pt) return;
+  bool any = false;
+  double v = 0.0;
+  for (int p = 0; p < n_par; ++p)
+    if (par_gas[p] == g) {
+      v = v + x[p] * prof[(size_t)(n_gas + p) * n_pt + i];
+      any = true;
+    }
+  if (any) prof[(size_t)g * n_pt + i] = v;
+}
+int launch_los_vmr_from_params(double *prof, int n_gas, int n_par, int n_pt, const int *par_gas, const double *x, hipStream_t st) {
+  if (n_pt <= 0 || n_gas <= 0 || n_par <= 0) return 0;
+  hipLaunchKernelGGL(sr_los_vmr_from_params_kernel, dim3((n_pt + 255) / 256, n_gas), dim3(256), 0, st, prof, n_gas, n_par, n_pt,
+                     par_gas, x);
+  return (int)hipGetLastError();
+}
+
 int launch_los_columns(const double *nd, const double *x, const double *prof, const double *scale, const int *pt_off,
                        int n_seg, int n_pt, int n_prof, double *col, hipStream_t st) {
   if (n_seg <= 0 || n_prof <= 0) return 0;

@@ -150,6 +150,8 @@ struct LimbOpts {
   int n_gas, n_seg_total, solo_absorption, init_mode, g_lo;
   double t_init, w0, gstep;
 };
+// prof[g] = sum_p x_p prof[n_gas + p] over the parameters of gas g (gases without parameters untouched)
+int launch_los_vmr_from_params(double *prof, int n_gas, int n_par, int n_pt, const int *par_gas, const double *x, hipStream_t st);
 int launch_los_columns(const double *nd, const double *x, const double *prof, const double *scale, const int *pt_off,
                        int n_seg, int n_pt, int n_prof, double *col, hipStream_t st);
 int launch_limb(const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, const int *seg_off,

@@ -637,6 +637,60 @@ def limb_rays_jacobian(coeffs, los, par_gas, par_w, grid=None, g_lo=0, rad0=None
     return (rad, jac, buf) if joint else (rad, jac)
 
 
+def fov_factors(pixel_rot):
+    """[n_pix, 7] = delta, delta^3, 2 dmax^2, edge, m2, esse, has_edge of the rotated square pixels (degrees): the geometry
+    factors of spect_main_module.fov_closed_form (FOV_integr_1D, spect_main_module.py:3342-3374), in its operations."""
+    out = np.zeros((len(pixel_rot), 7))
+    for i, rot_deg in enumerate(pixel_rot):
+        rot = abs(np.deg2rad(rot_deg))
+        dmax = np.sqrt(2.0) / 2.0 * np.cos(np.pi / 4 - rot)
+        delta = dmax - np.sin(rot)
+        esse = 1.0 / np.cos(rot)
+        edge = dmax - delta
+        m2 = dmax * (dmax ** 3 - delta ** 3) / 3.0 - (dmax ** 4 - delta ** 4) / 4.0
+        out[i] = (delta, delta ** 3, 2.0 * dmax ** 2, edge, m2, esse, 1.0 if edge > 1e-14 * dmax else 0.0)
+    return out
+
+
+def retrieval_forward(coeffs, los, par_gas, par_w, x, grid, centers_nm, widths_nm, out_units="Wm2", n_sigma=5.0, g_lo=0,
+                      fov=None, buf=None):
+    """The forward model of one retrieval iteration in ONE library call (sr_retrieval_forward_dev) on the batch's
+    device-resident form with these parameter arrays (LimbLOS.handle_par): parameter vector x -> VMRs of the retrieved
+    gases at the sample points -> columns -> radiances and parameter Jacobians -> instrument bands -> (fov: fov_factors
+    of the pixels, three rays each) the closed-form field-of-view integral.  Returns numpy [n_pix or n_rays, 1 + n_par,
+    n_bands]: row 0 the radiance, row 1 + p its derivative to x_p; a spectral shard (g_lo, the coefficient tables'
+    width) gives its partial band integrals.  The batch's host copy of the VMRs (los.vmr) is NOT updated: call
+    los.set_vmr when the loop ends.  buf: scratch from an earlier call (returned as second value)."""
+    a, e = _gas_stack(coeffs)
+    n_gas, n_layers, n_pts = a.shape
+    w0, step, n = grid_params(grid)
+    x_a, xp = _d(x)
+    n_par = x_a.size
+    centers_nm, cp = _d(centers_nm)
+    widths_nm, wp = _d(widths_nm)
+    if widths_nm.size != centers_nm.size:
+        raise ValueError("{} spectral widths for {} grid points".format(widths_nm.size, centers_nm.size))
+    if not (0 <= g_lo and g_lo + n_pts <= n):
+        raise ValueError("the coefficient tables cover grid points outside the grid")
+    h = los.handle_par(n_layers, par_gas, par_w, grid)
+    if np.asarray(par_gas).size != n_par:
+        raise ValueError("x must hold one value per parameter")
+    n_out = los.n_rays
+    fp = None
+    if fov is not None:
+        fov, fp = _d(fov)
+        if los.n_rays % 3 or fov.shape != (los.n_rays // 3, 7):
+            raise ValueError("fov must be [n_rays / 3, 7] (three rays per pixel)")
+        n_out = los.n_rays // 3
+    if buf is None or buf.shape != (los.n_rays * (1 + n_par), n_pts):
+        buf = torch.empty((los.n_rays * (1 + n_par), n_pts), dtype=torch.float64, device="cuda")
+    out = np.empty((n_out, 1 + n_par, centers_nm.size))
+    check(lib.sr_retrieval_forward_dev(a.data_ptr(), e.data_ptr(), n_layers, n_pts, h, int(g_lo), xp, w0, step, cp, wp,
+                                       centers_nm.size, float(n_sigma), _UNITS[out_units], fp, buf.data_ptr(),
+                                       out.ctypes.data_as(dp), _stream_ptr()), "sr_retrieval_forward_dev")
+    return out, buf
+
+
 def limb_rays_layer_jacobian(coeffs, dcoeffs, los, grid=None, g_lo=0):
     """d rad / d (one scalar per layer) [n_rays, n_layers, n_pts]; dcoeffs like coeffs: d(abs, emi of layer k) /
     d(parameter of layer k) per gas (sr_limb_rays_jac_layer_dev)."""

@@ -22,6 +22,10 @@ from . import spect_main_module as smm
 from . import synthetic as syn
 
 
+ONE_CALL = True   # simulate(arrays=True): the iteration's forward model in one library call (engine.retrieval_forward);
+                  # False: columns + Jacobians, instrument step and FOV as separate calls (the A/B partner and the check)
+
+
 class Spectrum(object):
     """Low-resolution spectrum holder with the attributes the smm algebra reads (.spectrum, .spectral_grid)."""
 
@@ -98,7 +102,7 @@ class LimbScene(object):
             self._stack_of = co          # keeps the ids alive
         return self._stack
 
-    def los(self, tangent_alts, **opts):
+    def los(self, tangent_alts, update=True, **opts):
         """engine.LimbLOS of rays with the given tangent altitudes (photon order) + the sample altitudes.  The geometry
         (paths, sample points, densities) depends on the altitudes alone and is kept; between the iterations of a
         retrieval only the VMRs at the sample points change."""
@@ -109,11 +113,14 @@ class LimbScene(object):
             top = self.z[-1] + (self.z[-1] - self.z[-2])
             geo = self._los_geo = (key, L, np.append(self.z, top))
         _, L, zz = geo
+        # the batch itself is kept too (photon order, no options): its device-resident form (engine.LimbLOS.handle_par)
+        # then needs only the new VMRs (LimbLOS.set_vmr: one small copy + the column kernel) -- or nothing at all
+        # (update=False) when the caller sets them on the device from the parameter vector (engine.retrieval_forward)
+        kept = getattr(self, "_los_obj", None)
+        if not update and not opts and kept is not None and kept[0] == key:
+            return kept[1], L["alt"]
         # (geometry._profiles: every VMR linear in altitude between the levels, constant above the last one)
         vmr = np.array([np.interp(L["alt"], zz, np.append(g.vmr, g.vmr[-1])) for g in self.gases])
-        # the batch itself is kept too (photon order, no options): its device-resident form (engine.LimbLOS.handle_par)
-        # then needs only the new VMRs (LimbLOS.set_vmr: one small copy + the column kernel)
-        kept = getattr(self, "_los_obj", None)
         if not opts and kept is not None and kept[0] == key:
             kept[1].set_vmr(vmr)
             return kept[1], L["alt"]
@@ -169,12 +176,36 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
     objects of an iteration were ~0.1 ms of its 0.65)."""
     from . import distributed as sd
     alts = [a for pix in pixels for a in pix.los_alts()]
-    los, alt = scene.los(alts)
     n_grid = len(scene.grid)
     g_lo, g_hi = (0, n_grid) if shard is None else shard_with_halo(n_grid, *shard)
     coeffs = scene.coefficient_stack(refresh=refresh, g_lo=g_lo, g_hi=g_hi)
     n_los = len(alts)
     lowres = lambda r: engine.hires_to_lowres(r, scene.grid, scene.bands_nm, scene.widths_nm, out_units=scene.out_units, g_lo=g_lo)
+    with_fov = sum(pix.fov_half > 0 for pix in pixels)
+    if arrays and ONE_CALL and bayes_set is not None and (with_fov == 0 or (with_fov == len(pixels) and fov_closed_form)) and \
+            all(type(st) in (smm.LinearProfile_1D_new, smm.LinearProfile_1D) for st in bayes_set.sets.values()):
+        # The iteration in ONE library call (engine.retrieval_forward): the VMRs of the retrieved gases are set on the
+        # device from the parameter vector (their profile IS sum_p mask_p x_p: LinearProfile_1D.profile), columns,
+        # radiances + Jacobians, instrument bands and the pixels' closed-form FOV integral follow; one copy comes back.
+        los, alt = scene.los(alts, update=getattr(scene, "_los_obj", None) is None)
+        par_gas, par_w = scene.profile_weights(bayes_set, alt)
+        rots = tuple(pix.pixel_rot for pix in pixels)
+        if with_fov and getattr(scene, "_fov_key", None) != rots:
+            scene._fov_key, scene._fov_fac = rots, engine.fov_factors(rots)
+        out, scene._fwd_buf = engine.retrieval_forward(coeffs, los, par_gas, par_w, bayes_set.param_vector(), scene.grid,
+                                                       scene.bands_nm, scene.widths_nm, out_units=scene.out_units, g_lo=g_lo,
+                                                       fov=scene._fov_fac if with_fov else None,
+                                                       buf=getattr(scene, "_fwd_buf", None))
+        if not with_fov:
+            out = out[1::3]
+        if shard is not None:
+            import torch
+            dev = "cuda" if (torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else "cpu"
+            t = torch.from_numpy(np.ascontiguousarray(out)).to(dev)
+            sd.all_reduce_sum(t)
+            out = t.cpu().numpy()
+        return out[:, 0, :], out[:, 1:, :]
+    los, alt = scene.los(alts)
     if bayes_set is None:
         rad = engine.limb_rays(coeffs, los)
         low = lowres(rad)
@@ -271,6 +302,7 @@ def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10,
             return sp
 
         def finish(low, dlow):
+            scene.los([a for pix in pixels for a in pix.los_alts()])   # the batch's VMRs = the final profiles (host copy too)
             for num in range(len(pixels)):
                 for ip, par in enumerate(bayes_set.params()):
                     par.store_deriv(wrap(dlow[num, ip]), num=num)              # :2929, 2940 (of the last iteration)

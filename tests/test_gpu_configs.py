@@ -399,6 +399,59 @@ print("rccl one-rank ok", sd.stats)
     assert p.returncode == 0 and "rccl one-rank ok" in out, out
 
 
+def test_retrieval_forward_in_one_call(eng):
+    """The iteration's forward model in ONE library call (sr_retrieval_forward_dev: parameter vector -> VMRs on the device
+    -> columns -> radiances + Jacobians -> instrument bands -> closed-form FOV per pixel) against the separate calls of
+    retrieval.simulate (VMR profiles interpolated on the host, LimbLOS.set_vmr, limb_rays_jacobian, hires_to_lowres,
+    smm.fov_closed_form): the same low-resolution spectra and derivatives to rounding (the device sums x_p w_p where the
+    host interpolates sum_p mask_p x_p), at the first guess and after a parameter update; the two loops then walk the
+    same chi-square history.  Pixels without a field of view (the centre rays), and a spectral shard's partial sums."""
+    import copy
+    import bench_configs as bc
+    from spectrobot_amd import retrieval
+    scene = bc.two_gas_scene(6000, 1500, 16000, 30)
+    bs, pixels, x_true = bc.retrieval_problem(scene)
+    bs0 = copy.deepcopy(bs)
+
+    def both_ways(pix, **kw):
+        out = []
+        for one in (False, True):
+            retrieval.ONE_CALL = one
+            try:
+                out.append(retrieval.simulate(scene, pix, bs, arrays=True, **kw))
+            finally:
+                retrieval.ONE_CALL = True
+        (l0, d0), (l1, d1) = out
+        assert l0.shape == l1.shape and d0.shape == d1.shape and d0.shape[1] == len(bs.params())
+        assert np.max(np.abs(l1 - l0)) <= 1e-12 * np.max(np.abs(l0))
+        assert np.max(np.abs(d1 - d0)) <= 1e-11 * np.max(np.abs(d0))
+        return l1, d1
+
+    for name in bs.sets:
+        scene.gas(name).add_clim(bs.sets[name].profile())
+    both_ways(pixels)
+    for k, par in enumerate(bs.params()):          # another point of the parameter space
+        par.value *= 1.0 + 0.07 * (k % 3 - 1)
+    for name in bs.sets:
+        scene.gas(name).add_clim(bs.sets[name].profile())
+    whole, _ = both_ways(pixels)
+    flat = [retrieval.LimbPixel(p.limb_tg_alt, fov_half=0.0, observation=p.observation, noise=p.noise) for p in pixels]
+    both_ways(flat)
+    n = len(scene.grid)
+    parts = [both_ways(pixels, shard=(lo, hi))[0] for lo, hi in ((0, n // 3), (n // 3, n))]
+    assert np.max(np.abs(parts[0] + parts[1] - whole)) <= 1e-12 * np.max(np.abs(whole))
+    hist = []
+    for one in (False, True):
+        retrieval.ONE_CALL = one
+        try:
+            _, _, _, b = retrieval.inversion_fast_limb(scene, copy.deepcopy(bs0), pixels, max_it=20)
+        finally:
+            retrieval.ONE_CALL = True
+        hist.append((list(b.history), b.param_vector(), b.stop))
+    assert len(hist[0][0]) == len(hist[1][0]) and hist[0][2] == hist[1][2]
+    assert np.allclose(hist[0][0], hist[1][0], rtol=1e-9) and np.allclose(hist[0][1], hist[1][1], rtol=1e-8)
+
+
 def test_config4_retrieval_sharded_over_two_ranks(eng, tmp_path):
     """configs[4] on N GPUs (Jacobian spectra follow the shard pattern, the algebra stays small): two
     fresh processes share the one GPU (gloo), each runs retrieval.inversion_fast_limb on its spectral shard --

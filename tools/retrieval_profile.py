@@ -36,6 +36,7 @@ def timed(obj, name, label):
 saved = [(type(scene), "los", timed(type(scene), "los", "scene.los (VMRs at the sample points, set_vmr)")),
          (type(scene), "profile_weights", timed(type(scene), "profile_weights", "profile_weights")),
          (type(scene), "coefficient_stack", timed(type(scene), "coefficient_stack", "coefficient_stack")),
+         (engine, "retrieval_forward", timed(engine, "retrieval_forward", "retrieval_forward (one call: enqueue + wait for the GPU + copy + FOV)")),
          (engine, "limb_rays_jacobian", timed(engine, "limb_rays_jacobian", "limb_rays_jacobian (enqueue)")),
          (engine, "hires_to_lowres", timed(engine, "hires_to_lowres", "hires_to_lowres (enqueue + wait for the GPU + copy)")),
          (smm, "fov_closed_form", timed(smm, "fov_closed_form", "fov_closed_form")),
@@ -51,7 +52,7 @@ dt = time.perf_counter() - t0
 n = len(b.history)
 print("phases of one iteration (%d iterations, %.3f ms each with the wrappers):" % (n, dt / n * 1e3))
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
-    print("  %-58s %7.1f us" % (k, v / n * 1e6))
+    print("  %-74s %7.1f us" % (k, v / n * 1e6))
 for obj, name, f in saved:
     setattr(obj, name, f)
 import cProfile, pstats
