@@ -4100,7 +4100,10 @@ __global__ __launch_bounds__(256) void sr_lowres_weights_kernel(int n_pts, int g
 }
 
 constexpr int kLowresBands = 16;   // bands per block of the apply kernel
-constexpr int kLowresChunk = 4096; // points per block: 144 spectra x 15 chunks fill the chip (a block per spectrum walked
+#ifndef SR_LOWRES_CHUNK
+#define SR_LOWRES_CHUNK 4096
+#endif
+constexpr int kLowresChunk = SR_LOWRES_CHUNK; // (2048 / 1024 measured 60 / 80 us against 56 for the 144 spectra of a configs[4] iteration) points per block: 144 spectra x 15 chunks fill the chip (a block per spectrum walked
                                    // its 60 000 points alone: 117 dependent rounds of 15 loads, 0.21 ms)
 __global__ __launch_bounds__(256) void sr_lowres_apply_kernel(const double *__restrict__ rad, int n_pts,
                                                               const double *__restrict__ W, const int *__restrict__ range,
@@ -4115,8 +4118,16 @@ __global__ __launch_bounds__(256) void sr_lowres_apply_kernel(const double *__re
   // W is zero outside a band's window: no per-point range test, only whole bands that miss the chunk are skipped
   // (block-uniform); the loads of a point's bands are independent of each other
   bool use[kLowresBands];
+  bool any_use = false;
 #pragma unroll
-  for (int q = 0; q < kLowresBands; ++q) use[q] = q < nb && range[2 * (b0 + q)] < c_hi && range[2 * (b0 + q) + 1] > c_lo;
+  for (int q = 0; q < kLowresBands; ++q) {
+    use[q] = q < nb && range[2 * (b0 + q)] < c_hi && range[2 * (b0 + q) + 1] > c_lo;
+    any_use = any_use || use[q];
+  }
+  if (!any_use) { // none of this block's bands reaches the chunk (block-uniform): zeros, and the spectrum is not read
+    if ((int)threadIdx.x < nb) part[((size_t)ray * n_chunks + chunk) * n_bands + b0 + threadIdx.x] = 0.0;
+    return;
+  }
   for (int j = c_lo + (int)threadIdx.x; j < c_hi; j += (int)blockDim.x) {
     const double sv = sp[j];
 #pragma unroll
