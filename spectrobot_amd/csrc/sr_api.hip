@@ -1850,6 +1850,7 @@ int sr_retrieval_forward_dev(const double *abs_c, const double *emi_c, int n_lay
                              int n_bands, double n_sigma, int out_units, const double *fov, double *buf, double *out,
                              void *stream) {
   if (!h || !x || !buf || !out || h->n_par <= 0 || n_bands <= 0) return SR_ERR_ARG;
+  if (h->opt.init_mode == 1) return SR_ERR_ARG; // (initial radiances from the output buffer: `buf` is scratch here)
   const int n_rays = h->opt.n_rays, n_par = h->n_par, n_row = 1 + n_par;
   if (fov && n_rays % 3 != 0) return SR_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
