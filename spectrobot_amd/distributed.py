@@ -71,7 +71,9 @@ def init_from_env(backend=None, single_rank_group=False):
             backend = os.environ.get("SR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", local)
+            # (the device the rank's engine uses: engine.set_device(local % device_count) -- a launcher that narrows
+            # each rank's HIP_VISIBLE_DEVICES to one GPU leaves LOCAL_RANK beyond the visible count)
+            kw["device_id"] = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world
 
