@@ -347,9 +347,10 @@ def test_few_broad_parameters_folded_vs_forward(eng):
                 assert float(jac.abs().max()) > 0
 
 
-def test_few_broad_parameters_many_shells_three_gases_asymmetric(eng):
+@pytest.mark.parametrize("n_g", [3, 4])
+def test_few_broad_parameters_many_shells_three_gases_asymmetric(eng, n_g):
     """The one-sweep kernel beyond what the retrieval case exercises: 150 layers (the ray's records pass through LDS in
-    three chunks of 64 shells, the coefficient prefetch restarts at every chunk), three gases with eight parameters, a
+    three chunks of 64 shells, the coefficient prefetch restarts at every chunk), three or four gases with eight parameters, a
     point count that is no multiple of the block (threads beyond the grid keep the block's barriers), and VMRs that
     differ between the two halves of the path (a shell's two segments then have different columns: the far pass and the
     near pass of a shell run one after the other) -- against the path-order forward-sensitivity kernel and against
@@ -361,10 +362,10 @@ def test_few_broad_parameters_many_shells_three_gases_asymmetric(eng):
     atm = _atm(nl)
     z = atm["z"]
     t = lambda v: torch.tensor(np.ascontiguousarray(v), device="cuda")
-    vm = [np.full(nl, 1.2e-2), np.linspace(2e-3, 5e-4, nl), np.linspace(1e-4, 3e-4, nl)]
+    vm = [np.full(nl, 1.2e-2), np.linspace(2e-3, 5e-4, nl), np.linspace(1e-4, 3e-4, nl), np.linspace(4e-5, 1e-5, nl)][:n_g]
     top = z[-1] + (z[-1] - z[-2])
     zz = np.append(z, top)
-    a = [rng.uniform(0, s_, (nl, n)) for s_ in (4e-18, 3e-17, 2e-16)]
+    a = [rng.uniform(0, s_, (nl, n)) for s_ in (4e-18, 3e-17, 2e-16, 9e-16)[:n_g]]
     e = [a_ * rng.uniform(1e-8, 1e-7, (nl, n)) for a_ in a]
     coeffs = [(t(a_), t(e_)) for a_, e_ in zip(a, e)]
     L = syn.limb_los(z, atm["nd"] * 1e-6, vm, [z[0] + 5.0, z[40] + 3.0, z[100] + 1.0, z[140] + 2.0])
@@ -374,14 +375,14 @@ def test_few_broad_parameters_many_shells_three_gases_asymmetric(eng):
         p0, p1 = L["pt_off"][L["seg_off"][r]], L["pt_off"][L["seg_off"][r + 1]]
         vmr[1, (p0 + p1) // 2:p1] *= 1.07
     W = np.array([np.interp(L["alt"], zz, np.exp(-0.5 * ((zz - z[k]) / (3.0 * (z[1] - z[0]) + 100.0)) ** 2)) for k in (0, 20, 45, 70, 95, 120, 149, 60)])
-    par_gas = np.array([0, 0, 1, 1, 1, 2, 2, 0], np.int32)
+    par_gas = np.array([0, 0, 1, 1, 1, 2, 2, n_g - 1], np.int32)
 
     def cmp(x, y, tol):
         sc = y.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
         return float(((x - y).abs() / sc).max())
 
     for opts in (dict(), dict(LOS_order="observer")):
-        los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], vmr, col_scale=[0.98827, 1.0, 1.0], **opts)
+        los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], vmr, col_scale=[0.98827, 1.0, 1.0, 1.0][:n_g], **opts)
         rad, jac = eng.limb_rays_jacobian(coeffs, los, par_gas, W)
         eng.set_jac_layer_mode(1)
         try:
@@ -397,7 +398,7 @@ def test_few_broad_parameters_many_shells_three_gases_asymmetric(eng):
         for sgn, out in ((1.0, rp), (-1.0, rm)):
             v2 = vmr.copy()
             v2[1] += sgn * h * W[3]
-            l2 = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], v2, col_scale=[0.98827, 1.0, 1.0], **opts)
+            l2 = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], v2, col_scale=[0.98827, 1.0, 1.0, 1.0][:n_g], **opts)
             out.append(eng.limb_rays(coeffs, l2))
         fd = (rp[0] - rm[0]) / (2 * h)
         assert cmp(jac[:, 3, :], fd, 0) < 1e-6, opts
