@@ -1,5 +1,6 @@
 """Soak of the device LOS pipeline: thousands of back-to-back radiance / Jacobian calls over changing ray batches
-(folded, dense-parameter, one-pass and path-order kernels, level-factored tables rebuilt in place); the device memory
+(folded, few-parameter one-sweep, one-pass and path-order kernels, the one-call forward model of a retrieval iteration,
+level-factored tables rebuilt in place); the device memory
 in use must not grow and every 200th result must equal the first of its shape."""
 import os, sys, time
 import numpy as np
@@ -33,12 +34,16 @@ def main(n_calls=3000):
         W = np.array([np.interp(Lr["alt"], zz, np.clip(1 - np.abs(zz - c) / 120.0, 0, None)) for c in rng.uniform(zz[0], zz[-1], npar)])
         shapes.append((co, dco, los, np.zeros(npar, np.int32), W, atm))
     lf = eng.LevelFactored(ls, shapes[0][5]["temps"], shapes[0][5]["press"], dT=0.02)
+    bands = np.linspace(1e7 / grid[-1] + 0.3, 1e7 / grid[0] - 0.3, 9)
     first, free0, t0 = {}, None, time.time()
     for c in range(n_calls):
         i = int(rng.integers(0, len(shapes)))
         co, dco, los, pg, W, atm = shapes[i]
-        kind = c % 4
-        if kind == 0:
+        kind = c % 5
+        if kind == 4:   # a retrieval iteration's forward model in one call, on the batch resident with its parameters
+            x = 1.0 + 0.1 * np.arange(len(pg))
+            out = torch.from_numpy(eng.retrieval_forward(co, los, pg, W, x, grid, bands, np.full(bands.size, 0.4))[0]).cuda()
+        elif kind == 0:
             out = eng.limb_rays(co, los)
         elif kind == 1:
             out = eng.limb_rays_jacobian(co, los, pg, W)[1]
@@ -52,7 +57,7 @@ def main(n_calls=3000):
         key = (i, kind)
         if key not in first:
             first[key] = out.clone()
-        elif c % 200 < 4:
+        elif c % 200 < 5:
             assert torch.equal(out, first[key]), (c, key)
         if c == 400:
             torch.cuda.synchronize()
