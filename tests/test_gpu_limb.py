@@ -404,6 +404,51 @@ def test_few_broad_parameters_many_shells_three_gases_asymmetric(eng, n_g):
         assert cmp(jac[:, 3, :], fd, 0) < 1e-6, opts
 
 
+@pytest.mark.parametrize("n_par,order", [(5, "photon"), (5, "observer"), (11, "photon")])
+def test_retrieval_forward_against_its_parts(eng, n_par, order):
+    """engine.retrieval_forward (sr_retrieval_forward_dev: parameter vector -> VMRs on the device -> columns -> radiances
+    + Jacobians -> instrument bands) against the same steps taken one by one from the host: the VMR of the retrieved
+    gas as sum_p x_p w_p on the host, a fresh LimbLOS with it, limb_rays_jacobian, hires_to_lowres.  Observer order (the
+    batch re-lists its sample points; the device sums its own rows) and more parameters than the one-sweep kernel
+    takes (the path-order forward sensitivities behind the same entry point).  Two gases, only the second retrieved."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(21)
+    nl, n = 30, 3000
+    atm = _atm(nl)
+    z = atm["z"]
+    grid = syn.make_grid(2975.0, 5e-4, n)
+    t = lambda v: torch.tensor(np.ascontiguousarray(v), device="cuda")
+    vm = [np.full(nl, 1.2e-2), np.linspace(2e-3, 5e-4, nl)]
+    a = [rng.uniform(0, 4e-18, (nl, n)), rng.uniform(0, 3e-17, (nl, n))]
+    e = [a[0] * rng.uniform(1e-8, 1e-7, (nl, n)), a[1] * rng.uniform(1e-8, 1e-7, (nl, n))]
+    coeffs = [(t(a[0]), t(e[0])), (t(a[1]), t(e[1]))]
+    L = syn.limb_los(z, atm["nd"] * 1e-6, vm, [z[0] + 5.0, z[8] + 3.0, z[20] + 1.0])
+    top = z[-1] + (z[-1] - z[-2])
+    zz = np.append(z, top)
+    nodes = np.linspace(z[0], z[-1], n_par)
+    W = np.array([np.interp(L["alt"], zz, np.clip(1.0 - np.abs(zz - c) / (nodes[1] - nodes[0]), 0.0, None)) for c in nodes])
+    par_gas = np.full(n_par, 1, np.int32)
+    x = np.linspace(2e-3, 5e-4, n_par) * rng.uniform(0.8, 1.2, n_par)
+    opts = dict() if order == "photon" else dict(LOS_order="observer")
+    bands = np.linspace(1e7 / grid[-1] + 0.05, 1e7 / grid[0] - 0.05, 7)
+    widths = np.full(7, 0.08)
+    los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827, 1.0], **opts)
+    out, _ = eng.retrieval_forward(coeffs, los, par_gas, W, x, grid, bands, widths)
+    assert out.shape == (los.n_rays, 1 + n_par, 7)
+    vmr2 = np.array(L["vmr"], dtype=float)
+    vmr2[1] = x @ W
+    los2 = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], vmr2, col_scale=[0.98827, 1.0], **opts)
+    rad, jac = eng.limb_rays_jacobian(coeffs, los2, par_gas, W)
+    lo_r = eng.hires_to_lowres(rad, grid, bands, widths)
+    lo_j = eng.hires_to_lowres(jac.reshape(-1, n), grid, bands, widths).reshape(los.n_rays, n_par, 7)
+    assert np.max(np.abs(out[:, 0] - lo_r)) <= 1e-12 * np.max(np.abs(lo_r))
+    assert np.max(np.abs(out[:, 1:] - lo_j)) <= 1e-11 * np.max(np.abs(lo_j)) and np.max(np.abs(lo_j)) > 0
+    # the first gas (no parameters) kept its VMRs: the same call again gives the same doubles
+    again, _ = eng.retrieval_forward(coeffs, los, par_gas, W, x, grid, bands, widths)
+    assert np.array_equal(again, out)
+
+
 def test_ray_batch_radiances_folded_vs_path_order(eng):
     """limb_rays on a launch of more than 2048 waves (ray batches: BASELINE configs[2]) runs the folded sweep
     (sr_limb_fold_fwd_kernel: a shell's coefficients and attenuation once for the ray's two segments); mode 2 keeps the
