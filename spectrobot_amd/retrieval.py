@@ -187,7 +187,12 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
         # The iteration in ONE library call (engine.retrieval_forward): the VMRs of the retrieved gases are set on the
         # device from the parameter vector (their profile IS sum_p mask_p x_p: LinearProfile_1D.profile), columns,
         # radiances + Jacobians, instrument bands and the pixels' closed-form FOV integral follow; one copy comes back.
-        los, alt = scene.los(alts, update=getattr(scene, "_los_obj", None) is None)
+        # (the gases WITHOUT parameters keep the VMRs the batch was last given: pushed again when one of them got a new
+        # profile -- add_clim replaces the array)
+        fixed = tuple(id(g.vmr) for g in scene.gases if g.name not in bayes_set.sets)
+        stale = getattr(scene, "_los_obj", None) is None or getattr(scene, "_fixed_vmr_key", None) != fixed
+        scene._fixed_vmr_key = fixed
+        los, alt = scene.los(alts, update=stale)
         par_gas, par_w = scene.profile_weights(bayes_set, alt)
         rots = tuple(pix.pixel_rot for pix in pixels)
         if with_fov and getattr(scene, "_fov_key", None) != rots:
