@@ -306,7 +306,11 @@ def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10,
             sp.spectrum, sp.spectral_grid = np.array(v), grid_lo
             return sp
 
+        low = dlow = None
+
         def finish(low, dlow):
+            if low is None:                                            # (max_it = 0: nothing was simulated)
+                return []
             scene.los([a for pix in pixels for a in pix.los_alts()])   # the batch's VMRs = the final profiles (host copy too)
             for num in range(len(pixels)):
                 for ip, par in enumerate(bayes_set.params()):
