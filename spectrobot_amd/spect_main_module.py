@@ -857,10 +857,10 @@ class BayesSet(object):
             p.update_par(d)
 
     def store_avk(self, av_kernel):
-        self.av_kernel = copy.deepcopy(av_kernel)
+        self.av_kernel = np.array(av_kernel, copy=True)   # (the reference deep-copies: a private array is the same thing)
 
     def store_VCM(self, VCM):
-        self.VCM = copy.deepcopy(VCM)
+        self.VCM = np.array(VCM, copy=True)
 
     def update_parerror(self):
         for i, p in enumerate(self.params()):
