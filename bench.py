@@ -153,7 +153,10 @@ def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total, 
     tv = None if atm["tvib"] is None else atm["tvib"][:, sel]
     offs, lays, cols = rays
     t0 = time.time()
-    abo, emo = O.abscoeff_layers(L, mm, e_lev, atm["temps"][sel], atm["press"][sel], q_part[sel], tv, grid, mode=1,
+    # the checker's Q(T) is the oracle's own (fixture table of the reference's Fortran), not the product's: q_part is
+    # what the product was given and is ignored here
+    q_or = O.partition_sums(6, 1, atm["temps"][sel])
+    abo, emo = O.abscoeff_layers(L, mm, e_lev, atm["temps"][sel], atm["press"][sel], q_or, tv, grid, mode=1,
                                  n_threads=cores)
     t_coef = time.time() - t0
     # the recursion over the sampled layers only (segments of the other layers skipped): same share of the work

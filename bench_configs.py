@@ -347,6 +347,9 @@ def main(args):
         full = torch.empty((n_rays, args.grid), dtype=torch.float64, device="cuda") if world > 1 else None
 
         def step():
+            # as the headline's step: the LOS columns are integrated again on the device from the resident batch's sample
+            # points (two launches), then coefficient op + folded recursion of the 64 rays
+            los.refresh_columns()
             ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"], g_lo=g_lo, g_hi=g_hi, out=(ab, em))
             rad = engine.limb_rays((ab, em), los)
             return sd.all_gather_spectrum(rad, args.grid, world, rank, out=full)
@@ -362,7 +365,8 @@ def main(args):
             kms, counts = B.serial_kernel_times_and_counts(engine, ls, lambda: ls.abscoeff_layers(
                 atm["temps"], atm["press"], tvib=atm["tvib"], g_lo=g_lo, g_hi=g_hi, out=(ab, em)))
             extra["roofline"] = B.coefficient_roofline(kms, counts)
-            extra["recursion"] = _event_time(lambda: engine.limb_rays((ab, em), los), "sr_los_columns_kernel + sr_limb_kernel<1>",
+            extra["recursion"] = _event_time(lambda: (los.refresh_columns(), engine.limb_rays((ab, em), los))[1],
+                                             "sr_los_columns_kernel + sr_fold_dense_pack_kernel + sr_limb_fold_fwd_kernel",
                                              bytes_alg=8.0 * (2 * ab.numel() + n_rays * ab.shape[1]),
                                              note="64 rays x 160 segments x %d points: algorithmic bytes = the two coefficient "
                                                   "tables once + the radiances; VALU-bound (one fused exp / expm1 per segment "

@@ -49,6 +49,15 @@ int sr_abi_version(void);
 /* Device selection / query (one process per GPU: call once per rank). */
 int sr_set_device(int device);
 int sr_device_info(char *name, int name_len, int *cu_count, double *hbm_gib);
+/* Hardware queues.  The coefficient op runs on SIX HIP streams (the caller's + five of its own: table preparation, two
+ * for the far-field chain, the zones kernel, a copy stream).  The ROCm runtime maps a process's streams onto
+ * GPU_MAX_HW_QUEUES hardware queues (environment variable, default 4, read ONCE when HIP initialises, i.e. at the
+ * process's first HIP call): with fewer queues than streams two streams share one and kernels no event orders wait for
+ * each other (measured: 5.63 instead of 5.47 ms per BASELINE step with 4; 6.01 with 2).  A host application exports
+ * GPU_MAX_HW_QUEUES=8 before its first HIP call (the Python package does so at import unless the caller already set it).
+ * *recommended = 8; *configured = what this process runs with (the variable's value, 4 when unset).  Returns SR_OK;
+ * either pointer may be NULL.  Results do not depend on the setting, only the schedule does. */
+int sr_recommended_hw_queues(int *recommended, int *configured);
 
 /* ------------------------------------------------------------------------ *
  * Fine-grained shims: the f2py call shapes, one reference routine each.     *
@@ -432,11 +441,16 @@ int sr_set_far_field(int on);
  * table preparation, the far-field chain (level-0 pass | S2M -> M2M -> M2L) and the zones kernel run on internal
  * streams on scratch of the call's parity, each as soon as what it reads is ready (the preparation of call c + 1
  * while call c computes), the zones kernel gated behind the level-0 pass and S2M of its own call; only the wings
- * kernel, which writes abs_out / emi_out, is on the caller's stream.  2: round 3's order (zones forked off the
- * caller's stream beside the far-field chain on it; the A/B partner, and what counting passes run).  0: the kernels
- * one after the other on the caller's stream (per-kernel times for sr_last_kernel_ms).  The caller's stream sees the
- * op complete in order in every mode. */
+ * kernel, which writes abs_out / emi_out, is on the caller's stream.  0: the kernels one after the other on the
+ * caller's stream (per-kernel times for sr_last_kernel_ms; what the exact mode and counting passes always run).  The
+ * caller's stream sees the op complete in order in both modes. */
 int sr_set_overlap(int on);
+/* Measurement hook of the serial schedule (sr_set_overlap(0)) only: kernel `kernel` of every coefficient op is launched n
+ * times back to back -- 0 sr_prep_kernel, 1 level-0 far-field pass, 2 S2M + M2M, 3 M2L, 4 zones, 5 wings; -1: off -- so
+ * that ONE kernel can run for seconds beside a power sampler (tools/energy_by_kernel.py).  The call's results are not
+ * meaningful while a repeat is set (a repeated M2L adds into its coefficients, the repeated zones kernel stores over the
+ * wings kernel's sums). */
+int sr_set_kernel_repeat(int kernel, int n);
 /* Memory knob: the per-(line, layer) record tables (128 B each, plus the far-field scratch of a layer) of one launch are kept
  * under this many bytes (default 48 GiB of the 288 GB); a longer layer stack (the reference
  * allows imxstp = 8000 LOS steps) is processed in batches of layers. */

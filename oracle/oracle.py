@@ -173,6 +173,16 @@ def calc_partition_sum(t_grid, q_grid, temp):
     return lib().sro_calc_partition_sum(tp, qp, t_grid.size, temp)
 
 
+def partition_sums(mol, iso, temps):
+    """Q(T) for the CHECKER's side of a comparison from the oracle alone: its Lagrange restatement
+    (spect_classes.py:1692-1710) over the table the reference's Fortran returned (tests/golden/tips2003.npz, written by
+    tests/golden/make_golden.py) -- nothing of the product enters (VERDICT rounds 3 and 5)."""
+    g = np.load(os.path.join(os.path.dirname(_HERE), "tests", "golden", "tips2003.npz"), allow_pickle=False)
+    keys = [tuple(int(v) for v in k) for k in g["keys"]]
+    tab = g["q_tab"][keys.index((int(mol), int(iso)))]
+    return np.array([calc_partition_sum(g["t_grid"], tab, float(t)) for t in np.atleast_1d(np.asarray(temps, float))])
+
+
 def curgod(which, nd, x, vmr=None, f=None):
     L = lib()
     nd, ndp = _d(nd)

@@ -65,6 +65,7 @@ SYMBOLS = {
     "sr_abi_version": (C.c_int, []),
     "sr_set_device": (C.c_int, [C.c_int]),
     "sr_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), dp]),
+    "sr_recommended_hw_queues": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sr_humliv_bb": (C.c_int, [dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, dp]),
     "sr_sum_all_lines": (C.c_int, [dp, C.c_int64, dp, ip, ip, C.c_int, C.c_int]),
     "sr_bd_tips_2003": (C.c_int, [C.c_int, C.c_int, dp, dp, dp]),
@@ -123,6 +124,7 @@ SYMBOLS = {
     "sr_last_limb_route": (C.c_int, []),
     "sr_set_far_field": (C.c_int, [C.c_int]),
     "sr_set_overlap": (C.c_int, [C.c_int]),
+    "sr_set_kernel_repeat": (C.c_int, [C.c_int, C.c_int]),
     "sr_set_table_budget": (C.c_int, [C.c_int64]),
     "sr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sr_set_counting": (C.c_int, [C.c_int]),

@@ -51,11 +51,14 @@ int hip_fail(hipError_t e, const char *what) {
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  unsigned gen = 0; // bumped whenever the block is (re)allocated or released: what a cache of the CONTENTS keys on (a new
+                    // block may come back at the old address)
   int ensure(size_t bytes) {
     if (bytes <= cap) return SR_OK;
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    ++gen;
     size_t want = bytes + bytes / 8 + 256;
     HIPCHK(hipMalloc(&p, want));
     cap = want;
@@ -65,6 +68,7 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    ++gen;
   }
   template <class T> T *as() const { return static_cast<T *>(p); }
 };
@@ -219,9 +223,14 @@ struct HostLines {
 // snapshot, so flipping a switch from another thread never changes a call half way.
 std::atomic<int> g_variant{8};   // points per lane in the exact wings kernel
 std::atomic<int> g_far_field{3}; // 1: far wings by per-line local expansions, 2: by box pairs (multipole -> local), 3 (default): 2, but sparse line sets by 1, 0: every evaluation exact
-std::atomic<int> g_overlap{1};   // 1 (default): the decoupled, phased pipeline; 2: round 3's order (zones forked off the caller's stream beside the far-field chain; the A/B partner); 0: kernels one after the other
+std::atomic<int> g_overlap{1};   // 1 (default): the decoupled, phased pipeline; 0: kernels one after the other
 // sr_set_jac_layer_mode; SR_JAC_LAYER_MODE (environment, read once at load): its initial value, for A/B runs of whole programs
 std::atomic<int> g_jac_layer_forward{[] { const char *e = getenv("SR_JAC_LAYER_MODE"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 3 ? v : 0; }()};
+// sr_set_kernel_repeat: a measurement hook of the SERIAL schedule -- kernel g_repeat_kernel of every call is launched
+// g_repeat_n times back to back (energy per launch: tools/energy_by_kernel.py loops one kernel for seconds beside a power
+// sampler).  0 prep, 1 level-0 far-field pass, 2 S2M + M2M, 3 M2L, 4 zones, 5 wings.  Results of a repeated M2L are NOT
+// valid (it adds into the level-0 coefficients); everything else stores.
+std::atomic<int> g_repeat_kernel{-1}, g_repeat_n{1};
 std::atomic<int> g_timing{1};    // 0: no timing events in the coefficient op (sr_set_timing: seven hipEventRecord fewer per call)
 std::atomic<int> g_counting{0};  // 1: counting instantiations of the far-field-mode kernels (sr_set_counting)
 std::atomic<size_t> g_table_budget{(size_t)48 << 30}; // bytes of FastRec + ColdRec tables per layer batch
@@ -366,6 +375,16 @@ int sr_device_info(char *name, int name_len, int *cu_count, double *hbm_gib) {
   return SR_OK;
 }
 
+int sr_recommended_hw_queues(int *recommended, int *configured) {
+  if (recommended) *recommended = 8;
+  if (configured) {
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    const int v = e ? atoi(e) : 0;
+    *configured = v > 0 ? v : 4; // the runtime's default
+  }
+  return SR_OK;
+}
+
 int sr_set_table_budget(int64_t bytes) {
   if (bytes < (int64_t)(sizeof(FastRec) + sizeof(ColdRec))) return SR_ERR_ARG;
   g_table_budget.store((size_t)bytes);
@@ -378,7 +397,14 @@ int sr_set_far_field(int on) {
 }
 
 int sr_set_overlap(int on) {
-  g_overlap.store(on < 0 ? 0 : (on > 2 ? 2 : on)); // see spectrobot_hip.h
+  g_overlap.store(on != 0 ? 1 : 0); // see spectrobot_hip.h
+  return SR_OK;
+}
+
+int sr_set_kernel_repeat(int kernel, int n) {
+  if (kernel < -1 || kernel > 5 || n < 1) return SR_ERR_ARG;
+  g_repeat_kernel.store(kernel);
+  g_repeat_n.store(kernel < 0 ? 1 : n);
   return SR_OK;
 }
 
@@ -709,7 +735,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   for (int k = 0; k < nl; ++k)
     if (!(atm->temps[k] > 0.0) || !(atm->press[k] >= 0.0)) return SR_ERR_ARG;
   // one snapshot of the mode switches per call
-  const int overlap = g_overlap.load(), variant = g_variant.load();
+  const int variant = g_variant.load();
   const bool timing = g_timing.load() != 0;
   // Sparse line sets (the per-level sub-linesets of the pair tables: 9-15 % of a hot-band list): the box-pair far field
   // has a fixed cost per box and layer -- S2M, M2M, M2L over every box whatever it holds -- that the per-line
@@ -721,6 +747,10 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   const bool sparse_set = far_mode == 3 && (double)ls->n_lines < sparse_thr * (double)ls->gp.n_grid;
   const int far_field = far_mode == 3 ? (sparse_set ? 1 : 2) : far_mode;
   const bool counting = g_counting.load() != 0 && far_field;
+  // 1: the decoupled, phased pipeline (far-field modes); 0: the kernels one after the other on the caller's stream, on
+  // table set 0 -- sr_set_overlap(0), the exact mode and the counting passes (whose counters are zeroed and read on the
+  // caller's stream).  (Round 3's order, overlap 2, was the A/B partner of rounds 4-5 and is gone.)
+  const int overlap = (g_overlap.load() != 0 && far_field && !counting) ? 1 : 0;
   const size_t table_budget = g_table_budget.load();
 
   // The per-(line, layer) record tables cost 128 B each, the far-field scratch of a layer (local coefficients
@@ -801,9 +831,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     }
     pst = w.prep_st;
   }
-  // overlap 1: the decoupled, phased pipeline (see the far-field branch below); counting passes and overlap 2 keep
-  // round 3's order (the counters are zeroed on the caller's stream)
-  const bool decoupled = overlap == 1 && far_field && !counting;
+  const bool decoupled = overlap == 1; // the decoupled, phased pipeline (see the far-field branch below)
   Stager &SL = w.s_layers[b];
   DevBuf &d_fast = w.d_fast[b], &d_cold = w.d_cold[b];
   int rc = SL.prepare(hl_bytes);
@@ -932,8 +960,12 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   if (rc) return rc;
 
 
+  // (measurement hook, serial schedule only: see g_repeat_kernel)
+  const int rep_k = overlap ? -1 : g_repeat_kernel.load(), rep_n = g_repeat_n.load();
+  auto reps = [&](int k) { return k == rep_k ? rep_n : 1; };
   if (timing) HIPCHK(hipEventRecord(w.ev[0], pst));
   // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
+  for (int r = 0; r < reps(0); ++r)
   LAUNCHCHK(launch_prep(ls->L, A, ls->gp, W, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
                         far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), pst));
   if (timing) HIPCHK(hipEventRecord(w.ev[1], pst));
@@ -984,10 +1016,15 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     }
     // far-field pass(es): per-line expansions (all levels, or level 0 of the box-pair mode), then the box pairs
     auto far_pass = [&](hipStream_t fs) -> int {
-      LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp,
-                                d_cnt, fs));
-      if (fp.m2l)
-        LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, fs));
+      for (int r = 0; r < reps(1); ++r)
+        LAUNCHCHK(launch_farfield(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp,
+                                  d_cnt, fs));
+      if (fp.m2l) {
+        for (int r = 0; r < reps(2); ++r)
+          LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, fs, 1));
+        for (int r = 0; r < reps(3); ++r)
+          LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, fs, 2));
+      }
       return SR_OK;
     };
     // Round 4: a decoupled, phased pipeline.  Between consecutive calls only the caller-visible output orders things:
@@ -1052,55 +1089,18 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       if (timing) HIPCHK(hipEventRecord(w.ev[3], st));
       if (timing) HIPCHK(hipEventRecord(w.ev[4], st));
       w.overlapped = true;
-    } else
-    if (overlap) {
-      // The zones kernel needs only the record tables, the wings kernel needs the far-field
-      // coefficients: zones runs on a second stream beside the far-field kernel and STORES its sums,
-      // the wings kernel waits for both and adds (9.9 -> 9.2 ms on config 2: the two VALU-bound
-      // kernels fill each other's idle issue slots and tails).
-      if (!w.aux) {
-        HIPCHK(hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
-      }
-      HIPCHK(hipEventRecord(w.ev_fork, st));
-      HIPCHK(hipStreamWaitEvent(w.aux, w.ev_fork, 0));
-      // Small shards do not fill the chip: there the wings kernel need not wait for the zones kernel
-      // either -- zones writes a private buffer, one pass adds it at the end (on the full grid the
-      // VALU is saturated and this variant measured slower: 9.26 vs 9.06 ms).
-      const bool small = n_pts * (size_t)nl <= (size_t)3000000; // point-layers
-      double *z_abs = abs_out, *z_emi = emi_out;
-      if (small) {
-        rc = w.d_zone.ensure(sizeof(double) * 2 * n_pts * nl);
-        if (rc) return rc;
-        z_abs = w.d_zone.as<double>();
-        z_emi = z_abs + n_pts * nl;
-      }
-      LAUNCHCHK(launch_near(2, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub,
-                            nl, (int)g_lo, (int)g_hi, ls->gp, fp, z_abs, z_emi, d_cnt, w.aux));
-      HIPCHK(hipEventRecord(w.ev_join, w.aux));
-      rc = far_pass(st);
-      if (rc) return rc;
-      if (timing) HIPCHK(hipEventRecord(w.ev[2], st));
-      if (!small) HIPCHK(hipStreamWaitEvent(st, w.ev_join, 0));
-      LAUNCHCHK(launch_near(1, small ? 0 : 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub,
-                            nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st));
-      if (timing) HIPCHK(hipEventRecord(w.ev[3], st));
-      if (small) {
-        HIPCHK(hipStreamWaitEvent(st, w.ev_join, 0));
-        LAUNCHCHK(launch_add2(abs_out, z_abs, emi_out, z_emi, n_pts * nl, st));
-      }
-      if (timing) HIPCHK(hipEventRecord(w.ev[4], st));
-      w.overlapped = true;
     } else {
       w.overlapped = false;
       rc = far_pass(st);
       if (rc) return rc;
       if (timing) HIPCHK(hipEventRecord(w.ev[2], st));
+      // wings (writes) then zones (adds); the repeat hook's zones launches store instead (idempotent)
       for (int part = 1; part <= 2; ++part) {
-        LAUNCHCHK(launch_near(part, part == 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix,
-                              zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out,
-                              d_cnt, st));
+        const int n_rep = reps(part == 1 ? 5 : 4);
+        for (int r = 0; r < n_rep; ++r)
+          LAUNCHCHK(launch_near(part, part == 2 && n_rep == 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix,
+                                zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, fp, abs_out, emi_out,
+                                d_cnt, st));
         if (timing) HIPCHK(hipEventRecord(w.ev[2 + part], st));
       }
     }
@@ -1116,7 +1116,9 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   }
   rc = add_outer(); // after the timing events: not part of the per-kernel times
   if (rc) return rc;
-  if (overlap) {
+  // a serial call reads table set 0 too: a later pipelined call, which prepares its set on prep_st without waiting for
+  // the caller's stream, must find the event behind THIS call's kernels
+  if (w.ev_tables_free[b]) {
     HIPCHK(hipEventRecord(w.ev_tables_free[b], st));
     w.free_recorded[b] = true;
   }
@@ -1709,23 +1711,49 @@ struct sr_los {
   int n_layers = 0, dev = -1;
   int n_par = 0;                 // column parameters staged with the batch (sr_los_create_par)
   std::vector<int32_t> par_gas;  // their gases (host copy: a kernel argument of the folded kernel)
+  // The handle's device state (profiles, columns, packed records) is rewritten by set_vmr / refresh_columns /
+  // retrieval_forward on whatever stream the caller passes: every entry point orders its stream after the handle's
+  // last use (as coef_op does with ev_last_done), so calls on streams that are not ordered against each other are safe
+  hipEvent_t ev_last = nullptr;
+  bool last_recorded = false;
 };
+
+// Entry of every call on a resident batch: the handle belongs to the device it was made on (its buffers, and the
+// pinned stagers that would rebuild themselves on another current device and then copy into this one's memory).
+static int los_enter(sr_los *h, hipStream_t st) {
+  int cur = -1;
+  HIPCHK(hipGetDevice(&cur));
+  if (cur != h->dev) {
+    g_err = "sr_los handle used on device " + std::to_string(cur) + ", made on device " + std::to_string(h->dev);
+    return SR_ERR_ARG;
+  }
+  if (h->last_recorded) HIPCHK(hipStreamWaitEvent(st, h->ev_last, 0));
+  return SR_OK;
+}
+static int los_leave(sr_los *h, hipStream_t st) {
+  if (!h->ev_last) HIPCHK(hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(h->ev_last, st));
+  h->last_recorded = true;
+  return SR_OK;
+}
 
 // the recursion of a resident LOS on `st`: launches only
 static int limb_rays_los(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
                          double *rad, hipStream_t st) {
+  const int rc0 = los_enter(h, st);
+  if (rc0) return rc0;
   sr_los_desc o = h->opt;
   o.g_lo = g_lo;
   if (h->F.n_rec > 0 && !limb_launch_is_small((int)n_pts, o.n_rays) && g_jac_layer_forward.load() == 0) {
     LAUNCHCHK(launch_fold_fwd(h->F.plan, h->D.col, h->D.n_seg, h->F.n_rec, h->F.rec, abs_c, emi_c, (int)n_pts, n_layers, o.n_rays,
                               h->F.n_vis, limb_opts(&o, h->D.n_seg), rad, st, /*pack=*/false));
     g_last_limb_route = 2;
-    return SR_OK;
+    return los_leave(h, st);
   }
   LAUNCHCHK(launch_limb(abs_c, emi_c, (int)n_pts, n_layers, o.n_rays, h->D.seg_off, h->D.seg_layer, h->D.col,
                         limb_opts(&o, h->D.n_seg), rad, st));
   g_last_limb_route = 1;
-  return SR_OK;
+  return los_leave(h, st);
 }
 
 extern "C" {
@@ -1770,6 +1798,7 @@ int sr_los_destroy(sr_los *h) {
   h->s_fold.release();
   h->s_vmr.release();
   h->s_x.release();
+  if (h->ev_last) (void)hipEventDestroy(h->ev_last);
   delete h;
   return SR_OK;
 }
@@ -1784,7 +1813,9 @@ int sr_los_set_vmr(sr_los *h, const double *vmr, void *stream) {
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t bytes = sizeof(double) * (size_t)h->opt.n_gas * h->D.n_pt;
-  int rc = h->s_vmr.prepare(bytes); // (waits for the previous update's copy: the one pinned buffer is being refilled)
+  int rc = los_enter(h, st);
+  if (rc) return rc;
+  rc = h->s_vmr.prepare(bytes); // (waits for the previous update's copy: the one pinned buffer is being refilled)
   if (rc) return rc;
   std::memcpy(h->s_vmr.host<char>(), vmr, bytes);
   // straight into the batch's profile table: [n_gas + n_par][n_pt], the gases first
@@ -1797,7 +1828,7 @@ int sr_los_set_vmr(sr_los *h, const double *vmr, void *stream) {
     LAUNCHCHK(launch_fold_fwd(h->F.plan, h->D.col, h->D.n_seg, h->F.n_rec, h->F.rec, nullptr, nullptr, 0, h->n_layers, h->opt.n_rays,
                               h->F.n_vis, o, nullptr, st));
   }
-  return SR_OK;
+  return los_leave(h, st);
 }
 
 // The Curtis-Godson columns of a resident batch integrated again from its staged sample points (and the folded
@@ -1807,13 +1838,15 @@ int sr_los_set_vmr(sr_los *h, const double *vmr, void *stream) {
 int sr_los_refresh_columns(sr_los *h, void *stream) {
   if (!h) return SR_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rc0 = los_enter(h, st);
+  if (rc0) return rc0;
   LAUNCHCHK(launch_los_columns(h->D.nd, h->D.x, h->D.prof, h->D.scale, h->D.pt_off, h->D.n_seg, h->D.n_pt, h->D.n_prof, h->D.col, st));
   if (h->n_par == 0 && h->F.n_rec > 0) {
     LimbOpts o = limb_opts(&h->opt, h->D.n_seg);
     LAUNCHCHK(launch_fold_fwd(h->F.plan, h->D.col, h->D.n_seg, h->F.n_rec, h->F.rec, nullptr, nullptr, 0, h->n_layers, h->opt.n_rays,
                               h->F.n_vis, o, nullptr, st));
   }
-  return SR_OK;
+  return los_leave(h, st);
 }
 
 // sr_limb_rays_jac_dev on a resident batch made with its column parameters (sr_los_create_par): launches only.
@@ -1822,17 +1855,19 @@ int sr_limb_rays_jac_los_dev(const double *abs_c, const double *emi_c, int n_lay
   if (!abs_c || !emi_c || !rad || !jac || !h || n_layers != h->n_layers || n_pts <= 0 || h->n_par <= 0) return SR_ERR_ARG;
   if (n_pts > 2000000) return SR_ERR_LIMIT;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rc0 = los_enter(h, st);
+  if (rc0) return rc0;
   sr_los_desc o = h->opt;
   o.g_lo = g_lo;
   if (h->n_par <= kFoldDensePar && h->F.n_rec > 0 && g_jac_layer_forward.load() == 0) {
     LAUNCHCHK(launch_fold_dense(h->F.plan, h->D.col, h->par_gas.data(), h->n_par, h->D.n_seg, h->F.n_rec, h->F.rec, abs_c, emi_c,
                                 (int)n_pts, n_layers, o.n_rays, h->F.n_vis, limb_opts(&o, h->D.n_seg), rad, jac, st));
-    return SR_OK;
+    return los_leave(h, st);
   }
   LAUNCHCHK(launch_limb_jac(abs_c, emi_c, (int)n_pts, n_layers, o.n_rays, h->D.seg_off, h->D.seg_layer, h->D.col,
                             h->D.col + (size_t)o.n_gas * h->D.n_seg, h->D.par_gas, h->n_par, limb_opts(&o, h->D.n_seg), rad,
                             jac, st));
-  return SR_OK;
+  return los_leave(h, st);
 }
 
 // The forward model of ONE retrieval iteration on a resident batch made with its parameters, in one call: parameter
@@ -1854,7 +1889,9 @@ int sr_retrieval_forward_dev(const double *abs_c, const double *emi_c, int n_lay
   const int n_rays = h->opt.n_rays, n_par = h->n_par, n_row = 1 + n_par;
   if (fov && n_rays % 3 != 0) return SR_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int rc = h->s_x.prepare(sizeof(double) * (size_t)n_par);
+  int rc = los_enter(h, st);
+  if (rc) return rc;
+  rc = h->s_x.prepare(sizeof(double) * (size_t)n_par);
   if (rc) return rc;
   std::memcpy(h->s_x.host<double>(), x, sizeof(double) * (size_t)n_par);
   rc = h->s_x.push(sizeof(double) * (size_t)n_par, st);
@@ -2399,24 +2436,37 @@ int sr_hires_to_lowres_shard_dev(const double *rad, int n_rays, int64_t n_pts, i
   static thread_local DevBuf d_weights; // the bands' weight table [n_bands][n_pts] + point ranges, then the partial sums
   // The table depends on the grid window and the bands alone: kept while they (and the buffer) stay the same -- the
   // instrument step of a retrieval iteration is then two launches and no upload (the weights kernel was 19 us of it)
+  // (the key held the buffer's ADDRESS; a call with more rays re-allocates the buffer -- the partial sums
+  // follow the table in it -- and the new block can come back at the old address with nothing in it.  The key is the
+  // buffer's generation now, and the device: the thread-local buffers follow a hipSetDevice())
   struct WeightKey {
     int64_t n_pts = -1, g_lo = 0;
     double w0 = 0, step = 0, n_sigma = 0;
-    void *buf = nullptr;
+    bool valid = false;
+    unsigned gen = 0;
+    int dev = -1;
     std::vector<double> bands;
   };
   static thread_local WeightKey s_key;
   const size_t nb = (size_t)n_bands;
+  int cur_dev = 0;
+  HIPCHK(hipGetDevice(&cur_dev));
+  if (s_key.dev != cur_dev) { // buffers of another device: start over on this one
+    d_out.release();
+    d_weights.release();
+    s_key.valid = false;
+    s_key.dev = cur_dev;
+  }
   int rc = d_out.ensure(sizeof(double) * nb * n_rays);
   if (rc) return rc;
   rc = d_weights.ensure(lowres_scratch_bytes((int)n_pts, n_bands, n_rays));
   if (rc) return rc;
-  const bool same = s_key.buf == d_weights.p && s_key.n_pts == n_pts && s_key.g_lo == g_lo && s_key.w0 == w0 && s_key.step == step &&
+  const bool same = s_key.valid && s_key.gen == d_weights.gen && s_key.n_pts == n_pts && s_key.g_lo == g_lo && s_key.w0 == w0 && s_key.step == step &&
                     s_key.n_sigma == n_sigma && s_key.bands.size() == 2 * nb &&
                     std::memcmp(s_key.bands.data(), centers_nm, sizeof(double) * nb) == 0 &&
                     std::memcmp(s_key.bands.data() + nb, widths_nm, sizeof(double) * nb) == 0;
   if (!same) {
-    s_key.buf = nullptr; // (until the launch below has been issued)
+    s_key.valid = false; // (until the launch below has been issued)
     rc = s_bands.prepare(sizeof(double) * 2 * nb);
     if (rc) return rc;
     std::memcpy(s_bands.host<double>(), centers_nm, sizeof(double) * nb);
@@ -2430,7 +2480,8 @@ int sr_hires_to_lowres_shard_dev(const double *rad, int n_rays, int64_t n_pts, i
     s_key.n_pts = n_pts; s_key.g_lo = g_lo; s_key.w0 = w0; s_key.step = step; s_key.n_sigma = n_sigma;
     s_key.bands.assign(centers_nm, centers_nm + nb);
     s_key.bands.insert(s_key.bands.end(), widths_nm, widths_nm + nb);
-    s_key.buf = d_weights.p; // (this call synchronises its stream below: the table is complete before any later call)
+    s_key.gen = d_weights.gen;
+    s_key.valid = true; // (this call synchronises its stream below: the table is complete before any later call)
   }
   HIPCHK(hipMemcpyAsync(out_host, d_out.p, sizeof(double) * nb * n_rays, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

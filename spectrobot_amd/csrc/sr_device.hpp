@@ -75,7 +75,7 @@ struct __attribute__((aligned(16))) FastRec {
   uint32_t ilir;     // region-1 boundaries il | ir << 16 (1-based window indices);
                      // one dword so that the whole record is scalar-loadable
 #if SR_FASTREC64
-  double pad_;
+  double w3;         // third weight of the multi-channel pass (kWeightChannels: the line's G_ind; 0 in every other mode)
 #endif
   __host__ __device__ inline int il() const { return (int)(ilir & 0xffffu); }
   __host__ __device__ inline int ir() const { return (int)(ilir >> 16); }
@@ -167,7 +167,7 @@ __device__ inline R1Coef r1_of(const FastRec &r) {
 __device__ inline void r1_set(FastRec &r, double ry) {
 #if SR_FASTREC64
   r.ry = ry;
-  r.pad_ = 0.0;
+  r.w3 = 0.0;
 #else
   region1_coef(ry, r.a, r.b, r.c, r.d);
 #endif

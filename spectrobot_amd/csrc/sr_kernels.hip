@@ -34,6 +34,7 @@ namespace sr {
 //   weights by W.mode (sr_kernels.hpp: WeightMode), already divided by fac (shape = y / fac, :2003)
 struct LinePhys {
   double lw, dwp, wabs, wemi;
+  double w3; // kWeightChannels only: the third weight (0 otherwise)
 };
 __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, const WeightMode W, int ln, int k) {
   LinePhys P;
@@ -75,6 +76,7 @@ __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, c
   const int lu = L.lev_up[ln], ll = L.lev_lo[ln];
   const double *pop = A.pop + (size_t)k * A.n_pop;
   double wabs, wemi;
+  P.w3 = 0.0;
   if (W.mode == kWeightFolded) { // spect_main_module.py:2073-2080 folded per line
     const double pu = pop[lu], pl = pop[ll];
     wabs = pl * g_ab - pu * g_in;
@@ -85,6 +87,10 @@ __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, c
   } else if (W.mode == kWeightGind) {    // ... ind_emission | nothing
     wabs = (W.level < 0 || lu == W.level) ? g_in : 0.0;
     wemi = 0.0;
+  } else if (W.mode == kWeightChannels) { // the multi-channel pass: the line's three G coefficients, each to its own channel
+    wabs = g_ab;                           // -> the absorption spectrum of the line's LOWER level
+    wemi = g_sp;                           // -> the sp_emission spectrum of its UPPER level
+    P.w3 = (W.level == 0 ? -g_in : g_in) / fac; // -> ind_emission of its UPPER level (level 0: subtracted from that level's absorption spectrum, smm:2078)
   } else if (W.mode == kWeightLevelPair) { // what pop_level multiplies in the combine loop (smm:2078-2080)
     const bool all = W.level < 0;          // no level table: the 'all' set (smm:2052-2057)
     wabs = ((all || ll == W.level) ? g_ab : 0.0) - ((all || lu == W.level) ? g_in : 0.0);
@@ -141,6 +147,9 @@ __global__ __launch_bounds__(kPrepBlock) void sr_prep_kernel(LinesDev L, LayersD
   r.xr = B.xr;
   r.xstep = B.xstep;
   r1_set(r, B.ry);
+#if SR_FASTREC64
+  r.w3 = ph.w3;
+#endif
   r.wabs = ph.wabs;
   r.wemi = ph.wemi;
   r.j1 = ic - kHalf;

@@ -29,7 +29,7 @@ struct LayersDev {
 
 // What the two output channels ("abs", "emi") of the coefficient kernels accumulate, chosen per call:
 // the weights of line i in layer k, from its three G coefficients and its levels' populations.
-enum { kWeightFolded = 0, kWeightGabsGsp = 1, kWeightGind = 2, kWeightTracked = 3, kWeightLevelPair = 4 };
+enum { kWeightFolded = 0, kWeightGabsGsp = 1, kWeightGind = 2, kWeightTracked = 3, kWeightLevelPair = 4, kWeightChannels = 5 };
 struct WeightMode {
   int mode;  // kWeightFolded: abs = pop_lo G_abs - pop_up G_ind, emi = pop_up G_sp (smm:2073-2080)
              // kWeightGabsGsp: abs = [lev_lo == level] G_abs, emi = [lev_up == level] G_sp   (BuildCoeff)
@@ -38,6 +38,9 @@ struct WeightMode {
              // kWeightLevelPair: abs = [lev_lo == level] G_abs - [lev_up == level] G_ind, emi = [lev_up == level] G_sp:
              //                 the two spectra the combine loop multiplies by pop_level (smm:2078-2080), i.e. the
              //                 tracked weights with unit populations -- the level-factored route (sr_glevel_pairs_dev)
+             // kWeightChannels: the multi-channel pass (sr_glevel_pairs_dev / sr_gcoeff_levels_dev): wabs = G_abs, wemi = G_sp,
+             //                 FastRec::w3 = -G_ind (level == 0: pair tables) or +G_ind (level == 1: three ctypes apart);
+             //                 which spectrum each goes to follows from the line's levels (McChannels)
   int level;
 };
 

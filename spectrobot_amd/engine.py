@@ -55,7 +55,10 @@ def device_info():
     cu = C.c_int(0)
     mem = C.c_double(0)
     check(lib.sr_device_info(name, 256, C.byref(cu), C.byref(mem)), "sr_device_info")
-    return dict(name=name.value.decode(), cu_count=cu.value, hbm_gib=mem.value)
+    rec, conf = C.c_int(0), C.c_int(0)
+    check(lib.sr_recommended_hw_queues(C.byref(rec), C.byref(conf)), "sr_recommended_hw_queues")
+    return dict(name=name.value.decode(), cu_count=cu.value, hbm_gib=mem.value, hw_queues=conf.value,
+                hw_queues_recommended=rec.value)
 
 
 def _stream_ptr():
@@ -445,8 +448,21 @@ def radiance_rays(abs_c, emi_c, seg_off, seg_layer, seg_col, rad0=None):
 
 
 class _ParHandle(object):
-    def __init__(self, h, keep):
-        self.h, self.keep = h, keep
+    def __init__(self, h):
+        self.h = h
+
+
+def _content_key(a):
+    """A key for an array's CONTENT (dtype, shape, bytes hashed): identity says nothing about an array edited in place or
+    about a new array that got a dead one's id."""
+    a = np.ascontiguousarray(a)
+    if a.nbytes <= 4096 or a.nbytes % 8:
+        return (a.dtype.str, a.shape, a.tobytes())
+    # large tables (a retrieval's parameter weights, every iteration): two vectorised reductions over the 64-bit words
+    # -- xor and a position-weighted wrapped sum -- instead of a cryptographic hash (30 us against 0.5 ms per call)
+    w = a.reshape(-1).view(np.uint64)
+    pos = np.arange(1, w.size + 1, dtype=np.uint64)
+    return (a.dtype.str, a.shape, int(np.bitwise_xor.reduce(w)), int((w * (pos | np.uint64(1))).sum(dtype=np.uint64)))
 
 
 class LimbLOS(object):
@@ -475,7 +491,18 @@ class LimbLOS(object):
         if LOS_order not in ('photon', 'observer'):
             raise ValueError("LOS_order must be 'photon' or 'observer'")
         self.LOS_order, self.solo_absorption, self.initial_temperature = LOS_order, bool(solo_absorption), initial_temperature
-        self._handles = {}
+        self._handles = {}      # insertion-ordered: least recently used first (see _keep)
+
+    MAX_HANDLES = 8   # resident forms kept per batch: each holds pinned and device memory until it is destroyed
+
+    def _keep(self, key, ent):
+        """Insert / refresh an entry of the bounded handle cache; the least recently used forms are destroyed."""
+        self._handles.pop(key, None)
+        self._handles[key] = ent
+        while len(self._handles) > self.MAX_HANDLES:
+            old = self._handles.pop(next(iter(self._handles)))
+            lib.sr_los_destroy(getattr(old, "h", old))
+        return ent
 
     def handle(self, n_layers, grid=None, rad0=False):
         """The batch resident on the device (sr_los_create): staged, its columns integrated and the folded sweep's
@@ -489,25 +516,26 @@ class LimbLOS(object):
             d = self.desc(grid, 0, rad0=rad0)
             h = C.c_void_p()
             check(lib.sr_los_create(C.byref(d), int(n_layers), C.byref(h)), "sr_los_create")
-            self._handles[key] = h
-        return h
+        return self._keep(key, h)
 
     def handle_par(self, n_layers, par_gas, par_w, grid=None, rad0=False):
         """handle() with the column parameters (par_gas [n_par], par_w [n_par, n_pt]) staged alongside
-        (sr_los_create_par): the batch of a retrieval.  Keyed on the two arrays' identity."""
+        (sr_los_create_par): the batch of a retrieval.  Keyed on the two arrays' CONTENT (a hash of their bytes: a
+        caller that builds par_w afresh every iteration finds its batch again, an in-place edit makes a new one); at
+        most MAX_HANDLES resident forms are kept, the least recently used is destroyed."""
         gp = None if (grid is None or self.initial_temperature is None or rad0) else grid_params(grid)[:2]
-        key = (int(n_layers), gp, bool(rad0), id(par_gas), id(par_w))
+        pg_a, pg = _i(par_gas)
+        pw_a, pw = _d(par_w)
+        if pw_a.shape != (pg_a.size, self.n_pt):
+            raise ValueError("par_w must be [n_par, n_pt]")
+        key = (int(n_layers), gp, bool(rad0), _content_key(pg_a), _content_key(pw_a))
         ent = self._handles.get(key)
         if ent is None:
-            pg_a, pg = _i(par_gas)
-            pw_a, pw = _d(par_w)
-            if pw_a.shape != (pg_a.size, self.n_pt):
-                raise ValueError("par_w must be [n_par, n_pt]")
             d = self.desc(grid, 0, rad0=rad0)
             h = C.c_void_p()
             check(lib.sr_los_create_par(C.byref(d), int(n_layers), pg_a.size, pg, pw, C.byref(h)), "sr_los_create_par")
-            ent = self._handles[key] = _ParHandle(h, (par_gas, par_w))     # (the arrays referenced: their ids stay theirs)
-        return ent.h
+            ent = _ParHandle(h)
+        return self._keep(key, ent).h
 
     def refresh_columns(self):
         """Integrate the Curtis-Godson columns of every resident form of the batch again, on the device, from the staged
@@ -521,6 +549,10 @@ class LimbLOS(object):
         v = np.ascontiguousarray(np.atleast_2d(vmr), dtype=np.float64)
         if v.shape != self.vmr.shape:
             raise ValueError("vmr must be [n_gas, n_pt]")
+        if self.LOS_order != 'photon' and self._handles:
+            # sr_los_set_vmr refuses observer-order batches (their sample points are re-listed): checked BEFORE the
+            # host copy changes, so that it and the resident forms never disagree -- drop the forms, they are rebuilt
+            self.close()
         self.vmr[...] = v
         for h in self._handles.values():
             check(lib.sr_los_set_vmr(getattr(h, "h", h), self._v, _stream_ptr()), "sr_los_set_vmr")

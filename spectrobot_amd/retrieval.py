@@ -106,7 +106,10 @@ class LimbScene(object):
         """engine.LimbLOS of rays with the given tangent altitudes (photon order) + the sample altitudes.  The geometry
         (paths, sample points, densities) depends on the altitudes alone and is kept; between the iterations of a
         retrieval only the VMRs at the sample points change."""
-        key = tuple(float(a) for a in tangent_alts)
+        # (the key holds everything the geometry is made from: altitudes of the rays, the level grid, the densities, the
+        # sub-stepping and the radius -- by content; ADVICE round 5)
+        key = (tuple(float(a) for a in tangent_alts), np.asarray(self.z, float).tobytes(), np.asarray(self.nd, float).tobytes(),
+               int(self.n_sub), float(self.R))
         geo = getattr(self, "_los_geo", None)
         if geo is None or geo[0] != key:
             L = syn.limb_los(self.z, self.nd, [g.vmr for g in self.gases], tangent_alts, R=self.R, n_sub=self.n_sub)
@@ -189,7 +192,8 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
         # radiances + Jacobians, instrument bands and the pixels' closed-form FOV integral follow; one copy comes back.
         # (the gases WITHOUT parameters keep the VMRs the batch was last given: pushed again when one of them got a new
         # profile -- add_clim replaces the array)
-        fixed = tuple(id(g.vmr) for g in scene.gases if g.name not in bayes_set.sets)
+        # by CONTENT: an id() can be re-used by a new array and says nothing about an in-place edit
+        fixed = tuple(np.asarray(g.vmr, float).tobytes() for g in scene.gases if g.name not in bayes_set.sets)
         stale = getattr(scene, "_los_obj", None) is None or getattr(scene, "_fixed_vmr_key", None) != fixed
         scene._fixed_vmr_key = fixed
         los, alt = scene.los(alts, update=stale)

@@ -405,7 +405,11 @@ def test_retrieval_forward_in_one_call(eng):
     retrieval.simulate (VMR profiles interpolated on the host, LimbLOS.set_vmr, limb_rays_jacobian, hires_to_lowres,
     smm.fov_closed_form): the same low-resolution spectra and derivatives to rounding (the device sums x_p w_p where the
     host interpolates sum_p mask_p x_p), at the first guess and after a parameter update; the two loops then walk the
-    same chi-square history.  Pixels without a field of view (the centre rays), and a spectral shard's partial sums."""
+    same chi-square history.  Pixels without a field of view (the centre rays), and a spectral shard's partial sums.
+
+    PARITY UNPINNED: checked against other product kernels (the separate calls) only -- the reference's
+    radtran_fast is in the absent spect_base_module; the instrument step and FOV closed form inside the call are pinned
+    to the reference separately (test_hires_to_lowres_golden, the FOV_integr_1D fixture)."""
     import copy
     import bench_configs as bc
     from spectrobot_amd import retrieval

@@ -299,7 +299,11 @@ def test_few_broad_parameters_folded_vs_forward(eng):
     """sr_limb_rays_jac_dev with up to eight parameters on 1-D limb / slant rays runs the folded recursion in one
     sweep (sr_limb_fold_sens_lds_kernel: forward sensitivities in fold order); the path-order forward-sensitivity kernel
     (mode 1) shares nothing with it but the segment's attenuation.  Broad masks (every parameter acts on every segment), two gases, both LOS
-    orders, solo absorption with a Planck background, an opaque case, slant rays (the outward half alone)."""
+    orders, solo absorption with a Planck background, an opaque case, slant rays (the outward half alone).
+
+    PARITY UNPINNED: the reference's radiance recursion and Jacobians live in the absent
+    spect_base_module; this test checks product kernels against OTHER product kernels and finite differences, not
+    against the reference."""
     import torch
     from spectrobot_amd import synthetic as syn
     rng = np.random.default_rng(5)
@@ -354,7 +358,11 @@ def test_few_broad_parameters_many_shells_three_gases_asymmetric(eng, n_g):
     point count that is no multiple of the block (threads beyond the grid keep the block's barriers), and VMRs that
     differ between the two halves of the path (a shell's two segments then have different columns: the far pass and the
     near pass of a shell run one after the other) -- against the path-order forward-sensitivity kernel and against
-    central differences of the radiance in one parameter."""
+    central differences of the radiance in one parameter.
+
+    PARITY UNPINNED: the reference's radiance recursion and Jacobians live in the absent
+    spect_base_module; this test checks product kernels against OTHER product kernels and finite differences, not
+    against the reference."""
     import torch
     from spectrobot_amd import synthetic as syn
     rng = np.random.default_rng(11)
@@ -410,7 +418,11 @@ def test_retrieval_forward_against_its_parts(eng, n_par, order):
     + Jacobians -> instrument bands) against the same steps taken one by one from the host: the VMR of the retrieved
     gas as sum_p x_p w_p on the host, a fresh LimbLOS with it, limb_rays_jacobian, hires_to_lowres.  Observer order (the
     batch re-lists its sample points; the device sums its own rows) and more parameters than the one-sweep kernel
-    takes (the path-order forward sensitivities behind the same entry point).  Two gases, only the second retrieved."""
+    takes (the path-order forward sensitivities behind the same entry point).  Two gases, only the second retrieved.
+
+    PARITY UNPINNED: the reference's radiance recursion and Jacobians live in the absent
+    spect_base_module; this test checks product kernels against OTHER product kernels and finite differences, not
+    against the reference."""
     import torch
     from spectrobot_amd import synthetic as syn
     rng = np.random.default_rng(21)
@@ -579,7 +591,7 @@ def test_resident_los_with_parameters_and_vmr_updates(eng):
     iteration through LimbLOS.set_vmr (one small copy + the column kernel).  Radiances and parameter Jacobians equal
     the per-call route's (everything staged on every call) bit for bit, before and after VMR updates, for the folded
     kernel (7 broad parameters) and the forward-sensitivity fallback (12 parameters); the radiance handle of the same
-    object follows the update too; observer-order batches refuse the update."""
+    object follows the update too; observer-order batches rebuild their resident form."""
     import torch
     from spectrobot_amd import synthetic as syn
     rng = np.random.default_rng(33)
@@ -608,10 +620,15 @@ def test_resident_los_with_parameters_and_vmr_updates(eng):
             assert torch.equal(r, r_ref) and torch.equal(j, j_ref), (n_par, it)
             assert torch.equal(eng.limb_rays(two, los), eng.limb_rays(two, fresh, resident=False)), (n_par, it)
         assert len(los._handles) == 2 and float(j.abs().max()) > 0
+    # observer-order batches re-list their sample points: sr_los_set_vmr refuses them, so LimbLOS.set_vmr drops their
+    # resident forms BEFORE it changes the host copy (the two never disagree) and the next call rebuilds
     obs = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], LOS_order="observer")
     eng.limb_rays(two, obs)
-    with pytest.raises(RuntimeError):
-        obs.set_vmr(L["vmr"] * 2.0)
+    assert len(obs._handles) == 1
+    obs.set_vmr(L["vmr"] * 2.0)
+    assert len(obs._handles) == 0
+    fresh = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"] * 2.0, LOS_order="observer")
+    assert torch.equal(eng.limb_rays(two, obs), eng.limb_rays(two, fresh, resident=False))
 
 
 def test_per_level_partial_radiances_sum_to_total(eng):

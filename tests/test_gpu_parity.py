@@ -316,6 +316,26 @@ def test_hires_to_lowres_golden(eng, golden):
         hi.hires_to_lowres(obs, spectral_widths=[1.0, 2.0])
 
 
+def test_hires_to_lowres_weight_cache_survives_a_reallocation(eng, golden):
+    """the band-weight table is cached between calls with the same bands and grid; the partial sums of
+    the rays follow it in the same buffer, so a call with many more rays re-allocates the buffer -- the cached table is
+    gone with it and must be rebuilt (the key used to be the buffer's address, which a new block can get again).
+    Same bands: 1 ray, then enough rays to outgrow the slack, then 1 again; every result against the golden values."""
+    import torch
+    g = golden("lowres_ils")
+    grid = _grid(g)
+    one = torch.tensor(g["spectrum"][None, :], device="cuda")
+    scale = 1.0 + np.arange(300) / 7.0
+    many = torch.tensor(g["spectrum"][None, :] * scale[:, None], device="cuda")
+    for rep in range(2):
+        low = eng.hires_to_lowres(one, grid, g["centers_nm"], g["widths_nm"], out_units="Wm2")
+        assert relerr(low[0], g["low_Wm2"]) < 1e-12
+        low = eng.hires_to_lowres(many, grid, g["centers_nm"], g["widths_nm"], out_units="Wm2")
+        assert relerr(low, scale[:, None] * g["low_Wm2"][None, :]) < 1e-12
+        many = torch.cat([many, many])      # the second round outgrows the buffer again
+        scale = np.concatenate([scale, scale])
+
+
 @pytest.mark.parametrize("far", [3, 2, 1])
 @pytest.mark.parametrize("seed", range(16))
 def test_randomized_configs_far_vs_exact_vs_oracle(eng, oracle, seed, far):
@@ -620,8 +640,8 @@ def test_two_gas_mixture_and_per_gas_jacobian(eng):
 def test_calls_on_unsynchronised_streams(eng):
     """Consecutive calls on ONE lineset from caller streams that are NOT ordered against each other (no
     wait_stream): the handle's shared scratch (far-field coefficients, zone sums, record tables) is
-    protected by the library's own end-of-previous-call event.  Every schedule: the decoupled pipeline (1, default),
-    round 3's order (2) and the serial one (0)."""
+    protected by the library's own end-of-previous-call event.  Both schedules: the decoupled pipeline (1, default)
+    and the serial one (0)."""
     import torch
     from spectrobot_amd import synthetic as syn
     grid = syn.make_grid(2987.0, 5e-4, 60000)
@@ -630,7 +650,7 @@ def test_calls_on_unsynchronised_streams(eng):
     atm = syn.make_atmosphere(24, 12)
     cases = [(atm["temps"] + 3.0 * i, atm["press"] * (1.0 + 0.5 * i), atm["tvib"] + 3.0 * i) for i in range(6)]
     try:
-        for overlap in (1, 2, 0):
+        for overlap in (1, 0):
             eng.set_overlap(0)
             ref = [ls.abscoeff_layers(T, P, tvib=tv) for T, P, tv in cases]
             torch.cuda.synchronize()
@@ -993,9 +1013,10 @@ def test_timing_events_can_be_switched_off(eng):
 
 @pytest.mark.gpu
 def test_schedules_agree_over_changing_shapes(eng):
-    """The three schedules of the coefficient op (sr_set_overlap: 1 the decoupled, phased pipeline on internal streams and
-    parity scratch, 2 round 3's order, 0 serial) over changing inputs, shard bounds, layer counts and weight modes --
-    every call re-sizes or re-uses the handle's scratch of its parity: same results bit for bit."""
+    """The two schedules of the coefficient op (sr_set_overlap: 1 the decoupled, phased pipeline on internal streams and
+    parity scratch, 0 serial on table set 0) over changing inputs, shard bounds, layer counts and weight modes, and
+    ALTERNATING between them (a serial call between pipelined ones shares their table set 0) -- every call re-sizes or
+    re-uses the handle's scratch: same results bit for bit."""
     import torch
     from spectrobot_amd import synthetic as syn
     grid = syn.make_grid(2980.0, 5e-4, 30000)
@@ -1003,19 +1024,21 @@ def test_schedules_agree_over_changing_shapes(eng):
     ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
     res = {}
     try:
-        for mode in (1, 2, 0):
-            eng.set_overlap(mode)
+        for mode in (1, 0, "alternating"):
+            eng.set_overlap(1 if mode == "alternating" else mode)
             out = []
             for rep in range(2):
                 for nl, lo, hi in ((10, 0, 30000), (7, 4000, 22000), (10, 0, 30000)):
                     atm = syn.make_atmosphere(nl, 12)
                     for shift in (0.0, 1.5, 3.0):
+                        if mode == "alternating":
+                            eng.set_overlap(len(out) // 2 % 2)
                         out.extend(ls.abscoeff_layers(atm["temps"] + shift, atm["press"], tvib=atm["tvib"] + shift, g_lo=lo, g_hi=hi))
                     out.append(ls.glevel_pairs(atm["temps"], atm["press"], g_lo=lo, g_hi=hi))
             torch.cuda.synchronize()
             res[mode] = out
     finally:
         eng.set_overlap(1)
-    for mode in (2, 0):
+    for mode in (0, "alternating"):
         assert len(res[mode]) == len(res[1]) == 42
         assert all(torch.equal(x, y) for x, y in zip(res[mode], res[1])), mode

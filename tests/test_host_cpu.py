@@ -187,6 +187,21 @@ def test_hardware_queues_default_is_set_before_hip_and_respects_the_caller():
     assert out.returncode == 0 and out.stdout.decode().strip() == "4"
 
 
+def test_c_abi_callers_learn_about_hardware_queues():
+    """a C-ABI caller that never imports the Python package gets the runtime's 4 hardware queues and a
+    3 % slower schedule unless told -- sr_recommended_hw_queues (no GPU needed) reports what to export and what the
+    process runs with."""
+    import ctypes as C
+    code = ("import ctypes as C, sys; L = C.CDLL(%r); r, c = C.c_int(0), C.c_int(0); "
+            "assert L.sr_recommended_hw_queues(C.byref(r), C.byref(c)) == 0; assert L.sr_recommended_hw_queues(None, None) == 0; "
+            "print(r.value, c.value)" % os.path.join(ROOT, "spectrobot_amd", "lib", "libspectrobot_hip.so"))
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    for given, want in ((None, "8 4"), ("8", "8 8"), ("2", "8 2")):
+        e = dict(env) if given is None else dict(env, GPU_MAX_HW_QUEUES=given)
+        out = subprocess.run([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert out.returncode == 0 and out.stdout.decode().strip() == want, (given, out.stdout, out.stderr.decode()[-500:])
+
+
 def test_async_gather_branch_bookkeeping(monkeypatch):
     """The asynchronous branch of all_gather_spectrum (taken for the RCCL backend only) with the collective
     replaced by a recorder: every Work handle is waited on exactly once -- on eviction (at most 4 in flight) or
