@@ -275,6 +275,8 @@ def main():
                     "(tuning aid for the multi-GPU shard size; not a bench line of the metric)")
     ap.add_argument("--3d", dest="three_d", action="store_true", help="--config 3 in its 3-D form: a coefficient row per LOS "
                     "step (P, T, T_vib at the local SZA along the path), Jacobians per altitude layer")
+    ap.add_argument("--level-route", type=int, default=1, choices=(0, 1), help="--config 3 / lut: level tables by the multi-channel "
+                    "pass (1, default: every line once) or by one coefficient op per level (0: the route of rounds 4-5)")
     ap.add_argument("--exact", action="store_true", help="evaluate every (line, point) exactly (no far-field expansions)")
     ap.add_argument("--far-field", type=int, default=3, choices=(1, 2, 3), help="3 (default): far-field expansions from box "
                     "pairs (multipole -> local), sparse line sets per line and box; 2: box pairs always; 1: per line and box")

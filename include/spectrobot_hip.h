@@ -220,12 +220,24 @@ int sr_abscoeff_level_dev(sr_lineset *ls, const sr_layers_desc *atm, int level, 
  * spect_main_module.py:1122-1168, spect_classes.py:1277-1337) and every LOS step is the population-weighted sum
  * abs += pop_L (Gabs_L - Gind_L), emi += pop_L Gsp_L over the levels (make_abscoeff_isomolec :2036-2106,
  * make_abscoeff_LUTS_fast :2200-2276).  Only the two spectra pop_L multiplies enter that sum, so the tables hold the
- * PAIR  A_L = Gabs_L - Gind_L,  E_L = Gsp_L  per level and (P, T) row: one pass of the coefficient kernels per level
- * over the lines whose upper or lower level is L (every line is evaluated twice in all; the three ctypes apart are
- * sr_gcoeff_layers_dev).  An iso-molecule without levels has the one pair of its 'all' set (n_levels counts as 1).
+ * PAIR  A_L = Gabs_L - Gind_L,  E_L = Gsp_L  per level and (P, T) row.
+ * Round 6: the MULTI-CHANNEL pass -- the near-field kernels walk the full line list ONCE (sr_zones_mc_kernel,
+ * sr_wings_mc_kernel: every line's three weighted contributions go to the LDS plane of the level they belong to), the
+ * far field stays one far-only pass per level sub-lineset (it is linear per output spectrum).  Before, every line was
+ * evaluated twice (in its upper level's pass and in its lower level's) and a sparse level's pass cost twice its lines'
+ * share; sr_set_level_route(0) keeps that route (one coefficient op per level), which the exact mode and counting
+ * passes always take.  The two routes differ by summation order only.  The three ctypes apart: sr_gcoeff_levels_dev.
+ * An iso-molecule without levels has the one pair of its 'all' set (n_levels counts as 1).
  * out: DEVICE [max(n_levels, 1)][2][n_layers][g_hi-g_lo] (level, A | E, row, point).  atm->tvib / q_part are not used.
  * Frozen region boundaries (sr_lineset_set_bounds_temps) apply as in every coefficient op. */
 int sr_glevel_pairs_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *out, void *stream);
+/* LookUpTable.make / LutSet.add_PT for ALL levels at once (spect_main_module.py:718-788, 1122-1168): the G spectra of
+ * every level and ctype on the (P, T) rows of atm, by the multi-channel pass (or, where it does not apply, by
+ * sr_gcoeff_layers_dev level by level).  g_out: DEVICE [max(n_levels, 1)][3][n_layers][g_hi-g_lo] =
+ * level, (sp_emission | ind_emission | absorption), row, point -- per level the layout of sr_gcoeff_layers_dev. */
+int sr_gcoeff_levels_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *g_out, void *stream);
+/* 1 (default): level tables by the multi-channel pass; 0: one coefficient op per level (the A/B partner and fallback). */
+int sr_set_level_route(int multi_channel);
 
 /* The combine loop of the level-factored route for n_steps LOS steps at once, each step on one (P, T) row of the
  * pair tables `tab` (as sr_glevel_pairs_dev writes them, n_rows rows):

@@ -78,6 +78,8 @@ SYMBOLS = {
                                          C.c_void_p, C.c_void_p]),
     "sr_abscoeff_layers": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int64, C.c_int64, dp, dp]),
     "sr_glevel_pairs_dev": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "sr_gcoeff_levels_dev": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "sr_set_level_route": (C.c_int, [C.c_int]),
     "sr_glevel_combine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, ip, dp, dp,
                                         C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_gcoeff_layers_dev": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int, C.c_int64, C.c_int64, C.c_void_p,

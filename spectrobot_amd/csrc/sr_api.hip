@@ -231,6 +231,7 @@ std::atomic<int> g_jac_layer_forward{[] { const char *e = getenv("SR_JAC_LAYER_M
 // sampler).  0 prep, 1 level-0 far-field pass, 2 S2M + M2M, 3 M2L, 4 zones, 5 wings.  Results of a repeated M2L are NOT
 // valid (it adds into the level-0 coefficients); everything else stores.
 std::atomic<int> g_repeat_kernel{-1}, g_repeat_n{1};
+std::atomic<int> g_level_route{1}; // sr_set_level_route: 1 (default) the multi-channel pass for level tables, 0 one coefficient op per level
 std::atomic<int> g_timing{1};    // 0: no timing events in the coefficient op (sr_set_timing: seven hipEventRecord fewer per call)
 std::atomic<int> g_counting{0};  // 1: counting instantiations of the far-field-mode kernels (sr_set_counting)
 std::atomic<size_t> g_table_budget{(size_t)48 << 30}; // bytes of FastRec + ColdRec tables per layer batch
@@ -304,6 +305,37 @@ struct CoefWork {
   }
 };
 
+// Scratch of the multi-channel pass (mc_pass): record tables of the FULL list with the three channel weights, the
+// far-only coefficients of the level passes, its zones stream, and the CoefWorks the far-only passes run through (not
+// the handle's shared one: folded ops on the handle and the passes of one table build do not wait for each other's scratch).
+constexpr int kMcFarLanes = 4; // far-only level passes in flight side by side (each on its own CoefWork: tables, streams, events)
+struct McWork {
+  CoefWork fw[kMcFarLanes];
+  bool fw_init = false, batch_pending = false;
+  Stager s_layers, s_far, s_batch;
+  DevBuf d_fast, d_cold, d_coef, d_outer_recs, d_bfast;
+  hipStream_t zst = nullptr;
+  hipEvent_t ev_prep = nullptr, ev_zones = nullptr;
+  void release() {
+    if (fw_init)
+      for (auto &f : fw) f.release();
+    fw_init = false;
+    s_layers.release();
+    s_far.release();
+    s_batch.release();
+    d_fast.release();
+    d_cold.release();
+    d_coef.release();
+    d_outer_recs.release();
+    d_bfast.release();
+    if (zst) (void)hipStreamDestroy(zst);
+    if (ev_prep) (void)hipEventDestroy(ev_prep);
+    if (ev_zones) (void)hipEventDestroy(ev_zones);
+    zst = nullptr;
+    ev_prep = ev_zones = nullptr;
+  }
+};
+
 struct sr_lineset {
   int64_t n_lines = 0; // main lines (centre inside its own window)
   HostLines host, host_outer; // host copies: per-level subsets are cut from them (level_set)
@@ -329,6 +361,7 @@ struct sr_lineset {
   int first_x0 = 0, first_n = 0; // IcIndex table domain
   CoefWork own_work;
   CoefWork *work = nullptr;      // &own_work, or the parent's for a per-level sub-lineset
+  McWork mc;                     // the multi-channel pass of this handle (parents only)
   std::vector<double> bounds_temps; // sr_lineset_set_bounds_temps: empty = boundaries at the call's own temperatures
   sr_lineset *parent = nullptr;     // per-level sub-lineset: the handle it was cut from (its bounds_temps apply)
   bool linear_weights = false;      // sr_lineset_set_linear_weights (takes effect with bounds_temps only)
@@ -405,6 +438,11 @@ int sr_set_kernel_repeat(int kernel, int n) {
   if (kernel < -1 || kernel > 5 || n < 1) return SR_ERR_ARG;
   g_repeat_kernel.store(kernel);
   g_repeat_n.store(kernel < 0 ? 1 : n);
+  return SR_OK;
+}
+
+int sr_set_level_route(int multi_channel) {
+  g_level_route.store(multi_channel ? 1 : 0);
   return SR_OK;
 }
 
@@ -693,6 +731,7 @@ int sr_lineset_destroy(sr_lineset *ls) {
   ls->d_lines.release();
   ls->d_first.release();
   if (ls->work == &ls->own_work) ls->own_work.release();
+  ls->mc.release();
   delete ls;
   return SR_OK;
 }
@@ -720,11 +759,137 @@ static int m2l_table_dev(const double **out) {
   return SR_OK;
 }
 
+// Downward-pass operator of the hierarchy (sr_l2l_kernel): built once per process and device (8 KB).
+static int l2l_table_dev(const double **out) {
+  static std::mutex mu;
+  static std::map<int, double *> tabs;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = tabs.find(dev);
+  if (it == tabs.end()) {
+    const size_t n = (size_t)2 * kFC * kFC;
+    std::vector<double> h(n);
+    l2l_table_host(h.data());
+    double *d = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), sizeof(double) * n));
+    HIPCHK(hipMemcpy(d, h.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    it = tabs.emplace(dev, d).first;
+  }
+  *out = it->second;
+  return SR_OK;
+}
+
+// Per-layer scalars of a call (host, fp64): T, P [atm], 296/T, sqrt(2 N_A k T ln2 / MM), the same at the boundary
+// temperatures, the level populations, then three int rows: pole margin, source pole radius, widest zone.
+//   mar: the lineset whose lines bound the margins -- the handle itself, or its PARENT for the far-only level passes of
+//        the multi-channel route (every kernel of that route must place a (line, slot) pair on the same side of the
+//        near / far split: the pole margin enters the admissibility threshold)
+static size_t layer_stage_doubles(int nl, int npop) { return (size_t)nl * (8 + npop); }
+static size_t layer_stage_bytes(int nl, int npop) { return sizeof(double) * layer_stage_doubles(nl, npop) + sizeof(int) * 3 * (size_t)nl; }
+static int fill_layer_stage(const sr_lineset *ls, const sr_lineset *mar, const sr_lineset *bown, const sr_layers_desc *atm, double *T) {
+  const int nl = atm->n_layers, nlev = ls->n_levels, npop = nlev > 0 ? nlev : 1;
+  const size_t hl_doubles = layer_stage_doubles(nl, npop);
+  const bool frozen = !bown->bounds_temps.empty();
+  double *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *ltr = sq + nl, *ltrb = ltr + nl, *sqb = ltrb + nl, *tb = sqb + nl,
+         *pop = tb + nl;
+  std::vector<double> q(nl);
+  if (atm->q_part) {
+    std::copy(atm->q_part, atm->q_part + nl, q.begin());
+  } else {
+    const int rc = sr_calc_partition_sum(ls->mol, ls->iso, atm->temps, nl, q.data());
+    if (rc) return rc;
+  }
+  for (int k = 0; k < nl; ++k) {
+    T[k] = atm->temps[k];
+    pa[k] = atm->press[k] * kHpaToAtm;                                        // spect_classes.py:2034
+    tr[k] = kTref / T[k];                                                     // :1972
+    sq[k] = std::sqrt(2 * kAvogadro * kKcgs * T[k] * kLn2 / ls->mm);          // :1984
+    ltr[k] = std::log(tr[k]);
+    {
+      const double Tb = frozen ? bown->bounds_temps[k] : T[k]; // where the region boundaries are placed
+      tb[k] = Tb;
+      ltrb[k] = std::log(kTref / Tb);
+      sqb[k] = std::sqrt(2 * kAvogadro * kKcgs * Tb * kLn2 / ls->mm);
+    }
+    {
+      // pole margin of the far-field expansions: the region-1 rational has its poles at
+      // |x| = sqrt(1/2 + ry^2), i.e. within 0.71 dw' of the line centre on the real axis.
+      // Frozen boundaries (sr_lineset_set_bounds_temps): the zone of a line is placed with the widths of the
+      // boundary temperature Tb, the poles sit where the call's own widths put them -- the bounds below cover both
+      // (with the call's T alone a frozen zone wider than zmax, Tb > T, lost its outer points: ADVICE round 3).
+      const double sq_w = std::max(sq[k], sqb[k]);
+      const double dwp_max = mar->freq_max / kCcgs * sq_w / std::sqrt(kLn2);
+      int *pmh = reinterpret_cast<int *>(T + hl_doubles);
+      pmh[k] = (int)std::ceil(0.71 * dwp_max / ls->gp.gstep) + 1;
+      // box-pair mode: the multipole series of a source box converges outside the largest |pole| =
+      // sqrt(1/2 + ry^2) dw' = sqrt(dw'^2 / 2 + lw^2) of its lines (bound over the lines of the layer)
+      const double trb = frozen ? kTref / bown->bounds_temps[k] : tr[k];
+      const double lw_max = mar->gamma_max * pa[k] *
+                            std::max(std::max(std::pow(tr[k], mar->ndep_min), std::pow(tr[k], mar->ndep_max)),
+                                     std::max(std::pow(trb, mar->ndep_min), std::pow(trb, mar->ndep_max)));
+      const double pole = std::sqrt(0.5 * dwp_max * dwp_max + lw_max * lw_max) / ls->gp.gstep;
+      pmh[nl + k] = (int)std::ceil(std::min(pole, 1e6));
+      // widest region-2/3/4 zone of the layer, in grid points from the line centre: region 1 starts where
+      // |x| - ry >= 15 (lineshape.f:447-454), i.e. (lw + 15 dw') / step points out, +-1 for the nint and the
+      // centre's offset inside its grid cell.  A bound over the lines (every kernel reads this one value, so they
+      // agree on who evaluates what); kernels clamp it to the window half-width.
+      pmh[2 * nl + k] = (int)std::min(std::ceil((lw_max + 15.0 * dwp_max) / ls->gp.gstep) + 2.0, (double)kHalf);
+    }
+    if (nlev > 0) {
+      for (int lv = 0; lv < nlev; ++lv) {
+        const double vibt = atm->tvib ? atm->tvib[(size_t)lv * nl + k] : T[k]; // smm:2062-2065
+        pop[(size_t)k * npop + lv] = std::exp(-kC2 * ls->e_lev[lv] / vibt) / q[k]; // smm:2073
+      }
+    } else {
+      pop[k] = 1 / q[k]; // smm:2054
+    }
+  }
+  return SR_OK;
+}
+// The device view of a pushed layer stage.  d_pm: [3][n_layers] pole margin | source pole radius | widest zone.
+static LayersDev layers_dev_of(const double *dl, int nl, int npop, bool frozen, bool linear_w, const int **d_pm) {
+  LayersDev A;
+  A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.ltrat = dl + 4 * nl;
+  A.ltrat_b = dl + 5 * nl; A.sqk_b = dl + 6 * nl; A.temps_b = dl + 7 * nl; A.pop = dl + 8 * nl;
+  A.frozen = frozen ? 1 : 0;
+  A.linear_w = frozen && linear_w ? 1 : 0;
+  A.n_layers = nl; A.n_pop = npop;
+  A.sqrt_ln2 = std::sqrt(kLn2);            // spect_classes.py:1999
+  A.sqrt_pi_ln2 = std::sqrt(kPi / kLn2);   // :1997
+  *d_pm = reinterpret_cast<const int *>(dl + layer_stage_doubles(nl, npop));
+  return A;
+}
+// The far-field box hierarchy of a shard of n_pts points (the part of FarParams every kernel agrees on)
+static void far_hierarchy(size_t n_pts, int nl, FarParams *fp) {
+  fp->n_levels = kMaxFarLevels;
+  fp->n_layers = nl;
+  fp->n_boxes_total = 0;
+  fp->top_first = n_pts <= 16384 ? 1 : 0; // see sr_farfield_kernel
+  for (int lv = 0; lv < kMaxFarLevels; ++lv) {
+    const int W = 64 << lv;
+    fp->box_count[lv] = (int)((n_pts + W - 1) / W);
+    fp->box_off[lv] = fp->n_boxes_total;
+    fp->n_boxes_total += fp->box_count[lv];
+  }
+}
+
+// Options of coef_op beyond the public entry points'.
+//   far_coef: a FAR-ONLY pass for the multi-channel route (mc_pass) -- tables and the far-field chain only, the
+//   coefficients [n_layers][n_boxes_total][2][kFC] written there and folded down to level 0 (sr_l2l_kernel: wider levels
+//   hold partial sums afterwards, level 0 everything); no near kernels, no outer lines, abs_out / emi_out
+//   untouched (may be null); the margins are the PARENT's (fill_layer_stage); *far_has = whether any line met the shard.
+struct CoefOpt {
+  double *far_coef = nullptr;
+  bool *far_has = nullptr;
+};
+
 // The coefficient op with the output weights of `W` (sr_kernels.hpp); the public entry points below
 // choose W.  abs_out / emi_out: DEVICE [n_layers][g_hi - g_lo].
 static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *abs_out,
-                   double *emi_out, void *stream, const WeightMode W) {
-  if (!ls || !atm || !abs_out || !emi_out) return SR_ERR_ARG;
+                   double *emi_out, void *stream, const WeightMode W, const CoefOpt opt = CoefOpt()) {
+  const bool far_only = opt.far_coef != nullptr;
+  if (!ls || !atm || (!far_only && (!abs_out || !emi_out))) return SR_ERR_ARG;
   if (atm->n_layers <= 0 || !atm->temps || !atm->press) return SR_ERR_ARG;
   if (g_lo < 0 || g_hi > ls->gp.n_grid || g_lo >= g_hi) return SR_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -746,6 +911,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   const int far_mode = g_far_field.load();
   const bool sparse_set = far_mode == 3 && (double)ls->n_lines < sparse_thr * (double)ls->gp.n_grid;
   const int far_field = far_mode == 3 ? (sparse_set ? 1 : 2) : far_mode;
+  if (far_only && !far_field) return SR_ERR_UNSUPPORTED; // (mc_pass takes the per-level route in the exact mode)
   const bool counting = g_counting.load() != 0 && far_field;
   // 1: the decoupled, phased pipeline (far-field modes); 0: the kernels one after the other on the caller's stream, on
   // table set 0 -- sr_set_overlap(0), the exact mode and the counting passes (whose counters are zeroed and read on the
@@ -767,6 +933,10 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
                              + (overlap ? 2 * sizeof(double) * n_pts_b : 0)          // the zones kernel's private sums (small shards)
                              + sizeof(OuterRec) * (size_t)std::max(ls->n_outer, 0);  // records of the outer lines
     const int nl_max = (int)std::max<size_t>(1, table_budget / per_layer);
+    if (nl > nl_max && far_only) {
+      g_err = "far-only pass over more layers than the table budget holds (mc_pass sizes its row batches for the parent)";
+      return SR_ERR_LIMIT;
+    }
     if (nl > nl_max) {
       const size_t n_pts_all = (size_t)(g_hi - g_lo);
       // sr_lineset_set_bounds_temps: every batch sees its own slice of the boundary temperatures
@@ -802,14 +972,13 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     }
   }
 
-  // per-layer scalars (host, fp64)
-  const size_t hl_doubles = (size_t)nl * (8 + npop);
+  // per-layer scalars (host, fp64: fill_layer_stage)
   const bool frozen = !bown->bounds_temps.empty(); // sr_lineset_set_bounds_temps
   if (frozen && (int)bown->bounds_temps.size() != nl) {
     g_err = "sr_lineset_set_bounds_temps was given another number of layers than this call";
     return SR_ERR_ARG;
   }
-  const size_t hl_bytes = sizeof(double) * hl_doubles + sizeof(int) * 3 * (size_t)nl; // + pole margins pm, pm_src, widest zone
+  const size_t hl_bytes = layer_stage_bytes(nl, npop);
   // Table set of this call and the stream its preparation runs on.  With overlap, call c + 1
   // prepares set (c + 1) % 2 on prep_st while the kernels of call c (which the caller's stream is
   // still running) read set c % 2: the HBM-write-bound prep kernel hides behind the VALU-bound ones.
@@ -836,75 +1005,15 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   DevBuf &d_fast = w.d_fast[b], &d_cold = w.d_cold[b];
   int rc = SL.prepare(hl_bytes);
   if (rc) return rc;
-  double *T = SL.host<double>(), *pa = T + nl, *tr = pa + nl, *sq = tr + nl, *ltr = sq + nl, *ltrb = ltr + nl,
-         *sqb = ltrb + nl, *tb = sqb + nl, *pop = tb + nl;
-  std::vector<double> q(nl);
-  if (atm->q_part) {
-    std::copy(atm->q_part, atm->q_part + nl, q.begin());
-  } else {
-    rc = sr_calc_partition_sum(ls->mol, ls->iso, atm->temps, nl, q.data());
-    if (rc) return rc;
-  }
-  for (int k = 0; k < nl; ++k) {
-    T[k] = atm->temps[k];
-    pa[k] = atm->press[k] * kHpaToAtm;                                        // spect_classes.py:2034
-    tr[k] = kTref / T[k];                                                     // :1972
-    sq[k] = std::sqrt(2 * kAvogadro * kKcgs * T[k] * kLn2 / ls->mm);          // :1984
-    ltr[k] = std::log(tr[k]);
-    {
-      const double Tb = frozen ? bown->bounds_temps[k] : T[k]; // where the region boundaries are placed
-      tb[k] = Tb;
-      ltrb[k] = std::log(kTref / Tb);
-      sqb[k] = std::sqrt(2 * kAvogadro * kKcgs * Tb * kLn2 / ls->mm);
-    }
-    {
-      // pole margin of the far-field expansions: the region-1 rational has its poles at
-      // |x| = sqrt(1/2 + ry^2), i.e. within 0.71 dw' of the line centre on the real axis.
-      // Frozen boundaries (sr_lineset_set_bounds_temps): the zone of a line is placed with the widths of the
-      // boundary temperature Tb, the poles sit where the call's own widths put them -- the bounds below cover both
-      // (with the call's T alone a frozen zone wider than zmax, Tb > T, lost its outer points: ADVICE round 3).
-      const double sq_w = std::max(sq[k], sqb[k]);
-      const double dwp_max = ls->freq_max / kCcgs * sq_w / std::sqrt(kLn2);
-      int *pmh = reinterpret_cast<int *>(T + hl_doubles);
-      pmh[k] = (int)std::ceil(0.71 * dwp_max / ls->gp.gstep) + 1;
-      // box-pair mode: the multipole series of a source box converges outside the largest |pole| =
-      // sqrt(1/2 + ry^2) dw' = sqrt(dw'^2 / 2 + lw^2) of its lines (bound over the lines of the layer)
-      const double trb = frozen ? kTref / bown->bounds_temps[k] : tr[k];
-      const double lw_max = ls->gamma_max * pa[k] *
-                            std::max(std::max(std::pow(tr[k], ls->ndep_min), std::pow(tr[k], ls->ndep_max)),
-                                     std::max(std::pow(trb, ls->ndep_min), std::pow(trb, ls->ndep_max)));
-      const double pole = std::sqrt(0.5 * dwp_max * dwp_max + lw_max * lw_max) / ls->gp.gstep;
-      pmh[nl + k] = (int)std::ceil(std::min(pole, 1e6));
-      // widest region-2/3/4 zone of the layer, in grid points from the line centre: region 1 starts where
-      // |x| - ry >= 15 (lineshape.f:447-454), i.e. (lw + 15 dw') / step points out, +-1 for the nint and the
-      // centre's offset inside its grid cell.  A bound over the lines (every kernel reads this one value, so they
-      // agree on who evaluates what); kernels clamp it to the window half-width.
-      pmh[2 * nl + k] = (int)std::min(std::ceil((lw_max + 15.0 * dwp_max) / ls->gp.gstep) + 2.0, (double)kHalf);
-    }
-    if (nlev > 0) {
-      for (int lv = 0; lv < nlev; ++lv) {
-        const double vibt = atm->tvib ? atm->tvib[(size_t)lv * nl + k] : T[k]; // smm:2062-2065
-        pop[(size_t)k * npop + lv] = std::exp(-kC2 * ls->e_lev[lv] / vibt) / q[k]; // smm:2073
-      }
-    } else {
-      pop[k] = 1 / q[k]; // smm:2054
-    }
-  }
+  rc = fill_layer_stage(ls, far_only && ls->parent ? ls->parent : ls, bown, atm, SL.host<double>());
+  if (rc) return rc;
   // set b was last read by the kernels of the call before the previous one
   if (overlap && w.free_recorded[b]) HIPCHK(hipStreamWaitEvent(pst, w.ev_tables_free[b], 0));
   rc = SL.push(hl_bytes, pst);
   if (rc) return rc;
-  LayersDev A;
-  const double *dl = SL.d.as<double>();
-  A.temps = dl; A.p_atm = dl + nl; A.trat = dl + 2 * nl; A.sqk = dl + 3 * nl; A.ltrat = dl + 4 * nl;
-  A.ltrat_b = dl + 5 * nl; A.sqk_b = dl + 6 * nl; A.temps_b = dl + 7 * nl; A.pop = dl + 8 * nl;
-  A.frozen = frozen ? 1 : 0;
-  A.linear_w = frozen && bown->linear_weights ? 1 : 0;
-  A.n_layers = nl; A.n_pop = npop;
-  const int *d_pm = reinterpret_cast<const int *>(dl + hl_doubles);
-  const int *zmax_dev = d_pm + 2 * nl; // [n_layers] widest zone (host bound, see above)
-  A.sqrt_ln2 = std::sqrt(kLn2);            // spect_classes.py:1999
-  A.sqrt_pi_ln2 = std::sqrt(kPi / kLn2);   // :1997
+  const int *d_pm = nullptr;
+  const LayersDev A = layers_dev_of(SL.d.as<double>(), nl, npop, frozen, bown->linear_weights, &d_pm);
+  const int *zmax_dev = d_pm + 2 * nl; // [n_layers] widest zone (host bound, see fill_layer_stage)
 
   // lines whose window [ic-6505, ic+6504] meets the shard
   const auto lo_it = std::lower_bound(ls->ic.begin(), ls->ic.end(), (int)g_lo - (kHalf - 1));
@@ -934,6 +1043,8 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
                            abs_out, emi_out, st));
     return SR_OK;
   };
+  if (opt.far_has) *opt.far_has = n_sub > 0;
+  if (n_sub <= 0 && far_only) return SR_OK; // nothing staged on the internal streams: no event to record
   if (n_sub <= 0) {
     HIPCHK(hipMemsetAsync(abs_out, 0, sizeof(double) * n_pts * nl, st));
     HIPCHK(hipMemsetAsync(emi_out, 0, sizeof(double) * n_pts * nl, st));
@@ -966,8 +1077,9 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   if (timing) HIPCHK(hipEventRecord(w.ev[0], pst));
   // cold records: far-field mode reads them for zones inside the shard only, exact mode for window ends too
   for (int r = 0; r < reps(0); ++r)
-  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, W, line_lo, n_sub, far_field ? (int)g_lo : INT_MIN / 2,
-                        far_field ? (int)g_hi - 1 : INT_MAX / 2, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), pst));
+  LAUNCHCHK(launch_prep(ls->L, A, ls->gp, W, line_lo, n_sub, far_only ? INT_MAX / 2 : (far_field ? (int)g_lo : INT_MIN / 2),
+                        far_only ? INT_MIN / 2 : (far_field ? (int)g_hi - 1 : INT_MAX / 2), d_fast.as<FastRec>(),
+                        d_cold.as<ColdRec>(), pst)); // (far-only: an empty cold range, no region-2..4 records)
   if (timing) HIPCHK(hipEventRecord(w.ev[1], pst));
   if (overlap) { // the caller's stream takes over once the tables are ready
     HIPCHK(hipEventRecord(w.ev_prep_done[b], pst));
@@ -976,20 +1088,13 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   }
   if (far_field) {
     FarParams fp;
-    fp.n_levels = kMaxFarLevels;
-    fp.n_layers = nl;
-    fp.n_boxes_total = 0;
-    fp.top_first = n_pts <= 16384 ? 1 : 0; // see sr_farfield_kernel
-    for (int lv = 0; lv < kMaxFarLevels; ++lv) {
-      const int W = 64 << lv;
-      fp.box_count[lv] = (int)((n_pts + W - 1) / W);
-      fp.box_off[lv] = fp.n_boxes_total;
-      fp.n_boxes_total += fp.box_count[lv];
+    far_hierarchy(n_pts, nl, &fp);
+    if (!far_only) {
+      rc = w.d_coef[b].ensure(sizeof(double) * (size_t)nl * fp.n_boxes_total * 2 * kFC);
+      if (rc) return rc;
     }
-    rc = w.d_coef[b].ensure(sizeof(double) * (size_t)nl * fp.n_boxes_total * 2 * kFC);
-    if (rc) return rc;
     fp.pm = d_pm;
-    fp.coef = w.d_coef[b].as<double>();
+    fp.coef = far_only ? opt.far_coef : w.d_coef[b].as<double>();
     fp.m2l = far_field == 2 ? 1 : 0;
     fp.rows = sparse_set ? 1 : 0; // the sparse sets' own kernel (sr_farfield_rows_kernel: a box for eight layers per wave)
     fp.pm_src = d_pm + nl;
@@ -1056,9 +1161,13 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
           HIPCHK(hipEventCreateWithFlags(&w.ev_s2m_done[i], hipEventDisableTiming));
         }
       }
-      rc = w.d_zone2[b].ensure(sizeof(double) * 2 * n_pts * nl);
-      if (rc) return rc;
-      double *z_abs = w.d_zone2[b].as<double>(), *z_emi = z_abs + n_pts * nl;
+      double *z_abs = nullptr, *z_emi = nullptr;
+      if (!far_only) {
+        rc = w.d_zone2[b].ensure(sizeof(double) * 2 * n_pts * nl);
+        if (rc) return rc;
+        z_abs = w.d_zone2[b].as<double>();
+        z_emi = z_abs + n_pts * nl;
+      }
       // (the buffers of parity b were last read by the wings kernel two calls ago: the preparation waited for that)
       // far-field chain: level-0 pass on one stream, moments + upward pass on another, translations behind both
       HIPCHK(hipStreamWaitEvent(w.chain_st, w.ev_prep_done[b], 0));
@@ -1073,7 +1182,16 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         LAUNCHCHK(launch_m2l(d_fast.as<FastRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, fp, d_cnt, w.chain2_st, 2));
         last = w.chain2_st;
       }
+      if (far_only) { // the downward pass: the wider levels into the level-0 coefficients, behind the chain on its stream
+        const double *l2l_tab = nullptr;
+        rc = l2l_table_dev(&l2l_tab);
+        if (rc) return rc;
+        LAUNCHCHK(launch_l2l(fp.coef, nl, fp, l2l_tab, last));
+      }
       HIPCHK(hipEventRecord(w.ev_far_done[b], last));
+      if (far_only) { // the coefficients are the result: the caller's stream sees them complete
+        HIPCHK(hipStreamWaitEvent(st, w.ev_far_done[b], 0));
+      } else {
       // zones: needs the tables only; gated behind the kernels that cannot run beside it
       HIPCHK(hipStreamWaitEvent(w.aux, w.ev_prep_done[b], 0));
       HIPCHK(hipStreamWaitEvent(w.aux, w.ev_l0_done[b], 0));
@@ -1086,6 +1204,7 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       HIPCHK(hipStreamWaitEvent(st, w.ev_zones_done[b], 0));
       LAUNCHCHK(launch_near(1, 0, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix, zmax_dev, n_sub, nl, (int)g_lo,
                             (int)g_hi, ls->gp, fp, abs_out, emi_out, d_cnt, st, z_abs, z_emi));
+      }
       if (timing) HIPCHK(hipEventRecord(w.ev[3], st));
       if (timing) HIPCHK(hipEventRecord(w.ev[4], st));
       w.overlapped = true;
@@ -1093,9 +1212,15 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       w.overlapped = false;
       rc = far_pass(st);
       if (rc) return rc;
+      if (far_only) {
+        const double *l2l_tab = nullptr;
+        rc = l2l_table_dev(&l2l_tab);
+        if (rc) return rc;
+        LAUNCHCHK(launch_l2l(fp.coef, nl, fp, l2l_tab, st));
+      }
       if (timing) HIPCHK(hipEventRecord(w.ev[2], st));
       // wings (writes) then zones (adds); the repeat hook's zones launches store instead (idempotent)
-      for (int part = 1; part <= 2; ++part) {
+      for (int part = 1; part <= 2 && !far_only; ++part) {
         const int n_rep = reps(part == 1 ? 5 : 4);
         for (int r = 0; r < n_rep; ++r)
           LAUNCHCHK(launch_near(part, part == 2 && n_rep == 1, d_fast.as<FastRec>(), d_cold.as<ColdRec>(), ix,
@@ -1114,8 +1239,10 @@ static int coef_op(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       if (timing) HIPCHK(hipEventRecord(w.ev[2 + which], st));
     }
   }
-  rc = add_outer(); // after the timing events: not part of the per-kernel times
-  if (rc) return rc;
+  if (!far_only) {
+    rc = add_outer(); // after the timing events: not part of the per-kernel times
+    if (rc) return rc;
+  }
   // a serial call reads table set 0 too: a later pipelined call, which prepares its set on prep_st without waiting for
   // the caller's stream, must find the event behind THIS call's kernels
   if (w.ev_tables_free[b]) {
@@ -1171,6 +1298,267 @@ static int level_set(sr_lineset *ls, int level, sr_lineset **out, bool up_only =
   return SR_OK;
 }
 
+// ------------------------------------------------------------------------
+// The multi-channel pass: all level spectra of a (P, T) row stack from ONE walk of the full line list (near field:
+// sr_zones_mc_kernel, sr_wings_mc_kernel) + one far-only pass per level sub-lineset (the far field is linear per output
+// spectrum: its translations and polynomials cost the same per level whoever sums them).
+//   ctypes3 = 0: out [n_levels][2][n_rows][n_pts], the pair tables of sr_glevel_pairs_dev
+//   ctypes3 = 1: out [n_levels][3][n_rows][n_pts], sp_emission | ind_emission | absorption (sr_gcoeff_levels_dev)
+// Returns SR_ERR_UNSUPPORTED (and does nothing) where the route does not apply -- exact mode, counting passes, more
+// channels than an LDS image holds, 80-byte records -- the callers then run one coefficient op per level.
+// spect_main_module.py:1122-1168 (add_PT per level), spect_classes.py:1304-1321 (which lines a level owns).
+// ------------------------------------------------------------------------
+static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *out, void *stream, int ctypes3) {
+#if !SR_FASTREC64
+  return SR_ERR_UNSUPPORTED;
+#else
+  const int nlev = ls->n_levels, n_rows = atm->n_layers;
+  const int far_mode = g_far_field.load();
+  if (nlev <= 0 || far_mode == 0 || g_counting.load() != 0 || g_level_route.load() == 0) return SR_ERR_UNSUPPORTED;
+  if (!atm->temps || !atm->press) return SR_ERR_ARG;
+  if (g_lo < 0 || g_hi > ls->gp.n_grid || g_lo >= g_hi) return SR_ERR_ARG;
+  for (int k = 0; k < n_rows; ++k)
+    if (!(atm->temps[k] > 0.0) || !(atm->press[k] >= 0.0)) return SR_ERR_ARG;
+  McChannels mc;
+  mc.stride = ctypes3 ? 3 : 2;
+  mc.o_lo = ctypes3 ? 2 : 0;
+  mc.o_up_e = ctypes3 ? 0 : 1;
+  mc.o_up_a = ctypes3 ? 1 : 0;
+  mc.n_ch = mc.stride * nlev;
+  if (mc.n_ch > 1023) return SR_ERR_UNSUPPORTED; // (10 bits per channel in the zones kernel's packed item word)
+  if (sizeof(double) * (size_t)mc.n_ch * (kMcImage + 2) + sizeof(int) * (size_t)kMcWaves * 2 * 4 * 64 > (size_t)160 * 1024 ||
+      sizeof(double) * (size_t)mc.n_ch * 64 > (size_t)64 * 1024)
+    return SR_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CoefWork &w = *ls->work;
+  McWork &m = ls->mc;
+  const size_t n_pts = (size_t)(g_hi - g_lo);
+  const int n_far = ctypes3 ? 2 * nlev : nlev;
+  FarParams fp0;
+  far_hierarchy(n_pts, 1, &fp0);
+  const size_t coef_row = (size_t)fp0.n_boxes_total * 2 * kFC; // doubles per (far pass, row)
+  // Row batches: the full list's records + every far pass's coefficients + what the largest level pass needs of the
+  // shared CoefWork (two table sets, far-field scratch) stay under the table budget
+  const size_t per_row = (size_t)std::max<int64_t>(ls->n_lines, 1) * (sizeof(FastRec) + sizeof(ColdRec)) * 4 +
+                         sizeof(double) * coef_row * (size_t)(n_far + 2) + 4 * ((n_pts + 64 * kSrcPad + kHalf) / 64 + 16) * (size_t)kMomPerBox * sizeof(double);
+  const int rows_max = (int)std::max<size_t>(1, g_table_budget.load() / per_row);
+  const std::vector<double> bounds_all = ls->bounds_temps;
+  if (!bounds_all.empty() && (int)bounds_all.size() != n_rows) {
+    g_err = "sr_lineset_set_bounds_temps was given another number of layers than this call";
+    return SR_ERR_ARG;
+  }
+  struct Restore {
+    sr_lineset *ls; const std::vector<double> &all;
+    ~Restore() { ls->bounds_temps = all; }
+  } restore{ls, bounds_all};
+  if (!m.zst) {
+    HIPCHK(hipStreamCreateWithFlags(&m.zst, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&m.ev_prep, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m.ev_zones, hipEventDisableTiming));
+  }
+  const int npop = nlev;
+  for (int k0 = 0; k0 < n_rows; k0 += rows_max) {
+    const int nl = std::min(rows_max, n_rows - k0);
+    sr_layers_desc sub = *atm;
+    sub.n_layers = nl;
+    sub.temps = atm->temps + k0;
+    sub.press = atm->press + k0;
+    sub.q_part = atm->q_part ? atm->q_part + k0 : nullptr;
+    sub.tvib = nullptr; // (no populations enter the level spectra)
+    if (!bounds_all.empty()) ls->bounds_temps.assign(bounds_all.begin() + k0, bounds_all.begin() + k0 + nl);
+    const bool frozen = !ls->bounds_temps.empty();
+    // this batch after everything earlier on the handle (the previous batch's kernels read the tables refilled below)
+    if (w.last_done_recorded) HIPCHK(hipStreamWaitEvent(st, w.ev_last_done, 0));
+    const size_t hl_bytes = layer_stage_bytes(nl, npop);
+    int rc = m.s_layers.prepare(hl_bytes);
+    if (rc) return rc;
+    rc = fill_layer_stage(ls, ls, ls, &sub, m.s_layers.host<double>());
+    if (rc) return rc;
+    rc = m.s_layers.push(hl_bytes, st);
+    if (rc) return rc;
+    const int *d_pm = nullptr;
+    const LayersDev A = layers_dev_of(m.s_layers.d.as<double>(), nl, npop, frozen, ls->linear_weights, &d_pm);
+    const int *zmax_dev = d_pm + 2 * nl;
+    const auto lo_it = std::lower_bound(ls->ic.begin(), ls->ic.end(), (int)g_lo - (kHalf - 1));
+    const auto hi_it = std::upper_bound(ls->ic.begin(), ls->ic.end(), (int)g_hi - 1 + kHalf);
+    const int line_lo = (int)(lo_it - ls->ic.begin());
+    const int n_sub = (int)(hi_it - lo_it);
+    const IcIndex ix{ls->d_first.as<int>(), ls->first_x0, ls->first_n, line_lo, n_sub};
+    auto chan_rows = [&](int c) { return out + ((size_t)c * n_rows + (size_t)k0) * n_pts; };
+    if (n_sub <= 0) {
+      for (int c = 0; c < mc.n_ch; ++c) HIPCHK(hipMemsetAsync(chan_rows(c), 0, sizeof(double) * n_pts * nl, st));
+    } else {
+      rc = m.d_fast.ensure(sizeof(FastRec) * ((size_t)n_sub * nl + 1));
+      if (rc) return rc;
+      rc = m.d_cold.ensure(sizeof(ColdRec) * ((size_t)n_sub * nl + 1));
+      if (rc) return rc;
+      rc = m.d_coef.ensure(sizeof(double) * coef_row * (size_t)nl * n_far);
+      if (rc) return rc;
+      LAUNCHCHK(launch_prep(ls->L, A, ls->gp, WeightMode{kWeightChannels, ctypes3 ? 1 : 0}, line_lo, n_sub, (int)g_lo, (int)g_hi - 1,
+                            m.d_fast.as<FastRec>(), m.d_cold.as<ColdRec>(), st));
+      // far-only passes of the level sub-linesets (their own tables and chain through the shared CoefWork)
+      rc = m.s_far.prepare(sizeof(McFarPass) * (size_t)n_far);
+      if (rc) return rc;
+      McFarPass *far = m.s_far.host<McFarPass>();
+      // The passes are independent of each other: kMcFarLanes of them in flight side by side, each through a CoefWork
+      // of its own (tables, streams, events) instead of the handle's shared one -- one after the other on one chain
+      // stream the eleven sparse passes (0.33 ms each, latency-bound) and the dense ground-state pass were 7.7 ms, longer
+      // than the zones kernel they run beside.  Largest sub-lineset first (its chain is the longest).
+      if (!m.fw_init) {
+        for (auto &fwk : m.fw) {
+          rc = fwk.init();
+          if (rc) return rc;
+        }
+        m.fw_init = true;
+      }
+      std::vector<sr_lineset *> child((size_t)n_far, nullptr);
+      std::vector<int> order((size_t)n_far);
+      for (int f = 0; f < n_far; ++f) {
+        rc = level_set(ls, ctypes3 ? f / 2 : f, &child[(size_t)f], ctypes3 && (f & 1)); // ind_emission: the lines whose UPPER level is lv only
+        if (rc) return rc;
+        order[(size_t)f] = f;
+      }
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return child[(size_t)x]->n_lines > child[(size_t)y]->n_lines; });
+      auto pass_of = [&](int f, int *lv, bool *ind) { *lv = ctypes3 ? f / 2 : f; *ind = ctypes3 && (f & 1); };
+      auto weights_of = [&](int lv, bool ind) {
+        return !ctypes3 ? WeightMode{kWeightLevelPair, lv} : (ind ? WeightMode{kWeightGind, lv} : WeightMode{kWeightGabsGsp, lv});
+      };
+      // SPARSE sub-linesets (coef_op's rule: far-field mode 3, fewer than 0.35 lines per grid point -- per-line expansions
+      // at every level, sr_farfield_rows_kernel): ALL of them in one batch of three launches -- tables, expansions, downward
+      // pass -- on the zones stream, beside the dense passes' chains.  One coefficient op each, they were eleven launches
+      // of 0.3 ms, latency-bound, each behind ~0.3 ms of host calls: 6 ms of a 13 ms build (gpurun_out/r06/tl_v4.txt).
+      // They share this pass's layer stage: their own would hold the same numbers (margins of the parent).
+      std::vector<int> dense;
+      {
+        rc = m.s_batch.prepare(sizeof(FarBatchItem) * (size_t)n_far);
+        if (rc) return rc;
+        FarBatchItem *items = m.s_batch.host<FarBatchItem>();
+        int n_items = 0, max_sub = 0;
+        size_t rec_total = 0;
+        std::vector<size_t> rec_off;
+        for (int q = 0; q < n_far; ++q) {
+          const int f = order[(size_t)q];
+          sr_lineset *c = child[(size_t)f];
+          const bool sparse = far_mode == 3 && (double)c->n_lines < 0.35 * (double)c->gp.n_grid;
+          if (!sparse) { dense.push_back(f); continue; }
+          int lv; bool ind;
+          pass_of(f, &lv, &ind);
+          far[f].ch_a = !ctypes3 ? 2 * lv : (ind ? 3 * lv + 1 : 3 * lv + 2);
+          far[f].ch_e = !ctypes3 ? 2 * lv + 1 : (ind ? -1 : 3 * lv);
+          const auto lo_c = std::lower_bound(c->ic.begin(), c->ic.end(), (int)g_lo - (kHalf - 1));
+          const auto hi_c = std::upper_bound(c->ic.begin(), c->ic.end(), (int)g_hi - 1 + kHalf);
+          const int c_sub = (int)(hi_c - lo_c);
+          if (c_sub <= 0) { far[f].coef = nullptr; continue; }
+          FarBatchItem &it = items[n_items++];
+          it.L = c->L;
+          it.first = c->d_first.as<int>();
+          it.first_x0 = c->first_x0;
+          it.first_n = c->first_n;
+          it.line_lo = (int)(lo_c - c->ic.begin());
+          it.n_sub = c_sub;
+          it.W = weights_of(lv, ind);
+          it.coef = m.d_coef.as<double>() + coef_row * (size_t)nl * f;
+          far[f].coef = it.coef;
+          rec_off.push_back(rec_total);
+          rec_total += (size_t)c_sub * nl;
+          max_sub = std::max(max_sub, c_sub);
+        }
+        if (n_items > 0) {
+          rc = m.d_bfast.ensure(sizeof(FastRec) * (rec_total + 1));
+          if (rc) return rc;
+          for (int i = 0; i < n_items; ++i) items[i].fast = m.d_bfast.as<FastRec>() + rec_off[(size_t)i];
+          HIPCHK(hipEventRecord(m.ev_prep, st)); // (the layer stage and everything earlier on the caller's stream)
+          HIPCHK(hipStreamWaitEvent(m.zst, m.ev_prep, 0));
+          rc = m.s_batch.push(sizeof(FarBatchItem) * (size_t)n_items, m.zst);
+          if (rc) return rc;
+          FarParams fpb;
+          far_hierarchy(n_pts, nl, &fpb);
+          fpb.pm = d_pm;
+          fpb.coef = nullptr;
+          fpb.m2l = 0; fpb.rows = 1; fpb.pm_src = d_pm + nl; fpb.disp_lo_end = 0; fpb.disp_hi_begin = 0; fpb.mom = nullptr; fpb.tab = nullptr;
+          for (int lv = 0; lv < kMaxFarLevels; ++lv) fpb.n_src[lv] = fpb.src_off[lv] = 0;
+          const double *l2l_tab = nullptr;
+          rc = l2l_table_dev(&l2l_tab);
+          if (rc) return rc;
+          LAUNCHCHK(launch_far_batch(m.s_batch.d.as<FarBatchItem>(), n_items, max_sub, A, ls->gp, zmax_dev, (int)g_lo, fpb, l2l_tab, m.zst));
+          HIPCHK(hipEventRecord(m.ev_zones, m.zst));
+          rc = m.s_batch.mark(m.zst);
+          if (rc) return rc;
+        }
+        m.batch_pending = n_items > 0;
+      }
+      // the dense passes (the ground state's, typically), each through a CoefWork of its own
+      for (size_t q = 0; q < dense.size(); ++q) {
+        const int f = dense[q];
+        int lv; bool ind;
+        pass_of(f, &lv, &ind);
+        sr_lineset *c = child[(size_t)f];
+        double *coef = m.d_coef.as<double>() + coef_row * (size_t)nl * f;
+        bool has = false;
+        CoefOpt o;
+        o.far_coef = coef;
+        o.far_has = &has;
+        CoefWork *const shared = c->work;
+        c->work = &m.fw[q % kMcFarLanes];
+        rc = coef_op(c, &sub, g_lo, g_hi, nullptr, nullptr, stream, weights_of(lv, ind), o);
+        c->work = shared;
+        if (rc) return rc;
+        far[f].coef = has ? coef : nullptr;
+        far[f].ch_a = !ctypes3 ? 2 * lv : (ind ? 3 * lv + 1 : 3 * lv + 2);
+        far[f].ch_e = !ctypes3 ? 2 * lv + 1 : (ind ? -1 : 3 * lv);
+      }
+      if (m.batch_pending) HIPCHK(hipStreamWaitEvent(st, m.ev_zones, 0));
+      // The zones kernel AFTER the level passes (every one of them has made the caller's stream wait for its chain): its
+      // 8-wave workgroups of 128 VGPRs and 58 KB fill every SIMD's register file, and the latency-bound chains of the
+      // sparse passes starved beside it -- seven of the twelve ran only when it had drained (6.5 ms), the wings kernel
+      // 3 ms later still (gpurun_out/r06/tl_v3.txt: 13.1 ms per build).
+      LAUNCHCHK(launch_zones_mc(m.d_fast.as<FastRec>(), m.d_cold.as<ColdRec>(), ls->L.lev_up + line_lo, ls->L.lev_lo + line_lo, ix,
+                                zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, mc, out, n_rows, k0, st));
+      rc = m.s_far.push(sizeof(McFarPass) * (size_t)n_far, st);
+      if (rc) return rc;
+      FarParams fp;
+      far_hierarchy(n_pts, nl, &fp);
+      fp.pm = d_pm;
+      fp.coef = nullptr;
+      fp.m2l = 0; fp.rows = 0; fp.pm_src = d_pm + nl; fp.disp_lo_end = 0; fp.disp_hi_begin = 0; fp.mom = nullptr; fp.tab = nullptr;
+      for (int lv = 0; lv < kMaxFarLevels; ++lv) fp.n_src[lv] = fp.src_off[lv] = 0;
+      LAUNCHCHK(launch_wings_mc(m.d_fast.as<FastRec>(), ls->L.lev_up + line_lo, ls->L.lev_lo + line_lo, ix, zmax_dev, n_sub, nl,
+                                (int)g_lo, (int)g_hi, fp, mc, m.s_far.d.as<McFarPass>(), n_far, out, n_rows, k0, st));
+      rc = m.s_far.mark(st);
+      if (rc) return rc;
+    }
+    // lines whose centre lies outside their window (humliv_bb's outer branches): per level, as the per-level route
+    if (ls->n_outer > 0) {
+      for (int f = 0; f < n_far; ++f) {
+        const int lv = ctypes3 ? f / 2 : f;
+        const bool ind = ctypes3 && (f & 1);
+        sr_lineset *c = nullptr;
+        rc = level_set(ls, lv, &c, ind);
+        if (rc) return rc;
+        if (c->n_outer <= 0) continue;
+        rc = m.d_outer_recs.ensure(sizeof(OuterRec) * (size_t)c->n_outer * nl);
+        if (rc) return rc;
+        double *o_a, *o_e;
+        if (!ctypes3) { o_a = chan_rows(2 * lv); o_e = chan_rows(2 * lv + 1); }
+        else if (!ind) { o_a = chan_rows(3 * lv + 2); o_e = chan_rows(3 * lv); }
+        else {
+          rc = ls->d_gscratch.ensure(sizeof(double) * n_pts * nl); // the unused second channel of the ind_emission weights
+          if (rc) return rc;
+          o_a = chan_rows(3 * lv + 1); o_e = ls->d_gscratch.as<double>();
+        }
+        const WeightMode W = !ctypes3 ? WeightMode{kWeightLevelPair, lv} : (ind ? WeightMode{kWeightGind, lv} : WeightMode{kWeightGabsGsp, lv});
+        LAUNCHCHK(launch_outer(c->Lo, c->n_outer, A, ls->gp, W, m.d_outer_recs.as<OuterRec>(), (int)g_lo, (int)g_hi, o_a, o_e, st));
+      }
+    }
+    rc = m.s_layers.mark(st);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(w.ev_last_done, st));
+    w.last_done_recorded = true;
+  }
+  return SR_OK;
+#endif
+}
+
 extern "C" {
 
 int sr_abscoeff_layers_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi,
@@ -1216,12 +1604,33 @@ int sr_glevel_pairs_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo,
   const size_t plane = (size_t)atm->n_layers * (size_t)(g_hi - g_lo);
   if (ls->n_levels == 0) // the 'all' set: every line, pop = 1 / Q in the combine (smm:2052-2057)
     return coef_op(ls, atm, g_lo, g_hi, out, out + plane, stream, WeightMode{kWeightLevelPair, -1});
+  {
+    // every line once, its three weights to the spectra of its two levels (mc_pass); where that route does not apply
+    // (exact mode, counting, sr_set_level_route(0)): one coefficient op per level, below
+    const int rc = mc_pass(ls, atm, g_lo, g_hi, out, stream, 0);
+    if (rc != SR_ERR_UNSUPPORTED) return rc;
+  }
   for (int lv = 0; lv < ls->n_levels; ++lv) {
     sr_lineset *c = nullptr;
     int rc = level_set(ls, lv, &c); // lines whose upper or lower level is lv
     if (rc) return rc;
     rc = coef_op(c, atm, g_lo, g_hi, out + (size_t)(2 * lv) * plane, out + (size_t)(2 * lv + 1) * plane, stream,
                  WeightMode{kWeightLevelPair, lv});
+    if (rc) return rc;
+  }
+  return SR_OK;
+}
+
+int sr_gcoeff_levels_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *g_out, void *stream) {
+  if (!ls || !atm || !g_out || atm->n_layers <= 0 || g_lo < 0 || g_lo >= g_hi) return SR_ERR_ARG;
+  if (ls->n_levels == 0) return sr_gcoeff_layers_dev(ls, atm, 0, g_lo, g_hi, g_out, stream);
+  {
+    const int rc = mc_pass(ls, atm, g_lo, g_hi, g_out, stream, 1);
+    if (rc != SR_ERR_UNSUPPORTED) return rc;
+  }
+  const size_t plane3 = 3 * (size_t)atm->n_layers * (size_t)(g_hi - g_lo);
+  for (int lv = 0; lv < ls->n_levels; ++lv) {
+    const int rc = sr_gcoeff_layers_dev(ls, atm, lv, g_lo, g_hi, g_out + plane3 * (size_t)lv, stream);
     if (rc) return rc;
   }
   return SR_OK;

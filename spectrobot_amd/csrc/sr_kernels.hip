@@ -17,6 +17,7 @@
 //   sr_radiance_kernel / sr_radiance_jac_kernel   the same recursion on host-built columns
 //   sr_lowres_kernel    Gaussian ILS onto low-resolution bands (hires_to_lowres)
 //   shims               humliv_bb / sum_all_lines / curgod_fort_N call shapes.
+#include <climits>
 #include <cstdlib>
 
 #include "sr_device.hpp"
@@ -108,17 +109,18 @@ __device__ inline LinePhys line_physics(const LinesDev &L, const LayersDev &A, c
 constexpr int kPrepBlock = 64; // one wave per block: a four-wave block with 20 KB of LDS never found room beside the zones
                                // kernel (16 one-wave blocks of 10 KB fill a CU's LDS; a retiring wave frees ONE slot)
                                // or the wings kernel, and the next call's preparation ran after them instead of beside
-__global__ __launch_bounds__(kPrepBlock) void sr_prep_kernel(LinesDev L, LayersDev A, GridParams gp, WeightMode W,
-                                                      int line_lo, int n_sub, int cold_lo, int cold_hi,
-                                                      FastRec *__restrict__ fast,
-                                                      ColdRec *__restrict__ cold) {
+// (the body apart from its kernel: sr_prep_batch_kernel runs it for every sparse far-only pass of a multi-channel
+// table build in one launch; bx, k: the block's line chunk and layer)
+__device__ __forceinline__ void prep_body(const LinesDev &L, const LayersDev &A, const GridParams &gp, const WeightMode W,
+                                          int line_lo, int n_sub, int cold_lo, int cold_hi, FastRec *__restrict__ fast,
+                                          ColdRec *__restrict__ cold, const int bx, const int k) {
   // records leave through LDS: stored from the registers, a lane's 80 / 128 B record goes out in 16-byte pieces at
   // a 80 / 128 B stride across the lanes; the wave's 64 records are contiguous in the table, so they are transposed
   // and stored 1 KB of consecutive bytes per instruction instead (the kernel writes its 1.63 GB at 5.2 TB/s).
   __shared__ uint4 s_rec[kPrepBlock / 64][64 * sizeof(FastRec) / 16]; // per wave: 64 fast records, then its 64 cold records
   static_assert(sizeof(ColdRec) <= sizeof(FastRec), "the cold records share the fast records' staging buffer");
-  const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y; // (layers on the fast grid axis instead -- the line arrays then stay in L2 -- measured slower: 0.32 vs 0.29 ms, the record rows of consecutive blocks lie 8 MB apart)
+  const int i0 = bx * blockDim.x + threadIdx.x;
+  // (k = blockIdx.y; layers on the fast grid axis instead -- the line arrays then stay in L2 -- measured slower: 0.32 vs 0.29 ms, the record rows of consecutive blocks lie 8 MB apart)
   const int wave_first = i0 - (threadIdx.x & 63);
   if (wave_first >= n_sub) return; // whole wave out of range
   const bool valid = i0 < n_sub;
@@ -198,6 +200,18 @@ __global__ __launch_bounds__(kPrepBlock) void sr_prep_kernel(LinesDev L, LayersD
   // (The widest zone of the layer, which the other kernels use to bound their candidate ranges, comes from the host
   // as a bound -- (lw_max + 15 dw'_max) / step: the wave maxima + one atomicMax per wave on the layer's single counter
   // serialised in L2 and WERE this kernel's 0.8 ms: it took as long with its stores or its arithmetic compiled out.)
+}
+__global__ __launch_bounds__(kPrepBlock) void sr_prep_kernel(LinesDev L, LayersDev A, GridParams gp, WeightMode W,
+                                                      int line_lo, int n_sub, int cold_lo, int cold_hi,
+                                                      FastRec *__restrict__ fast,
+                                                      ColdRec *__restrict__ cold) {
+  prep_body(L, A, gp, W, line_lo, n_sub, cold_lo, cold_hi, fast, cold, (int)blockIdx.x, (int)blockIdx.y);
+}
+// The tables of ALL sparse far-only passes of a table build (FarBatchItem) in one launch: grid (line chunks of the
+// largest item, layers, items); fast records only (an empty cold range).
+__global__ __launch_bounds__(kPrepBlock) void sr_prep_batch_kernel(const FarBatchItem *__restrict__ items, LayersDev A, GridParams gp) {
+  const FarBatchItem it = items[blockIdx.z];
+  prep_body(it.L, A, gp, it.W, it.line_lo, it.n_sub, INT_MAX / 2, INT_MIN / 2, it.fast, nullptr, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------
@@ -891,10 +905,10 @@ constexpr int lane_reduce_left() { // values per lane after lane_reduce<N, M>
   if constexpr (M >= 1) return lane_reduce_left<N / 2 + (N & 1), M / 2>(); else return N;
 }
 template <bool COUNT>
-__global__ __launch_bounds__(64) void sr_farfield_rows_kernel(const FastRec *__restrict__ fast, IcIndex ix,
-                                                              const int *__restrict__ zmax, int n_sub, int g_lo, FarParams fp,
-                                                              unsigned long long *__restrict__ cnt) {
-  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+__device__ __forceinline__ void farfield_rows_body(const FastRec *__restrict__ fast, const IcIndex ix,
+                                                   const int *__restrict__ zmax, int n_sub, int g_lo, const FarParams &fp,
+                                                   unsigned long long *__restrict__ cnt, const int bx, const int gx) {
+  const int wid = xcd_remap(bx, gx);
   const int grp = wid / fp.n_boxes_total; // group of kFarRows layers
   int idx = wid - grp * fp.n_boxes_total, level = fp.n_levels - 1;
   while (level > 0 && idx >= fp.box_count[level]) { // widest level first
@@ -1024,6 +1038,21 @@ __global__ __launch_bounds__(64) void sr_farfield_rows_kernel(const FastRec *__r
     for (int n = 0; n < kLeft; ++n) out[slot[n]] = v[n]; // (an unpaired value is held by two lanes: the same sum twice)
   }
   if (COUNT) count_add(cnt, kCntExpansions, n_exp, lane);
+}
+template <bool COUNT>
+__global__ __launch_bounds__(64) void sr_farfield_rows_kernel(const FastRec *__restrict__ fast, IcIndex ix,
+                                                              const int *__restrict__ zmax, int n_sub, int g_lo, FarParams fp,
+                                                              unsigned long long *__restrict__ cnt) {
+  farfield_rows_body<COUNT>(fast, ix, zmax, n_sub, g_lo, fp, cnt, (int)blockIdx.x, (int)gridDim.x);
+}
+// ... of every sparse far-only pass of a table build in one launch (grid.y = item): one at a time these launches --
+// eleven of 0.3 ms, latency-bound, each behind ~0.3 ms of host calls -- were 6 ms of a 13 ms build
+__global__ __launch_bounds__(64) void sr_farfield_rows_batch_kernel(const FarBatchItem *__restrict__ items, const int *__restrict__ zmax,
+                                                                    int g_lo, FarParams fp) {
+  const FarBatchItem it = items[blockIdx.y];
+  fp.coef = it.coef;
+  farfield_rows_body<false>(it.fast, IcIndex{it.first, it.first_x0, it.first_n, it.line_lo, it.n_sub}, zmax, it.n_sub, g_lo, fp, nullptr,
+                            (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------
@@ -1972,6 +2001,539 @@ __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_abscoeff_near_zones_
     }
   }
 }
+
+
+// ------------------------------------------------------------------------
+// The multi-channel pass (level pair tables, G-coefficient tables): every line ONCE, each of its three weighted
+// contributions to the spectrum of the level it belongs to.
+//
+// The per-level route evaluates every line twice (in its upper level's pass and in its lower level's) and pays the
+// fixed cost of a (slot, layer) wave twelve times -- a 9 %-of-the-lines pass cost 1.08 ms where its lines' share of a
+// full pass is 0.48 (3.1-3.4 coefficient-op equivalents for twelve levels).  Here the near-field
+// kernels walk the FULL sorted list once, exactly as the folded op does, and the accumulation goes to an LDS image
+// with one plane per output spectrum: wabs -> plane (lev_lo, o_lo), wemi -> (lev_up, o_up_e), w3 -> (lev_up, o_up_a)
+// (McChannels).  An image of n_ch x 256 points is shared by the NW waves of a workgroup (return-less ds_add_f64 from
+// all of them: the sums' order of addition depends on timing at the 1e-16 level, unlike the one-wave images of the folded op).
+// The far field stays per level (its translations and polynomials are linear per output spectrum anyway): far-only
+// passes of the level sub-linesets leave their coefficients for sr_wings_mc_kernel's polynomial stage.
+// ------------------------------------------------------------------------
+// ------------------------------------------------------------------------
+// Local-to-local translation (the downward pass of the hierarchy).  A box's local expansion IS a polynomial of degree
+// kFD over the box, so its restriction to a child box is the same polynomial re-centred: with t_parent = s/2 + t_child/2
+// (s = -1 left, +1 right child)  child_n += sum_{m >= n} 2^-m C(m, n) s^(m-n) parent_m  -- exact algebra, no truncation,
+// operator entries exact in fp64 (an integer below 2^53 times a power of two).  After it the level-0 coefficients hold
+// every level's far field and a point evaluates ONE polynomial per output instead of one per hierarchy level.  For the
+// multi-channel pass (n_far x 2 outputs per point: 5 x 12 x 2 Horner chains of 22 fma per point were 2.3 of
+// sr_wings_mc_kernel's 5.2 ms); the folded op keeps its five polynomials (176 fma of a ~4100-instruction wave).
+// One wave per (layer, widest box) of a far pass: the box's tree of 31 coefficient sets in LDS, levels top down.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sr_l2l_kernel(double *__restrict__ coef_one, const FarBatchItem *__restrict__ items, FarParams fp,
+                                                    const double *__restrict__ tab) {
+  double *const coef = items ? items[blockIdx.z].coef : coef_one; // one pass, or item blockIdx.z of a batch
+  constexpr int kBlk = 2 * kFC, kTop = kMaxFarLevels - 1;
+  constexpr int kTree = (2 << kTop) - 1; // boxes of the tree under one widest box: 1 + 2 + ... + 2^kTop
+  __shared__ double s_c[kTree * kBlk];
+  const int layer = blockIdx.y, top = blockIdx.x, lane = threadIdx.x;
+  double *cl = coef + (size_t)layer * fp.n_boxes_total * kBlk;
+  const int lq = min(lane, kBlk - 1), ch = lq / kFC, n = lq - ch * kFC; // lanes 0 .. 2 kFC - 1: (output, coefficient)
+  // this lane's two operator rows in registers (zeros left of the diagonal: the inner loop needs no bounds); in LDS the
+  // 8.5 KB table held a CU to eight of these waves (first build: 2.2 ms for 0.3 ms of work)
+  double T0[kFC], T1[kFC];
+#pragma unroll
+  for (int m = 0; m < kFC; ++m) {
+    T0[m] = tab[(size_t)n * kFC + m];
+    T1[m] = tab[((size_t)kFC + n) * kFC + m];
+  }
+  // tree slot of box j (0-based within this top box) of level lv: the levels stored widest first
+  auto slot = [&](int lv, int j) { return ((1 << (kTop - lv)) - 1) + j; };
+  for (int lv = kTop; lv >= 0; --lv) {
+    const int nb = 1 << (kTop - lv);
+    for (int j = 0; j < nb; ++j) {
+      const int b = top * nb + j;
+      if (lane < kBlk) s_c[slot(lv, j) * kBlk + lane] = b < fp.box_count[lv] ? cl[(size_t)(fp.box_off[lv] + b) * kBlk + lane] : 0.0;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int lv = kTop; lv >= 1; --lv) {
+    const int nb = 1 << (kTop - lv);
+    for (int j = 0; j < nb; ++j) {
+      const double *par = s_c + slot(lv, j) * kBlk + ch * kFC;
+      double *c0 = s_c + slot(lv - 1, 2 * j) * kBlk + lq, *c1 = c0 + kBlk;
+      double a0 = *c0, a1 = *c1;
+#pragma unroll
+      for (int m = 0; m < kFC; ++m) {
+        const double pm = par[m];
+        a0 = fma(T0[m], pm, a0);
+        a1 = fma(T1[m], pm, a1);
+      }
+      if (lane < kBlk) {
+        *c0 = a0;
+        *c1 = a1;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const int nb0 = 1 << kTop;
+  for (int j = 0; j < nb0; ++j) {
+    const int b = top * nb0 + j;
+    if (lane < kBlk && b < fp.box_count[0]) cl[(size_t)(fp.box_off[0] + b) * kBlk + lane] = s_c[slot(0, j) * kBlk + lane];
+  }
+}
+void l2l_table_host(double *tab) { // [2: left, right child][n][m]
+  for (int sg = 0; sg < 2; ++sg)
+    for (int n = 0; n < kFC; ++n)
+      for (int m = 0; m < kFC; ++m) {
+        long double v = 0.0L;
+        if (m >= n) {
+          v = 1.0L;
+          for (int k = 1; k <= n; ++k) v = v * (long double)(m - n + k) / (long double)k; // C(m, n)
+          for (int k = 0; k < m; ++k) v *= 0.5L;
+          if (sg == 0 && ((m - n) & 1)) v = -v;
+        }
+        tab[((size_t)sg * kFC + n) * kFC + m] = (double)v;
+      }
+}
+int launch_l2l(double *coef, int n_layers, const FarParams &fp, const double *tab, hipStream_t st) {
+  if (n_layers <= 0) return 0;
+  hipLaunchKernelGGL(sr_l2l_kernel, dim3((unsigned)fp.box_count[kMaxFarLevels - 1], (unsigned)n_layers), dim3(64), 0, st, coef,
+                     (const FarBatchItem *)nullptr, fp, tab);
+  return (int)hipGetLastError();
+}
+// tables, per-line expansions at every level and the downward pass of n_items sparse far-only passes, three launches
+int launch_far_batch(const FarBatchItem *items, int n_items, int max_n_sub, const LayersDev &A, const GridParams &gp, const int *zmax,
+                     int g_lo, const FarParams &fp, const double *l2l_tab, hipStream_t st) {
+  if (n_items <= 0 || A.n_layers <= 0 || max_n_sub <= 0) return 0;
+  hipLaunchKernelGGL(sr_prep_batch_kernel, dim3((unsigned)((max_n_sub + kPrepBlock - 1) / kPrepBlock), (unsigned)A.n_layers, (unsigned)n_items),
+                     dim3(kPrepBlock), 0, st, items, A, gp);
+  const unsigned gx = (unsigned)(fp.n_boxes_total * ((A.n_layers + kFarRows - 1) / kFarRows));
+  hipLaunchKernelGGL(sr_farfield_rows_batch_kernel, dim3(gx, (unsigned)n_items), dim3(64), 0, st, items, zmax, g_lo, fp);
+  hipLaunchKernelGGL(sr_l2l_kernel, dim3((unsigned)fp.box_count[kMaxFarLevels - 1], (unsigned)A.n_layers, (unsigned)n_items), dim3(64), 0, st,
+                     (double *)nullptr, items, fp, l2l_tab);
+  return (int)hipGetLastError();
+}
+
+#if SR_FASTREC64
+__device__ inline int mc_base(const McChannels &mc, int level, int off, int plane) { return (mc.stride * level + off) * plane; }
+
+template <int WT, int NW>
+__global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_zones_mc_kernel(
+    const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, const int *__restrict__ lev_up,
+    const int *__restrict__ lev_lo, IcIndex ix, const int *__restrict__ zmax, int n_sub, int n_groups, int g_lo, int g_hi,
+    GridParams gp, McChannels mc, double *__restrict__ out, int n_rows_total, int row0) {
+  extern __shared__ double s_dyn[];
+  constexpr int kPlane = WT + 2;             // point p of the group lives at element p + 1 of its plane (see the folded kernel)
+  double *const s_img = s_dyn;               // [n_ch][kPlane]
+  int *const s_item_all = reinterpret_cast<int *>(s_dyn + (size_t)mc.n_ch * kPlane); // [NW][2][4][64]
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int layer = wg / n_groups, grp = wg - layer * n_groups;
+  const int wlo = g_lo + grp * WT;
+  const int whi = min(wlo + WT, g_hi) - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int *const s_item = s_item_all + wave * (2 * 4 * 64);
+  auto item = [&](int region, int field, int at) -> int & { return s_item[(region * 4 + field) * 64 + at]; };
+  const int zm = min(zmax[layer], kHalf - 1);
+  for (int e = threadIdx.x; e < mc.n_ch * kPlane; e += 64 * NW) s_img[e] = 0.;
+  __syncthreads();
+  const double p6_vgpr = vgpr_constant(SR_F32(.56419)); // see core_region4_m
+  const int l0 = lower_bound_ic(ix, wlo - zm), l1 = lower_bound_ic(ix, whi + zm + 1);
+  const FastRec *frow = fast + (size_t)layer * n_sub;
+  const ColdRec *crow = cold + (size_t)layer * n_sub;
+  const int n_chunks = (l1 - l0 + 63) >> 6;
+  for (int ci = wave; ci < n_chunks; ci += NW) {
+    const int base = l0 + 64 * ((grp & 1) ? n_chunks - 1 - ci : ci); // serpentine sweep, see the folded kernel
+    const int lv = min(base + lane, l1 - 1);
+    bool act;
+    unsigned run2l, run2r, run4l, run4r;
+    int n_items2, n_items4;
+    {
+      // ---- lane = line: interval arithmetic of every line, region 3 (see sr_abscoeff_near_zones_kernel)
+      const FastRec &r = frow[lv];
+      const int j1 = r.j1, il = r.il(), ir = r.ir();
+      const int zl = max(j1 + il - 1, j1), zh = min(j1 + ir - 1, j1 + (kImxsig - 1));
+      act = base + lane < l1 && zl <= whi && zh >= wlo;
+      if (__ballot(act) == 0) continue;
+      const ColdRec &z = crow[lv];
+      const int k3lo = z.k3lo(), k3hi = z.k3hi();
+      const int il2 = z.il2(), ir2 = z.ir2();
+      const int k_lo = max(wlo - j1 + 1, 1), k_hi = min(whi - j1 + 1, kImxsig);
+      {
+        const int a0 = max(il, k_lo), a1 = il < il2 ? min(il2, k_hi) : a0 - 1;
+        const int b0 = max(ir2, k_lo), b1 = ir2 < ir ? min(ir, k_hi) : b0 - 1;
+        run2l = (unsigned)a0 | ((unsigned)max(a1 - a0 + 1, 0) << 16);
+        run2r = (unsigned)b0 | ((unsigned)max(b1 - b0 + 1, 0) << 16);
+      }
+      const int c_lo = max(((il2 == il) ? il - 1 : il2) + 1, k_lo), c_hi = min(((ir2 == ir) ? ir + 1 : ir2) - 1, k_hi);
+      const bool has3 = k3lo <= k3hi;
+      {
+        const int a0 = c_lo, a1 = has3 ? min(k3lo - 1, c_hi) : c_hi;
+        const int b0 = has3 ? max(k3hi + 1, c_lo) : c_hi + 1, b1 = c_hi;
+        run4l = (unsigned)a0 | ((unsigned)max(a1 - a0 + 1, 0) << 16);
+        run4r = (unsigned)b0 | ((unsigned)max(b1 - b0 + 1, 0) << 16);
+      }
+      const int e0 = max(k3lo, c_lo), e1 = min(k3hi, c_hi);
+      const int n3 = (act && has3) ? max(e1 - e0 + 1, 0) : 0;
+      const bool w2 = act && ((run2l >> 16) + (run2r >> 16)) > 0, w4 = act && ((run4l >> 16) + (run4r >> 16)) > 0;
+      // the three planes of the lane's line, as element offsets, packed for the rows: 3 x 10 bits of channel index
+      const int lu = lev_up[lv], ll = lev_lo[lv];
+      const int ch_lo = mc.stride * ll + mc.o_lo, ch_ue = mc.stride * lu + mc.o_up_e, ch_ua = mc.stride * lu + mc.o_up_a;
+      const int chans = ch_lo | (ch_ue << 10) | (ch_ua << 20);
+      if (__any(n3 > 0 || w4)) {
+        const WinX xf{gp.lin_start, gp.lin_delta, grid_at(gp, j1 + kHalf)};
+        const double x0 = z.x0, dwp = z.dwp, inv_dwp = cold_inv_dwp(z.dwp), ryf = cold_ryf(z.ry);
+        const double wa = r.wabs, we = r.wemi, w3 = r.w3;
+        const int ibase = j1 - wlo; // element = point + 1
+        {
+          const double rx_max = fmax(fabs(xf((int)(run4l & 0xffffu)) - x0),
+                                     fabs(xf((int)(run4r & 0xffffu) + (int)(run4r >> 16) - 1) - x0)) * inv_dwp * 1.001;
+          const double ui_max = (ryf + ryf) * rx_max;
+          run4l |= (ui_max < 6.5e-3 ? 2u : (ui_max < 0.78 ? 1u : 0u)) << 30;
+        }
+        double *const p_lo = s_img + ch_lo * kPlane + ibase, *const p_ue = s_img + ch_ue * kPlane + ibase,
+                     *const p_ua = s_img + ch_ua * kPlane + ibase;
+        for (int t = 0; __any(t < n3); ++t) {
+          if (t < n3) {
+            const int k = e0 + t;
+            const double d = fabs(xf(k) - x0);
+            double rx = d * inv_dwp;
+            rx = fma(fma(-dwp, rx, d), inv_dwp, rx);
+            const double y = core_region3(ryf, (double)(float)(-rx));
+            atomicAdd(&p_lo[k], wa * y);
+            atomicAdd(&p_ue[k], we * y);
+            atomicAdd(&p_ua[k], w3 * y);
+          }
+        }
+      }
+      const unsigned long long m2 = __ballot(w2), m4 = __ballot(w4);
+      n_items2 = __builtin_popcountll(m2);
+      n_items4 = __builtin_popcountll(m4);
+      if (w2) {
+        const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0u));
+        item(0, 0, at) = lane;
+        item(0, 1, at) = (int)run2l;
+        item(0, 2, at) = (int)run2r;
+        item(0, 3, at) = chans;
+      }
+      if (w4) {
+        const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m4 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m4, 0u));
+        item(1, 0, at) = lane;
+        item(1, 1, at) = (int)run4l;
+        item(1, 2, at) = (int)run4r;
+        item(1, 3, at) = chans;
+      }
+    }
+    {
+      constexpr int kRowLanes = SR_ZONES_ROW, kRows = 64 / kRowLanes;
+      const int row = lane / kRowLanes, col = lane % kRowLanes;
+      // region 2 (lineshape.f:503-522), eight lines at a time (see the folded kernel)
+      for (int g = 0; g < n_items2; g += kRows) {
+        const int it = min(g + row, n_items2 - 1);
+        const bool live = g + row < n_items2;
+        const int ls_ = item(0, 0, it);
+        const FastRec &r = frow[base + ls_];
+        const ColdRec &z = crow[base + ls_];
+        const unsigned ul = (unsigned)item(0, 1, it), ur = (unsigned)item(0, 2, it);
+        const int chans = item(0, 3, it);
+        const int a0 = (int)(ul & 0xffffu), na = (int)(ul >> 16), b0 = (int)(ur & 0xffffu), nb = (int)(ur >> 16);
+        const double xstep = r.xstep, wa = r.wabs, we = r.wemi, w3 = r.w3;
+        double q2[8];
+        region2_coef_fma(z.ry, q2);
+        const int base_idx = r.j1 - wlo; // element = point + 1
+        // byte offsets of the line's second and third plane relative to its first
+        const int d_ue = (((chans >> 10) & 0x3ff) - (chans & 0x3ff)) * (kPlane * 8), d_ua = ((chans >> 20) - (chans & 0x3ff)) * (kPlane * 8);
+        char *const plane0 = reinterpret_cast<char *>(s_img + (chans & 0x3ff) * kPlane);
+        auto run = [&](const int n, const int n_max, const double c, const int i0) {
+          const int n_steps = (n_max + kRowLanes - 1) / kRowLanes;
+          double xt = fma((double)col, xstep, c);
+          const double xs8 = (double)kRowLanes * xstep;
+          int ab = (col + i0) * 8;
+          const int ab_end = (n + i0) * 8;
+          for (int st = 0; st < n_steps; ++st, ab += 8 * kRowLanes) {
+            if (ab < ab_end) {
+              const double y = region2_val(q2, xt);
+              xt += xs8;
+              atomicAdd(reinterpret_cast<double *>(plane0 + ab), wa * y);
+              atomicAdd(reinterpret_cast<double *>(plane0 + ab + d_ue), we * y);
+              atomicAdd(reinterpret_cast<double *>(plane0 + ab + d_ua), w3 * y);
+            }
+          }
+        };
+        run(live ? na : 0, rows_max(live ? na : 0), fma((double)(a0 - r.il()), xstep, -z.xs2l), a0 + base_idx);
+        run(live ? nb : 0, rows_max(live ? nb : 0), fma((double)(b0 - z.ir2()), xstep, z.xs2r), b0 + base_idx);
+      }
+      // region 4 (lineshape.f:530-546), on both sides of the region-3 interval
+      for (int g = 0; g < n_items4; g += kRows) {
+        const int it = min(g + row, n_items4 - 1);
+        const bool live = g + row < n_items4;
+        const int ls_ = item(1, 0, it);
+        const FastRec &r = frow[base + ls_];
+        const ColdRec &z = crow[base + ls_];
+        const unsigned ul = (unsigned)item(1, 1, it), ur = (unsigned)item(1, 2, it);
+        const int chans = item(1, 3, it);
+        const int a0 = (int)(ul & 0xffffu), na = (int)((ul >> 16) & 0x3fffu), b0 = (int)(ur & 0xffffu), nb = (int)(ur >> 16);
+        const int n = live ? na + nb : 0;
+        const int j1 = r.j1;
+        const int ebase = j1 - wlo; // element = point + 1
+        const double gc = grid_at(gp, j1 + kHalf), x0 = z.x0, dwp = z.dwp, inv_dwp = cold_inv_dwp(z.dwp);
+        const double ryf = cold_ryf(z.ry), ryf2 = ryf * ryf, two_ryf = ryf + ryf;
+        const double wa = r.wabs, we = r.wemi, w3 = r.w3;
+        double *const p_lo = s_img + (chans & 0x3ff) * kPlane + ebase, *const p_ue = s_img + ((chans >> 10) & 0x3ff) * kPlane + ebase,
+                     *const p_ua = s_img + (chans >> 20) * kPlane + ebase;
+        const int tier_ = live ? (int)(ul >> 30) : 2;
+        const int cos_tier = __all(tier_ == 2) ? 2 : (__all(tier_ >= 1) ? 1 : 0);
+        const int n_steps = (rows_max(n) + kRowLanes - 1) / kRowLanes;
+        const WinX xf{gp.lin_start, gp.lin_delta, gc};
+        for (int st = 0; st < n_steps; ++st) {
+          const int t = col + kRowLanes * st;
+          const int k = t < na ? a0 + t : b0 + (t - na);
+          if (t < n) {
+            const double d = fabs(xf(k) - x0);
+            double rx = d * inv_dwp; // |x(k)-x0|/dw correctly rounded: one residual correction
+            rx = fma(fma(-dwp, rx, d), inv_dwp, rx);
+            const double y = core_region4_m(ryf, ryf2, two_ryf, (double)(float)rx, cos_tier, p6_vgpr);
+            atomicAdd(&p_lo[k], wa * y);
+            atomicAdd(&p_ue[k], we * y);
+            atomicAdd(&p_ua[k], w3 * y);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // the image's planes to their spectra: out [n_ch][n_rows_total][n_pts], stores (sr_wings_mc_kernel adds)
+  const size_t n_pts = (size_t)(g_hi - g_lo);
+  const int n_here = whi - wlo + 1;
+  for (int c = wave; c < mc.n_ch; c += NW) {
+    double *o = out + ((size_t)c * n_rows_total + (size_t)(row0 + layer)) * n_pts + (size_t)(wlo - g_lo);
+    for (int p = lane; p < n_here; p += 64) o[p] = s_img[c * kPlane + p + 1];
+  }
+}
+
+// wave-uniform loads of far-field coefficients through the constant address space: scalar loads whatever LDS traffic
+// precedes them (profiles/r05_wings_experiments.md: behind any LDS store the compiler turned these loads, through a flat
+// pointer, into 24 vector loads per level)
+typedef const double __attribute__((address_space(4))) *kconst_ptr;
+__device__ inline kconst_ptr as_kconst(const double *p) { return (kconst_ptr)(uintptr_t)p; }
+
+// sr_wings_mc_kernel (one 64-point slot per wave, as sr_abscoeff_near_wings_kernel): every region-1 point of the lines
+// that no far-field level owns for the slot -- window ends and starts included: the per-channel suffix sums of the
+// folded kernel's window-end scan would be n_ch scans -- in rows, summed into the wave's LDS image [n_ch][64]; then one
+// far-field polynomial per (far pass, hierarchy level) from the coefficients the level sub-linesets' far-only passes
+// left; ADDS to out (sr_zones_mc_kernel stored).
+__global__ __launch_bounds__(64 * kMcWingWaves) void sr_wings_mc_kernel(
+    const FastRec *__restrict__ fast, const int *__restrict__ lev_up, const int *__restrict__ lev_lo, IcIndex ix,
+    const int *__restrict__ zmax, int n_sub, int n_tiles, int g_lo, int g_hi, FarParams fp, McChannels mc,
+    const McFarPass *__restrict__ far, int n_far, double *__restrict__ out, int n_rows_total, int row0) {
+  extern __shared__ double s_dyn[];
+  double *const s_img = s_dyn; // [n_ch][64]
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int layer = wg / n_tiles, tile = wg - layer * n_tiles;
+  const int wlo = g_lo + tile * 64;
+  const int whi = min(wlo + 64, g_hi) - 1;
+  // kMcWingWaves waves share the slot's image and take its candidate chunks, far passes and output planes in turn: one
+  // wave per slot with its 12 KB image kept a CU to 11 of these latency-bound waves (24 of the folded kernel's fit)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pm = fp.pm[layer];
+  const int thr0 = ff_thr2(0, pm);
+  int rs[3], re[3];
+  near_ranges(ix, wlo, 64, min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1), rs, re);
+  for (int c = wave; c < mc.n_ch; c += kMcWingWaves) s_img[c * 64 + lane] = 0.;
+  __syncthreads();
+  constexpr int kRowLanes = 8, kRows = 8;
+  const int row = lane / kRowLanes, col = lane % kRowLanes;
+  const FastRec *frow = fast + (size_t)layer * n_sub;
+#ifdef SR_MC_DIAG_NOROWS // diagnostic variant builds: which part of the kernel takes its time
+  if (n_sub < 0)
+#endif
+  int turn = 0; // chunks of all three ranges dealt to the waves in turn
+  for (int rg = 0; rg < 3; ++rg) {
+    for (int base = rs[rg]; base < re[rg]; base += 64) {
+      if ((turn++) % kMcWingWaves != wave) continue;
+      const int lv = base + lane;
+      bool has_l = false, has_r = false; // region-1 points of the lane's line in this slot that no far-field level owns
+      if (lv < re[rg]) {
+        const int j1 = frow[lv].j1;
+        const unsigned ilir = frow[lv].ilir;
+        const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
+        if (jN >= wlo && j1 <= whi && !ff_admissible(j1, il, ir, wlo, wlo + 63, thr0)) {
+          has_l = max(wlo, j1) <= min(whi, j1 + il - 2); // points with 1 <= k < il
+          has_r = max(wlo, j1 + ir) <= min(whi, jN);     // points with ir < k <= 13010
+        }
+      }
+      unsigned long long m_l = __ballot(has_l), m_r = __ballot(has_r);
+      while (m_l | m_r) {
+        int code = -1; // this row's item: line (index into the chunk) | wing << 6; -1: none left
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+          int c_ = -1; // wave-uniform
+          if (m_l) {
+            c_ = __builtin_ctzll(m_l);
+            asm("s_bitset0_b64 %0, %1" : "+s"(m_l) : "s"(c_));
+          } else if (m_r) {
+            const int cr = __builtin_ctzll(m_r);
+            asm("s_bitset0_b64 %0, %1" : "+s"(m_r) : "s"(cr));
+            c_ = cr | 64;
+          }
+          code = row == q ? c_ : code;
+        }
+        const bool live = code >= 0, rw = live && (code & 64);
+        const int li = base + (live ? (code & 63) : 0);
+        const FastRec &r = frow[li];
+        const R1Coef rq = r1_of(r);
+        const double xstep = r.xstep, a = rq.a, b = rq.b, c = rq.c, d = rq.d, wa = r.wabs, we = r.wemi, w3 = r.w3;
+        const int j1 = r.j1, il = r.il(), ir = r.ir();
+        const int lu = lev_up[li], ll = lev_lo[li];
+        double *const p_lo = s_img + (mc.stride * ll + mc.o_lo) * 64 + col, *const p_ue = s_img + (mc.stride * lu + mc.o_up_e) * 64 + col,
+                     *const p_ua = s_img + (mc.stride * lu + mc.o_up_a) * 64 + col;
+        const int kb0 = wlo - j1 + 1 + col;              // window index of this lane's point at step 0
+        const int k_last = min(kImxsig, whi - j1 + 1);  // last window index inside the slot, the grid and the window
+        const int k_a = rw ? ir + 1 : 1, k_b = rw ? k_last : min(il - 1, k_last);
+        const unsigned n_on = live ? (unsigned)max(k_b - k_a + 1, 0) : 0u;
+        const int t0 = kb0 - k_a;                        // step q is on for this lane: (unsigned)(t0 + 8 q) < n_on
+        const double x0 = fma((double)(kb0 - (rw ? ir : 1)), xstep, rw ? r.xr : -r.xl);
+        // The rows take the slot's eight 8-point groups in ROTATED order -- row r does group (q + r) mod 8 at step q:
+        // most lines share their lower level (the ground state), so in lockstep all eight rows would add to the same
+        // eight doubles of that plane at every step (an eight-way same-address conflict in the LDS atomic unit);
+        // rotated, the rows of a step hit eight different groups, two per bank set: the 64 adds' minimum.
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+          const int g8 = ((q + row) & (kRows - 1)) * kRowLanes; // first point of this row's group at step q
+          if ((unsigned)(t0 + g8) < n_on) {
+            const double x = fma((double)g8, xstep, x0);
+            const double x2 = x * x;
+            const double y = fma(x2, b, a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, d), c));
+            atomicAdd(&p_lo[g8], wa * y); // return-less LDS adds: rows of different lines may hit the same point
+            atomicAdd(&p_ue[g8], we * y);
+            atomicAdd(&p_ua[g8], w3 * y);
+          }
+        }
+      }
+    }
+  }
+  // far field: one polynomial per (far pass, hierarchy level), added to the pass's two planes at this lane's point.
+  // The coefficients of a pass -- kMaxFarLevels x 2 kFC doubles, one block per hierarchy level -- come in by four
+  // coalesced vector loads (lane = coefficient), go through an LDS staging row and are read back as broadcasts; the next
+  // pass's loads are in flight while this one is evaluated.  (Round 6, first build: wave-uniform scalar loads, one
+  // (pass, level) block of 92 SGPRs at a time, each waited for before its 44 fma -- 60 dependent round trips per wave
+  // and most of the kernel's 4.9 ms.)
+  __syncthreads(); // the rows' sums of every wave are in the image
+#ifdef SR_MC_DIAG_NOPOLY
+  if (n_sub < 0)
+#endif
+  {
+    constexpr int kEvalLevels = 1; // sr_l2l_kernel has folded the wider levels into level 0
+    constexpr int kBlk = 2 * kFC, kTot = kEvalLevels * kBlk;
+    constexpr int kLoads = (kTot + 63) / 64; // loads per lane that cover a pass
+    double *const s_cf = s_img + mc.n_ch * 64 + wave * (64 * kLoads); // [64 kLoads] per wave
+    double tt[kMaxFarLevels];
+    int cidx[kLoads]; // element of the pass's coefficient table this lane fetches in load j (-1: none)
+#pragma unroll
+    for (int lv = 0; lv < kMaxFarLevels; ++lv) {
+      const int W = 64 << lv;
+      const int blo = g_lo + ((wlo - g_lo) >> (6 + lv)) * W;
+      tt[lv] = (double)(2 * (wlo + lane - blo) - (W - 1)) * (1.0 / 64 / (double)(1 << lv)); // exact: W = 2^(6+lv)
+    }
+#pragma unroll
+    for (int q = 0; q < kLoads; ++q) {
+      const int e = lane + 64 * q, lv = e / kBlk;
+      cidx[q] = e < kTot ? (fp.box_off[min(lv, kMaxFarLevels - 1)] + ((wlo - g_lo) >> (6 + lv))) * kBlk + (e - lv * kBlk) : -1;
+    }
+    const size_t lrow = (size_t)layer * fp.n_boxes_total * kBlk;
+    auto next_pass = [&](int f) { // first pass >= f of this wave (passes f = wave, wave + kMcWingWaves, ...) with coefficients
+      while (f < n_far && !far[f].coef) f += kMcWingWaves;
+      return f;
+    };
+    double reg[kLoads];
+    auto fetch = [&](int f) {
+      const double *cl = far[f].coef + lrow;
+#pragma unroll
+      for (int q = 0; q < kLoads; ++q) reg[q] = cidx[q] >= 0 ? cl[cidx[q]] : 0.0;
+    };
+    int f = next_pass(wave);
+    if (f < n_far) fetch(f);
+    while (f < n_far) {
+      __builtin_amdgcn_wave_barrier(); // (the previous pass's broadcast reads are done: LDS is in order per wave)
+#pragma unroll
+      for (int q = 0; q < kLoads; ++q) s_cf[lane + 64 * q] = reg[q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int ch_a = far[f].ch_a, ch_e = far[f].ch_e;
+      const int fn = next_pass(f + kMcWingWaves);
+      if (fn < n_far) fetch(fn);
+      // one Horner chain (kFC broadcast reads, then kFC - 1 fma) at a time: unrolled over levels and outputs the
+      // compiler hoisted all 230 reads of a pass (256 VGPRs, or 171 spills at 128)
+      double sa = 0., se = 0.;
+#pragma unroll 1
+      for (int h = 0; h < 2 * kEvalLevels; ++h) {
+        const int lv = h >> 1;
+        const double *c = s_cf + h * kFC; // block lv: [abs kFC | emi kFC]
+        double t = tt[0];
+#pragma unroll
+        for (int q = 1; q < kMaxFarLevels; ++q) t = lv == q ? tt[q] : t;
+        double cv[kFC];
+#pragma unroll
+        for (int n = 0; n < kFC; ++n) cv[n] = c[n];
+        double pv = cv[kFC - 1];
+#pragma unroll
+        for (int n = kFC - 2; n >= 0; --n) pv = fma(pv, t, cv[n]);
+        if (h & 1) se += pv; else sa += pv;
+      }
+      if (ch_a >= 0) s_img[ch_a * 64 + lane] += sa;
+      if (ch_e >= 0) s_img[ch_e * 64 + lane] += se;
+      f = fn;
+    }
+  }
+  __syncthreads(); // (a pass's two planes are its wave's alone, but the output planes below are dealt by index)
+  const int j = wlo + lane;
+  if (j <= whi) {
+    const size_t n_pts = (size_t)(g_hi - g_lo);
+    double *o = out + (size_t)(row0 + layer) * n_pts + (size_t)(j - g_lo);
+    const size_t cstride = (size_t)n_rows_total * n_pts;
+#ifdef SR_MC_DIAG_NORMW
+    for (int c = wave; c < mc.n_ch; c += kMcWingWaves) o[c * cstride] = s_img[c * 64 + lane];
+#else
+    for (int c = wave; c < mc.n_ch; c += kMcWingWaves) o[c * cstride] += s_img[c * 64 + lane];
+#endif
+  }
+}
+
+int launch_zones_mc(const FastRec *fast, const ColdRec *cold, const int *lev_up, const int *lev_lo, const IcIndex &ix,
+                    const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const McChannels &mc,
+                    double *out, int n_rows_total, int row0, hipStream_t st) {
+  if (g_hi <= g_lo || n_layers <= 0) return 0;
+  constexpr int WT = kMcImage, NW = kMcWaves;
+  const int n_t = (g_hi - g_lo + WT - 1) / WT;
+  const size_t lds = sizeof(double) * (size_t)mc.n_ch * (WT + 2) + sizeof(int) * (size_t)NW * 2 * 4 * 64;
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  static bool attr_set = false; // (more than 64 KB of dynamic LDS needs the attribute once per process and kernel)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sr_zones_mc_kernel<WT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((sr_zones_mc_kernel<WT, NW>), dim3((unsigned)(n_t * n_layers)), dim3(64 * NW), lds, st, fast, cold, lev_up, lev_lo,
+                     ix, zmax, n_sub, n_t, g_lo, g_hi, gp, mc, out, n_rows_total, row0);
+  return (int)hipGetLastError();
+}
+
+int launch_wings_mc(const FastRec *fast, const int *lev_up, const int *lev_lo, const IcIndex &ix, const int *zmax, int n_sub,
+                    int n_layers, int g_lo, int g_hi, const FarParams &fp, const McChannels &mc, const McFarPass *far, int n_far,
+                    double *out, int n_rows_total, int row0, hipStream_t st) {
+  if (g_hi <= g_lo || n_layers <= 0) return 0;
+  const int n_g1 = (g_hi - g_lo + 63) / 64;
+  const size_t lds = sizeof(double) * ((size_t)mc.n_ch * 64 + 64 * kMcWingWaves); // the image + the polynomial stage's staging rows
+  if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(sr_wings_mc_kernel, dim3((unsigned)(n_g1 * n_layers)), dim3(64 * kMcWingWaves), lds, st, fast, lev_up, lev_lo, ix, zmax, n_sub,
+                     n_g1, g_lo, g_hi, fp, mc, far, n_far, out, n_rows_total, row0);
+  return (int)hipGetLastError();
+}
+
+#else // 80-byte records carry no third weight: mc_pass never takes this route then (SR_ERR_UNSUPPORTED)
+int launch_zones_mc(const FastRec *, const ColdRec *, const int *, const int *, const IcIndex &, const int *, int, int, int, int,
+                    const GridParams &, const McChannels &, double *, int, int, hipStream_t) { return (int)hipErrorNotSupported; }
+int launch_wings_mc(const FastRec *, const int *, const int *, const IcIndex &, const int *, int, int, int, int, const FarParams &,
+                    const McChannels &, const McFarPass *, int, double *, int, int, hipStream_t) { return (int)hipErrorNotSupported; }
+#endif
 
 // a += za, e += ze (small shards: the zones kernel's private result joins the wings kernel's)
 __global__ __launch_bounds__(256) void sr_add2_kernel(double *__restrict__ a, const double *__restrict__ za,

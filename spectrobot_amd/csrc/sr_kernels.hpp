@@ -137,6 +137,55 @@ int launch_near(int part, int add, const FastRec *fast, const ColdRec *cold, con
                 double *abs_out, double *emi_out, unsigned long long *cnt, hipStream_t st, const double *z_abs = nullptr,
                 const double *z_emi = nullptr);
 
+// ---- the multi-channel pass (sr_zones_mc_kernel, sr_wings_mc_kernel) ----
+// Which output spectrum ("channel") each of a line's three weights goes to: channel = stride * level + offset.
+//   pair tables  (sr_glevel_pairs_dev):  stride 2; wabs -> (lev_lo, 0) abs, wemi -> (lev_up, 1) emi, w3 = -G_ind -> (lev_up, 0) abs
+//   three ctypes (sr_gcoeff_levels_dev): stride 3; wemi -> (lev_up, 0) sp_emission, w3 = +G_ind -> (lev_up, 1) ind_emission,
+//                                        wabs -> (lev_lo, 2) absorption
+struct McChannels {
+  int stride, o_lo, o_up_e, o_up_a, n_ch; // n_ch = stride * n_levels
+};
+// One far-only pass of a level sub-lineset: its coefficients [n_layers][n_boxes_total][2][kFC] (nullptr: no lines) and
+// the channels its two outputs belong to (-1: none)
+struct McFarPass {
+  const double *coef;
+  int ch_a, ch_e;
+};
+#ifndef SR_MC_IMAGE
+#define SR_MC_IMAGE 256
+#endif
+#ifndef SR_MC_WAVES
+#define SR_MC_WAVES 8
+#endif
+#ifndef SR_MC_WING_WAVES
+#define SR_MC_WING_WAVES 2
+#endif
+constexpr int kMcWingWaves = SR_MC_WING_WAVES; // waves sharing a slot's image in sr_wings_mc_kernel
+constexpr int kMcImage = SR_MC_IMAGE, kMcWaves = SR_MC_WAVES; // points per LDS image of sr_zones_mc_kernel, waves sharing it
+// lev_up / lev_lo: the lineset's arrays offset to the first line of the shard's record table (IcIndex::line_lo)
+// out [n_ch][n_rows_total][g_hi - g_lo]; the launch's layers are rows row0 .. row0 + n_layers - 1.  zones stores, wings adds.
+// One SPARSE far-only pass of a table build's batch (launch_far_batch): the sub-lineset's lines and centre index, the
+// lines whose windows meet the shard, the weights, where its records [n_layers][n_sub] and coefficients go
+struct FarBatchItem {
+  LinesDev L;
+  const int *first;
+  int first_x0, first_n, line_lo, n_sub;
+  WeightMode W;
+  FastRec *fast;
+  double *coef;
+};
+int launch_far_batch(const FarBatchItem *items, int n_items, int max_n_sub, const LayersDev &A, const GridParams &gp, const int *zmax,
+                     int g_lo, const FarParams &fp, const double *l2l_tab, hipStream_t st);
+// the downward pass: a far pass's wider levels folded into its level-0 coefficients (in place); tab: l2l_table_host
+void l2l_table_host(double *tab); // [2][kFC][kFC]
+int launch_l2l(double *coef, int n_layers, const FarParams &fp, const double *tab, hipStream_t st);
+int launch_zones_mc(const FastRec *fast, const ColdRec *cold, const int *lev_up, const int *lev_lo, const IcIndex &ix,
+                    const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const McChannels &mc,
+                    double *out, int n_rows_total, int row0, hipStream_t st);
+int launch_wings_mc(const FastRec *fast, const int *lev_up, const int *lev_lo, const IcIndex &ix, const int *zmax, int n_sub,
+                    int n_layers, int g_lo, int g_hi, const FarParams &fp, const McChannels &mc, const McFarPass *far, int n_far,
+                    double *out, int n_rows_total, int row0, hipStream_t st);
+
 int launch_prep(const LinesDev &L, const LayersDev &A, const GridParams &gp, const WeightMode &W, int line_lo,
                 int n_sub, int cold_lo, int cold_hi, FastRec *fast, ColdRec *cold, hipStream_t st);
 // Lines whose centre lies outside their own window (humliv_bb's outer branches, lineshape.f:272-442):

@@ -206,6 +206,23 @@ class LineSet(object):
                                        C.c_void_p(g.data_ptr()), _stream_ptr()), "sr_gcoeff_layers_dev")
         return g
 
+    def gcoeff_levels(self, temps, press, g_lo=0, g_hi=None, out=None):
+        """G-coefficient spectra of ALL levels at every (P, T): CUDA float64 [n_levels or 1, 3, n_rows, g_hi-g_lo], ctype
+        0 sp_emission, 1 ind_emission, 2 absorption -- LookUpTable.make's inner loop over the levels
+        (spect_main_module.py:759-772) in one call (sr_gcoeff_levels_dev: the multi-channel pass, every line once)."""
+        g_hi = self.n_grid if g_hi is None else int(g_hi)
+        desc, keep, n = self._layers(temps, press, None, None)
+        npts = g_hi - int(g_lo)
+        if npts <= 0:
+            raise ValueError("empty shard")
+        nl = max(int(self.level_energies.size), 1)
+        if out is None:
+            out = torch.empty((nl, 3, n, npts), dtype=torch.float64, device="cuda")
+        assert out.shape == (nl, 3, n, npts) and out.is_contiguous() and out.dtype == torch.float64
+        check(lib.sr_gcoeff_levels_dev(self._h, C.byref(desc), int(g_lo), g_hi, C.c_void_p(out.data_ptr()), _stream_ptr()),
+              "sr_gcoeff_levels_dev")
+        return out
+
     def glevel_pairs(self, temps, press, g_lo=0, g_hi=None, out=None):
         """Level-pair tables of the level-factored route (sr_glevel_pairs_dev): CUDA float64
         [n_levels or 1, 2, n_rows, g_hi-g_lo] with [L, 0] = Gabs_L - Gind_L and [L, 1] = Gsp_L at every (P, T) row --
@@ -940,6 +957,12 @@ def temperature_jacobian(ls, temps, press, seg_off, seg_layer, seg_col, tvib=Non
 
 def set_points_per_lane(p):
     check(lib.sr_set_points_per_lane(int(p)), "sr_set_points_per_lane")
+
+
+def set_level_route(multi_channel):
+    """1 (default): level tables (glevel_pairs, gcoeff_levels) by the multi-channel pass -- every line once --; 0: one
+    coefficient op per level (sr_set_level_route)."""
+    check(lib.sr_set_level_route(int(multi_channel)), "sr_set_level_route")
 
 
 def set_overlap(on):

@@ -287,8 +287,9 @@ class LookUpTable(object):
     def make(self, spectral_grid, lines, PTcouples, export_levels=True, cartLUTs=None, control=True,
              n_threads=n_threads, pt_batch=64):
         """G spectra of every level at every [P, T] of PTcouples (spect_main_module.py:718-788): the
-        reference's loop over PT couples x levels x ctypes is one sr_gcoeff_layers_dev call per level and batch
-        of pt_batch couples.  cartLUTs: when given, every LutSet is also streamed to a file there."""
+        reference's loop over PT couples x levels x ctypes is one sr_gcoeff_levels_dev call per batch of pt_batch
+        couples (non-LTE: all levels at once), or one sr_gcoeff_layers_dev call per batch for the LTE 'all' set.
+        cartLUTs: when given, every LutSet is also streamed to a file there."""
         self.PTcouples = copy.deepcopy(PTcouples)
         self.spectral_grid = copy.deepcopy(spectral_grid)
         lineset = _as_lineset(lines, spectral_grid, self.isomolec)
@@ -298,6 +299,7 @@ class LookUpTable(object):
             todo = [(lev, getattr(self.isomolec, lev), i) for i, lev in enumerate(self.isomolec.levels)]
         else:
             todo = [('all', None, -1 if self.isomolec.levels else 0)]
+        sets = []
         for name, level, index in todo:
             fn = None if cartLUTs is None else find_free_name(                                      # :737
                 cartLUTs + self.tag + '_' + (name if level is not None else 'alllev') + date_stamp() + '.pic', maxnum=10, split_at='.pic')
@@ -305,14 +307,22 @@ class LookUpTable(object):
             st.spectral_grid = self.spectral_grid
             if fn is not None:
                 st.prepare_export(PTcouples, self.spectral_grid)
-            for b0 in range(0, len(PTcouples), pt_batch):
-                sl = slice(b0, b0 + pt_batch)
-                g3 = lineset.gcoeff_layers(Ts[sl], Ps[sl], level=index)
+            sets.append((name, st, index, fn))
+        # Round 6: ALL levels of a batch of couples from one multi-channel pass (engine.LineSet.gcoeff_levels: every line
+        # evaluated once, its three G-weighted shapes added to the spectra of its two levels) instead of one
+        # sr_gcoeff_layers_dev call per level -- the reference's loop order (:759-772: couples outside, levels inside)
+        all_levels = (not self.LTE) and lineset.level_energies.size == len(todo)
+        for b0 in range(0, len(PTcouples), pt_batch):
+            sl = slice(b0, b0 + pt_batch)
+            g_all = lineset.gcoeff_levels(Ts[sl], Ps[sl]) if all_levels else None
+            for name, st, index, fn in sets:
+                g3 = g_all[index] if g_all is not None else lineset.gcoeff_layers(Ts[sl], Ps[sl], level=index)
                 if fn is not None:
                     gh = g3.cpu().numpy()
                     for i, pt in enumerate(PTcouples[sl]):
                         st.add_dump(st._host_set(gh[:, i], pt[0], pt[1], grid=False))
                 st._append(g3, PTcouples[sl])
+        for name, st, index, fn in sets:
             st.finalize_IO()
             self.sets[name] = st
 

@@ -192,3 +192,87 @@ def test_level_pairs_on_a_shard_with_lines_beyond_the_grid(eng):
     a_in, _ = lsi.abscoeff_layers(T[:1], P[:1], tvib=atm["tvib"][:, :1])
     a_all, _ = ls.abscoeff_layers(T[:1], P[:1], tvib=atm["tvib"][:, :1])
     assert float(((a_all - a_in).abs() / a_all.abs()).max()) > 1e-6
+
+
+def _plane_err(a, b):
+    """max |a - b| relative to the largest |b| of each (level, channel, row) spectrum."""
+    s = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+    return float(((a - b).abs() / s).max())
+
+
+@pytest.mark.parametrize("case", ["dense", "sparse_shard", "frozen_linear", "outer_lines", "low_pressure"])
+def test_multichannel_route_equals_the_per_level_route(eng, case):
+    """Round 6: the level tables by the multi-channel pass (every line ONCE: sr_zones_mc_kernel / sr_wings_mc_kernel add
+    its three weighted contributions to the LDS planes of its two levels; far field by far-only passes of the level
+    sub-linesets) against one coefficient op per level (sr_set_level_route(0): the route of rounds 4-5, itself pinned
+    to the reference's add_PT -> BuildCoeff run by test_gcoeff_levels_golden).  Pair tables AND the three ctypes; whole
+    grids and shards whose lines reach beyond the grid; frozen boundaries with linearised weights (the T + dT build of
+    configs[3]); lines whose centre lies outside their window; Doppler-dominated rows (wide region-3 cores).  The two
+    routes differ by the order of summation only: <= 2e-12 of a spectrum's largest value."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    n_grid, n_lines, nl, lo, hi, w0 = 40000, 30000, 6, 0, None, 2985.0
+    kw = {}
+    if case == "sparse_shard":
+        n_lines, lo, hi = 5000, 3001, 33333
+    elif case == "outer_lines":
+        n_grid, n_lines, lo, hi = 20000, 8000, 0, None
+    grid = syn.make_grid(w0, 5e-4, n_grid)
+    L = syn.make_lines(n_lines, grid, seed=61, n_levels=12, config_id=2)
+    if case == "outer_lines":   # some lines up to 6 cm-1 beyond the grid ends: their windows sit on the end points
+        rng = np.random.default_rng(4)
+        k = rng.choice(n_lines, 400, replace=False)
+        L = dict(L)
+        L["freq"] = L["freq"].copy()
+        L["freq"][k[:200]] = grid[0] - rng.uniform(0.0, 6.0, 200)
+        L["freq"][k[200:]] = grid[-1] + rng.uniform(0.0, 6.0, 200)
+    atm = syn.make_atmosphere(nl, 12)
+    T, P = atm["temps"], atm["press"] * (1e-3 if case == "low_pressure" else 1.0)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    try:
+        if case == "frozen_linear":
+            ls.set_bounds_temps(T, linear_weights=True)
+            T = T + 0.02
+        res = {}
+        for route in (1, 0):
+            eng.set_level_route(route)
+            res[route] = (ls.glevel_pairs(T, P, g_lo=lo, g_hi=hi), ls.gcoeff_levels(T, P, g_lo=lo, g_hi=hi))
+            torch.cuda.synchronize()
+    finally:
+        eng.set_level_route(1)
+        ls.set_bounds_temps(None)
+    assert float(res[0][0].abs().max()) > 0 and float(res[0][1].abs().max()) > 0
+    assert _plane_err(res[1][0], res[0][0]) < 2e-12, case
+    assert _plane_err(res[1][1], res[0][1]) < 2e-12, case
+    # the per-level entry point of the three ctypes is untouched by the route: level 5 of the all-levels call
+    if case != "frozen_linear":   # (the boundaries were released above)
+        assert _plane_err(res[1][1][5], ls.gcoeff_layers(T, P, level=5, g_lo=lo, g_hi=hi)) < 2e-12
+
+
+def test_multichannel_route_in_row_batches_and_after_other_calls(eng):
+    """The multi-channel pass under a small table budget (row batches: every batch writes its rows of every channel)
+    and interleaved with folded ops on the same handle (shared scratch of the level sub-linesets, own tables of the
+    pass) on unsynchronised streams: same tables as one unbatched call."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2990.0, 5e-4, 16000)
+    L = syn.make_lines(6000, grid, seed=8, n_levels=12, config_id=2)
+    atm = syn.make_atmosphere(9, 12)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    ref = ls.glevel_pairs(atm["temps"], atm["press"])
+    a0, e0 = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
+    torch.cuda.synchronize()
+    try:
+        eng.set_table_budget(6000 * 112 * 3 * 4 + 4 * 16000 * 100)   # a few rows per batch
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(s1):
+            t1 = ls.glevel_pairs(atm["temps"], atm["press"])
+        with torch.cuda.stream(s2):
+            a1, e1 = ls.abscoeff_layers(atm["temps"], atm["press"], tvib=atm["tvib"])
+        with torch.cuda.stream(s1):
+            t2 = ls.glevel_pairs(atm["temps"], atm["press"])
+        torch.cuda.synchronize()
+    finally:
+        eng.set_table_budget(48 << 30)
+    assert _plane_err(t1, ref) < 2e-12 and _plane_err(t2, ref) < 2e-12
+    assert torch.equal(a1, a0) and torch.equal(e1, e0)

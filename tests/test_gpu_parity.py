@@ -1016,7 +1016,8 @@ def test_schedules_agree_over_changing_shapes(eng):
     """The two schedules of the coefficient op (sr_set_overlap: 1 the decoupled, phased pipeline on internal streams and
     parity scratch, 0 serial on table set 0) over changing inputs, shard bounds, layer counts and weight modes, and
     ALTERNATING between them (a serial call between pipelined ones shares their table set 0) -- every call re-sizes or
-    re-uses the handle's scratch: same results bit for bit."""
+    re-uses the handle's scratch: same results bit for bit (the level pair tables, whose multi-channel pass adds from
+    several waves into one LDS image, to 2e-12 of a spectrum's largest value: their order of addition is not fixed)."""
     import torch
     from spectrobot_amd import synthetic as syn
     grid = syn.make_grid(2980.0, 5e-4, 30000)
@@ -1039,6 +1040,10 @@ def test_schedules_agree_over_changing_shapes(eng):
             res[mode] = out
     finally:
         eng.set_overlap(1)
+    def same(x, y):
+        if x.dim() == 4:     # level pair tables
+            return float(((x - y).abs() / y.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)).max()) < 2e-12
+        return torch.equal(x, y)
     for mode in (0, "alternating"):
         assert len(res[mode]) == len(res[1]) == 42
-        assert all(torch.equal(x, y) for x, y in zip(res[mode], res[1])), mode
+        assert all(same(x, y) for x, y in zip(res[mode], res[1])), mode
