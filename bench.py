@@ -277,6 +277,8 @@ def main():
                     "step (P, T, T_vib at the local SZA along the path), Jacobians per altitude layer")
     ap.add_argument("--level-route", type=int, default=1, choices=(0, 1), help="--config 3 / lut: level tables by the multi-channel "
                     "pass (1, default: every line once) or by one coefficient op per level (0: the route of rounds 4-5)")
+    ap.add_argument("--balanced", action="store_true", help="N > 1: shards of equal line-window WORK (distributed.shard_bounds_balanced) "
+                    "instead of equal width; the gather then pads to the widest shard")
     ap.add_argument("--exact", action="store_true", help="evaluate every (line, point) exactly (no far-field expansions)")
     ap.add_argument("--far-field", type=int, default=3, choices=(1, 2, 3), help="3 (default): far-field expansions from box "
                     "pairs (multipole -> local), sparse line sets per line and box; 2: box pairs always; 1: per line and box")
@@ -313,7 +315,11 @@ def main():
     los, Lr = build_rays(syn, engine, atm, args.rays)
 
     ls = engine.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)     # lines -> HBM (outside the timed region)
-    g_lo, g_hi = sd.shard_bounds(args.grid, world, rank)
+    # the ranks' spectral shards: equal width (default: one in-place all-gather) or equal modelled work (--balanced)
+    bounds = [sd.shard_bounds(args.grid, world, r) for r in range(world)]
+    if args.balanced and world > 1:
+        bounds = sd.shard_bounds_balanced(L["freq"], grid, world)
+    g_lo, g_hi = bounds[rank]
     if args.shard:
         assert world == 1
         g_lo, g_hi = sd.shard_bounds(args.grid, int(args.shard.split("/")[1]), int(args.shard.split("/")[0]))
@@ -333,10 +339,14 @@ def main():
             return rad
         # async: the next step's kernels need not wait for this step's (latency-bound) gather; barrier() below
         # synchronises the device, collectives included, before any time is taken or `full` is read
-        return sd.all_gather_spectrum(rad, args.grid, world, rank, out=full, async_op=ASYNC_GATHER)
+        return sd.all_gather_spectrum(rad, args.grid, world, rank, out=full, bounds=bounds, async_op=ASYNC_GATHER)
+
+    wait_s = [0.0]   # time this rank's host spent in wait_gathers() (the asynchronous gathers still outstanding at a barrier)
 
     def barrier():
+        t_w = time.perf_counter()
         sd.wait_gathers()
+        wait_s[0] += time.perf_counter() - t_w
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -355,11 +365,14 @@ def main():
     engine.set_timing(0)          # no per-kernel timing events in the timed steps (diagnostics: the pass below has them)
     step()
     barrier()
+    wait_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):   # no host synchronisation inside: consecutive steps pipeline on the GPU
         spec = step()
+    t_enq = time.perf_counter() - t0                       # host time to enqueue the timed steps
     barrier()
     elapsed = time.perf_counter() - t0
+    wait_timed = wait_s[0]
     engine.set_timing(1)
     for _ in range(args.steps):   # HIP-event times of this rank's kernels (each query synchronises that step)
         step()
@@ -367,15 +380,29 @@ def main():
     barrier()
     dist_rec = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dev_t = "cuda" if torch.distributed.get_backend() == "nccl" else "cpu"
+        # every rank's own numbers, for rank 0's line (the first real SCALE run must be diagnosable from
+        # its one line): elapsed, host enqueue time, host time in wait_gathers(), all over the timed steps
+        mine = torch.tensor([elapsed, t_enq, wait_timed], dtype=torch.float64, device=dev_t)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        per_rank = np.array([e.cpu().numpy() for e in every])
+        elapsed = float(per_rank[:, 0].max())              # the bench contract: MAX over ranks
+        costs, n_lines_rank = sd.shard_costs(L["freq"], grid, bounds)
         # what the collective really was, and the asynchronous gather of the last timed step against a blocking one
         # of the same shard (outside the timed region)
-        dist_rec = dict(sd.dist_info(), async_gather=bool(ASYNC_GATHER), gathers=dict(sd.stats))
+        dist_rec = dict(sd.dist_info(), async_gather=bool(ASYNC_GATHER), gathers=dict(sd.stats),
+                        shards={"bounds": [list(b) for b in bounds], "balanced": bool(args.balanced),
+                                "points": [hi - lo for lo, hi in bounds], "lines_prepared": n_lines_rank,
+                                "model_cost_max_over_mean": float(max(costs) / (sum(costs) / len(costs)))},
+                        per_rank={"ms_per_step": [float(v) / args.steps * 1e3 for v in per_rank[:, 0]],
+                                  "ms_per_step_min": float(per_rank[:, 0].min()) / args.steps * 1e3,
+                                  "ms_per_step_max": float(per_rank[:, 0].max()) / args.steps * 1e3,
+                                  "host_enqueue_ms_per_step": [float(v) / args.steps * 1e3 for v in per_rank[:, 1]],
+                                  "host_ms_in_wait_gathers": [float(v) * 1e3 for v in per_rank[:, 2]]},
+                        rank0_ms_in_wait_gathers=float(per_rank[0, 2]) * 1e3)
         rad_chk = engine.limb_rays((ab, em), los, resident=False)   # (the per-call staging route: a second opinion)
-        blocking = sd.all_gather_spectrum(rad_chk, args.grid, world, rank, async_op=False)
+        blocking = sd.all_gather_spectrum(rad_chk, args.grid, world, rank, bounds=bounds, async_op=False)
         torch.cuda.synchronize()
         dist_rec["async_equals_blocking"] = bool(torch.equal(blocking, spec))
     kms /= args.steps

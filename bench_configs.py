@@ -593,6 +593,19 @@ def main(args):
                      "against round 4's two-sweep kernel)"
                      % (len(alts), len(par_gas), n_sh))
             out["roofline"]["traffic"] = None
+            # the kernel's own counters say 63 % VALU-issue-busy and 87 % L2 hits -- its bound is the fp64
+            # vector unit (and the latency of a ray's 60 dependent shell visits), not HBM: the line's fraction is flop based.
+            # Flop model per (point, ray, shell visit) of the one-sweep kernel (sr_limb_fold_sens_lds_kernel): the
+            # far and the near segment's attenuation (one fused exp / expm1 / quotient each, ~34 flop), tau and the source of
+            # the gases (6 flop per gas and segment), the recursion itself (12), five fma per parameter.
+            n_seg_all = int(los.seg_off[-1])                   # both segments of every shell a ray crosses
+            n_par_, n_gas_ = len(par_gas), len(coeffs)
+            flops = float(n_sh) * (n_seg_all * (34.0 + 6.0 * n_gas_ + 6.0) + 0.5 * n_seg_all * 10.0 * n_par_)
+            hb = dict(out["roofline"])
+            out["roofline"].update({"bound": "fp64-valu", "achieved": flops / (hb["ms"] * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                    "frac": flops / (hb["ms"] * 1e-3) / 1e12 / 78.6, "flops_per_launch": flops,
+                                    "hbm_view": {"achieved_gbs": hb["achieved"], "frac_of_8_tb_s": hb["frac"],
+                                                 "bytes_per_launch": hb["bytes_per_launch"]}})
             if world == 1 and args.cpu_seconds > 0:
                 # CPU leg: the oracle's recursion (two gases mixed on the host) for the 18 LOS, once for the radiances and
                 # once per parameter -- what a CPU port without the sensitivity recursion does per iteration (finite

@@ -1396,7 +1396,15 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       if (rc) return rc;
       LAUNCHCHK(launch_prep(ls->L, A, ls->gp, WeightMode{kWeightChannels, ctypes3 ? 1 : 0}, line_lo, n_sub, (int)g_lo, (int)g_hi - 1,
                             m.d_fast.as<FastRec>(), m.d_cold.as<ColdRec>(), st));
-      // far-only passes of the level sub-linesets (their own tables and chain through the shared CoefWork)
+      HIPCHK(hipEventRecord(m.ev_prep, st)); // the layer stage, the tables and everything earlier on the caller's stream
+      // The zones kernel beside the far passes.  The build is bound by its kernels' WORK, not by their order -- 13.25 / 13.32
+      // ms with the zones kernel gated behind the far passes, 13.06 / 13.13 beside them (one box, alternating); the sparse
+      // passes' single batched launch no longer starves beside it as their twelve small chains did (tl_v3 vs tl_v5).
+      {
+        LAUNCHCHK(launch_zones_mc(m.d_fast.as<FastRec>(), m.d_cold.as<ColdRec>(), ls->L.lev_up + line_lo, ls->L.lev_lo + line_lo, ix,
+                                  zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, mc, out, n_rows, k0, st));
+      }
+      // far-only passes of the level sub-linesets
       rc = m.s_far.prepare(sizeof(McFarPass) * (size_t)n_far);
       if (rc) return rc;
       McFarPass *far = m.s_far.host<McFarPass>();
@@ -1467,7 +1475,6 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
           rc = m.d_bfast.ensure(sizeof(FastRec) * (rec_total + 1));
           if (rc) return rc;
           for (int i = 0; i < n_items; ++i) items[i].fast = m.d_bfast.as<FastRec>() + rec_off[(size_t)i];
-          HIPCHK(hipEventRecord(m.ev_prep, st)); // (the layer stage and everything earlier on the caller's stream)
           HIPCHK(hipStreamWaitEvent(m.zst, m.ev_prep, 0));
           rc = m.s_batch.push(sizeof(FarBatchItem) * (size_t)n_items, m.zst);
           if (rc) return rc;
@@ -1508,12 +1515,6 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         far[f].ch_e = !ctypes3 ? 2 * lv + 1 : (ind ? -1 : 3 * lv);
       }
       if (m.batch_pending) HIPCHK(hipStreamWaitEvent(st, m.ev_zones, 0));
-      // The zones kernel AFTER the level passes (every one of them has made the caller's stream wait for its chain): its
-      // 8-wave workgroups of 128 VGPRs and 58 KB fill every SIMD's register file, and the latency-bound chains of the
-      // sparse passes starved beside it -- seven of the twelve ran only when it had drained (6.5 ms), the wings kernel
-      // 3 ms later still (gpurun_out/r06/tl_v3.txt: 13.1 ms per build).
-      LAUNCHCHK(launch_zones_mc(m.d_fast.as<FastRec>(), m.d_cold.as<ColdRec>(), ls->L.lev_up + line_lo, ls->L.lev_lo + line_lo, ix,
-                                zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, mc, out, n_rows, k0, st));
       rc = m.s_far.push(sizeof(McFarPass) * (size_t)n_far, st);
       if (rc) return rc;
       FarParams fp;

@@ -56,6 +56,22 @@ def shard_bounds_balanced(line_freq, grid, world_size, zone_weight=1.5, align=64
     return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
+def shard_costs(line_freq, grid, bounds, zone_weight=1.5, point_weight=0.0):
+    """The work model of shard_bounds_balanced summed over each of the given shards [(lo, hi)]: per-shard cost (arbitrary
+    units) and the number of lines whose 13010-point window meets the shard (what the rank prepares records for)."""
+    import numpy as np
+    grid = np.asarray(grid, dtype=float)
+    n, half = grid.size, 6505
+    ic = np.clip(np.rint((np.asarray(line_freq, dtype=float) - grid[0]) / (grid[1] - grid[0])).astype(np.int64), 0, n - 1)
+    centres = np.bincount(ic, minlength=n).astype(float)
+    cum = np.concatenate([[0.0], np.cumsum(centres)])
+    cover = cum[np.minimum(np.arange(n) + half, n)] - cum[np.maximum(np.arange(n) - half + 1, 0)]
+    c = np.concatenate([[0.0], np.cumsum(cover + zone_weight * 13010.0 * centres + point_weight * 13010.0)])
+    costs = [float(c[hi] - c[lo]) for lo, hi in bounds]
+    lines = [int(cum[min(hi + half, n)] - cum[max(lo - (half - 1), 0)]) for lo, hi in bounds]
+    return costs, lines
+
+
 def init_from_env(backend=None, single_rank_group=False):
     """torch.distributed rendezvous from RANK / WORLD_SIZE / MASTER_* (torchrun).  single_rank_group: form a
     process group even for WORLD_SIZE = 1 (the RCCL hardware test on a one-GPU box)."""

@@ -162,7 +162,7 @@ def shard_with_halo(n_grid, g_lo, g_hi):
     return int(g_lo), int(min(g_hi + 1, n_grid))
 
 
-def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, refresh=False, arrays=False):
+def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, refresh=False, arrays=False, group=None):
     """One forward-model pass for all pixels (the body of the reference's iteration,
     spect_main_module.py:2736-2940): returns (sims, derivs) with sims[i] the FOV-integrated low-resolution
     spectrum of pixel i (Spectrum) and derivs[i][p] its derivative w.r.t. parameter p of bayes_set.
@@ -176,16 +176,25 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
 
     arrays=True (every pixel with a field of view and the closed form -- or none with a field of view): returns
     (low [n_pix, n_bands], dlow [n_pix, n_par, n_bands]) instead of the spectrum objects (the retrieval loop: the
-    objects of an iteration were ~0.1 ms of its 0.65)."""
+    objects of an iteration were ~0.1 ms of its 0.65).
+
+    group = (alt_step_sims, alt_first_los): the reference's group_observations route (spect_main_module.py:2668-2670,
+    2908-2930, 3056-3058, 3263-3273) -- the forward model runs on a regular ladder of tangent altitudes
+    (smm.make_group_observations) instead of three LOS per pixel, and the pixels' LOS spectra (and derivatives) are read
+    off quadratic splines in tangent altitude (smm.make_radtran_spline) before the FOV integration."""
     from . import distributed as sd
     alts = [a for pix in pixels for a in pix.los_alts()]
+    alts_pix = None
+    if group is not None:
+        alts_sim, _ = smm.make_group_observations(list(pixels), alt_step=group[0], alt_first_los=group[1])
+        alts_pix, alts = alts, [float(a) for a in alts_sim]
     n_grid = len(scene.grid)
     g_lo, g_hi = (0, n_grid) if shard is None else shard_with_halo(n_grid, *shard)
     coeffs = scene.coefficient_stack(refresh=refresh, g_lo=g_lo, g_hi=g_hi)
     n_los = len(alts)
     lowres = lambda r: engine.hires_to_lowres(r, scene.grid, scene.bands_nm, scene.widths_nm, out_units=scene.out_units, g_lo=g_lo)
     with_fov = sum(pix.fov_half > 0 for pix in pixels)
-    if arrays and ONE_CALL and bayes_set is not None and (with_fov == 0 or (with_fov == len(pixels) and fov_closed_form)) and \
+    if arrays and ONE_CALL and group is None and bayes_set is not None and (with_fov == 0 or (with_fov == len(pixels) and fov_closed_form)) and \
             all(type(st) in (smm.LinearProfile_1D_new, smm.LinearProfile_1D) for st in bayes_set.sets.values()):
         # The iteration in ONE library call (engine.retrieval_forward): the VMRs of the retrieved gases are set on the
         # device from the parameter vector (their profile IS sum_p mask_p x_p: LinearProfile_1D.profile), columns,
@@ -233,6 +242,14 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
         t = torch.from_numpy(np.ascontiguousarray(both)).to(dev)
         sd.all_reduce_sum(t)
         both = t.cpu().numpy()
+    if alts_pix is not None:
+        # group_observations: every quantity (radiance, each derivative) from its spline over the simulated ladder
+        at = np.empty((len(alts_pix),) + both.shape[1:])
+        for q in range(both.shape[1]):
+            f = smm.make_radtran_spline(alts, np.ascontiguousarray(both[:, q, :]))
+            for i, a in enumerate(alts_pix):
+                at[i, q] = f(a)
+        both = at
     low = both[:, 0, :]
     dlow = None if bayes_set is None else both[:, 1:, :]
     sims, derivs = [], []
@@ -279,13 +296,15 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
 
 
 def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10, lambda_LM=0.1, L1_reg=False,
-                        solo_simulation=False, check_log=None, fov_closed_form=True, shard=None, refresh=False):
+                        solo_simulation=False, check_log=None, fov_closed_form=True, shard=None, refresh=False,
+                        group_observations=False, alt_step_sims=50., alt_first_los=None):
     """The retrieval loop of spect_main_module.inversion_fast_limb (:2725-2987): Levenberg-Marquardt
     optimal estimation of the VMR-profile parameters in bayes_set from the pixels' observations.
     Returns (chi, obs, sims, bayes_set) like the reference, plus .history on bayes_set (chi per iteration)
     and .stop ('converged' | 'raised' | 'max_it').  shard / refresh: see simulate (every rank of a multi-GPU run
     calls this with its own spectral shard; all ranks hold the same chi square history and parameters)."""
     pixels = sorted(pixels, key=lambda x: x.limb_tg_alt)                       # :2607
+    group = (alt_step_sims, alt_first_los) if group_observations else None     # :2668-2670
     for name in bayes_set.sets.keys():                                         # :2624-2625
         scene.gas(name).add_clim(bayes_set.sets[name].profile())
     obs = [pix.observation for pix in pixels]
@@ -322,13 +341,13 @@ def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10,
             return [wrap(v) for v in low]
     for num_it in range(max_it):
         if fast:
-            low, dlow = simulate(scene, pixels, bayes_set, fov_closed_form=fov_closed_form, shard=shard, refresh=refresh, arrays=True)
+            low, dlow = simulate(scene, pixels, bayes_set, fov_closed_form=fov_closed_form, shard=shard, refresh=refresh, arrays=True, group=group)
             for par in bayes_set.params():
                 par.set_used()
             sim_vec = low.reshape(-1) if masktot is None else low.reshape(-1)[masktot]
             chi = np.sum(((obs_vec - sim_vec) / noi_vec) ** 2) / (len(obs_vec) - bayes_set.n_used_par())   # chicalc, :2949
         else:
-            sims, derivs = simulate(scene, pixels, bayes_set, fov_closed_form=fov_closed_form, shard=shard, refresh=refresh)
+            sims, derivs = simulate(scene, pixels, bayes_set, fov_closed_form=fov_closed_form, shard=shard, refresh=refresh, group=group)
             if solo_simulation:
                 return None
             for num, row in enumerate(derivs):
@@ -447,6 +466,9 @@ def inversion(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10, lambda_LM
     return None
 
 
-def radtrans(scene, pixels, fov_closed_form=True, shard=None):
-    """Simulation only (spect_main_module.radtrans, :2990-3287): the FOV-integrated low-resolution spectra."""
-    return simulate(scene, pixels, None, fov_closed_form=fov_closed_form, shard=shard)[0]
+def radtrans(scene, pixels, fov_closed_form=True, shard=None, group_observations=False, alt_step_sims=50., alt_first_los=None):
+    """Simulation only (spect_main_module.radtrans, :2990-3287): the FOV-integrated low-resolution spectra.
+    group_observations / alt_step_sims / alt_first_los as in the reference's signature (:2990): simulate a ladder of
+    tangent altitudes and spline to the pixels' lines of sight (simulate(group=...))."""
+    group = (alt_step_sims, alt_first_los) if group_observations else None
+    return simulate(scene, pixels, None, fov_closed_form=fov_closed_form, shard=shard, group=group)[0]

@@ -898,6 +898,61 @@ def _clone_spectrum(obj, spectrum=None):
     return out
 
 
+def make_group_observations(pixels, alt_step=50., alt_first_los=None):
+    """The set of tangent altitudes a group of pixels with similar geometry is simulated on, a regular ladder of
+    step alt_step from the lowest pixel's lower LOS to (just beyond) the highest pixel's upper LOS
+    (spect_main_module.py:3290-3338).  Sorts `pixels` by tangent altitude in place, like the reference.  The pixels
+    need limb_tg_alt and the three lines of sight (low_LOS() / LOS() / up_LOS() objects with get_tangent_altitude(), or
+    los_alts() of the stand-in retrieval.LimbPixel).  Returns (alts, mean) with mean = {lat, lon, sza} of the pixels
+    that carry limb_tg_lat / limb_tg_lon / limb_tg_sza (the reference builds its LineOfSight objects, absent module,
+    from these means and the first pixel's spacecraft position and sub-solar point)."""
+    pixels.sort(key=lambda x: x.limb_tg_alt)                                              # :3298
+
+    def tg_alts(pix):
+        if hasattr(pix, "los_alts"):
+            return pix.los_alts()
+        return [lo.get_tangent_altitude() for lo in (pix.low_LOS(), pix.LOS(), pix.up_LOS())]
+    lo0, _, up0 = tg_alts(pixels[0])
+    first = lo0 if not lo0 > pixels[0].limb_tg_alt else up0                               # :3301-3303
+    loN, _, upN = tg_alts(pixels[-1])
+    last = upN if not upN < pixels[-1].limb_tg_alt else loN                               # :3304-3306
+    alt_range = [first, last]
+    if alt_first_los is None or alt_first_los > alt_range[0]:                             # :3309-3312
+        alt_first_los = alt_range[0]
+    alts = np.arange(alt_first_los, alt_range[1] + alt_step, alt_step)                    # :3329
+    mean = {}
+    for key, attr in (("lat", "limb_tg_lat"), ("lon", "limb_tg_lon"), ("sza", "limb_tg_sza")):
+        vals = [getattr(pi, attr) for pi in pixels if hasattr(pi, attr)]
+        if len(vals) == len(pixels):
+            mean[key] = np.mean(vals)                                                      # :3322-3324
+    return alts, mean
+
+
+def make_radtran_spline(alts, radtrans):
+    """Interpolation of simulated LOS spectra to an arbitrary tangent altitude: the reference's
+    RectBivariateSpline(alts, grid, spectra, kx=2, ky=2) (spect_main_module.py:3377-3396), evaluated on the spectra's own
+    grid -- there the tensor spline is, column by column, FITPACK's quadratic interpolating spline in altitude.
+    radtrans: spectrum objects (.spectrum, .spectral_grid.grid) or an array [n_alts, n_grid] with `grid` taken as its
+    index.  Returns f(x) -> the interpolated spectrum (object like radtrans[0], or an array for array input); the whole
+    grid in one evaluation (the reference evaluates point by point: the same numbers)."""
+    from scipy.interpolate import RectBivariateSpline as spline2D
+    alts = np.array(alts, dtype=float)
+    as_arrays = isinstance(radtrans, np.ndarray)
+    spectrums = np.asarray(radtrans, dtype=float) if as_arrays else np.array([rad.spectrum for rad in radtrans])
+    grid = np.arange(spectrums.shape[1], dtype=float) if as_arrays else np.asarray(radtrans[0].spectral_grid.grid, dtype=float)
+    intens_spl = spline2D(alts, grid, spectrums, kx=2, ky=2)
+
+    def radtran_alt(x):
+        res = np.array(intens_spl(float(x), grid)).reshape(-1)
+        if as_arrays:
+            return res
+        res_spe = copy.deepcopy(radtrans[0])
+        res_spe.spectrum = res
+        return res_spe
+
+    return radtran_alt
+
+
 def fov_closed_form(s0, s1, s2, pixel_rot=0.0):
     """The closed form of FOV_integr_1D on arrays of any (common) shape: the spectra of the three lines of sight -- or
     stacks of them, e.g. a pixel's radiances and all its parameter derivatives at once (the integral is linear in them)."""

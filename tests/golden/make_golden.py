@@ -832,3 +832,99 @@ def golden_containers():
 
 if __name__ == "__main__" and "--containers" in sys.argv:
     golden_containers()
+
+
+def golden_group_obs():
+    """The group_observations route of the reference's drivers (What's missing 2):
+    make_group_observations (spect_main_module.py:3290-3338: the coarse set of tangent altitudes a pixel set is
+    simulated on) and make_radtran_spline (:3377-3396: RectBivariateSpline(kx=2, ky=2) over tangent altitude x spectral
+    grid, evaluated at a pixel's three LOS altitudes), run under Python 3.  The absent spect_base_module is stubbed with
+    what the two call: Coords / LineOfSight as plain holders; the pixels are plain objects with the VIMSPixel members
+    the function reads (limb_tg_alt / lat / lon / sza, LOS() / low_LOS() / up_LOS(), sub_solar_point())."""
+    spcl, RF = import_reference_spcl()
+    m_mp = types.ModuleType("memory_profiler")
+    m_mp.profile = lambda f: f
+    sys.modules["memory_profiler"] = m_mp
+    sbm = sys.modules["spect_base_module"]
+
+    class Coords(object):
+        def __init__(self, c, s_ref="Spherical"):
+            self.c = list(c)
+
+        def Spherical(self):
+            return self.c
+
+    class LineOfSight(object):
+        def __init__(self, start, tg):
+            self.starting_point, self.tg = start, tg
+
+        def get_tangent_altitude(self):
+            return self.tg.c[2]
+
+        def get_tangent_point(self):
+            return self.tg
+
+    sbm.Coords, sbm.LineOfSight = Coords, LineOfSight
+    sbm.rad = lambda deg: deg * np.pi / 180.0
+    import spect_main_module as smm
+
+    class Pix(object):
+        def __init__(self, alt, half, lat, lon, sza):
+            self.limb_tg_alt, self.half, self.limb_tg_lat, self.limb_tg_lon, self.limb_tg_sza = alt, half, lat, lon, sza
+
+        def _los(self, alt):
+            return LineOfSight("spacecraft", Coords([self.limb_tg_lat, self.limb_tg_lon, alt]))
+
+        def LOS(self):
+            return self._los(self.limb_tg_alt)
+
+        def low_LOS(self):
+            return self._los(self.limb_tg_alt - self.half)
+
+        def up_LOS(self):
+            return self._los(self.limb_tg_alt + self.half)
+
+        def sub_solar_point(self):
+            return (0.0, 10.0)
+
+    rng = np.random.default_rng(20260006)
+    out = {}
+    cases = [dict(alts=[412.0, 187.5, 655.0, 301.0, 533.0], half=12.5, step=50.0, first=None),
+             dict(alts=[250.0, 275.0, 300.0], half=20.0, step=30.0, first=200.0),
+             dict(alts=[150.0, 480.0], half=7.0, step=75.0, first=400.0)]      # alt_first_los above the range: clamped
+    for i, c in enumerate(cases):
+        pix = [Pix(a, c["half"], -40.0 + 3.0 * k, 120.0 + k, 55.0 + 2.0 * k) for k, a in enumerate(c["alts"])]
+        los, alts, ssps, fszas = smm.make_group_observations(pix, alt_step=c["step"], alt_first_los=c["first"])
+        out["go%d_pix_alts" % i] = np.array(c["alts"])
+        out["go%d_half" % i], out["go%d_step" % i] = c["half"], c["step"]
+        out["go%d_first" % i] = np.nan if c["first"] is None else c["first"]
+        out["go%d_alts" % i] = np.array(alts, dtype=float)
+        out["go%d_los_alts" % i] = np.array([l.get_tangent_altitude() for l in los])
+        out["go%d_sza" % i] = np.array(fszas, dtype=float)
+        out["go%d_latlon" % i] = np.array([los[0].tg.c[0], los[0].tg.c[1]])
+        out["go%d_sorted" % i] = np.array([p.limb_tg_alt for p in pix])          # (the function sorts the caller's list)
+    # make_radtran_spline: 9 simulated altitudes x 40 bands, smooth + noisy columns, evaluated inside and at the nodes
+    alts = np.arange(150.0, 551.0, 50.0)
+    grid = np.linspace(3.2, 3.6, 40)
+
+    class Rad(object):
+        pass
+    rads = []
+    for a in alts:
+        r = Rad()
+        r.spectrum = np.exp(-a / 180.0) * (1.0 + 0.3 * np.sin(7.0 * grid)) + 1e-3 * rng.standard_normal(grid.size)
+        r.spectral_grid = Rad()
+        r.spectral_grid.grid = grid
+        rads.append(r)
+    f = smm.make_radtran_spline(alts, rads)
+    xs = np.array([150.0, 171.3, 200.0, 337.5, 349.9, 512.0, 550.0])
+    out["spl_alts"], out["spl_grid"] = alts, grid
+    out["spl_spectra"] = np.array([r.spectrum for r in rads])
+    out["spl_x"] = xs
+    out["spl_values"] = np.array([f(x).spectrum for x in xs])
+    np.savez_compressed(os.path.join(HERE, "group_obs.npz"), **out)
+    print("group_obs: alts", [list(out["go%d_alts" % i]) for i in range(3)], "spline", out["spl_values"][:, 0])
+
+
+if __name__ == "__main__" and "--group-obs" in sys.argv:
+    golden_group_obs()

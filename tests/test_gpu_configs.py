@@ -276,6 +276,25 @@ def test_bench_gpus2_launches_itself(eng):
     assert rec["n_gpus"] == 2 and rec["dist"]["world_size"] == 2 and rec["dist"]["backend"] == "gloo"
     assert rec["dist"]["async_equals_blocking"] is True
     assert rec["value"] > 0 and rec["steps"] == 5 and rec["scaling"] == "strong"
+    # round 6: the N > 1 line carries what a first real SCALE run needs to be read -- per-rank step times (the value is
+    # their MAX), host enqueue time, host time in wait_gathers(), the shards with their line counts and modelled balance
+    d = rec["dist"]
+    assert len(d["per_rank"]["ms_per_step"]) == 2 and d["per_rank"]["ms_per_step_min"] <= d["per_rank"]["ms_per_step_max"]
+    assert abs(d["per_rank"]["ms_per_step_max"] - rec["ms_per_step"]) < 1e-9
+    assert len(d["per_rank"]["host_enqueue_ms_per_step"]) == 2 and len(d["per_rank"]["host_ms_in_wait_gathers"]) == 2
+    assert d["rank0_ms_in_wait_gathers"] >= 0.0
+    sh = d["shards"]
+    assert sh["balanced"] is False and sh["bounds"] == [[0, 20000], [20000, 40000]] and sh["points"] == [20000, 20000]
+    assert len(sh["lines_prepared"]) == 2 and min(sh["lines_prepared"]) > 10000 and sh["model_cost_max_over_mean"] >= 1.0
+    # --balanced: work-balanced bounds (multiples of 64 points), the gather pads to the widest shard
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--balanced",
+                        "--lines", "20000", "--grid", "40000", "--layers", "8", "--cpu-seconds", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    rec = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    sh = rec["dist"]["shards"]
+    assert sh["balanced"] is True and sh["bounds"][0][0] == 0 and sh["bounds"][1][1] == 40000 and sh["bounds"][0][1] % 64 == 0
+    assert rec["dist"]["async_equals_blocking"] is True
 
 
 def test_bench_gpus2_under_torchrun(eng):
@@ -846,3 +865,53 @@ def test_inversion_first_driver_direct_and_lut_route(eng):
     n_obs = sum(len(p.observation.spectrum) for p in pixels)
     # same forward model: chi^2 (n_obs - n_used) = chi^2' (n_obs - n_tot); every parameter is in use here
     assert np.allclose(bsf.history[:2], res[False].history[:2], rtol=1e-9)
+
+
+def test_group_observations_route(eng):
+    """The reference's group_observations route (spect_main_module.py:2668-2670, 2908-2930, 3263-3273) through the GPU
+    path: radtrans / simulate on a ladder of tangent altitudes (smm.make_group_observations), the pixels' three LOS
+    read off quadratic splines in altitude (smm.make_radtran_spline -- both pinned to the reference by
+    tests/golden/group_obs.npz, test_group_observations_golden), then the usual FOV integration.
+      * EXACTLY the spline of the coarse set: the same spectra as the spline + FOV steps applied by hand to a plain
+        simulation of the ladder's rays;
+      * against the all-pixels run within the spline's own error: halving the ladder's step shrinks the deviation,
+        and it is ~1e-2 of a spectrum's largest band at the reference's default 50 km;
+      * derivatives too (inversion_fast_limb's deriv_splines), and the retrieval loop runs on the route."""
+    import copy
+    import bench_configs as bc
+    from spectrobot_amd import retrieval, spect_main_module as smm
+    scene = bc.two_gas_scene(5000, 1200, 12000, 30)
+    bs, pixels, x_true = bc.retrieval_problem(scene, n_pix=5)
+    pixels = sorted(pixels, key=lambda p: p.limb_tg_alt)
+    direct = np.array([s.spectrum for s in retrieval.radtrans(scene, pixels)])
+    dev = {}
+    for step in (50.0, 25.0):
+        got = np.array([s.spectrum for s in retrieval.radtrans(scene, pixels, group_observations=True, alt_step_sims=step)])
+        # by hand: the ladder's rays as pixels without a field of view, spline, closed-form FOV
+        alts, _ = smm.make_group_observations(list(pixels), alt_step=step)
+        ladder = [retrieval.LimbPixel(a) for a in alts]
+        coarse = np.array([s.spectrum for s in retrieval.radtrans(scene, ladder)])
+        f = smm.make_radtran_spline(alts, coarse)
+        for i, pix in enumerate(pixels):
+            s3 = [f(a) for a in pix.los_alts()]
+            want = smm.fov_closed_form(s3[0], s3[1], s3[2], pix.pixel_rot)
+            assert np.max(np.abs(got[i] - want)) <= 1e-12 * np.max(np.abs(want)), (step, i)
+        dev[step] = float(np.max(np.abs(got - direct) / np.max(np.abs(direct), axis=1, keepdims=True)))
+    # (1.1e-2 / 7.5e-3 of a spectrum's largest band here: the radiance of a 30-shell atmosphere has a kink in tangent
+    # altitude at every shell boundary, 27 km apart, which no spline through a coarser ladder follows)
+    assert dev[25.0] < dev[50.0] and dev[50.0] < 2e-2 and dev[25.0] < 1e-2, dev
+    # derivatives through their own splines, and the loop on the route: same stopping behaviour, parameters close to the
+    # all-pixels retrieval's
+    sims_d, der_d = retrieval.simulate(scene, pixels, bs)
+    sims_g, der_g = retrieval.simulate(scene, pixels, bs, group=(25.0, None))
+    for p in range(len(der_d[0])):
+        # (relative to the parameter's largest derivative over the pixels: where a parameter's mask does not reach a
+        # pixel's rays the direct derivative is exactly 0 and the spline rings at ~1e-7 of its neighbours)
+        scale = max(np.max(np.abs(der_d[i][p].spectrum)) for i in range(len(pixels)))
+        for i in range(len(pixels)):
+            assert np.max(np.abs(der_g[i][p].spectrum - der_d[i][p].spectrum)) < 3e-2 * scale, (i, p)
+    r_d = retrieval.inversion_fast_limb(scene, copy.deepcopy(bs), pixels, max_it=8)
+    r_g = retrieval.inversion_fast_limb(scene, copy.deepcopy(bs), pixels, max_it=8, group_observations=True, alt_step_sims=25.0)
+    x_d, x_g = r_d[3].param_vector(), r_g[3].param_vector()
+    assert r_g[3].stop in ("converged", "raised", "max_it") and len(r_g[3].history) >= 2
+    assert np.max(np.abs(x_g - x_d) / np.abs(x_d)) < 0.15

@@ -175,6 +175,82 @@ def test_bench_launches_its_own_ranks(tmp_path, capfd):
     assert time.time() - t0 < 30.0
 
 
+def test_group_observations_golden():
+    """smm.make_group_observations / make_radtran_spline (the group_observations route of the reference's drivers,
+    spect_main_module.py:3290-3338, 3377-3396) against the reference's own functions run under Python 3
+    (tests/golden/group_obs.npz, written by make_golden.py --group-obs): the ladder of simulated tangent altitudes --
+    exact, incl. the clamp of alt_first_los and the in-place sort of the pixels -- and the spline's values."""
+    sys.path.insert(0, ROOT)
+    from spectrobot_amd import spect_main_module as smm, retrieval
+    g = np.load(os.path.join(ROOT, "tests", "golden", "group_obs.npz"))
+    for i in range(3):
+        first = None if np.isnan(g["go%d_first" % i]) else float(g["go%d_first" % i])
+        pix = [retrieval.LimbPixel(a, fov_half=float(g["go%d_half" % i])) for a in g["go%d_pix_alts" % i]]
+        alts, mean = smm.make_group_observations(pix, alt_step=float(g["go%d_step" % i]), alt_first_los=first)
+        assert np.array_equal(alts, g["go%d_alts" % i]) and np.array_equal(alts, g["go%d_los_alts" % i])
+        assert [p.limb_tg_alt for p in pix] == list(g["go%d_sorted" % i]) and mean == {}
+        for k, p in enumerate(pix):     # with the geometry attributes: the means the reference builds its LOS from
+            p.limb_tg_lat, p.limb_tg_lon, p.limb_tg_sza = -40.0 + 3.0 * k, 120.0 + k, 55.0 + 2.0 * k
+    f = smm.make_radtran_spline(g["spl_alts"], g["spl_spectra"])
+    v = np.array([f(x) for x in g["spl_x"]])
+    assert np.max(np.abs(v - g["spl_values"])) <= 4e-16 * np.max(np.abs(g["spl_values"]))
+    # spectrum objects in, a spectrum object out (the reference's call shape)
+    rads = [retrieval.Spectrum(sp, g["spl_grid"]) for sp in g["spl_spectra"]]
+    out = smm.make_radtran_spline(g["spl_alts"], rads)(337.5)
+    assert np.max(np.abs(out.spectrum - g["spl_values"][3])) <= 4e-16 * np.max(np.abs(g["spl_values"]))
+    assert np.array_equal(out.spectral_grid.grid, g["spl_grid"])
+
+
+def test_eight_ranks_through_the_launcher(tmp_path, capfd):
+    """eight ranks had never run, even on gloo.  bench.launch_ranks with a CPU stand-in of the bench's
+    N > 1 path: 8 ranks, an UNEQUAL split (n_grid = 100001: shard_bounds gives the first rank one point more; the
+    gather pads), 6 steps of gather + the per-rank record exchange the bench line does (all_gather of [elapsed, enqueue,
+    wait]), shard_costs' line counts; then the same job with a rank that dies in step 3: the launcher returns its code
+    and ends the seven ranks left waiting in the collective."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    body = (
+        "import os, sys, json, time, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from spectrobot_amd import distributed as sd\n"
+        "rank, local, world = sd.init_from_env(backend='gloo')\n"
+        "assert world == 8\n"
+        "n = 100001\n"
+        "bounds = [sd.shard_bounds(n, world, r) for r in range(world)]\n"
+        "lo, hi = bounds[rank]\n"
+        "full = torch.zeros((1, n), dtype=torch.float64)\n"
+        "t0 = time.perf_counter()\n"
+        "for step in range(6):\n"
+        "    if DIE and rank == 5 and step == 3:\n"
+        "        os._exit(7)\n"
+        "    ref = torch.arange(n, dtype=torch.float64).reshape(1, n) + 1e6 * step\n"
+        "    out = sd.all_gather_spectrum(ref[:, lo:hi].contiguous(), n, world, rank, out=full, bounds=bounds, async_op=True)\n"
+        "    sd.wait_gathers()\n"
+        "    assert torch.equal(out, ref), (rank, step)\n"
+        "mine = torch.tensor([time.perf_counter() - t0, 0.0, 0.0], dtype=torch.float64)\n"
+        "every = [torch.zeros_like(mine) for _ in range(world)]\n"
+        "torch.distributed.all_gather(every, mine)\n"
+        "freq = 2975.0 + 50.0 * np.random.default_rng(1).random(5000)\n"
+        "costs, lines = sd.shard_costs(freq, 2975.0 + 5e-4 * np.arange(n), bounds)\n"
+        "if rank == 0:\n"
+        "    print(json.dumps({'world': world, 'points': [b - a for a, b in bounds], 'n_times': len(every), 'lines': lines,\n"
+        "                      'balance': max(costs) / (sum(costs) / len(costs))}))\n"
+        "torch.distributed.barrier()\n" % ROOT)
+    ok = tmp_path / "ok8.py"
+    ok.write_text("DIE = False\n" + body)
+    capfd.readouterr()
+    assert bench.launch_ranks(8, argv=[str(ok)], build=False) == 0
+    rec = json.loads([ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("{")][-1])
+    assert rec["world"] == 8 and rec["n_times"] == 8 and sum(rec["points"]) == 100001 and max(rec["points"]) - min(rec["points"]) == 1
+    assert len(rec["lines"]) == 8 and sum(rec["lines"]) > 5000 and rec["balance"] >= 1.0     # (window halos are counted twice)
+    bad = tmp_path / "bad8.py"
+    bad.write_text("DIE = True\n" + body)
+    t0 = time.time()
+    assert bench.launch_ranks(8, argv=[str(bad)], build=False) == 7
+    assert time.time() - t0 < 60.0
+
+
 def test_hardware_queues_default_is_set_before_hip_and_respects_the_caller():
     """The coefficient op runs on six HIP streams; the package asks ROCm for eight hardware queues (GPU_MAX_HW_QUEUES) at
     import -- the runtime reads it at its first HIP call -- unless the caller has set the variable (spectrobot_amd/__init__.py)."""
