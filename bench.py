@@ -435,8 +435,8 @@ def main():
         gbs = alg_bytes / (main_ms * 1e-3) / 1e9
         # HBM traffic from the PMC counters: only for the build it was measured on (sources hash)
         traffic, traffic_src = None, None
-        pmc_name = next((f for f in ("r05_pmc_hbm.json", "r04_pmc_hbm.json", "r03_pmc_hbm.json")
-                         if os.path.exists(os.path.join(ROOT, "profiles", f))), "r05_pmc_hbm.json")
+        pmc_name = next((f for f in ("r06_pmc_hbm.json", "r05_pmc_hbm.json", "r04_pmc_hbm.json", "r03_pmc_hbm.json")
+                         if os.path.exists(os.path.join(ROOT, "profiles", f))), "r06_pmc_hbm.json")
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc) and world == 1 and args.lines == 100000 and args.grid == 100000 and not args.shard:
             try:

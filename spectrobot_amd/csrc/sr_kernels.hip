@@ -981,6 +981,9 @@ __device__ __forceinline__ void farfield_rows_body(const FastRec *__restrict__ f
     }
   }
 
+  // (Round 6 tried two phases -- the admissibility tests over all candidates first, every layer row queueing its
+  // admissible lines in LDS, then eight queued lines of a row at a time: 333 -> 1109 us per sparse pass; the candidates
+  // of a box are mostly its own already, the queue's round trip and the second record fetch were pure cost.)
   double v[2 * kFC];
 #pragma unroll
   for (int n = 0; n < 2 * kFC; ++n) v[n] = 0.;
