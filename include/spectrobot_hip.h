@@ -353,6 +353,30 @@ int sr_retrieval_forward_dev(const double *abs_c, const double *emi_c, int n_lay
                              const double *x, double w0, double step, const double *centers_nm, const double *widths_nm,
                              int n_bands, double n_sigma, int out_units, const double *fov, double *buf, double *out,
                              void *stream);
+/* ... and the rest of the iteration in the same call: chi square of the simulated pixels against the observations and the
+ * Levenberg-Marquardt step of the optimal-estimation algebra (inversion_algebra, spect_main_module.py:3433-3469) on the
+ * band spectra and Jacobians the call has just brought to the host -- K^T S_y^-1 K, S^-1 = G + S_a^-1, S_x, the averaging
+ * kernel, dx = (S^-1 + lambda diag S^-1)^-1 (K^T S_y^-1 (y - F) + S_a^-1 (x_a - x)); n_par x n_par LU with partial
+ * pivoting, host fp64 (the system is n_par <= 64 wide: nothing for a GPU).  What the caller keeps: the positivity rule
+ * of the update (:633-641), the stopping rule (:2963-2973), its bookkeeping.  Single process only (a spectral shard's
+ * band integrals are partial: all-reduce first and use the Python algebra).
+ *   oe->obs / noise [n_pix n_bands] pixel-major, mask [n_pix n_bands] (1 = used) or NULL, sa_inv [n_par][n_par],
+ *   x_apriori [n_par]; pixels = rays / 3 with fov, or the centre ray of every three without (fov == NULL).
+ *   out as sr_retrieval_forward_dev's with fov ([n_pix][1 + n_par][n_bands]; without fov the centre rays' rows);
+ *   chi_sum = sum over the used elements of ((obs - sim) / noise)^2, n_used their number; dx [n_par], s_x / avk
+ *   [n_par][n_par].  SR_ERR_TABLE when the system is singular. */
+typedef struct {
+  int32_t n_obs;
+  const double *obs, *noise;
+  const uint8_t *mask;
+  const double *sa_inv, *x_apriori;
+  double lambda_lm;
+} sr_oe_desc;
+int sr_retrieval_step_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
+                          const double *x, double w0, double step, const double *centers_nm, const double *widths_nm,
+                          int n_bands, double n_sigma, int out_units, const double *fov, double *buf, double *out,
+                          const sr_oe_desc *oe, double *chi_sum, int32_t *n_used, double *dx, double *s_x, double *avk,
+                          void *stream);
 /* sr_limb_rays_dev on a resident LOS: kernel launches only (no staging copy, no column kernel, no host plan).
  * g_lo: grid index of abs_c's first point (Planck initial intensity, init_mode 2). */
 int sr_limb_rays_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,

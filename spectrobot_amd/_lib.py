@@ -58,6 +58,11 @@ class LosDesc(C.Structure):
                 ("step", C.c_double), ("g_lo", C.c_int64)]
 
 
+class OeDesc(C.Structure):
+    _fields_ = [("n_obs", C.c_int32), ("obs", dp), ("noise", dp), ("mask", C.POINTER(C.c_uint8)), ("sa_inv", dp),
+                ("x_apriori", dp), ("lambda_lm", C.c_double)]
+
+
 # every symbol include/spectrobot_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "sr_strerror": (C.c_char_p, [C.c_int]),
@@ -102,6 +107,9 @@ SYMBOLS = {
                                        C.c_void_p]),
     "sr_retrieval_forward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, dp, C.c_double,
                                            C.c_double, dp, dp, C.c_int, C.c_double, C.c_int, dp, C.c_void_p, dp, C.c_void_p]),
+    "sr_retrieval_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, dp, C.c_double,
+                                        C.c_double, dp, dp, C.c_int, C.c_double, C.c_int, dp, C.c_void_p, dp, C.POINTER(OeDesc), dp,
+                                        C.POINTER(C.c_int32), dp, dp, dp, C.c_void_p]),
     "sr_limb_step_dev": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_limb_rays_jac_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(LosDesc), C.c_int, ip, dp,

@@ -2341,6 +2341,116 @@ int sr_retrieval_forward_dev(const double *abs_c, const double *emi_c, int n_lay
   return SR_OK;
 }
 
+// n x n systems of the optimal-estimation step, host fp64: LU with partial pivoting (what numpy.linalg.solve / inv do
+// through LAPACK's dgesv, unblocked).  a: [n][n] row-major, destroyed; b: [n][m] right-hand sides, overwritten with
+// the solutions.  false: singular.
+static bool lu_solve(std::vector<double> &a, int n, std::vector<double> &b, int m) {
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(a[(size_t)i * n + k]) > std::fabs(a[(size_t)piv * n + k])) piv = i;
+    if (a[(size_t)piv * n + k] == 0.0) return false;
+    if (piv != k) {
+      for (int j = 0; j < n; ++j) std::swap(a[(size_t)k * n + j], a[(size_t)piv * n + j]);
+      for (int j = 0; j < m; ++j) std::swap(b[(size_t)k * m + j], b[(size_t)piv * m + j]);
+    }
+    for (int i = k + 1; i < n; ++i) {
+      const double f = a[(size_t)i * n + k] / a[(size_t)k * n + k];
+      if (f == 0.0) continue;
+      for (int j = k + 1; j < n; ++j) a[(size_t)i * n + j] -= f * a[(size_t)k * n + j];
+      for (int j = 0; j < m; ++j) b[(size_t)i * m + j] -= f * b[(size_t)k * m + j];
+    }
+  }
+  for (int k = n - 1; k >= 0; --k)
+    for (int j = 0; j < m; ++j) {
+      double v = b[(size_t)k * m + j];
+      for (int i = k + 1; i < n; ++i) v -= a[(size_t)k * n + i] * b[(size_t)i * m + j];
+      b[(size_t)k * m + j] = v / a[(size_t)k * n + k];
+    }
+  return true;
+}
+
+int sr_retrieval_step_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
+                          const double *x, double w0, double step, const double *centers_nm, const double *widths_nm,
+                          int n_bands, double n_sigma, int out_units, const double *fov, double *buf, double *out,
+                          const sr_oe_desc *oe, double *chi_sum, int32_t *n_used, double *dx, double *s_x, double *avk,
+                          void *stream) {
+  if (!h || !oe || !oe->obs || !oe->noise || !oe->sa_inv || !oe->x_apriori || !chi_sum || !n_used || !dx || !s_x || !avk)
+    return SR_ERR_ARG;
+  const int n_rays = h->opt.n_rays, n_par = h->n_par, n_row = 1 + n_par;
+  if (n_rays % 3 != 0 || n_par <= 0 || n_par > 64) return SR_ERR_ARG;
+  const int n_pix = n_rays / 3;
+  if (oe->n_obs != n_pix * n_bands) return SR_ERR_ARG;
+  // forward model: with a field of view straight into `out`; without one the centre ray of every three
+  static thread_local std::vector<double> rays;
+  double *fwd = out;
+  if (!fov) {
+    rays.resize((size_t)n_rays * n_row * n_bands);
+    fwd = rays.data();
+  }
+  const int rc = sr_retrieval_forward_dev(abs_c, emi_c, n_layers, n_pts, h, g_lo, x, w0, step, centers_nm, widths_nm, n_bands,
+                                          n_sigma, out_units, fov, buf, fwd, stream);
+  if (rc) return rc;
+  if (!fov)
+    for (int px = 0; px < n_pix; ++px)
+      std::memcpy(out + (size_t)px * n_row * n_bands, fwd + (size_t)(3 * px + 1) * n_row * n_bands, sizeof(double) * n_row * n_bands);
+  // the used observations: K [n_used][n_par] (build_jacobian: pixel-major, band-minor), y - F, 1 / sigma^2
+  const int n_obs = oe->n_obs;
+  std::vector<double> K, resid, w;
+  K.reserve((size_t)n_obs * n_par);
+  resid.reserve(n_obs);
+  w.reserve(n_obs);
+  double chi = 0.0;
+  for (int px = 0; px < n_pix; ++px)
+    for (int b = 0; b < n_bands; ++b) {
+      const int i = px * n_bands + b;
+      if (oe->mask && !oe->mask[i]) continue;
+      const double *rowp = out + (size_t)px * n_row * n_bands;
+      const double d = oe->obs[i] - rowp[b];
+      const double q = d / oe->noise[i];
+      chi += q * q;                                                   // chicalc, :3400-3410
+      resid.push_back(d);
+      w.push_back(1.0 / (oe->noise[i] * oe->noise[i]));
+      for (int p = 0; p < n_par; ++p) K.push_back(rowp[(size_t)(1 + p) * n_bands + b]);
+    }
+  const int nu = (int)resid.size();
+  *chi_sum = chi;
+  *n_used = nu;
+  // inversion_algebra (:3433-3469)
+  const size_t np2 = (size_t)n_par * n_par;
+  std::vector<double> G(np2, 0.0), rhs((size_t)n_par, 0.0);
+  for (int i = 0; i < nu; ++i) {
+    const double *k = K.data() + (size_t)i * n_par;
+    for (int p = 0; p < n_par; ++p) {
+      const double kw = k[p] * w[i];                                   // KtSy[p][i]
+      rhs[p] += kw * resid[i];
+      for (int q = 0; q < n_par; ++q) G[(size_t)p * n_par + q] += kw * k[q];
+    }
+  }
+  std::vector<double> S_inv(np2), A(np2), I(np2, 0.0);
+  for (size_t e = 0; e < np2; ++e) S_inv[e] = G[e] + oe->sa_inv[e];
+  for (int p = 0; p < n_par; ++p) {
+    double acc = 0.0;
+    for (int q = 0; q < n_par; ++q) acc += oe->sa_inv[(size_t)p * n_par + q] * (oe->x_apriori[q] - x[q]);
+    rhs[p] += acc;
+    I[(size_t)p * n_par + p] = 1.0;
+  }
+  A = S_inv;
+  if (!lu_solve(A, n_par, I, n_par)) return SR_ERR_TABLE;              // S_x = inv(S_inv)
+  std::memcpy(s_x, I.data(), sizeof(double) * np2);
+  for (int p = 0; p < n_par; ++p)
+    for (int q = 0; q < n_par; ++q) {
+      double acc = 0.0;
+      for (int r = 0; r < n_par; ++r) acc += I[(size_t)p * n_par + r] * G[(size_t)r * n_par + q];
+      avk[(size_t)p * n_par + q] = acc;                                // AVK = S_x G
+    }
+  A = S_inv;
+  for (int p = 0; p < n_par; ++p) A[(size_t)p * n_par + p] += oe->lambda_lm * S_inv[(size_t)p * n_par + p];
+  if (!lu_solve(A, n_par, rhs, 1)) return SR_ERR_TABLE;
+  std::memcpy(dx, rhs.data(), sizeof(double) * (size_t)n_par);
+  return SR_OK;
+}
+
 int sr_limb_rays_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
                          double *rad, void *stream) {
   if (!abs_c || !emi_c || !rad || !h || n_layers != h->n_layers || n_pts <= 0) return SR_ERR_ARG;

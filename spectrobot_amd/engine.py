@@ -465,8 +465,18 @@ def radiance_rays(abs_c, emi_c, seg_off, seg_layer, seg_col, rad0=None):
 
 
 class _ParHandle(object):
-    def __init__(self, h):
-        self.h = h
+    def __init__(self, h, keep=None):
+        self.h, self.keep = h, keep     # keep: the arrays an identity key refers to (their ids stay theirs while kept)
+
+
+def _array_key(a):
+    """Key of an array for the resident-handle cache: a READ-ONLY ndarray cannot change under its identity (and the cache
+    entry keeps it alive, so the id is not re-used): ("id", id(a)), free; anything else by content (_content_key).
+    retrieval.LimbScene.profile_weights hands out read-only arrays: a retrieval iteration then pays no hashing of its
+    60 000-entry weight table (60-100 us of a 480 us iteration)."""
+    if isinstance(a, np.ndarray) and not a.flags.writeable:
+        return ("id", id(a))
+    return _content_key(a)
 
 
 def _content_key(a):
@@ -538,20 +548,21 @@ class LimbLOS(object):
     def handle_par(self, n_layers, par_gas, par_w, grid=None, rad0=False):
         """handle() with the column parameters (par_gas [n_par], par_w [n_par, n_pt]) staged alongside
         (sr_los_create_par): the batch of a retrieval.  Keyed on the two arrays' CONTENT (a hash of their bytes: a
-        caller that builds par_w afresh every iteration finds its batch again, an in-place edit makes a new one); at
-        most MAX_HANDLES resident forms are kept, the least recently used is destroyed."""
+        caller that builds par_w afresh every iteration finds its batch again, an in-place edit makes a new one) -- or,
+        for read-only arrays, on their identity (_array_key); at most MAX_HANDLES resident forms are kept, the least
+        recently used is destroyed."""
         gp = None if (grid is None or self.initial_temperature is None or rad0) else grid_params(grid)[:2]
         pg_a, pg = _i(par_gas)
         pw_a, pw = _d(par_w)
         if pw_a.shape != (pg_a.size, self.n_pt):
             raise ValueError("par_w must be [n_par, n_pt]")
-        key = (int(n_layers), gp, bool(rad0), _content_key(pg_a), _content_key(pw_a))
+        key = (int(n_layers), gp, bool(rad0), _array_key(par_gas), _array_key(par_w))
         ent = self._handles.get(key)
         if ent is None:
             d = self.desc(grid, 0, rad0=rad0)
             h = C.c_void_p()
             check(lib.sr_los_create_par(C.byref(d), int(n_layers), pg_a.size, pg, pw, C.byref(h)), "sr_los_create_par")
-            ent = _ParHandle(h)
+            ent = _ParHandle(h, keep=(par_gas, par_w))
         return self._keep(key, ent).h
 
     def refresh_columns(self):
@@ -738,6 +749,63 @@ def retrieval_forward(coeffs, los, par_gas, par_w, x, grid, centers_nm, widths_n
                                        centers_nm.size, float(n_sigma), _UNITS[out_units], fp, buf.data_ptr(),
                                        out.ctypes.data_as(dp), _stream_ptr()), "sr_retrieval_forward_dev")
     return out, buf
+
+
+class OeProblem(object):
+    """What sr_retrieval_step_dev needs of a retrieval besides the forward model, marshalled once per loop: observations,
+    noise and mask of the pixels (pixel-major, band-minor, as genvec concatenates them), the inverse a-priori
+    covariance, the a-priori vector, the Levenberg-Marquardt factor."""
+
+    def __init__(self, obs, noise, mask, sa_inv, x_apriori, lambda_lm):
+        self.obs, self._o = _d(np.asarray(obs, float).reshape(-1))
+        self.noise, self._n = _d(np.asarray(noise, float).reshape(-1))
+        self.mask = None if mask is None else np.ascontiguousarray(np.asarray(mask).reshape(-1), dtype=np.uint8)
+        self.sa_inv, self._s = _d(sa_inv)
+        self.x_ap, self._x = _d(x_apriori)
+        n_par = self.x_ap.size
+        if self.sa_inv.shape != (n_par, n_par) or self.noise.size != self.obs.size or (self.mask is not None and self.mask.size != self.obs.size):
+            raise ValueError("inconsistent optimal-estimation problem")
+        self.desc = _lib.OeDesc(self.obs.size, self._o, self._n,
+                                None if self.mask is None else self.mask.ctypes.data_as(C.POINTER(C.c_uint8)), self._s, self._x,
+                                float(lambda_lm))
+        self.n_par = n_par
+
+
+def retrieval_step(coeffs, los, par_gas, par_w, x, grid, centers_nm, widths_nm, oe, out_units="Wm2", n_sigma=5.0, fov=None,
+                   buf=None):
+    """retrieval_forward + the rest of the iteration in the same library call (sr_retrieval_step_dev): chi square of the
+    pixels against the observations and the Levenberg-Marquardt step of the optimal-estimation algebra
+    (spect_main_module.inversion_algebra) on the band spectra and Jacobians the call brings to the host.  oe: OeProblem.
+    Returns (out [n_pix, 1 + n_par, n_bands], chi_sum, n_used, dx [n_par], S_x, AVK [n_par, n_par], buf).  Single process
+    only (a shard's band integrals are partial)."""
+    a, e = _gas_stack(coeffs)
+    n_gas, n_layers, n_pts = a.shape
+    w0, step, n = grid_params(grid)
+    if n_pts != n:
+        raise ValueError("retrieval_step needs the whole grid (a spectral shard's band integrals are partial)")
+    x_a, xp = _d(x)
+    n_par = x_a.size
+    centers_nm, cp = _d(centers_nm)
+    widths_nm, wp = _d(widths_nm)
+    h = los.handle_par(n_layers, par_gas, par_w, grid)
+    if np.asarray(par_gas).size != n_par or oe.n_par != n_par or los.n_rays % 3:
+        raise ValueError("x, the parameters and the problem must agree; three rays per pixel")
+    n_pix = los.n_rays // 3
+    fp = None
+    if fov is not None:
+        fov, fp = _d(fov)
+        if fov.shape != (n_pix, 7):
+            raise ValueError("fov must be [n_rays / 3, 7]")
+    if buf is None or buf.shape != (los.n_rays * (1 + n_par), n_pts):
+        buf = torch.empty((los.n_rays * (1 + n_par), n_pts), dtype=torch.float64, device="cuda")
+    out = np.empty((n_pix, 1 + n_par, centers_nm.size))
+    chi, n_used = C.c_double(0.0), C.c_int32(0)
+    dx, s_x, avk = np.empty(n_par), np.empty((n_par, n_par)), np.empty((n_par, n_par))
+    check(lib.sr_retrieval_step_dev(a.data_ptr(), e.data_ptr(), n_layers, n_pts, h, 0, xp, w0, step, cp, wp, centers_nm.size,
+                                    float(n_sigma), _UNITS[out_units], fp, buf.data_ptr(), out.ctypes.data_as(dp), C.byref(oe.desc),
+                                    C.byref(chi), C.byref(n_used), dx.ctypes.data_as(dp), s_x.ctypes.data_as(dp),
+                                    avk.ctypes.data_as(dp), _stream_ptr()), "sr_retrieval_step_dev")
+    return out, chi.value, n_used.value, dx, s_x, avk, buf
 
 
 def limb_rays_layer_jacobian(coeffs, dcoeffs, los, grid=None, g_lo=0):

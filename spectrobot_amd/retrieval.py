@@ -22,6 +22,8 @@ from . import spect_main_module as smm
 from . import synthetic as syn
 
 
+STEP_IN_ONE_CALL = True   # inversion_fast_limb: forward model + chi square + the optimal-estimation algebra of an iteration
+                          # in one library call (engine.retrieval_step); False: the algebra in numpy (the check)
 ONE_CALL = True   # simulate(arrays=True): the iteration's forward model in one library call (engine.retrieval_forward);
                   # False: columns + Jacobians, instrument step and FOV as separate calls (the A/B partner and the check)
 
@@ -151,8 +153,33 @@ class LimbScene(object):
             m = np.asarray(par.maskgrid.mask, dtype=float)
             par_w.append(np.interp(alt, zz, np.append(m, m[-1])))
         out = (np.array(par_gas, np.int32), np.array(par_w))
+        for a in out:
+            a.setflags(write=False)     # shared with every caller until the masks change: engine keys resident batches on them
         self._weights_cache = (key, out[0], out[1])
         return out
+
+
+def _one_call_eligible(pixels, bayes_set, fov_closed_form):
+    """The one-call routes (engine.retrieval_forward / retrieval_step) take: every pixel with the closed-form field of view
+    or none with one, every retrieved set a linear altitude profile (its VMR at a sample point is sum_p x_p w_p)."""
+    with_fov = sum(pix.fov_half > 0 for pix in pixels)
+    return ONE_CALL and bayes_set is not None and (with_fov == 0 or (with_fov == len(pixels) and fov_closed_form)) and \
+        all(type(st) in (smm.LinearProfile_1D_new, smm.LinearProfile_1D) for st in bayes_set.sets.values())
+
+
+def _one_call_batch(scene, pixels, bayes_set, alts, with_fov):
+    """The resident LOS batch, the parameter weights and the pixels' FOV factors (scene._fov_fac) of a one-call forward
+    model.  The gases WITHOUT parameters keep the VMRs the batch was last given: pushed again when one of them got a new
+    profile (by CONTENT: an id() can be re-used by a new array and says nothing about an in-place edit)."""
+    fixed = tuple(np.asarray(g.vmr, float).tobytes() for g in scene.gases if g.name not in bayes_set.sets)
+    stale = getattr(scene, "_los_obj", None) is None or getattr(scene, "_fixed_vmr_key", None) != fixed
+    scene._fixed_vmr_key = fixed
+    los, alt = scene.los(alts, update=stale)
+    par_gas, par_w = scene.profile_weights(bayes_set, alt)
+    rots = tuple(pix.pixel_rot for pix in pixels)
+    if with_fov and getattr(scene, "_fov_key", None) != rots:
+        scene._fov_key, scene._fov_fac = rots, engine.fov_factors(rots)
+    return los, par_gas, par_w
 
 
 def shard_with_halo(n_grid, g_lo, g_hi):
@@ -194,22 +221,11 @@ def simulate(scene, pixels, bayes_set=None, fov_closed_form=True, shard=None, re
     n_los = len(alts)
     lowres = lambda r: engine.hires_to_lowres(r, scene.grid, scene.bands_nm, scene.widths_nm, out_units=scene.out_units, g_lo=g_lo)
     with_fov = sum(pix.fov_half > 0 for pix in pixels)
-    if arrays and ONE_CALL and group is None and bayes_set is not None and (with_fov == 0 or (with_fov == len(pixels) and fov_closed_form)) and \
-            all(type(st) in (smm.LinearProfile_1D_new, smm.LinearProfile_1D) for st in bayes_set.sets.values()):
+    if arrays and group is None and _one_call_eligible(pixels, bayes_set, fov_closed_form):
         # The iteration in ONE library call (engine.retrieval_forward): the VMRs of the retrieved gases are set on the
         # device from the parameter vector (their profile IS sum_p mask_p x_p: LinearProfile_1D.profile), columns,
         # radiances + Jacobians, instrument bands and the pixels' closed-form FOV integral follow; one copy comes back.
-        # (the gases WITHOUT parameters keep the VMRs the batch was last given: pushed again when one of them got a new
-        # profile -- add_clim replaces the array)
-        # by CONTENT: an id() can be re-used by a new array and says nothing about an in-place edit
-        fixed = tuple(np.asarray(g.vmr, float).tobytes() for g in scene.gases if g.name not in bayes_set.sets)
-        stale = getattr(scene, "_los_obj", None) is None or getattr(scene, "_fixed_vmr_key", None) != fixed
-        scene._fixed_vmr_key = fixed
-        los, alt = scene.los(alts, update=stale)
-        par_gas, par_w = scene.profile_weights(bayes_set, alt)
-        rots = tuple(pix.pixel_rot for pix in pixels)
-        if with_fov and getattr(scene, "_fov_key", None) != rots:
-            scene._fov_key, scene._fov_fac = rots, engine.fov_factors(rots)
+        los, par_gas, par_w = _one_call_batch(scene, pixels, bayes_set, alts, with_fov)
         out, scene._fwd_buf = engine.retrieval_forward(coeffs, los, par_gas, par_w, bayes_set.param_vector(), scene.grid,
                                                        scene.bands_nm, scene.widths_nm, out_units=scene.out_units, g_lo=g_lo,
                                                        fov=scene._fov_fac if with_fov else None,
@@ -335,12 +351,38 @@ def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10,
             if low is None:                                            # (max_it = 0: nothing was simulated)
                 return []
             scene.los([a for pix in pixels for a in pix.los_alts()])   # the batch's VMRs = the final profiles (host copy too)
+            jac = np.transpose(dlow, (1, 0, 2)).reshape(dlow.shape[1], -1)     # build_jacobian's rows, of the last iteration
+            bayes_set.jacobian = (jac if masktot is None else jac[:, masktot]).T
             for num in range(len(pixels)):
                 for ip, par in enumerate(bayes_set.params()):
                     par.store_deriv(wrap(dlow[num, ip]), num=num)              # :2929, 2940 (of the last iteration)
             return [wrap(v) for v in low]
+    # Round 6: the whole iteration in ONE library call where it can be (engine.retrieval_step: forward model, chi square
+    # and the Levenberg-Marquardt algebra -- the n_par x n_par systems in the library's host code -- on one process, the
+    # whole grid, no observation grouping); what stays here is the reference's bookkeeping: the positivity rule of the
+    # update, the stopping rule, the history.
+    one_step = STEP_IN_ONE_CALL and fast and shard is None and group is None and _one_call_eligible(pixels, bayes_set, fov_closed_form)
+    if one_step:
+        n_pb = len(pixels) * len(scene.bands_nm)
+        obs_all = np.concatenate([np.asarray(o.spectrum, float) for o in obs])
+        noi_all = np.concatenate([np.asarray(nz.spectrum, float) for nz in noise])
+        oe = engine.OeProblem(obs_all, noi_all, masktot, Sa_inv, bayes_set.apriori_vector(), lambda_LM)
+        assert obs_all.size == n_pb
+        alts_all = [a for pix in pixels for a in pix.los_alts()]
+    step_out = None
     for num_it in range(max_it):
-        if fast:
+        if one_step:
+            coeffs = scene.coefficient_stack(refresh=refresh)
+            los_b, par_gas, par_w = _one_call_batch(scene, pixels, bayes_set, alts_all, with_fov)
+            both, chi_sum, n_used, dx, S_x, AVK, scene._fwd_buf = engine.retrieval_step(
+                coeffs, los_b, par_gas, par_w, bayes_set.param_vector(), scene.grid, scene.bands_nm, scene.widths_nm, oe,
+                out_units=scene.out_units, fov=scene._fov_fac if with_fov else None, buf=getattr(scene, "_fwd_buf", None))
+            low, dlow = both[:, 0, :], both[:, 1:, :]
+            for par in bayes_set.params():
+                par.set_used()
+            chi = chi_sum / (n_used - bayes_set.n_used_par())                                              # chicalc, :2949
+            step_out = (dx, S_x, AVK)
+        elif fast:
             low, dlow = simulate(scene, pixels, bayes_set, fov_closed_form=fov_closed_form, shard=shard, refresh=refresh, arrays=True, group=group)
             for par in bayes_set.params():
                 par.set_used()
@@ -363,7 +405,12 @@ def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10,
             bayes_set.stop = why
             return chi, obs, (finish(low, dlow) if fast else sims), bayes_set
         chi_old = chi
-        if fast:
+        if one_step:
+            dx, S_x, AVK = step_out                                            # inversion_algebra's results, :2977
+            bayes_set.update_params(dx)
+            bayes_set.store_avk(AVK)
+            bayes_set.store_VCM(S_x)
+        elif fast:
             n_par = dlow.shape[1]
             jac = np.transpose(dlow, (1, 0, 2)).reshape(n_par, -1)             # build_jacobian's rows
             jac = (jac if masktot is None else jac[:, masktot]).T
