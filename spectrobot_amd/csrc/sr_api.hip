@@ -1397,13 +1397,12 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       LAUNCHCHK(launch_prep(ls->L, A, ls->gp, WeightMode{kWeightChannels, ctypes3 ? 1 : 0}, line_lo, n_sub, (int)g_lo, (int)g_hi - 1,
                             m.d_fast.as<FastRec>(), m.d_cold.as<ColdRec>(), st));
       HIPCHK(hipEventRecord(m.ev_prep, st)); // the layer stage, the tables and everything earlier on the caller's stream
-      // The zones kernel beside the far passes.  The build is bound by its kernels' WORK, not by their order -- 13.25 / 13.32
-      // ms with the zones kernel gated behind the far passes, 13.06 / 13.13 beside them (one box, alternating); the sparse
-      // passes' single batched launch no longer starves beside it as their twelve small chains did (tl_v3 vs tl_v5).
-      {
-        LAUNCHCHK(launch_zones_mc(m.d_fast.as<FastRec>(), m.d_cold.as<ColdRec>(), ls->L.lev_up + line_lo, ls->L.lev_lo + line_lo, ix,
-                                  zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, mc, out, n_rows, k0, st));
-      }
+      // The zones kernel beside the far passes, the wings kernel after both.  The build is bound by its kernels' WORK, not
+      // their order -- 13.25 / 13.32 ms with the zones kernel gated behind the far passes, 13.06 / 13.13 beside them; the
+      // sparse passes' single batched launch no longer starves beside it as their twelve small chains did
+      // (profiles/r06_mc_timeline_v3 / v5).
+      LAUNCHCHK(launch_zones_mc(m.d_fast.as<FastRec>(), m.d_cold.as<ColdRec>(), ls->L.lev_up + line_lo, ls->L.lev_lo + line_lo, ix,
+                                zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, mc, out, n_rows, k0, st));
       // far-only passes of the level sub-linesets
       rc = m.s_far.prepare(sizeof(McFarPass) * (size_t)n_far);
       if (rc) return rc;

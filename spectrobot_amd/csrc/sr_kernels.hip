@@ -1042,15 +1042,23 @@ __device__ __forceinline__ void farfield_rows_body(const FastRec *__restrict__ f
   }
   if (COUNT) count_add(cnt, kCntExpansions, n_exp, lane);
 }
+#ifndef SR_ROWS_WAVES_PER_EU
+#define SR_ROWS_WAVES_PER_EU 0 // tuning knob: waves per SIMD to compile the sparse sets' kernels for (0: unconstrained, 138 VGPRs = 3; 4: 128 VGPRs + 48 B of scratch in the batch kernel: a table build 13.4 -> 15.1 ms)
+#endif
+#if SR_ROWS_WAVES_PER_EU > 0
+#define SR_ROWS_ATTR __attribute__((amdgpu_waves_per_eu(SR_ROWS_WAVES_PER_EU)))
+#else
+#define SR_ROWS_ATTR
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(64) void sr_farfield_rows_kernel(const FastRec *__restrict__ fast, IcIndex ix,
+__global__ __launch_bounds__(64) SR_ROWS_ATTR void sr_farfield_rows_kernel(const FastRec *__restrict__ fast, IcIndex ix,
                                                               const int *__restrict__ zmax, int n_sub, int g_lo, FarParams fp,
                                                               unsigned long long *__restrict__ cnt) {
   farfield_rows_body<COUNT>(fast, ix, zmax, n_sub, g_lo, fp, cnt, (int)blockIdx.x, (int)gridDim.x);
 }
 // ... of every sparse far-only pass of a table build in one launch (grid.y = item): one at a time these launches --
 // eleven of 0.3 ms, latency-bound, each behind ~0.3 ms of host calls -- were 6 ms of a 13 ms build
-__global__ __launch_bounds__(64) void sr_farfield_rows_batch_kernel(const FarBatchItem *__restrict__ items, const int *__restrict__ zmax,
+__global__ __launch_bounds__(64) SR_ROWS_ATTR void sr_farfield_rows_batch_kernel(const FarBatchItem *__restrict__ items, const int *__restrict__ zmax,
                                                                     int g_lo, FarParams fp) {
   const FarBatchItem it = items[blockIdx.y];
   fp.coef = it.coef;
@@ -2120,6 +2128,161 @@ int launch_far_batch(const FarBatchItem *items, int n_items, int max_n_sub, cons
 #if SR_FASTREC64
 __device__ inline int mc_base(const McChannels &mc, int level, int off, int plane) { return (mc.stride * level + off) * plane; }
 
+// The two stages of a 64-point slot's near wings (sr_wings_mc_kernel):
+// img = plane 0 at the slot's first point, `plane` doubles between planes; the slot's n_waves waves (this one: `wave`) take
+// its candidate chunks and far passes in turn.
+__device__ __forceinline__ void wings_mc_rows(const FastRec *__restrict__ frow, const int *__restrict__ lev_up,
+                                              const int *__restrict__ lev_lo, const IcIndex &ix, const int zm_near, const int wlo,
+                                              const int whi, const int thr0, const McChannels &mc, double *const img,
+                                              const int plane, const int lane, const int wave, const int n_waves) {
+  int rs[3], re[3];
+  near_ranges(ix, wlo, 64, zm_near, rs, re);
+  constexpr int kRowLanes = 8, kRows = 8;
+  const int row = lane / kRowLanes, col = lane % kRowLanes;
+  int turn = 0; // chunks of all three ranges dealt to the waves in turn
+  for (int rg = 0; rg < 3; ++rg) {
+    for (int base = rs[rg]; base < re[rg]; base += 64) {
+      if ((turn++) % n_waves != wave) continue;
+      const int lv = base + lane;
+      bool has_l = false, has_r = false; // region-1 points of the lane's line in this slot that no far-field level owns
+      if (lv < re[rg]) {
+        const int j1 = frow[lv].j1;
+        const unsigned ilir = frow[lv].ilir;
+        const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
+        if (jN >= wlo && j1 <= whi && !ff_admissible(j1, il, ir, wlo, wlo + 63, thr0)) {
+          has_l = max(wlo, j1) <= min(whi, j1 + il - 2); // points with 1 <= k < il
+          has_r = max(wlo, j1 + ir) <= min(whi, jN);     // points with ir < k <= 13010
+        }
+      }
+      unsigned long long m_l = __ballot(has_l), m_r = __ballot(has_r);
+      while (m_l | m_r) {
+        int code = -1; // this row's item: line (index into the chunk) | wing << 6; -1: none left
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+          int c_ = -1; // wave-uniform
+          if (m_l) {
+            c_ = __builtin_ctzll(m_l);
+            asm("s_bitset0_b64 %0, %1" : "+s"(m_l) : "s"(c_));
+          } else if (m_r) {
+            const int cr = __builtin_ctzll(m_r);
+            asm("s_bitset0_b64 %0, %1" : "+s"(m_r) : "s"(cr));
+            c_ = cr | 64;
+          }
+          code = row == q ? c_ : code;
+        }
+        const bool live = code >= 0, rw = live && (code & 64);
+        const int li = base + (live ? (code & 63) : 0);
+        const FastRec &r = frow[li];
+        const R1Coef rq = r1_of(r);
+        const double xstep = r.xstep, a = rq.a, b = rq.b, c = rq.c, d = rq.d, wa = r.wabs, we = r.wemi, w3 = r.w3;
+        const int j1 = r.j1, il = r.il(), ir = r.ir();
+        const int lu = lev_up[li], ll = lev_lo[li];
+        double *const p_lo = img + (mc.stride * ll + mc.o_lo) * plane + col, *const p_ue = img + (mc.stride * lu + mc.o_up_e) * plane + col,
+                     *const p_ua = img + (mc.stride * lu + mc.o_up_a) * plane + col;
+        const int kb0 = wlo - j1 + 1 + col;              // window index of this lane's point at step 0
+        const int k_last = min(kImxsig, whi - j1 + 1);  // last window index inside the slot, the grid and the window
+        const int k_a = rw ? ir + 1 : 1, k_b = rw ? k_last : min(il - 1, k_last);
+        const unsigned n_on = live ? (unsigned)max(k_b - k_a + 1, 0) : 0u;
+        const int t0 = kb0 - k_a;                        // step q is on for this lane: (unsigned)(t0 + 8 q) < n_on
+        const double x0 = fma((double)(kb0 - (rw ? ir : 1)), xstep, rw ? r.xr : -r.xl);
+        // The rows take the slot's eight 8-point groups in ROTATED order -- row r does group (q + r) mod 8 at step q:
+        // most lines share their lower level (the ground state), so in lockstep all eight rows would add to the same
+        // eight doubles of that plane at every step (an eight-way same-address conflict in the LDS atomic unit);
+        // rotated, the rows of a step hit eight different groups, two per bank set: the 64 adds' minimum.
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+          const int g8 = ((q + row) & (kRows - 1)) * kRowLanes; // first point of this row's group at step q
+          if ((unsigned)(t0 + g8) < n_on) {
+            const double x = fma((double)g8, xstep, x0);
+            const double x2 = x * x;
+            const double y = fma(x2, b, a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, d), c));
+            atomicAdd(&p_lo[g8], wa * y); // return-less LDS adds: rows of different lines may hit the same point
+            atomicAdd(&p_ue[g8], we * y);
+            atomicAdd(&p_ua[g8], w3 * y);
+          }
+        }
+      }
+    }
+  }
+  // far field: one polynomial per (far pass, hierarchy level), added to the pass's two planes at this lane's point.
+  // The coefficients of a pass -- kMaxFarLevels x 2 kFC doubles, one block per hierarchy level -- come in by four
+  // coalesced vector loads (lane = coefficient), go through an LDS staging row and are read back as broadcasts; the next
+  // pass's loads are in flight while this one is evaluated.  (Round 6, first build: wave-uniform scalar loads, one
+  // (pass, level) block of 92 SGPRs at a time, each waited for before its 44 fma -- 60 dependent round trips per wave
+  // and most of the kernel's 4.9 ms.)
+}
+__device__ __forceinline__ void wings_mc_polys(const McFarPass *__restrict__ far, const int n_far, const FarParams &fp, const int layer,
+                                               const int g_lo, const int wlo, double *const img, const int plane,
+                                               double *const s_cf, const int lane, const int wave, const int n_waves) {
+  {
+    constexpr int kEvalLevels = 1; // sr_l2l_kernel has folded the wider levels into level 0
+    constexpr int kBlk = 2 * kFC, kTot = kEvalLevels * kBlk;
+    constexpr int kLoads = (kTot + 63) / 64; // loads per lane that cover a pass
+    // s_cf: [64 kLoads] staging row of this wave
+    double tt[kMaxFarLevels];
+    int cidx[kLoads]; // element of the pass's coefficient table this lane fetches in load j (-1: none)
+#pragma unroll
+    for (int lv = 0; lv < kMaxFarLevels; ++lv) {
+      const int W = 64 << lv;
+      const int blo = g_lo + ((wlo - g_lo) >> (6 + lv)) * W;
+      tt[lv] = (double)(2 * (wlo + lane - blo) - (W - 1)) * (1.0 / 64 / (double)(1 << lv)); // exact: W = 2^(6+lv)
+    }
+#pragma unroll
+    for (int q = 0; q < kLoads; ++q) {
+      const int e = lane + 64 * q, lv = e / kBlk;
+      cidx[q] = e < kTot ? (fp.box_off[min(lv, kMaxFarLevels - 1)] + ((wlo - g_lo) >> (6 + lv))) * kBlk + (e - lv * kBlk) : -1;
+    }
+    const size_t lrow = (size_t)layer * fp.n_boxes_total * kBlk;
+    auto next_pass = [&](int f) { // first pass >= f of this wave (passes f = wave, wave + kMcWingWaves, ...) with coefficients
+      while (f < n_far && !far[f].coef) f += n_waves;
+      return f;
+    };
+    double reg[kLoads];
+    auto fetch = [&](int f) {
+      const double *cl = far[f].coef + lrow;
+#pragma unroll
+      for (int q = 0; q < kLoads; ++q) reg[q] = cidx[q] >= 0 ? cl[cidx[q]] : 0.0;
+    };
+    int f = next_pass(wave);
+    if (f < n_far) fetch(f);
+    while (f < n_far) {
+      __builtin_amdgcn_wave_barrier(); // (the previous pass's broadcast reads are done: LDS is in order per wave)
+#pragma unroll
+      for (int q = 0; q < kLoads; ++q) s_cf[lane + 64 * q] = reg[q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int ch_a = far[f].ch_a, ch_e = far[f].ch_e;
+      const int fn = next_pass(f + n_waves);
+      if (fn < n_far) fetch(fn);
+      // one Horner chain (kFC broadcast reads, then kFC - 1 fma) at a time: unrolled over levels and outputs the
+      // compiler hoisted all 230 reads of a pass (256 VGPRs, or 171 spills at 128)
+      double sa = 0., se = 0.;
+#pragma unroll 1
+      for (int h = 0; h < 2 * kEvalLevels; ++h) {
+        const int lv = h >> 1;
+        const double *c = s_cf + h * kFC; // block lv: [abs kFC | emi kFC]
+        double t = tt[0];
+#pragma unroll
+        for (int q = 1; q < kMaxFarLevels; ++q) t = lv == q ? tt[q] : t;
+        double cv[kFC];
+#pragma unroll
+        for (int n = 0; n < kFC; ++n) cv[n] = c[n];
+        double pv = cv[kFC - 1];
+#pragma unroll
+        for (int n = kFC - 2; n >= 0; --n) pv = fma(pv, t, cv[n]);
+        if (h & 1) se += pv; else sa += pv;
+      }
+      if (ch_a >= 0) img[ch_a * plane + lane] += sa;
+      if (ch_e >= 0) img[ch_e * plane + lane] += se;
+      f = fn;
+    }
+  }
+}
+
+// (Round 6 also built this kernel FUSED with the near wings and the polynomials -- wings_mc_rows / wings_mc_polys on the
+// same image, two waves per 64-point slot, the tables stored once instead of stored, read and stored again: 13.5 vs 13.1
+// ms per build of the pair tables, 24.0 vs 21.5 for the three ctypes.  The wings stages ran at this kernel's 16 waves per
+// CU instead of their own 24, behind barriers, and the zones part no longer ran beside the far passes.  Removed.)
 template <int WT, int NW>
 __global__ __launch_bounds__(64 * NW) SR_ZONES_ATTR void sr_zones_mc_kernel(
     const FastRec *__restrict__ fast, const ColdRec *__restrict__ cold, const int *__restrict__ lev_up,
@@ -2338,166 +2501,19 @@ __global__ __launch_bounds__(64 * kMcWingWaves) void sr_wings_mc_kernel(
   // wave per slot with its 12 KB image kept a CU to 11 of these latency-bound waves (24 of the folded kernel's fit)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pm = fp.pm[layer];
-  const int thr0 = ff_thr2(0, pm);
-  int rs[3], re[3];
-  near_ranges(ix, wlo, 64, min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1), rs, re);
   for (int c = wave; c < mc.n_ch; c += kMcWingWaves) s_img[c * 64 + lane] = 0.;
   __syncthreads();
-  constexpr int kRowLanes = 8, kRows = 8;
-  const int row = lane / kRowLanes, col = lane % kRowLanes;
-  const FastRec *frow = fast + (size_t)layer * n_sub;
-#ifdef SR_MC_DIAG_NOROWS // diagnostic variant builds: which part of the kernel takes its time
-  if (n_sub < 0)
-#endif
-  int turn = 0; // chunks of all three ranges dealt to the waves in turn
-  for (int rg = 0; rg < 3; ++rg) {
-    for (int base = rs[rg]; base < re[rg]; base += 64) {
-      if ((turn++) % kMcWingWaves != wave) continue;
-      const int lv = base + lane;
-      bool has_l = false, has_r = false; // region-1 points of the lane's line in this slot that no far-field level owns
-      if (lv < re[rg]) {
-        const int j1 = frow[lv].j1;
-        const unsigned ilir = frow[lv].ilir;
-        const int il = (int)(ilir & 0xffffu), ir = (int)(ilir >> 16), jN = j1 + (kImxsig - 1);
-        if (jN >= wlo && j1 <= whi && !ff_admissible(j1, il, ir, wlo, wlo + 63, thr0)) {
-          has_l = max(wlo, j1) <= min(whi, j1 + il - 2); // points with 1 <= k < il
-          has_r = max(wlo, j1 + ir) <= min(whi, jN);     // points with ir < k <= 13010
-        }
-      }
-      unsigned long long m_l = __ballot(has_l), m_r = __ballot(has_r);
-      while (m_l | m_r) {
-        int code = -1; // this row's item: line (index into the chunk) | wing << 6; -1: none left
-#pragma unroll
-        for (int q = 0; q < kRows; ++q) {
-          int c_ = -1; // wave-uniform
-          if (m_l) {
-            c_ = __builtin_ctzll(m_l);
-            asm("s_bitset0_b64 %0, %1" : "+s"(m_l) : "s"(c_));
-          } else if (m_r) {
-            const int cr = __builtin_ctzll(m_r);
-            asm("s_bitset0_b64 %0, %1" : "+s"(m_r) : "s"(cr));
-            c_ = cr | 64;
-          }
-          code = row == q ? c_ : code;
-        }
-        const bool live = code >= 0, rw = live && (code & 64);
-        const int li = base + (live ? (code & 63) : 0);
-        const FastRec &r = frow[li];
-        const R1Coef rq = r1_of(r);
-        const double xstep = r.xstep, a = rq.a, b = rq.b, c = rq.c, d = rq.d, wa = r.wabs, we = r.wemi, w3 = r.w3;
-        const int j1 = r.j1, il = r.il(), ir = r.ir();
-        const int lu = lev_up[li], ll = lev_lo[li];
-        double *const p_lo = s_img + (mc.stride * ll + mc.o_lo) * 64 + col, *const p_ue = s_img + (mc.stride * lu + mc.o_up_e) * 64 + col,
-                     *const p_ua = s_img + (mc.stride * lu + mc.o_up_a) * 64 + col;
-        const int kb0 = wlo - j1 + 1 + col;              // window index of this lane's point at step 0
-        const int k_last = min(kImxsig, whi - j1 + 1);  // last window index inside the slot, the grid and the window
-        const int k_a = rw ? ir + 1 : 1, k_b = rw ? k_last : min(il - 1, k_last);
-        const unsigned n_on = live ? (unsigned)max(k_b - k_a + 1, 0) : 0u;
-        const int t0 = kb0 - k_a;                        // step q is on for this lane: (unsigned)(t0 + 8 q) < n_on
-        const double x0 = fma((double)(kb0 - (rw ? ir : 1)), xstep, rw ? r.xr : -r.xl);
-        // The rows take the slot's eight 8-point groups in ROTATED order -- row r does group (q + r) mod 8 at step q:
-        // most lines share their lower level (the ground state), so in lockstep all eight rows would add to the same
-        // eight doubles of that plane at every step (an eight-way same-address conflict in the LDS atomic unit);
-        // rotated, the rows of a step hit eight different groups, two per bank set: the 64 adds' minimum.
-#pragma unroll
-        for (int q = 0; q < kRows; ++q) {
-          const int g8 = ((q + row) & (kRows - 1)) * kRowLanes; // first point of this row's group at step q
-          if ((unsigned)(t0 + g8) < n_on) {
-            const double x = fma((double)g8, xstep, x0);
-            const double x2 = x * x;
-            const double y = fma(x2, b, a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, d), c));
-            atomicAdd(&p_lo[g8], wa * y); // return-less LDS adds: rows of different lines may hit the same point
-            atomicAdd(&p_ue[g8], we * y);
-            atomicAdd(&p_ua[g8], w3 * y);
-          }
-        }
-      }
-    }
-  }
-  // far field: one polynomial per (far pass, hierarchy level), added to the pass's two planes at this lane's point.
-  // The coefficients of a pass -- kMaxFarLevels x 2 kFC doubles, one block per hierarchy level -- come in by four
-  // coalesced vector loads (lane = coefficient), go through an LDS staging row and are read back as broadcasts; the next
-  // pass's loads are in flight while this one is evaluated.  (Round 6, first build: wave-uniform scalar loads, one
-  // (pass, level) block of 92 SGPRs at a time, each waited for before its 44 fma -- 60 dependent round trips per wave
-  // and most of the kernel's 4.9 ms.)
+  wings_mc_rows(fast + (size_t)layer * n_sub, lev_up, lev_lo, ix, min(max(zmax[layer], kTheta * 32 + pm + 1), kHalf - 1), wlo, whi,
+                ff_thr2(0, pm), mc, s_img, 64, lane, wave, kMcWingWaves);
   __syncthreads(); // the rows' sums of every wave are in the image
-#ifdef SR_MC_DIAG_NOPOLY
-  if (n_sub < 0)
-#endif
-  {
-    constexpr int kEvalLevels = 1; // sr_l2l_kernel has folded the wider levels into level 0
-    constexpr int kBlk = 2 * kFC, kTot = kEvalLevels * kBlk;
-    constexpr int kLoads = (kTot + 63) / 64; // loads per lane that cover a pass
-    double *const s_cf = s_img + mc.n_ch * 64 + wave * (64 * kLoads); // [64 kLoads] per wave
-    double tt[kMaxFarLevels];
-    int cidx[kLoads]; // element of the pass's coefficient table this lane fetches in load j (-1: none)
-#pragma unroll
-    for (int lv = 0; lv < kMaxFarLevels; ++lv) {
-      const int W = 64 << lv;
-      const int blo = g_lo + ((wlo - g_lo) >> (6 + lv)) * W;
-      tt[lv] = (double)(2 * (wlo + lane - blo) - (W - 1)) * (1.0 / 64 / (double)(1 << lv)); // exact: W = 2^(6+lv)
-    }
-#pragma unroll
-    for (int q = 0; q < kLoads; ++q) {
-      const int e = lane + 64 * q, lv = e / kBlk;
-      cidx[q] = e < kTot ? (fp.box_off[min(lv, kMaxFarLevels - 1)] + ((wlo - g_lo) >> (6 + lv))) * kBlk + (e - lv * kBlk) : -1;
-    }
-    const size_t lrow = (size_t)layer * fp.n_boxes_total * kBlk;
-    auto next_pass = [&](int f) { // first pass >= f of this wave (passes f = wave, wave + kMcWingWaves, ...) with coefficients
-      while (f < n_far && !far[f].coef) f += kMcWingWaves;
-      return f;
-    };
-    double reg[kLoads];
-    auto fetch = [&](int f) {
-      const double *cl = far[f].coef + lrow;
-#pragma unroll
-      for (int q = 0; q < kLoads; ++q) reg[q] = cidx[q] >= 0 ? cl[cidx[q]] : 0.0;
-    };
-    int f = next_pass(wave);
-    if (f < n_far) fetch(f);
-    while (f < n_far) {
-      __builtin_amdgcn_wave_barrier(); // (the previous pass's broadcast reads are done: LDS is in order per wave)
-#pragma unroll
-      for (int q = 0; q < kLoads; ++q) s_cf[lane + 64 * q] = reg[q];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int ch_a = far[f].ch_a, ch_e = far[f].ch_e;
-      const int fn = next_pass(f + kMcWingWaves);
-      if (fn < n_far) fetch(fn);
-      // one Horner chain (kFC broadcast reads, then kFC - 1 fma) at a time: unrolled over levels and outputs the
-      // compiler hoisted all 230 reads of a pass (256 VGPRs, or 171 spills at 128)
-      double sa = 0., se = 0.;
-#pragma unroll 1
-      for (int h = 0; h < 2 * kEvalLevels; ++h) {
-        const int lv = h >> 1;
-        const double *c = s_cf + h * kFC; // block lv: [abs kFC | emi kFC]
-        double t = tt[0];
-#pragma unroll
-        for (int q = 1; q < kMaxFarLevels; ++q) t = lv == q ? tt[q] : t;
-        double cv[kFC];
-#pragma unroll
-        for (int n = 0; n < kFC; ++n) cv[n] = c[n];
-        double pv = cv[kFC - 1];
-#pragma unroll
-        for (int n = kFC - 2; n >= 0; --n) pv = fma(pv, t, cv[n]);
-        if (h & 1) se += pv; else sa += pv;
-      }
-      if (ch_a >= 0) s_img[ch_a * 64 + lane] += sa;
-      if (ch_e >= 0) s_img[ch_e * 64 + lane] += se;
-      f = fn;
-    }
-  }
+  wings_mc_polys(far, n_far, fp, layer, g_lo, wlo, s_img, 64, s_img + mc.n_ch * 64 + wave * 64, lane, wave, kMcWingWaves);
   __syncthreads(); // (a pass's two planes are its wave's alone, but the output planes below are dealt by index)
   const int j = wlo + lane;
   if (j <= whi) {
     const size_t n_pts = (size_t)(g_hi - g_lo);
     double *o = out + (size_t)(row0 + layer) * n_pts + (size_t)(j - g_lo);
     const size_t cstride = (size_t)n_rows_total * n_pts;
-#ifdef SR_MC_DIAG_NORMW
-    for (int c = wave; c < mc.n_ch; c += kMcWingWaves) o[c * cstride] = s_img[c * 64 + lane];
-#else
     for (int c = wave; c < mc.n_ch; c += kMcWingWaves) o[c * cstride] += s_img[c * 64 + lane];
-#endif
   }
 }
 
