@@ -1326,8 +1326,7 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
   mc.o_up_a = ctypes3 ? 1 : 0;
   mc.n_ch = mc.stride * nlev;
   if (mc.n_ch > 1023) return SR_ERR_UNSUPPORTED; // (10 bits per channel in the zones kernel's packed item word)
-  if (sizeof(double) * (size_t)mc.n_ch * (kMcImage + 2) + sizeof(int) * (size_t)kMcWaves * 2 * 4 * 64 > (size_t)160 * 1024 ||
-      sizeof(double) * (size_t)mc.n_ch * 64 > (size_t)64 * 1024)
+  if (zones_mc_image(mc.n_ch) == 0 || wings_mc_lds(mc.n_ch) > (size_t)160 * 1024)
     return SR_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   CoefWork &w = *ls->work;

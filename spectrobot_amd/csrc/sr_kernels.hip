@@ -2517,37 +2517,62 @@ __global__ __launch_bounds__(64 * kMcWingWaves) void sr_wings_mc_kernel(
   }
 }
 
-int launch_zones_mc(const FastRec *fast, const ColdRec *cold, const int *lev_up, const int *lev_lo, const IcIndex &ix,
-                    const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const McChannels &mc,
-                    double *out, int n_rows_total, int row0, hipStream_t st) {
-  if (g_hi <= g_lo || n_layers <= 0) return 0;
-  constexpr int WT = kMcImage, NW = kMcWaves;
+// Image width by what fits: two workgroups of kMcImage points per CU when their planes allow (24 planes x 258 doubles =
+// 49.5 KB), else 128-point images (36 planes -- the three ctypes of twelve levels -- are 74 KB at 256 points: ONE workgroup,
+// eight waves per CU; at 128 points 37 KB: two).  Up to 146 planes (64 levels' pair tables).
+size_t zones_mc_lds(int n_ch, int wt) { return sizeof(double) * (size_t)n_ch * (wt + 2) + sizeof(int) * (size_t)kMcWaves * 2 * 4 * 64; }
+int zones_mc_image(int n_ch) {
+  if (2 * zones_mc_lds(n_ch, kMcImage) <= (size_t)160 * 1024) return kMcImage;
+  return zones_mc_lds(n_ch, 128) <= (size_t)160 * 1024 ? 128 : 0;
+}
+template <int WT>
+static int launch_zones_mc_wt(const FastRec *fast, const ColdRec *cold, const int *lev_up, const int *lev_lo, const IcIndex &ix,
+                              const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const McChannels &mc,
+                              double *out, int n_rows_total, int row0, hipStream_t st) {
+  constexpr int NW = kMcWaves;
   const int n_t = (g_hi - g_lo + WT - 1) / WT;
-  const size_t lds = sizeof(double) * (size_t)mc.n_ch * (WT + 2) + sizeof(int) * (size_t)NW * 2 * 4 * 64;
-  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   static bool attr_set = false; // (more than 64 KB of dynamic LDS needs the attribute once per process and kernel)
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sr_zones_mc_kernel<WT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((sr_zones_mc_kernel<WT, NW>), dim3((unsigned)(n_t * n_layers)), dim3(64 * NW), lds, st, fast, cold, lev_up, lev_lo,
-                     ix, zmax, n_sub, n_t, g_lo, g_hi, gp, mc, out, n_rows_total, row0);
+  hipLaunchKernelGGL((sr_zones_mc_kernel<WT, NW>), dim3((unsigned)(n_t * n_layers)), dim3(64 * NW), zones_mc_lds(mc.n_ch, WT), st, fast, cold,
+                     lev_up, lev_lo, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, mc, out, n_rows_total, row0);
   return (int)hipGetLastError();
 }
+int launch_zones_mc(const FastRec *fast, const ColdRec *cold, const int *lev_up, const int *lev_lo, const IcIndex &ix,
+                    const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const McChannels &mc,
+                    double *out, int n_rows_total, int row0, hipStream_t st) {
+  if (g_hi <= g_lo || n_layers <= 0) return 0;
+  const int wt = zones_mc_image(mc.n_ch);
+  if (wt == kMcImage)
+    return launch_zones_mc_wt<kMcImage>(fast, cold, lev_up, lev_lo, ix, zmax, n_sub, n_layers, g_lo, g_hi, gp, mc, out, n_rows_total, row0, st);
+  if (wt == 128)
+    return launch_zones_mc_wt<128>(fast, cold, lev_up, lev_lo, ix, zmax, n_sub, n_layers, g_lo, g_hi, gp, mc, out, n_rows_total, row0, st);
+  return (int)hipErrorInvalidValue;
+}
 
+size_t wings_mc_lds(int n_ch) { return sizeof(double) * ((size_t)n_ch * 64 + 64 * kMcWingWaves); }
 int launch_wings_mc(const FastRec *fast, const int *lev_up, const int *lev_lo, const IcIndex &ix, const int *zmax, int n_sub,
                     int n_layers, int g_lo, int g_hi, const FarParams &fp, const McChannels &mc, const McFarPass *far, int n_far,
                     double *out, int n_rows_total, int row0, hipStream_t st) {
   if (g_hi <= g_lo || n_layers <= 0) return 0;
   const int n_g1 = (g_hi - g_lo + 63) / 64;
-  const size_t lds = sizeof(double) * ((size_t)mc.n_ch * 64 + 64 * kMcWingWaves); // the image + the polynomial stage's staging rows
-  if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+  const size_t lds = wings_mc_lds(mc.n_ch); // the image + the polynomial stage's staging rows
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sr_wings_mc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(sr_wings_mc_kernel, dim3((unsigned)(n_g1 * n_layers)), dim3(64 * kMcWingWaves), lds, st, fast, lev_up, lev_lo, ix, zmax, n_sub,
                      n_g1, g_lo, g_hi, fp, mc, far, n_far, out, n_rows_total, row0);
   return (int)hipGetLastError();
 }
 
 #else // 80-byte records carry no third weight: mc_pass never takes this route then (SR_ERR_UNSUPPORTED)
+int zones_mc_image(int) { return 0; }
+size_t wings_mc_lds(int) { return 0; }
 int launch_zones_mc(const FastRec *, const ColdRec *, const int *, const int *, const IcIndex &, const int *, int, int, int, int,
                     const GridParams &, const McChannels &, double *, int, int, hipStream_t) { return (int)hipErrorNotSupported; }
 int launch_wings_mc(const FastRec *, const int *, const int *, const IcIndex &, const int *, int, int, int, int, const FarParams &,

@@ -179,6 +179,8 @@ int launch_far_batch(const FarBatchItem *items, int n_items, int max_n_sub, cons
 // the downward pass: a far pass's wider levels folded into its level-0 coefficients (in place); tab: l2l_table_host
 void l2l_table_host(double *tab); // [2][kFC][kFC]
 int launch_l2l(double *coef, int n_layers, const FarParams &fp, const double *tab, hipStream_t st);
+int zones_mc_image(int n_ch);     // points per image sr_zones_mc_kernel takes for n_ch planes (0: they do not fit the LDS)
+size_t wings_mc_lds(int n_ch);    // bytes of LDS of a sr_wings_mc_kernel workgroup
 int launch_zones_mc(const FastRec *fast, const ColdRec *cold, const int *lev_up, const int *lev_lo, const IcIndex &ix,
                     const int *zmax, int n_sub, int n_layers, int g_lo, int g_hi, const GridParams &gp, const McChannels &mc,
                     double *out, int n_rows_total, int row0, hipStream_t st);

@@ -200,15 +200,16 @@ def _plane_err(a, b):
     return float(((a - b).abs() / s).max())
 
 
-@pytest.mark.parametrize("case", ["dense", "sparse_shard", "frozen_linear", "outer_lines", "low_pressure"])
+@pytest.mark.parametrize("case", ["dense", "sparse_shard", "frozen_linear", "outer_lines", "low_pressure", "forty_levels"])
 def test_multichannel_route_equals_the_per_level_route(eng, case):
     """Round 6: the level tables by the multi-channel pass (every line ONCE: sr_zones_mc_kernel / sr_wings_mc_kernel add
     its three weighted contributions to the LDS planes of its two levels; far field by far-only passes of the level
     sub-linesets) against one coefficient op per level (sr_set_level_route(0): the route of rounds 4-5, itself pinned
     to the reference's add_PT -> BuildCoeff run by test_gcoeff_levels_golden).  Pair tables AND the three ctypes; whole
     grids and shards whose lines reach beyond the grid; frozen boundaries with linearised weights (the T + dT build of
-    configs[3]); lines whose centre lies outside their window; Doppler-dominated rows (wide region-3 cores).  The two
-    routes differ by the order of summation only: <= 2e-12 of a spectrum's largest value."""
+    configs[3]); lines whose centre lies outside their window; Doppler-dominated rows (wide region-3 cores); an
+    iso-molecule with forty levels (80 / 120 planes: the zones kernel's 128-point images).  The two routes differ by the
+    order of summation only: <= 2e-12 of a spectrum's largest value."""
     import torch
     from spectrobot_amd import synthetic as syn
     n_grid, n_lines, nl, lo, hi, w0 = 40000, 30000, 6, 0, None, 2985.0
@@ -217,8 +218,12 @@ def test_multichannel_route_equals_the_per_level_route(eng, case):
         n_lines, lo, hi = 5000, 3001, 33333
     elif case == "outer_lines":
         n_grid, n_lines, lo, hi = 20000, 8000, 0, None
+    n_lev, e_lev = 12, syn.CH4_LEVEL_ENERGIES
+    if case == "forty_levels":
+        n_grid, n_lines, nl, n_lev = 12000, 9000, 3, 40
+        e_lev = np.concatenate([[0.0], np.linspace(1300.0, 6000.0, 39)])
     grid = syn.make_grid(w0, 5e-4, n_grid)
-    L = syn.make_lines(n_lines, grid, seed=61, n_levels=12, config_id=2)
+    L = syn.make_lines(n_lines, grid, seed=61, n_levels=n_lev, config_id=2)
     if case == "outer_lines":   # some lines up to 6 cm-1 beyond the grid ends: their windows sit on the end points
         rng = np.random.default_rng(4)
         k = rng.choice(n_lines, 400, replace=False)
@@ -228,7 +233,7 @@ def test_multichannel_route_equals_the_per_level_route(eng, case):
         L["freq"][k[200:]] = grid[-1] + rng.uniform(0.0, 6.0, 200)
     atm = syn.make_atmosphere(nl, 12)
     T, P = atm["temps"], atm["press"] * (1e-3 if case == "low_pressure" else 1.0)
-    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, e_lev)
     try:
         if case == "frozen_linear":
             ls.set_bounds_temps(T, linear_weights=True)
@@ -276,3 +281,28 @@ def test_multichannel_route_in_row_batches_and_after_other_calls(eng):
         eng.set_table_budget(48 << 30)
     assert _plane_err(t1, ref) < 2e-12 and _plane_err(t2, ref) < 2e-12
     assert torch.equal(a1, a0) and torch.equal(e1, e0)
+
+
+@pytest.mark.parametrize("far", [1, 2])
+def test_multichannel_route_under_forced_far_field_modes(eng, far):
+    """sr_set_far_field(1) / (2) force the per-line expansions / the box-pair chain for EVERY sub-lineset: the far-only
+    passes of the multi-channel route then all run through coef_op's far-only option on their own CoefWork lanes (no
+    sparse batch: that is mode 3's rule), and the tables must still equal the per-level route's under the same mode and
+    the default mode's."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    grid = syn.make_grid(2988.0, 5e-4, 20000)
+    L = syn.make_lines(12000, grid, seed=17, n_levels=12, config_id=2)
+    atm = syn.make_atmosphere(5, 12)
+    ls = eng.LineSet(L, grid, 6, 1, syn.CH4_MM, syn.CH4_LEVEL_ENERGIES)
+    ref = ls.glevel_pairs(atm["temps"], atm["press"])
+    try:
+        eng.set_far_field(far)
+        t_mc = ls.glevel_pairs(atm["temps"], atm["press"])
+        eng.set_level_route(0)
+        t_pl = ls.glevel_pairs(atm["temps"], atm["press"])
+        torch.cuda.synchronize()
+    finally:
+        eng.set_level_route(1)
+        eng.set_far_field(eng.FAR_FIELD_DEFAULT)
+    assert _plane_err(t_mc, t_pl) < 2e-12 and _plane_err(t_mc, ref) < 5e-12
