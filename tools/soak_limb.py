@@ -58,7 +58,14 @@ def main(n_calls=3000):
         if key not in first:
             first[key] = out.clone()
         elif c % 200 < 5:
-            assert torch.equal(out, first[key]), (c, key)
+            if kind == 3:
+                # the level tables come from the multi-channel pass (round 6): several waves add into one LDS image, the
+                # tables are reproducible to ~1e-15 of a spectrum's largest value, their difference quotient over 0.02 K
+                # to ~1e-12 of the derivative's -- not bit for bit
+                s_ = first[key].abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+                assert float(((out - first[key]).abs() / s_).max()) < 1e-9, (c, key)
+            else:
+                assert torch.equal(out, first[key]), (c, key)
         if c == 400:
             torch.cuda.synchronize()
             free0 = torch.cuda.mem_get_info()[0]
