@@ -2185,20 +2185,20 @@ __device__ __forceinline__ void wings_mc_rows(const FastRec *__restrict__ frow, 
         const unsigned n_on = live ? (unsigned)max(k_b - k_a + 1, 0) : 0u;
         const int t0 = kb0 - k_a;                        // step q is on for this lane: (unsigned)(t0 + 8 q) < n_on
         const double x0 = fma((double)(kb0 - (rw ? ir : 1)), xstep, rw ? r.xr : -r.xl);
-        // The rows take the slot's eight 8-point groups in ROTATED order -- row r does group (q + r) mod 8 at step q:
-        // most lines share their lower level (the ground state), so in lockstep all eight rows would add to the same
-        // eight doubles of that plane at every step (an eight-way same-address conflict in the LDS atomic unit);
-        // rotated, the rows of a step hit eight different groups, two per bank set: the 64 adds' minimum.
+        // (The rows take the slot's eight 8-point groups in lockstep -- row r and row r' add to the same eight doubles of a
+        // plane when their lines share a level, as most do with the ground state.  Taking them in ROTATED order, row r at
+        // group (q + r) mod 8, removes that same-address conflict: built -- a table build 13.02 (lockstep) vs 13.17 ms (rotated), three
+        // alternating runs: the three more integer instructions per step cost more than the conflicts.)
 #pragma unroll
         for (int q = 0; q < kRows; ++q) {
-          const int g8 = ((q + row) & (kRows - 1)) * kRowLanes; // first point of this row's group at step q
-          if ((unsigned)(t0 + g8) < n_on) {
-            const double x = fma((double)g8, xstep, x0);
+          if ((unsigned)(t0 + kRowLanes * q) < n_on) {
+            double x = x0;
+            if (q > 0) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(x) : "s"((double)(kRowLanes * q)), "v"(xstep), "v"(x0));
             const double x2 = x * x;
             const double y = fma(x2, b, a) * fast_rcp<1>(fma(x2, fma(x2, 4.0, d), c));
-            atomicAdd(&p_lo[g8], wa * y); // return-less LDS adds: rows of different lines may hit the same point
-            atomicAdd(&p_ue[g8], we * y);
-            atomicAdd(&p_ua[g8], w3 * y);
+            atomicAdd(&p_lo[kRowLanes * q], wa * y); // return-less LDS adds: rows of different lines may hit the same point
+            atomicAdd(&p_ue[kRowLanes * q], we * y);
+            atomicAdd(&p_ua[kRowLanes * q], w3 * y);
           }
         }
       }
