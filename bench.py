@@ -139,6 +139,39 @@ def coefficient_roofline(serial_kms, counts, far_field=3):
             "mode": "far-field (box pairs)" if far_field in (2, 3) else "far-field (per line)"}
 
 
+def level_tables_roofline(engine, ls, build, folded_op, n=3):
+    """roofline object of the dominant kernel of a level-table build (the multi-channel pass): sr_zones_mc_kernel's
+    executed flops / its stand-alone HIP-event duration.  Its evaluations are the folded zones kernel's of the FULL line
+    list on the same rows (same ownership rules: counted by the folded op's counting instantiation, `folded_op`), each
+    with one more weighted accumulation (three planes instead of two: + 2 flop); durations from a build under the serial
+    schedule (sr_set_overlap(0): the far passes queue behind the zones kernel on the caller's stream)."""
+    engine.set_overlap(0)
+    folded_op()
+    engine.set_counting(1)
+    folded_op()
+    counts = ls.last_eval_counts()
+    engine.set_counting(0)
+    build()
+    ms = np.zeros(4)
+    for _ in range(n):
+        build()
+        ms += np.array(ls.last_level_tables_ms()) / n
+    engine.set_overlap(1)
+    fz = float(sum((FLOP[c] + 2) * counts[c] for c in ("region2_evals", "region3_evals", "region4_evals")))
+    fw = float((FLOP["region1_evals"] + 2) * counts["region1_evals"])
+    return {"bound": "fp64-valu", "achieved": fz / (ms[1] * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": fz / (ms[1] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, "traffic": None, "kernel": "sr_zones_mc_kernel<256, 8>",
+            "kernel_ms": float(ms[1]), "flops_per_launch": fz,
+            "kernels": {"sr_prep_kernel (full list, three weights)": {"ms": float(ms[0])},
+                        "sr_zones_mc_kernel": {"ms": float(ms[1]), "executed_flops": fz},
+                        "far-only passes left after the zones kernel (serial schedule: all of them)": {"ms": float(ms[2])},
+                        "sr_wings_mc_kernel": {"ms": float(ms[3]), "executed_flops_rows_only": fw,
+                                               "note": "window ends run in rows here (the folded kernel scans them): their "
+                                                       "evaluations and the far passes' polynomials are not in the count"}},
+            "executed_counts": counts,
+            "note": "one multi-channel build of all levels on these rows: every line evaluated once, three LDS adds per evaluation"}
+
+
 def cpu_baseline(L, atm, grid, mm, e_lev, q_part, seconds_hint, n_layers_total, rays, gpu=None):
     """Oracle (kind 'port', mode 1 = direct accumulate) on all host cores over a bounded sample of the
     SAME workload: all lines, full grid, `ns` evenly spaced layers -- coefficients AND the radiance

@@ -463,6 +463,14 @@ def main(args):
             a0 = atms[0]
             kms, counts = B.serial_kernel_times_and_counts(engine, ls, lambda: ls.abscoeff_layers(a0["temps"], a0["press"], tvib=a0["tvib"]), n=3)
             extra["roofline"] = B.coefficient_roofline(kms, counts)
+            if ROUTE != "direct" and getattr(args, "level_route", 1) == 1:
+                # the step's dominant kernel is the table builds' sr_zones_mc_kernel (two builds per step): its roofline is the
+                # line's; the folded op's kernels (the direct route's) beside it
+                tab_tmp = torch.empty((12, 2, len(T_rows), n_grid), dtype=torch.float64, device="cuda")
+                extra["roofline_folded_op"] = extra["roofline"]
+                extra["roofline"] = B.level_tables_roofline(engine, ls, lambda: ls.glevel_pairs(T_rows, P_rows, out=tab_tmp),
+                                                            lambda: ls.abscoeff_layers(T_rows, P_rows))
+                del tab_tmp
             co, dco = coef3(a0)
             jac_bytes = 8.0 * (res[1].numel() + res[2].numel())
             extra["jacobian_kernel"] = _event_time(
@@ -675,10 +683,18 @@ def main(args):
             kms, counts = B.serial_kernel_times_and_counts(engine, ls, lambda: ls.abscoeff_level(
                 [pt[1] for pt in PT], [pt[0] for pt in PT], 0), n=3)
             extra["roofline"] = B.coefficient_roofline(kms, counts)
-            extra["roofline"]["note"] = ("the largest of the build's 24 coefficient ops (the pass over the lines whose lower or "
+            extra["roofline"]["note"] = ("the largest of the per-level route's 24 coefficient ops (the pass over the lines whose lower or "
                                          "upper level is level 0: 80 %% of the list, %d (P, T) rows; timed with the tracked-level "
                                          "weights, the same kernels): executed flops of its dominant kernel / its stand-alone "
                                          "HIP-event duration" % len(PT))
+            if getattr(args, "level_route", 1) == 1:
+                Tl, Pl = np.array([pt[1] for pt in PT]), np.array([pt[0] for pt in PT])
+                g_tmp = torch.empty((12, 3, len(PT), len(grid)), dtype=torch.float64, device="cuda")
+                extra["roofline_per_level_op"] = extra["roofline"]
+                extra["roofline"] = B.level_tables_roofline(engine, ls, lambda: ls.gcoeff_levels(Tl, Pl, out=g_tmp),
+                                                            lambda: ls.abscoeff_layers(Tl, Pl))
+                extra["roofline"]["kernel"] = "sr_zones_mc_kernel<128, 8>"
+                del g_tmp
             if world == 1 and args.cpu_seconds > 0:
                 from oracle import oracle as O
                 import time as _t
@@ -705,11 +721,14 @@ def main(args):
                                        "source": "spect_main_module.py:791-801: n_lines x 3 / 30000 x n_PT minutes = 6 ms per "
                                                  "(line, PT couple) with n_threads worker processes, hardware not stated "
                                                  "(BASELINE.md 1); for this table: %.0f minutes" % (n_pairs * 6e-3 / 60.0)},
-                   config={"workload": "LookUpTable.make (spect_main_module.py:718-788): %d lines x 12 levels x 3 ctypes x %d (P, T) "
+                   config={"route": "multi-channel pass: all levels and ctypes of a batch of couples from one walk of the line list "
+                                    "(sr_gcoeff_levels_dev)" if getattr(args, "level_route", 1) == 1 else "one coefficient op per level and ctype pair (sr_gcoeff_layers_dev)",
+                           "workload": "LookUpTable.make (spect_main_module.py:718-788): %d lines x 12 levels x 3 ctypes x %d (P, T) "
                                        "couples (calc_PT_couples_atmosphere of the configs[1] atmosphere, temp_step 5 K, pres_step_log "
                                        "1.0) x %d-pt grid = %.1f GB of G spectra, resident in HBM" % (ls.n_kept, len(PT), len(grid), gb),
-                           "line_evaluations_per_line": "3: absorption + sp_emission in one pass over the lines whose lower or upper "
-                                                        "level is L, ind_emission in a second pass over the upper-level lines only",
+                           "line_evaluations_per_line": "1 (multi-channel pass; the per-level route: 3 -- absorption + sp_emission in one pass "
+                                                        "over the lines whose lower or upper level is L, ind_emission in a second pass "
+                                                        "over the upper-level lines only)",
                            "device": info["name"]})
     else:
         raise SystemExit("--config must be 1..4 or lut")

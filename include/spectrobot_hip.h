@@ -238,6 +238,11 @@ int sr_glevel_pairs_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo,
 int sr_gcoeff_levels_dev(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int64_t g_hi, double *g_out, void *stream);
 /* 1 (default): level tables by the multi-channel pass; 0: one coefficient op per level (the A/B partner and fallback). */
 int sr_set_level_route(int multi_channel);
+/* HIP-event times [ms] of the last multi-channel table build on the handle (its last row batch; sr_set_timing(1)), on the
+ * caller's stream: ms4[0] the full list's tables (sr_prep_kernel), [1] sr_zones_mc_kernel, [2] what was left of the far-only
+ * passes when it ended, [3] sr_wings_mc_kernel.  With sr_set_overlap(0) the far passes run on the caller's stream too,
+ * behind the zones kernel: [1] and [3] are then the two kernels' stand-alone durations.  SR_ERR_ARG if no timed build. */
+int sr_last_level_tables_ms(sr_lineset *ls, float *ms4);
 
 /* The combine loop of the level-factored route for n_steps LOS steps at once, each step on one (P, T) row of the
  * pair tables `tab` (as sr_glevel_pairs_dev writes them, n_rows rows):

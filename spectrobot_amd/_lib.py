@@ -85,6 +85,7 @@ SYMBOLS = {
     "sr_glevel_pairs_dev": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "sr_gcoeff_levels_dev": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "sr_set_level_route": (C.c_int, [C.c_int]),
+    "sr_last_level_tables_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sr_glevel_combine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, ip, dp, dp,
                                         C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_gcoeff_layers_dev": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int, C.c_int64, C.c_int64, C.c_void_p,

@@ -316,6 +316,8 @@ struct McWork {
   DevBuf d_fast, d_cold, d_coef, d_outer_recs, d_bfast;
   hipStream_t zst = nullptr;
   hipEvent_t ev_prep = nullptr, ev_zones = nullptr;
+  hipEvent_t ev_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // timing: start, after the tables, after the zones kernel, before / after the wings kernel
+  bool timed = false;
   void release() {
     if (fw_init)
       for (auto &f : fw) f.release();
@@ -331,6 +333,8 @@ struct McWork {
     if (zst) (void)hipStreamDestroy(zst);
     if (ev_prep) (void)hipEventDestroy(ev_prep);
     if (ev_zones) (void)hipEventDestroy(ev_zones);
+    for (auto &e : ev_t)
+      if (e) { (void)hipEventDestroy(e); e = nullptr; }
     zst = nullptr;
     ev_prep = ev_zones = nullptr;
   }
@@ -1354,7 +1358,10 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     HIPCHK(hipStreamCreateWithFlags(&m.zst, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&m.ev_prep, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m.ev_zones, hipEventDisableTiming));
+    for (auto &e : m.ev_t) HIPCHK(hipEventCreate(&e));
   }
+  const bool timing = g_timing.load() != 0; // (the events of the LAST row batch stay readable: sr_last_level_tables_ms)
+  m.timed = false;
   const int npop = nlev;
   for (int k0 = 0; k0 < n_rows; k0 += rows_max) {
     const int nl = std::min(rows_max, n_rows - k0);
@@ -1393,8 +1400,10 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       if (rc) return rc;
       rc = m.d_coef.ensure(sizeof(double) * coef_row * (size_t)nl * n_far);
       if (rc) return rc;
+      if (timing) HIPCHK(hipEventRecord(m.ev_t[0], st));
       LAUNCHCHK(launch_prep(ls->L, A, ls->gp, WeightMode{kWeightChannels, ctypes3 ? 1 : 0}, line_lo, n_sub, (int)g_lo, (int)g_hi - 1,
                             m.d_fast.as<FastRec>(), m.d_cold.as<ColdRec>(), st));
+      if (timing) HIPCHK(hipEventRecord(m.ev_t[1], st));
       HIPCHK(hipEventRecord(m.ev_prep, st)); // the layer stage, the tables and everything earlier on the caller's stream
       // The zones kernel beside the far passes, the wings kernel after both.  The build is bound by its kernels' WORK, not
       // their order -- 13.25 / 13.32 ms with the zones kernel gated behind the far passes, 13.06 / 13.13 beside them; the
@@ -1402,6 +1411,7 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       // (profiles/r06_mc_timeline_v3 / v5).
       LAUNCHCHK(launch_zones_mc(m.d_fast.as<FastRec>(), m.d_cold.as<ColdRec>(), ls->L.lev_up + line_lo, ls->L.lev_lo + line_lo, ix,
                                 zmax_dev, n_sub, nl, (int)g_lo, (int)g_hi, ls->gp, mc, out, n_rows, k0, st));
+      if (timing) HIPCHK(hipEventRecord(m.ev_t[2], st));
       // far-only passes of the level sub-linesets
       rc = m.s_far.prepare(sizeof(McFarPass) * (size_t)n_far);
       if (rc) return rc;
@@ -1473,8 +1483,10 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
           rc = m.d_bfast.ensure(sizeof(FastRec) * (rec_total + 1));
           if (rc) return rc;
           for (int i = 0; i < n_items; ++i) items[i].fast = m.d_bfast.as<FastRec>() + rec_off[(size_t)i];
-          HIPCHK(hipStreamWaitEvent(m.zst, m.ev_prep, 0));
-          rc = m.s_batch.push(sizeof(FarBatchItem) * (size_t)n_items, m.zst);
+          // (serial schedule, sr_set_overlap(0): everything on the caller's stream, one kernel after the other)
+          hipStream_t bst = g_overlap.load() != 0 ? m.zst : st;
+          if (bst != st) HIPCHK(hipStreamWaitEvent(bst, m.ev_prep, 0));
+          rc = m.s_batch.push(sizeof(FarBatchItem) * (size_t)n_items, bst);
           if (rc) return rc;
           FarParams fpb;
           far_hierarchy(n_pts, nl, &fpb);
@@ -1485,9 +1497,9 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
           const double *l2l_tab = nullptr;
           rc = l2l_table_dev(&l2l_tab);
           if (rc) return rc;
-          LAUNCHCHK(launch_far_batch(m.s_batch.d.as<FarBatchItem>(), n_items, max_sub, A, ls->gp, zmax_dev, (int)g_lo, fpb, l2l_tab, m.zst));
-          HIPCHK(hipEventRecord(m.ev_zones, m.zst));
-          rc = m.s_batch.mark(m.zst);
+          LAUNCHCHK(launch_far_batch(m.s_batch.d.as<FarBatchItem>(), n_items, max_sub, A, ls->gp, zmax_dev, (int)g_lo, fpb, l2l_tab, bst));
+          HIPCHK(hipEventRecord(m.ev_zones, bst));
+          rc = m.s_batch.mark(bst);
           if (rc) return rc;
         }
         m.batch_pending = n_items > 0;
@@ -1521,8 +1533,13 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
       fp.coef = nullptr;
       fp.m2l = 0; fp.rows = 0; fp.pm_src = d_pm + nl; fp.disp_lo_end = 0; fp.disp_hi_begin = 0; fp.mom = nullptr; fp.tab = nullptr;
       for (int lv = 0; lv < kMaxFarLevels; ++lv) fp.n_src[lv] = fp.src_off[lv] = 0;
+      if (timing) HIPCHK(hipEventRecord(m.ev_t[3], st));
       LAUNCHCHK(launch_wings_mc(m.d_fast.as<FastRec>(), ls->L.lev_up + line_lo, ls->L.lev_lo + line_lo, ix, zmax_dev, n_sub, nl,
                                 (int)g_lo, (int)g_hi, fp, mc, m.s_far.d.as<McFarPass>(), n_far, out, n_rows, k0, st));
+      if (timing) {
+        HIPCHK(hipEventRecord(m.ev_t[4], st));
+        m.timed = true;
+      }
       rc = m.s_far.mark(st);
       if (rc) return rc;
     }
@@ -1726,6 +1743,17 @@ int sr_last_kernel_ms(sr_lineset *ls, float *ms5) {
   }
   for (int i = 1; i < ls->work->n_timed; ++i)
     HIPCHK(hipEventElapsedTime(&ms5[i], i == 1 ? first : ls->work->ev[i], ls->work->ev[i + 1]));
+  return SR_OK;
+}
+
+int sr_last_level_tables_ms(sr_lineset *ls, float *ms4) {
+  if (!ls || !ms4 || !ls->mc.timed) return SR_ERR_ARG;
+  const McWork &m = ls->mc;
+  HIPCHK(hipEventSynchronize(m.ev_t[4]));
+  HIPCHK(hipEventElapsedTime(&ms4[0], m.ev_t[0], m.ev_t[1])); // tables of the full list
+  HIPCHK(hipEventElapsedTime(&ms4[1], m.ev_t[1], m.ev_t[2])); // sr_zones_mc_kernel (beside the far passes unless the schedule is serial)
+  HIPCHK(hipEventElapsedTime(&ms4[2], m.ev_t[2], m.ev_t[3])); // what of the far passes was left when it ended
+  HIPCHK(hipEventElapsedTime(&ms4[3], m.ev_t[3], m.ev_t[4])); // sr_wings_mc_kernel
   return SR_OK;
 }
 

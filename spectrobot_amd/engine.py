@@ -301,6 +301,13 @@ class LineSet(object):
         return tuple(ms)
 
 
+    def last_level_tables_ms(self):
+        """HIP-event times [ms] of the last multi-channel table build (glevel_pairs / gcoeff_levels): (tables, zones kernel,
+        rest of the far passes, wings kernel); under set_overlap(0) the two kernels' stand-alone durations."""
+        ms = (C.c_float * 4)()
+        check(lib.sr_last_level_tables_ms(self._h, ms), "sr_last_level_tables_ms")
+        return [float(v) for v in ms]
+
     def last_eval_counts(self):
         """Executed-work counters of the last abscoeff_layers call made under set_counting(1)
         (sr_last_eval_counts): dict name -> count."""
