@@ -1376,6 +1376,10 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     // this batch after everything earlier on the handle (the previous batch's kernels read the tables refilled below)
     if (w.last_done_recorded) HIPCHK(hipStreamWaitEvent(st, w.ev_last_done, 0));
     const size_t hl_bytes = layer_stage_bytes(nl, npop);
+    // (prepare() waits on the HOST for the mark behind the previous batch's -- or build's -- last kernel: nothing of this
+    // batch is enqueued before the previous one has finished with the pass's scratch.  That is what keeps the far passes
+    // below, whose internal streams are not ordered after the caller's, from writing m.d_coef under the wings kernel of
+    // the batch before.)
     int rc = m.s_layers.prepare(hl_bytes);
     if (rc) return rc;
     rc = fill_layer_stage(ls, ls, ls, &sub, m.s_layers.host<double>());
@@ -1545,6 +1549,10 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
     }
     // lines whose centre lies outside their window (humliv_bb's outer branches): per level, as the per-level route
     if (ls->n_outer > 0) {
+      // (one record buffer for the largest level: sized per level, a growing buffer was freed -- a device synchronisation --
+      // between the levels' launches)
+      rc = m.d_outer_recs.ensure(sizeof(OuterRec) * (size_t)ls->n_outer * nl);
+      if (rc) return rc;
       for (int f = 0; f < n_far; ++f) {
         const int lv = ctypes3 ? f / 2 : f;
         const bool ind = ctypes3 && (f & 1);
@@ -1552,8 +1560,6 @@ static int mc_pass(sr_lineset *ls, const sr_layers_desc *atm, int64_t g_lo, int6
         rc = level_set(ls, lv, &c, ind);
         if (rc) return rc;
         if (c->n_outer <= 0) continue;
-        rc = m.d_outer_recs.ensure(sizeof(OuterRec) * (size_t)c->n_outer * nl);
-        if (rc) return rc;
         double *o_a, *o_e;
         if (!ctypes3) { o_a = chan_rows(2 * lv); o_e = chan_rows(2 * lv + 1); }
         else if (!ind) { o_a = chan_rows(3 * lv + 2); o_e = chan_rows(3 * lv); }

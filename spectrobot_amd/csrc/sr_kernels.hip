@@ -2531,10 +2531,14 @@ static int launch_zones_mc_wt(const FastRec *fast, const ColdRec *cold, const in
                               double *out, int n_rows_total, int row0, hipStream_t st) {
   constexpr int NW = kMcWaves;
   const int n_t = (g_hi - g_lo + WT - 1) / WT;
-  static bool attr_set = false; // (more than 64 KB of dynamic LDS needs the attribute once per process and kernel)
-  if (!attr_set) {
+  // (more than 64 KB of dynamic LDS needs the attribute once per kernel and DEVICE: a process that moves to another
+  // device sets it there too)
+  static unsigned long long attr_set = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(attr_set >> (dev & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sr_zones_mc_kernel<WT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set |= 1ull << (dev & 63);
   }
   hipLaunchKernelGGL((sr_zones_mc_kernel<WT, NW>), dim3((unsigned)(n_t * n_layers)), dim3(64 * NW), zones_mc_lds(mc.n_ch, WT), st, fast, cold,
                      lev_up, lev_lo, ix, zmax, n_sub, n_t, g_lo, g_hi, gp, mc, out, n_rows_total, row0);
@@ -2560,10 +2564,12 @@ int launch_wings_mc(const FastRec *fast, const int *lev_up, const int *lev_lo, c
   const int n_g1 = (g_hi - g_lo + 63) / 64;
   const size_t lds = wings_mc_lds(mc.n_ch); // the image + the polynomial stage's staging rows
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0; // (per kernel and device, see launch_zones_mc_wt)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(attr_set >> (dev & 63) & 1ull)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sr_wings_mc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set |= 1ull << (dev & 63);
   }
   hipLaunchKernelGGL(sr_wings_mc_kernel, dim3((unsigned)(n_g1 * n_layers)), dim3(64 * kMcWingWaves), lds, st, fast, lev_up, lev_lo, ix, zmax, n_sub,
                      n_g1, g_lo, g_hi, fp, mc, far, n_far, out, n_rows_total, row0);
