@@ -429,7 +429,7 @@ def lut_coefficients(scene, temp_step=5.0, pres_step_log=1.0, refresh=False, **_
     `inversion(..., useLUTs=True)` (spect_main_module.py:2447-2467 -> check_and_build_allluts; per LOS step
     LutSet.calculate, :997-1066): per gas and level the three G spectra on a rectangular (P, T) lattice that
     covers the atmosphere (temp_step [K], pres_step_log [ln hPa]: the reference's LUTopt keys) -- one
-    sr_gcoeff_layers_dev call per level, the table stays in HBM -- then per layer the bilinear interpolation and the
+    sr_gcoeff_levels_dev call per gas (all levels from one walk of its lines), the table stays in HBM -- then per layer the bilinear interpolation and the
     population-weighted combine on the device (LutSet.combine_steps).  Tables are built once per scene."""
     import torch
     from . import spect_classes as spcl
@@ -443,9 +443,11 @@ def lut_coefficients(scene, temp_step=5.0, pres_step_log=1.0, refresh=False, **_
         n_lev = ls.level_energies.size
         if getattr(g, "luts", None) is None or refresh:
             g.luts = []
+            # all levels of the lattice from one walk of the line list (sr_gcoeff_levels_dev: the multi-channel pass)
+            g_all = ls.gcoeff_levels([pt[1] for pt in PT], [pt[0] for pt in PT])
             for lev in range(max(n_lev, 1)):
                 lut = smm.LutSet(ls.mol, ls.iso, ls.mm, level=None, level_index=lev if n_lev else None)
-                lut._append(ls.gcoeff_layers([pt[1] for pt in PT], [pt[0] for pt in PT], level=lev if n_lev else 0), PT)
+                lut._append(g_all[lev], PT)
                 g.luts.append(lut)
         q = np.atleast_1d(spcl.CalcPartitionSum(ls.mol, ls.iso, temps))
         ab = torch.zeros((len(temps), ls.n_grid), dtype=torch.float64, device="cuda")
