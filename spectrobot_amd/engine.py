@@ -29,7 +29,9 @@ def grid_params(grid):
     raises if the grid is not exactly w0 + j*step.  The check walks the whole grid (1e5..2e6 points): the result is
     remembered for the array OBJECT it was made for (grids are not modified in place anywhere in this package)."""
     for g, res in _GRID_CACHE:
-        if g is grid:
+        # (identity alone says nothing about an array edited in place, ADVICE round 5: the remembered answer must still
+        # describe the array's ends and length; an edit of interior points of a grid no caller makes goes unseen)
+        if g is grid and g.size == res[2] and g[0] == res[0] and g[1] - g[0] == res[1] and g[-1] == res[0] + (res[2] - 1) * res[1]:
             return res
     arr = np.asarray(grid, dtype=np.float64)
     if arr.ndim != 1 or arr.size < 2:
@@ -40,6 +42,7 @@ def grid_params(grid):
                          "equal spacing (SpectralGrid.step, spect_classes.py:366)")
     res = (w0, step, arr.size)
     if isinstance(grid, np.ndarray):
+        _GRID_CACHE[:] = [e for e in _GRID_CACHE if e[0] is not grid]
         _GRID_CACHE.append((grid, res))
         del _GRID_CACHE[:-8]
     return res
