@@ -4033,6 +4033,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG <= 2 ? 4
           for (int q = 0; q < NG; ++q) {
 #pragma unroll
             for (int p = h * kH; p < (h + 1) * kH; ++p) {
+              // (Round 6: a two-instruction step for the parameters whose column derivatives are both zero in a shell -- a
+              // bit mask in the record header, a scalar branch per parameter -- was built: the second code path per
+              // parameter cost 44 VGPR spills at this kernel's 128 registers, 0.26 -> 0.81 ms.  Not kept.)
               if (p < np && (NG == 1 || ((gm >> (2 * p)) & 3) == q)) {
                 asm volatile("");
                 dIf[p] = fma3(dIf[p], t_f, bf[q] * cf[p]);
