@@ -382,6 +382,26 @@ int sr_retrieval_step_dev(const double *abs_c, const double *emi_c, int n_layers
                           int n_bands, double n_sigma, int out_units, const double *fov, double *buf, double *out,
                           const sr_oe_desc *oe, double *chi_sum, int32_t *n_used, double *dx, double *s_x, double *avk,
                           void *stream);
+/* ... and the loop around it, for a retrieval whose coefficient spectra stay as they are (only VMRs are retrieved: the
+ * loop of inversion_fast_limb, spect_main_module.py:2725-2987): per iteration sr_retrieval_step_dev at the current
+ * parameter vector, chi = chi_sum / (n_used - n_dof_par) (:2949), the stopping rule (:2960-2973: relative change below
+ * chi_threshold -> *stop = 1 "converged", chi increased -> 2 "raised", else 0 after max_it), then x += dx with the
+ * positivity rule (:616-624: a step that would leave a constrained parameter <= 0 is halved until it does not).
+ *   chi_hist [max_it], *n_it of them filled; x_hist [max_it + 1][n_par]: the vector before every iteration and after
+ *   the last update (*n_it updates when *stop == 0, *n_it - 1 otherwise); out: the LAST iteration's band spectra and
+ *   Jacobians; s_x / avk: of the last iteration whose update was applied (as the reference stores them after
+ *   inversion_algebra; untouched when there was none).  What the caller keeps is object bookkeeping. */
+typedef struct {
+  int32_t max_it;
+  double chi_threshold;
+  const uint8_t *positive; /* [n_par]: 1 = constrain_positive */
+  int32_t n_dof_par;       /* parameters in use */
+} sr_loop_desc;
+int sr_retrieval_loop_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
+                          const double *x0, double w0, double step, const double *centers_nm, const double *widths_nm,
+                          int n_bands, double n_sigma, int out_units, const double *fov, double *buf, double *out,
+                          const sr_oe_desc *oe, const sr_loop_desc *lp, double *chi_hist, double *x_hist, int32_t *n_it,
+                          int32_t *stop, double *s_x, double *avk, void *stream);
 /* sr_limb_rays_dev on a resident LOS: kernel launches only (no staging copy, no column kernel, no host plan).
  * g_lo: grid index of abs_c's first point (Planck initial intensity, init_mode 2). */
 int sr_limb_rays_los_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
@@ -508,6 +528,11 @@ int sr_set_table_budget(int64_t bytes);
  * of 16) -- kept as the check of the others.  2: one pass per ray in path order, one ray per thread, always.
  * 3: path order, two rays per thread sharing a shell's coefficient loads (sr_limb_adjoint_sync_kernel; the bits of 2). */
 int sr_set_jac_layer_mode(int forward);
+/* sr_retrieval_forward_dev / _step_dev / _loop_dev with up to 8 parameters on a folded batch: 1 (default) the recursion
+ * kernel integrates the instrument bands in its epilogue (partial sums per 64 points; the 1 + n_par spectra per ray
+ * are never written: `buf` stays untouched); 0: spectra into `buf`, then sr_hires_to_lowres_shard_dev's kernels -- the
+ * same numbers up to the summation order (<= 1e-13 relative), kept as the check and the A/B partner. */
+int sr_set_band_fusion(int on);
 /* Which recursion kernel the most recent sr_limb_rays_dev call on this thread launched: 1 the path-order kernels
  * (sr_limb_kernel / sr_limb_split_kernel), 2 the folded sweep (sr_limb_fold_fwd_kernel: ray batches that share their
  * shells), 0 none yet.  Diagnostic (tests pin the choice: a 3-D batch with a coefficient row per LOS step must not fold). */
@@ -538,6 +563,10 @@ int sr_last_kernel_ms(sr_lineset *ls, float *ms5);
 /* 0: the coefficient op records no timing events (seven hipEventRecord fewer per call: a 1/8 spectral shard's step is
  * bound by the host's enqueue time before anything else); sr_last_kernel_ms then returns SR_ERR_ARG.  1 (default). */
 int sr_set_timing(int on);
+/* sr_set_timing(2): additionally two events around the recursion of sr_retrieval_forward_dev / _step_dev / _loop_dev
+ * (record packing + the one-sweep kernel with the bands in its epilogue); sr_los_last_kernel_ms: their HIP-event time for
+ * the most recent such call on the handle (SR_ERR_ARG when it was not timed).  Synchronises.  bench.py --config 4. */
+int sr_los_last_kernel_ms(sr_los *h, float *ms);
 
 #ifdef __cplusplus
 }

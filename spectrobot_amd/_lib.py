@@ -63,6 +63,11 @@ class OeDesc(C.Structure):
                 ("x_apriori", dp), ("lambda_lm", C.c_double)]
 
 
+class LoopDesc(C.Structure):
+    _fields_ = [("max_it", C.c_int32), ("chi_threshold", C.c_double), ("positive", C.POINTER(C.c_uint8)),
+                ("n_dof_par", C.c_int32)]
+
+
 # every symbol include/spectrobot_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "sr_strerror": (C.c_char_p, [C.c_int]),
@@ -111,6 +116,9 @@ SYMBOLS = {
     "sr_retrieval_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, dp, C.c_double,
                                         C.c_double, dp, dp, C.c_int, C.c_double, C.c_int, dp, C.c_void_p, dp, C.POINTER(OeDesc), dp,
                                         C.POINTER(C.c_int32), dp, dp, dp, C.c_void_p]),
+    "sr_retrieval_loop_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, dp, C.c_double,
+                                        C.c_double, dp, dp, C.c_int, C.c_double, C.c_int, dp, C.c_void_p, dp, C.POINTER(OeDesc),
+                                        C.POINTER(LoopDesc), dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, C.c_void_p]),
     "sr_limb_step_dev": (C.c_int, [C.c_void_p, C.POINTER(LayersDesc), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_limb_rays_jac_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.POINTER(LosDesc), C.c_int, ip, dp,
@@ -131,6 +139,8 @@ SYMBOLS = {
     "sr_hires_to_lowres_shard_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_double, C.c_double, dp, dp,
                                                C.c_int, C.c_double, C.c_int, dp, C.c_void_p]),
     "sr_set_points_per_lane": (C.c_int, [C.c_int]),
+    "sr_set_band_fusion": (C.c_int, [C.c_int]),
+    "sr_los_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sr_set_jac_layer_mode": (C.c_int, [C.c_int]),
     "sr_last_limb_route": (C.c_int, []),
     "sr_set_far_field": (C.c_int, [C.c_int]),

@@ -225,6 +225,7 @@ std::atomic<int> g_variant{8};   // points per lane in the exact wings kernel
 std::atomic<int> g_far_field{3}; // 1: far wings by per-line local expansions, 2: by box pairs (multipole -> local), 3 (default): 2, but sparse line sets by 1, 0: every evaluation exact
 std::atomic<int> g_overlap{1};   // 1 (default): the decoupled, phased pipeline; 0: kernels one after the other
 // sr_set_jac_layer_mode; SR_JAC_LAYER_MODE (environment, read once at load): its initial value, for A/B runs of whole programs
+std::atomic<int> g_band_fusion{1}; // sr_set_band_fusion
 std::atomic<int> g_jac_layer_forward{[] { const char *e = getenv("SR_JAC_LAYER_MODE"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 3 ? v : 0; }()};
 // sr_set_kernel_repeat: a measurement hook of the SERIAL schedule -- kernel g_repeat_kernel of every call is launched
 // g_repeat_n times back to back (energy per launch: tools/energy_by_kernel.py loops one kernel for seconds beside a power
@@ -451,7 +452,7 @@ int sr_set_level_route(int multi_channel) {
 }
 
 int sr_set_timing(int on) {
-  g_timing.store(on ? 1 : 0);
+  g_timing.store(on == 2 ? 2 : (on ? 1 : 0));
   return SR_OK;
 }
 
@@ -462,6 +463,11 @@ int sr_set_counting(int on) {
 
 int sr_set_jac_layer_mode(int forward) {
   g_jac_layer_forward.store(forward == 2 || forward == 3 ? forward : (forward ? 1 : 0)); // see spectrobot_hip.h
+  return SR_OK;
+}
+
+int sr_set_band_fusion(int on) {
+  g_band_fusion.store(on ? 1 : 0);
   return SR_OK;
 }
 
@@ -2158,6 +2164,8 @@ struct sr_los {
   // last use (as coef_op does with ev_last_done), so calls on streams that are not ordered against each other are safe
   hipEvent_t ev_last = nullptr;
   bool last_recorded = false;
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr; // around the recursion of the last forward model (sr_set_timing(2))
+  bool k_timed = false;
 };
 
 // Entry of every call on a resident batch: the handle belongs to the device it was made on (its buffers, and the
@@ -2176,6 +2184,87 @@ static int los_leave(sr_los *h, hipStream_t st) {
   if (!h->ev_last) HIPCHK(hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
   HIPCHK(hipEventRecord(h->ev_last, st));
   h->last_recorded = true;
+  return SR_OK;
+}
+
+// ------------------------------------------------------------------------
+// The instrument step's per-thread device state (sr_hires_to_lowres_shard_dev, and sr_retrieval_forward_dev whose
+// recursion kernel integrates the bands itself).
+// The weight table depends on the grid window and the bands alone: kept while they (and the buffer) stay the same -- the
+// instrument step of a retrieval iteration is then launches only, no upload (the weights kernel was 19 us of it).
+// (the key held the buffer's ADDRESS; a call with more rays re-allocates the buffer -- the partial sums
+// follow the table in it -- and the new block can come back at the old address with nothing in it.  The key is the
+// buffer's generation now, and the device: the thread-local buffers follow a hipSetDevice())
+struct LowresState {
+  Stager s_bands, s_land; // the bands' centres / widths on their way up; the band spectra's pinned landing buffer
+  DevBuf d_out;
+  DevBuf d_weights;       // the bands' weight table [n_bands][n_pts] + point ranges, then the partial sums
+  int64_t n_pts = -1, g_lo = 0;
+  double w0 = 0, step = 0, n_sigma = 0;
+  bool valid = false;
+  unsigned gen = 0;
+  int dev = -1;
+  std::vector<double> bands;
+};
+static thread_local LowresState t_lowres;
+
+// Arguments checked, buffers for n_rows spectra in place, the weight table valid on `st` (its kernel launched there when
+// the key changed: *fresh).  fused: partial sums per 64-point slot (launch_fold_dense with the scratch).
+static int lowres_prepare(int n_rows, int64_t n_pts, int64_t g_lo, double w0, double step, const double *centers_nm,
+                          const double *widths_nm, int n_bands, double n_sigma, int out_units, bool fused, hipStream_t st,
+                          bool *fresh) {
+  if (!centers_nm || !widths_nm || n_rows <= 0 || n_pts < 2 || n_bands <= 0 || g_lo < 0) return SR_ERR_ARG;
+  if (g_lo + n_pts > 2000000) return SR_ERR_LIMIT;
+  if (!(step > 0.0) || !(w0 > 0.0) || !(n_sigma > 0.0) || out_units < 0 || out_units > 2) return SR_ERR_ARG;
+  for (int b = 0; b < n_bands; ++b)
+    if (!(widths_nm[b] > 0.0)) return SR_ERR_ARG;
+  LowresState &L = t_lowres;
+  const size_t nb = (size_t)n_bands;
+  int cur_dev = 0;
+  HIPCHK(hipGetDevice(&cur_dev));
+  if (L.dev != cur_dev) { // buffers of another device: start over on this one
+    L.d_out.release();
+    L.d_weights.release();
+    L.valid = false;
+    L.dev = cur_dev;
+  }
+  int rc = L.d_out.ensure(sizeof(double) * nb * n_rows);
+  if (rc) return rc;
+  rc = L.d_weights.ensure(lowres_scratch_bytes((int)n_pts, n_bands, n_rows, fused));
+  if (rc) return rc;
+  const bool same = L.valid && L.gen == L.d_weights.gen && L.n_pts == n_pts && L.g_lo == g_lo && L.w0 == w0 && L.step == step &&
+                    L.n_sigma == n_sigma && L.bands.size() == 2 * nb &&
+                    std::memcmp(L.bands.data(), centers_nm, sizeof(double) * nb) == 0 &&
+                    std::memcmp(L.bands.data() + nb, widths_nm, sizeof(double) * nb) == 0;
+  *fresh = !same;
+  if (same) return SR_OK;
+  L.valid = false; // (until the launch below has been issued)
+  rc = L.s_bands.prepare(sizeof(double) * 2 * nb);
+  if (rc) return rc;
+  std::memcpy(L.s_bands.host<double>(), centers_nm, sizeof(double) * nb);
+  std::memcpy(L.s_bands.host<double>() + nb, widths_nm, sizeof(double) * nb);
+  rc = L.s_bands.push(sizeof(double) * 2 * nb, st);
+  if (rc) return rc;
+  LAUNCHCHK(launch_lowres_weights((int)n_pts, (int)g_lo, w0, step, L.s_bands.d.as<double>(), L.s_bands.d.as<double>() + nb, n_bands,
+                                  n_sigma, L.d_weights.p, st));
+  L.n_pts = n_pts; L.g_lo = g_lo; L.w0 = w0; L.step = step; L.n_sigma = n_sigma;
+  L.bands.assign(centers_nm, centers_nm + nb);
+  L.bands.insert(L.bands.end(), widths_nm, widths_nm + nb);
+  L.gen = L.d_weights.gen;
+  L.valid = true; // (the callers synchronise `st` before they return: the table is complete before any later call)
+  return SR_OK;
+}
+
+// d_out [n_rows][n_bands] to the host through a pinned buffer of the library's own (a copy into the caller's pageable
+// memory is staged by the runtime); synchronises `st`
+static int lowres_land(int n_rows, int n_bands, double *out_host, hipStream_t st) {
+  LowresState &L = t_lowres;
+  const size_t bytes = sizeof(double) * (size_t)n_bands * n_rows;
+  const int rc = L.s_land.prepare(bytes);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(L.s_land.h, L.d_out.p, bytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::memcpy(out_host, L.s_land.h, bytes);
   return SR_OK;
 }
 
@@ -2241,6 +2330,8 @@ int sr_los_destroy(sr_los *h) {
   h->s_vmr.release();
   h->s_x.release();
   if (h->ev_last) (void)hipEventDestroy(h->ev_last);
+  if (h->ev_k0) (void)hipEventDestroy(h->ev_k0);
+  if (h->ev_k1) (void)hipEventDestroy(h->ev_k1);
   delete h;
   return SR_OK;
 }
@@ -2333,21 +2424,51 @@ int sr_retrieval_forward_dev(const double *abs_c, const double *emi_c, int n_lay
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = los_enter(h, st);
   if (rc) return rc;
-  rc = h->s_x.prepare(sizeof(double) * (size_t)n_par);
-  if (rc) return rc;
-  std::memcpy(h->s_x.host<double>(), x, sizeof(double) * (size_t)n_par);
-  rc = h->s_x.push(sizeof(double) * (size_t)n_par, st);
-  if (rc) return rc;
-  LAUNCHCHK(launch_los_vmr_from_params(const_cast<double *>(h->D.prof), h->opt.n_gas, n_par, h->D.n_pt, h->D.par_gas,
-                                       h->s_x.d.as<double>(), st));
+  LAUNCHCHK(launch_los_vmr_from_params(const_cast<double *>(h->D.prof), h->opt.n_gas, n_par, h->D.n_pt, h->D.par_gas, x, st));
   LAUNCHCHK(launch_los_columns(h->D.nd, h->D.x, h->D.prof, h->D.scale, h->D.pt_off, h->D.n_seg, h->D.n_pt, h->opt.n_gas, h->D.col, st));
-  rc = sr_limb_rays_jac_los_dev(abs_c, emi_c, n_layers, n_pts, h, g_lo, buf, buf + (size_t)n_rays * n_pts, stream);
-  if (rc) return rc;
   static thread_local std::vector<double> low; // [n_rays + n_rays n_par][n_bands]
   low.resize((size_t)n_rays * n_row * n_bands);
-  rc = sr_hires_to_lowres_shard_dev(buf, n_rays * n_row, n_pts, g_lo, w0, step, centers_nm, widths_nm, n_bands, n_sigma, out_units,
-                                    low.data(), stream);
-  if (rc) return rc;
+  if (g_band_fusion.load() && n_par <= kFoldDensePar && h->F.n_rec > 0 && g_jac_layer_forward.load() == 0) {
+    // the one-sweep kernel integrates the bands in its epilogue: no spectra are written (`buf` stays untouched)
+    if (!abs_c || !emi_c || n_layers != h->n_layers || n_pts <= 0) return SR_ERR_ARG;
+    if (n_pts > 2000000) return SR_ERR_LIMIT;
+    bool fresh = false;
+    rc = lowres_prepare(n_rays * n_row, n_pts, g_lo, w0, step, centers_nm, widths_nm, n_bands, n_sigma, out_units, /*fused=*/true, st,
+                        &fresh);
+    if (rc) return rc;
+    sr_los_desc o = h->opt;
+    o.g_lo = g_lo;
+    const bool timed = g_timing.load() == 2;
+    if (timed) {
+      if (!h->ev_k0) {
+        HIPCHK(hipEventCreate(&h->ev_k0));
+        HIPCHK(hipEventCreate(&h->ev_k1));
+      }
+      HIPCHK(hipEventRecord(h->ev_k0, st));
+    }
+    LAUNCHCHK(launch_fold_dense(h->F.plan, h->D.col, h->par_gas.data(), n_par, h->D.n_seg, h->F.n_rec, h->F.rec, abs_c, emi_c,
+                                (int)n_pts, n_layers, n_rays, h->F.n_vis, limb_opts(&o, h->D.n_seg), buf, buf + (size_t)n_rays * n_pts,
+                                st, t_lowres.d_weights.p, n_bands));
+    if (timed) HIPCHK(hipEventRecord(h->ev_k1, st));
+    h->k_timed = timed;
+    rc = los_leave(h, st);
+    if (rc) return rc;
+    // the sums go straight into the library's pinned landing buffer (16 KB over the bus from the kernel itself: no copy
+    // command behind it)
+    const size_t low_bytes = sizeof(double) * (size_t)n_rays * n_row * n_bands;
+    rc = t_lowres.s_land.prepare(low_bytes);
+    if (rc) return rc;
+    LAUNCHCHK(launch_lowres_sum_blocks((int)n_pts, n_rays * n_row, n_bands, out_units, static_cast<double *>(t_lowres.s_land.h),
+                                       t_lowres.d_weights.p, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::memcpy(low.data(), t_lowres.s_land.h, low_bytes);
+  } else {
+    rc = sr_limb_rays_jac_los_dev(abs_c, emi_c, n_layers, n_pts, h, g_lo, buf, buf + (size_t)n_rays * n_pts, stream);
+    if (rc) return rc;
+    rc = sr_hires_to_lowres_shard_dev(buf, n_rays * n_row, n_pts, g_lo, w0, step, centers_nm, widths_nm, n_bands, n_sigma, out_units,
+                                      low.data(), stream);
+    if (rc) return rc;
+  }
   // row of (ray r, quantity q): q = 0 the radiance, q = 1 + p the derivative to parameter p
   auto row = [&](int r, int q) { return low.data() + (size_t)(q == 0 ? r : n_rays + r * n_par + (q - 1)) * n_bands; };
   if (!fov) {
@@ -2480,6 +2601,63 @@ int sr_retrieval_step_dev(const double *abs_c, const double *emi_c, int n_layers
   for (int p = 0; p < n_par; ++p) A[(size_t)p * n_par + p] += oe->lambda_lm * S_inv[(size_t)p * n_par + p];
   if (!lu_solve(A, n_par, rhs, 1)) return SR_ERR_TABLE;
   std::memcpy(dx, rhs.data(), sizeof(double) * (size_t)n_par);
+  return SR_OK;
+}
+
+int sr_los_last_kernel_ms(sr_los *h, float *ms) {
+  if (!h || !ms || !h->k_timed) return SR_ERR_ARG;
+  HIPCHK(hipEventSynchronize(h->ev_k1));
+  HIPCHK(hipEventElapsedTime(ms, h->ev_k0, h->ev_k1));
+  return SR_OK;
+}
+
+// The retrieval loop itself (spect_main_module.py:2725-2987 with fixed coefficient spectra): sr_retrieval_step_dev per
+// iteration, reduced chi square (:2949), stopping rule (:2960-2973), the update with the positivity rule (:616-624).
+int sr_retrieval_loop_dev(const double *abs_c, const double *emi_c, int n_layers, int64_t n_pts, sr_los *h, int64_t g_lo,
+                          const double *x0, double w0, double step, const double *centers_nm, const double *widths_nm,
+                          int n_bands, double n_sigma, int out_units, const double *fov, double *buf, double *out,
+                          const sr_oe_desc *oe, const sr_loop_desc *lp, double *chi_hist, double *x_hist, int32_t *n_it,
+                          int32_t *stop, double *s_x, double *avk, void *stream) {
+  if (!h || !x0 || !oe || !lp || !lp->positive || !chi_hist || !x_hist || !n_it || !stop || !s_x || !avk || lp->max_it < 0)
+    return SR_ERR_ARG;
+  const int n_par = h->n_par;
+  if (n_par <= 0 || n_par > 64) return SR_ERR_ARG;
+  const size_t np2 = (size_t)n_par * n_par;
+  std::vector<double> x(x0, x0 + n_par), dx((size_t)n_par), sx(np2), av(np2);
+  std::memcpy(x_hist, x.data(), sizeof(double) * (size_t)n_par);
+  *n_it = 0;
+  *stop = 0;
+  double chi_old = 0.0;
+  for (int it = 0; it < lp->max_it; ++it) {
+    double chi_sum = 0.0;
+    int32_t nu = 0;
+    const int rc = sr_retrieval_step_dev(abs_c, emi_c, n_layers, n_pts, h, g_lo, x.data(), w0, step, centers_nm, widths_nm,
+                                         n_bands, n_sigma, out_units, fov, buf, out, oe, &chi_sum, &nu, dx.data(), sx.data(),
+                                         av.data(), stream);
+    if (rc) return rc;
+    const double chi = chi_sum / (double)(nu - lp->n_dof_par);
+    chi_hist[it] = chi;
+    *n_it = it + 1;
+    if (it > 0) {
+      if (std::fabs(chi - chi_old) / chi_old < lp->chi_threshold) { *stop = 1; break; }
+      if (chi > chi_old) { *stop = 2; break; }
+    }
+    chi_old = chi;
+    for (int p = 0; p < n_par; ++p) {
+      double d = dx[p];
+      if (lp->positive[p]) {
+        if (!(x[p] > 0.0)) { // (the reference would halve for ever)
+          g_err = "sr_retrieval_loop_dev: a positive-constrained parameter is not positive";
+          return SR_ERR_ARG;
+        }
+        while (x[p] + d <= 0.0) d /= 2;
+      }
+      x[p] = x[p] + d;
+    }
+    std::memcpy(s_x, sx.data(), sizeof(double) * np2);
+    std::memcpy(avk, av.data(), sizeof(double) * np2);
+    std::memcpy(x_hist + (size_t)(it + 1) * n_par, x.data(), sizeof(double) * (size_t)n_par);
+  }
   return SR_OK;
 }
 
@@ -2977,67 +3155,15 @@ int sr_hires_to_lowres_dev(const double *rad, int n_rays, int64_t n_pts, double 
 int sr_hires_to_lowres_shard_dev(const double *rad, int n_rays, int64_t n_pts, int64_t g_lo, double w0, double step,
                                  const double *centers_nm, const double *widths_nm, int n_bands, double n_sigma,
                                  int out_units, double *out_host, void *stream) {
-  if (!rad || !centers_nm || !widths_nm || !out_host || n_rays <= 0 || n_pts < 2 || n_bands <= 0 || g_lo < 0) return SR_ERR_ARG;
-  if (g_lo + n_pts > 2000000) return SR_ERR_LIMIT;
-  if (!(step > 0.0) || !(w0 > 0.0) || !(n_sigma > 0.0) || out_units < 0 || out_units > 2) return SR_ERR_ARG;
-  for (int b = 0; b < n_bands; ++b)
-    if (!(widths_nm[b] > 0.0)) return SR_ERR_ARG;
+  if (!rad || !out_host) return SR_ERR_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static thread_local Stager s_bands;
-  static thread_local DevBuf d_out;
-  static thread_local DevBuf d_weights; // the bands' weight table [n_bands][n_pts] + point ranges, then the partial sums
-  // The table depends on the grid window and the bands alone: kept while they (and the buffer) stay the same -- the
-  // instrument step of a retrieval iteration is then two launches and no upload (the weights kernel was 19 us of it)
-  // (the key held the buffer's ADDRESS; a call with more rays re-allocates the buffer -- the partial sums
-  // follow the table in it -- and the new block can come back at the old address with nothing in it.  The key is the
-  // buffer's generation now, and the device: the thread-local buffers follow a hipSetDevice())
-  struct WeightKey {
-    int64_t n_pts = -1, g_lo = 0;
-    double w0 = 0, step = 0, n_sigma = 0;
-    bool valid = false;
-    unsigned gen = 0;
-    int dev = -1;
-    std::vector<double> bands;
-  };
-  static thread_local WeightKey s_key;
-  const size_t nb = (size_t)n_bands;
-  int cur_dev = 0;
-  HIPCHK(hipGetDevice(&cur_dev));
-  if (s_key.dev != cur_dev) { // buffers of another device: start over on this one
-    d_out.release();
-    d_weights.release();
-    s_key.valid = false;
-    s_key.dev = cur_dev;
-  }
-  int rc = d_out.ensure(sizeof(double) * nb * n_rays);
+  bool fresh = false;
+  int rc = lowres_prepare(n_rays, n_pts, g_lo, w0, step, centers_nm, widths_nm, n_bands, n_sigma, out_units, /*fused=*/false, st, &fresh);
   if (rc) return rc;
-  rc = d_weights.ensure(lowres_scratch_bytes((int)n_pts, n_bands, n_rays));
-  if (rc) return rc;
-  const bool same = s_key.valid && s_key.gen == d_weights.gen && s_key.n_pts == n_pts && s_key.g_lo == g_lo && s_key.w0 == w0 && s_key.step == step &&
-                    s_key.n_sigma == n_sigma && s_key.bands.size() == 2 * nb &&
-                    std::memcmp(s_key.bands.data(), centers_nm, sizeof(double) * nb) == 0 &&
-                    std::memcmp(s_key.bands.data() + nb, widths_nm, sizeof(double) * nb) == 0;
-  if (!same) {
-    s_key.valid = false; // (until the launch below has been issued)
-    rc = s_bands.prepare(sizeof(double) * 2 * nb);
-    if (rc) return rc;
-    std::memcpy(s_bands.host<double>(), centers_nm, sizeof(double) * nb);
-    std::memcpy(s_bands.host<double>() + nb, widths_nm, sizeof(double) * nb);
-    rc = s_bands.push(sizeof(double) * 2 * nb, st);
-    if (rc) return rc;
-  }
-  LAUNCHCHK(launch_lowres(rad, (int)n_pts, (int)g_lo, n_rays, w0, step, s_bands.d.as<double>(), s_bands.d.as<double>() + nb,
-                          n_bands, n_sigma, out_units, d_out.as<double>(), d_weights.p, st, !same));
-  if (!same) {
-    s_key.n_pts = n_pts; s_key.g_lo = g_lo; s_key.w0 = w0; s_key.step = step; s_key.n_sigma = n_sigma;
-    s_key.bands.assign(centers_nm, centers_nm + nb);
-    s_key.bands.insert(s_key.bands.end(), widths_nm, widths_nm + nb);
-    s_key.gen = d_weights.gen;
-    s_key.valid = true; // (this call synchronises its stream below: the table is complete before any later call)
-  }
-  HIPCHK(hipMemcpyAsync(out_host, d_out.p, sizeof(double) * nb * n_rays, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  return SR_OK;
+  LowresState &L = t_lowres;
+  LAUNCHCHK(launch_lowres(rad, (int)n_pts, (int)g_lo, n_rays, w0, step, nullptr, nullptr, n_bands, n_sigma, out_units,
+                          L.d_out.as<double>(), L.d_weights.p, st, /*weights=*/false));
+  return lowres_land(n_rays, n_bands, out_host, st);
 }
 
 // ------------------------------------------------------------------------

@@ -2937,23 +2937,31 @@ __global__ void sr_los_columns_kernel(const double *__restrict__ nd, const doubl
 // sample points.  (A profile that is sum_p mask_p x_p on the altitude levels, interpolated linearly to the sample
 // points, is the same sum of the interpolated masks: spect_main_module.py LinearProfile_1D.profile.)  Gases without
 // parameters keep their row.
+// The parameter vector travels as a kernel argument (up to kVmrParArg values: no staging copy in front of a retrieval
+// iteration's first kernel); longer ones in blocks of kVmrParArg, each block adding to the row the first one started.
+struct ParVec { double x[kVmrParArg]; };
 __global__ void sr_los_vmr_from_params_kernel(double *__restrict__ prof, int n_gas, int n_par, int n_pt,
-                                              const int *__restrict__ par_gas, const double *__restrict__ x) {
+                                              const int *__restrict__ par_gas, ParVec xv, int p0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
   if (i >= n_pt) return;
   bool any = false;
-  double v = 0.0;
-  for (int p = 0; p < n_par; ++p)
+  for (int p = 0; p < p0; ++p) any = any || par_gas[p] == g; // (an earlier block started the row)
+  double v = any ? prof[(size_t)g * n_pt + i] : 0.0;
+  for (int p = p0; p < min(n_par, p0 + kVmrParArg); ++p)
     if (par_gas[p] == g) {
-      v = v + x[p] * prof[(size_t)(n_gas + p) * n_pt + i];
+      v = v + xv.x[p - p0] * prof[(size_t)(n_gas + p) * n_pt + i];
       any = true;
     }
   if (any) prof[(size_t)g * n_pt + i] = v;
 }
-int launch_los_vmr_from_params(double *prof, int n_gas, int n_par, int n_pt, const int *par_gas, const double *x, hipStream_t st) {
+int launch_los_vmr_from_params(double *prof, int n_gas, int n_par, int n_pt, const int *par_gas, const double *x_host, hipStream_t st) {
   if (n_pt <= 0 || n_gas <= 0 || n_par <= 0) return 0;
-  hipLaunchKernelGGL(sr_los_vmr_from_params_kernel, dim3((n_pt + 255) / 256, n_gas), dim3(256), 0, st, prof, n_gas, n_par, n_pt,
-                     par_gas, x);
+  for (int p0 = 0; p0 < n_par; p0 += kVmrParArg) {
+    ParVec xv;
+    for (int p = 0; p < kVmrParArg; ++p) xv.x[p] = p0 + p < n_par ? x_host[p0 + p] : 0.0;
+    hipLaunchKernelGGL(sr_los_vmr_from_params_kernel, dim3((n_pt + 255) / 256, n_gas), dim3(256), 0, st, prof, n_gas, n_par, n_pt,
+                       par_gas, xv, p0);
+  }
   return (int)hipGetLastError();
 }
 
@@ -3827,6 +3835,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SR_FOLD_WAV
 // and repeats it per block of four, segment by segment; here a shell's coefficients are loaded once for its two
 // segments and every parameter (up to kFoldDensePar) is carried along in ONE sweep: sr_limb_fold_sens_lds_kernel below.
 // ------------------------------------------------------------------------
+// the instrument step's device scratch (launch_lowres): the bands' weight table and point ranges, then partial sums
+struct LowresScratch {
+  double *W;   // [n_bands][n_pts]
+  int *range;  // [n_bands][2]
+  double *Wt;  // [band tiles][n_pts][16]: the same weights, band-minor in tiles of 16 (zero columns beyond n_bands)
+  double *part;
+};
+static LowresScratch lowres_layout(void *scratch, int n_pts, int n_bands) {
+  LowresScratch L;
+  L.W = static_cast<double *>(scratch);
+  L.range = reinterpret_cast<int *>(L.W + (size_t)n_bands * n_pts); // (before the partial sums: their size follows n_rays)
+  L.Wt = reinterpret_cast<double *>(L.range + 2 * (size_t)n_bands + 2);
+  L.part = L.Wt + (size_t)((n_bands + 15) / 16) * 16 * n_pts;
+  return L;
+}
 struct __attribute__((aligned(16))) FoldDense { // one ray in one shell
   int layer, has, pad0, pad1;                // has: as FoldRec
   double u_f[4], u_n[4];
@@ -3915,12 +3938,32 @@ __device__ inline Atten attenuation_sc(double tau) {
 constexpr int kSensChunk = 64;
 constexpr int kSensRecD = 26; // doubles per FoldDense
 static_assert(sizeof(FoldDense) == kSensRecD * 8, "FoldDense in doubles");
-template <int NG>
+// BANDS (round 6): the instrument bands in the epilogue.  A retrieval iteration wants the band integrals of the block's
+// eight or nine spectra (radiance + derivatives), not the spectra: S[q][b] = sum_j val_q(j) W_b(j) over the block's 256
+// points is a [9 x 256] x [256 x n_bands] product -- a wave's values go through LDS and it multiplies its own 64 points
+// with v_mfma_f64_16x16x4 (A = the values, rows padded to 16; B = a 16-band tile of the band-minor weight table) and
+// stores ONE partial sum per (spectrum, band) and wave -- the 69 MB of spectra a configs[4] iteration wrote and
+// sr_lowres_apply_kernel read again (57 us of a 350 us iteration) never exist.  (First version: per band a product per
+// value and a lane reduction, 26 ds_bpermute each; configs[4]'s 14 bands all cover its whole grid: +27 us on the kernel's
+// 260.)  part: [n_rays (1 + n_par)][64-point slots][band tiles][16], rows as sr_retrieval_forward_dev orders them;
+// sr_lowres_sum_blocks_kernel adds a band's slots.
+struct FoldBands {
+  const double *Wt;  // [band tiles][n_pts][16]
+  const int *range;  // [n_bands][2]
+  double *part;
+  int n_bands;
+};
+constexpr int kBandVals = kFoldDensePar + 1;  // spectra per ray: the radiance and its derivatives
+constexpr int kBandRow = 68;                  // doubles per row of a wave's tile of values (64 + padding: rows 8 banks apart)
+template <int NG, bool BANDS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG <= 2 ? 4 : 3, NG <= 2 ? 4 : 3))) void sr_limb_fold_sens_lds_kernel(
     const double *__restrict__ abs_c, const double *__restrict__ emi_c, int n_pts, int n_layers,
     const FoldDense *__restrict__ rec, // [n_rays][n_visits]
-    int n_par, ParGas pg, LimbOpts o, int n_visits, int n_rays, double *__restrict__ rad, double *__restrict__ jac_par) {
-  __shared__ double lrec[kSensChunk * kSensRecD + kFoldDensePar]; // + a row of zeros
+    int n_par, ParGas pg, LimbOpts o, int n_visits, int n_rays, double *__restrict__ rad, double *__restrict__ jac_par,
+    FoldBands bd) {
+  // the ray's records + a row of zeros; BANDS: + every wave's tile of values
+  constexpr int kRecDoubles = kSensChunk * kSensRecD + kFoldDensePar;
+  __shared__ double lrec[kRecDoubles + (BANDS ? 4 * kBandVals * kBandRow : 0)];
   int pb, ray; // all rays of a point block on one XCD, one after the other
   if (!limb_block((n_pts + 255) / 256, n_rays, pb, ray)) return; // (block-uniform)
   const int j0 = pb * 256 + threadIdx.x;
@@ -4049,6 +4092,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG <= 2 ? 4
       }
     }
   }
+  if constexpr (BANDS) {
+    // Wave by wave, no block barrier: a wave's values go through ITS rows of the tile, its 9 x 16 sums to its own slot of
+    // `part`.  configs[4] (variant builds that leave parts out): main loop 259 us, + 23 here -- the sixteen MFMAs 9 (their
+    // flops at the fp64 rate: rows and bands padded to 16), the stores 5, LDS 3; the weight loads nothing.
+    constexpr int kV = kBandVals;
+    const int c_lo = pb * 256, n_slots = 4 * ((n_pts + 255) / 256);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lo = lane & 15, kq = lane >> 4;
+    const int n_tiles = (bd.n_bands + 15) >> 4;
+    double *vt = lrec + kRecDoubles + wave * (kV * kBandRow);
+    vt[lane] = live ? fma(If, Tn, cs) : 0.0;
+#pragma unroll
+    for (int p = 0; p < kFoldDensePar; ++p)
+      vt[(1 + p) * kBandRow + lane] = live && p < n_par ? fma(Tn, fma(-If, Dn[p], dIf[p]), dcs[p]) : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // A[row = lane & 15][k = lane >> 4], B[k][col = lane & 15], D[row = (lane >> 4) + 4 r][col]
+    const double *va = vt + min(lo, kV - 1) * kBandRow + kq;
+    double A[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) A[ks] = lo < kV ? va[4 * ks] : 0.0;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+      const double *wt = bd.Wt + (size_t)tile * n_pts * 16 + lo;
+      double Bv[16]; // a tile's sixteen B operands requested together
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) Bv[ks] = wt[(size_t)min(c_lo + 64 * wave + 4 * ks + kq, n_pts - 1) * 16]; // (beyond the grid A is zero)
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks], Bv[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = kq + 4 * r;
+        if (q <= n_par) {
+          const size_t row = q == 0 ? (size_t)ray : (size_t)n_rays + (size_t)ray * n_par + (q - 1);
+          bd.part[((row * n_slots + 4 * pb + wave) * n_tiles + tile) * 16 + lo] = acc[r];
+        }
+      }
+    }
+    return;
+  }
   if (!live) return;
 #pragma unroll
   for (int p = 0; p < kFoldDensePar; ++p)
@@ -4139,14 +4222,26 @@ size_t fold_dense_bytes(int n_rec) { return sizeof(FoldDense) * (size_t)n_rec; }
 
 int launch_fold_dense(const int *plan, const double *col, const int *par_gas_host, int n_par, int n_seg, int n_rec, FoldDense *rec,
                       const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, int n_visits,
-                      const LimbOpts &o, double *rad, double *jac_par, hipStream_t st) {
+                      const LimbOpts &o, double *rad, double *jac_par, hipStream_t st, const void *lowres_scratch, int n_bands) {
   if (n_rec <= 0 || n_pts <= 0 || n_rays <= 0 || n_par <= 0 || n_par > kFoldDensePar) return 0;
   hipLaunchKernelGGL(sr_fold_dense_pack_kernel, dim3((n_rec + 63) / 64), dim3(64), 0, st, plan, col, o.n_gas, n_par, n_seg, n_rec, rec);
   ParGas pg;
   for (int p = 0; p < kFoldDensePar; ++p) pg.g[p] = p < n_par ? par_gas_host[p] : 0;
   const dim3 grid(limb_grid((n_pts + 255) / 256, n_rays));
-#define SR_FD(NG) hipLaunchKernelGGL(sr_limb_fold_sens_lds_kernel<NG>, grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, rec, n_par, pg, \
-                                     o, n_visits, n_rays, rad, jac_par)
+  FoldBands bd{nullptr, nullptr, nullptr, 0};
+  if (lowres_scratch) {
+    const LowresScratch L = lowres_layout(const_cast<void *>(lowres_scratch), n_pts, n_bands);
+    bd = FoldBands{L.Wt, L.range, L.part, n_bands};
+  }
+#define SR_FD(NG)                                                                                                                  \
+  do {                                                                                                                             \
+    if (lowres_scratch)                                                                                                            \
+      hipLaunchKernelGGL((sr_limb_fold_sens_lds_kernel<NG, true>), grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, rec, n_par, \
+                         pg, o, n_visits, n_rays, rad, jac_par, bd);                                                               \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((sr_limb_fold_sens_lds_kernel<NG, false>), grid, dim3(256), 0, st, abs_c, emi_c, n_pts, n_layers, rec, n_par, \
+                         pg, o, n_visits, n_rays, rad, jac_par, bd);                                                               \
+  } while (0)
   switch (o.n_gas) { case 1: SR_FD(1); break; case 2: SR_FD(2); break; case 3: SR_FD(3); break; default: SR_FD(4); break; }
 #undef SR_FD
   return (int)hipGetLastError();
@@ -4687,9 +4782,15 @@ __global__ void sr_curgod_kernel(int which, const double *__restrict__ nd, const
 // chunks' partial sums added in chunk order by sr_lowres_sum_kernel.
 __global__ __launch_bounds__(256) void sr_lowres_weights_kernel(int n_pts, int g_lo, double w0, double gstep,
                                                                 const double *__restrict__ cen, const double *__restrict__ wid,
-                                                                double n_sigma, double *__restrict__ W, // [n_bands][n_pts]
-                                                                int *__restrict__ range) {               // [n_bands][2]: j_lo, j_hi (exclusive)
+                                                                double n_sigma, int n_bands, double *__restrict__ W, // [n_bands][n_pts]
+                                                                int *__restrict__ range,  // [n_bands][2]: j_lo, j_hi (exclusive)
+                                                                double *__restrict__ Wt) { // [gridDim.y / 16][n_pts][16]
   const int b = blockIdx.y;
+  if (b >= n_bands) { // the zero columns that fill the last tile of Wt
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_pts) Wt[((size_t)(b >> 4) * n_pts + j) * 16 + (b & 15)] = 0.0;
+    return;
+  }
   const double f = cen[b], w = wid[b];
   const double lo = f - n_sigma * w, hi = f + n_sigma * w;
   const double fac = 1 / (w * sqrt(2. * kPi));
@@ -4721,6 +4822,7 @@ __global__ __launch_bounds__(256) void sr_lowres_weights_kernel(int n_pts, int g
     wgt = u * ((xr - xl) / 2.0);
   }
   W[(size_t)b * n_pts + j] = wgt;
+  Wt[((size_t)(b >> 4) * n_pts + j) * 16 + (b & 15)] = wgt;
 }
 
 constexpr int kLowresBands = 16;   // bands per block of the apply kernel
@@ -4785,10 +4887,56 @@ __global__ void sr_lowres_sum_kernel(const double *__restrict__ part, int n_rays
   out[t] = v;
 }
 
+// ... of the partial sums sr_limb_fold_sens_lds_kernel<., true> leaves per 64-point slot (a wave's points): a block per
+// (spectrum, band tile), thread = (band of the tile, one of 16 interleaved slices of the slots); a band's slots inside its
+// window only; slice sums added in slice order: deterministic.
+__global__ __launch_bounds__(256) void sr_lowres_sum_blocks_kernel(const double *__restrict__ part, const int *__restrict__ range,
+                                                                   int n_blocks, int n_bands, int out_units, double *__restrict__ out) {
+  __shared__ double red[16][16];
+  const int row = blockIdx.x, tile = blockIdx.y, n_tiles = gridDim.y;
+  const int col = threadIdx.x & 15, slice = threadIdx.x >> 4, b = 16 * tile + col;
+  double v = 0.0;
+  if (b < n_bands) {
+    const int r0 = range[2 * b], r1 = range[2 * b + 1];
+    if (r1 > r0)
+      for (int c = (r0 >> 6) + slice; c <= (r1 - 1) >> 6; c += 16) v += part[(((size_t)row * n_blocks + c) * n_tiles + tile) * 16 + col];
+  }
+  red[slice][col] = v;
+  __syncthreads();
+  if (slice != 0 || b >= n_bands) return;
+  v = 0.0;
+#pragma unroll
+  for (int sl = 0; sl < 16; ++sl) v += red[sl][col];
+  v = v * 1.e-3;                    // as sr_lowres_sum_kernel
+  if (out_units == 1) v = v * 1.e3;
+  if (out_units == 2) v = v * 1.e5;
+  out[(size_t)row * n_bands + b] = v;
+}
+
 static int lowres_chunks(int n_pts) { return (n_pts + kLowresChunk - 1) / kLowresChunk; }
-size_t lowres_scratch_bytes(int n_pts, int n_bands, int n_rays) {
-  return sizeof(double) * (size_t)n_bands * n_pts + sizeof(double) * (size_t)n_rays * lowres_chunks(n_pts) * n_bands +
+// fused: the partial sums are per wave of the recursion (launch_fold_dense with the scratch)
+size_t lowres_scratch_bytes(int n_pts, int n_bands, int n_rays, bool fused) {
+  const size_t tiles16 = (size_t)((n_bands + 15) / 16) * 16;
+  const size_t n_part = fused ? 4 * (size_t)((n_pts + 255) / 256) * tiles16 : (size_t)lowres_chunks(n_pts) * n_bands;
+  return sizeof(double) * ((size_t)n_bands + tiles16) * n_pts + sizeof(double) * (size_t)n_rays * n_part +
          sizeof(int) * (2 * (size_t)n_bands + 2);
+}
+
+int launch_lowres_weights(int n_pts, int g_lo, double w0, double gstep, const double *cen, const double *wid, int n_bands,
+                          double n_sigma, void *scratch, hipStream_t st) {
+  if (n_bands <= 0) return 0;
+  const LowresScratch L = lowres_layout(scratch, n_pts, n_bands);
+  hipLaunchKernelGGL(sr_lowres_weights_kernel, dim3((n_pts + 255) / 256, (n_bands + 15) / 16 * 16), dim3(256), 0, st, n_pts, g_lo, w0,
+                     gstep, cen, wid, n_sigma, n_bands, L.W, L.range, L.Wt);
+  return (int)hipGetLastError();
+}
+
+int launch_lowres_sum_blocks(int n_pts, int n_rows, int n_bands, int out_units, double *out, void *scratch, hipStream_t st) {
+  if (n_bands <= 0 || n_rows <= 0) return 0;
+  const LowresScratch L = lowres_layout(scratch, n_pts, n_bands);
+  hipLaunchKernelGGL(sr_lowres_sum_blocks_kernel, dim3(n_rows, (n_bands + 15) / 16), dim3(256), 0, st, L.part, L.range,
+                     4 * ((n_pts + 255) / 256), n_bands, out_units, out);
+  return (int)hipGetLastError();
 }
 
 int launch_lowres(const double *rad, int n_pts, int g_lo, int n_rays, double w0, double gstep, const double *cen,
@@ -4796,15 +4944,11 @@ int launch_lowres(const double *rad, int n_pts, int g_lo, int n_rays, double w0,
                   bool weights) {
   if (n_bands <= 0 || n_rays <= 0) return 0;
   const int n_chunks = lowres_chunks(n_pts);
-  double *W = static_cast<double *>(scratch);
-  int *range = reinterpret_cast<int *>(W + (size_t)n_bands * n_pts); // (before the partial sums: their size follows n_rays)
-  double *part = reinterpret_cast<double *>(range + 2 * (size_t)n_bands + 2);
-  if (weights)
-    hipLaunchKernelGGL(sr_lowres_weights_kernel, dim3((n_pts + 255) / 256, n_bands), dim3(256), 0, st, n_pts, g_lo, w0, gstep, cen,
-                       wid, n_sigma, W, range);
+  const LowresScratch L = lowres_layout(scratch, n_pts, n_bands);
+  if (weights) launch_lowres_weights(n_pts, g_lo, w0, gstep, cen, wid, n_bands, n_sigma, scratch, st);
   hipLaunchKernelGGL(sr_lowres_apply_kernel, dim3(n_rays, n_chunks, (n_bands + kLowresBands - 1) / kLowresBands), dim3(256), 0, st,
-                     rad, n_pts, W, range, n_bands, n_chunks, part);
-  hipLaunchKernelGGL(sr_lowres_sum_kernel, dim3((n_rays * n_bands + 255) / 256), dim3(256), 0, st, part, n_rays, n_chunks, n_bands,
+                     rad, n_pts, L.W, L.range, n_bands, n_chunks, L.part);
+  hipLaunchKernelGGL(sr_lowres_sum_kernel, dim3((n_rays * n_bands + 255) / 256), dim3(256), 0, st, L.part, n_rays, n_chunks, n_bands,
                      out_units, out);
   return (int)hipGetLastError();
 }

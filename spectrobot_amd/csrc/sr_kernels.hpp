@@ -205,7 +205,9 @@ struct LimbOpts {
   double t_init, w0, gstep;
 };
 // prof[g] = sum_p x_p prof[n_gas + p] over the parameters of gas g (gases without parameters untouched)
-int launch_los_vmr_from_params(double *prof, int n_gas, int n_par, int n_pt, const int *par_gas, const double *x, hipStream_t st);
+// x_host: HOST [n_par] (passed as kernel arguments, kVmrParArg per launch)
+constexpr int kVmrParArg = 32;
+int launch_los_vmr_from_params(double *prof, int n_gas, int n_par, int n_pt, const int *par_gas, const double *x_host, hipStream_t st);
 int launch_los_columns(const double *nd, const double *x, const double *prof, const double *scale, const int *pt_off,
                        int n_seg, int n_pt, int n_prof, double *col, hipStream_t st);
 int launch_limb(const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, const int *seg_off,
@@ -259,7 +261,11 @@ struct FoldDense;
 size_t fold_dense_bytes(int n_rec);
 int launch_fold_dense(const int *plan, const double *col, const int *par_gas_host, int n_par, int n_seg, int n_rec, FoldDense *rec,
                       const double *abs_c, const double *emi_c, int n_pts, int n_layers, int n_rays, int n_visits,
-                      const LimbOpts &o, double *rad, double *jac_par, hipStream_t st);
+                      const LimbOpts &o, double *rad, double *jac_par, hipStream_t st, const void *lowres_scratch = nullptr,
+                      int n_bands = 0);
+// (lowres_scratch: the instrument step's scratch with its weight table in place (launch_lowres_weights) -- the kernel then
+// leaves the band integrals' partial sums per wave (64 points) there instead of the spectra in rad / jac_par:
+// launch_lowres_sum_blocks finishes them)
 // The radiances of a ray batch, folded (sr_limb_fold_fwd_kernel; the plan and records of launch_fold_dense with no parameters)
 // pack = false: `rec` was packed by an earlier call with the same plan and columns (a device-resident LOS, sr_los_create)
 int launch_fold_fwd(const int *plan, const double *col, int n_seg, int n_rec, FoldDense *rec, const double *abs_c,
@@ -284,7 +290,10 @@ int launch_sum_lines(double *spe, long n_spe, const double *rows, const int *ini
 // scratch: lowres_scratch_bytes(...) of device memory (the bands' weight table and point ranges, then the chunks' partial
 // sums).  weights = false: the table and ranges at the head of `scratch` are those of an earlier call with the same
 // grid window and bands (a retrieval's instrument step: every iteration the same bands)
-size_t lowres_scratch_bytes(int n_pts, int n_bands, int n_rays);
+size_t lowres_scratch_bytes(int n_pts, int n_bands, int n_rays, bool fused = false);
+int launch_lowres_weights(int n_pts, int g_lo, double w0, double gstep, const double *cen, const double *wid, int n_bands,
+                          double n_sigma, void *scratch, hipStream_t st);
+int launch_lowres_sum_blocks(int n_pts, int n_rows, int n_bands, int out_units, double *out, void *scratch, hipStream_t st);
 int launch_lowres(const double *rad, int n_pts, int g_lo, int n_rays, double w0, double gstep, const double *cen,
                   const double *wid, int n_bands, double n_sigma, int out_units, double *out, void *scratch, hipStream_t st,
                   bool weights = true);

@@ -442,7 +442,8 @@ class LevelFactored(object):
 
 
 def set_timing(on):
-    """0: no timing events in the coefficient op (host-bound loops: small shards); last_kernel_ms is then unavailable."""
+    """0: no timing events in the coefficient op (host-bound loops: small shards); last_kernel_ms is then unavailable.
+    2: also around the recursion of the retrieval's forward model (LimbLOS.last_forward_kernel_ms)."""
     check(lib.sr_set_timing(int(on)), "sr_set_timing")
 
 
@@ -574,6 +575,14 @@ class LimbLOS(object):
             check(lib.sr_los_create_par(C.byref(d), int(n_layers), pg_a.size, pg, pw, C.byref(h)), "sr_los_create_par")
             ent = _ParHandle(h, keep=(par_gas, par_w))
         return self._keep(key, ent).h
+
+    def last_forward_kernel_ms(self, n_layers, par_gas, par_w, grid=None):
+        """HIP-event time [ms] of the recursion (record packing + the one-sweep kernel with the bands in its epilogue) of
+        the most recent retrieval_forward / _step / _loop on this batch with these parameters, made under set_timing(2)
+        (sr_los_last_kernel_ms)."""
+        ms = C.c_float(0.0)
+        check(lib.sr_los_last_kernel_ms(self.handle_par(n_layers, par_gas, par_w, grid), C.byref(ms)), "sr_los_last_kernel_ms")
+        return float(ms.value)
 
     def refresh_columns(self):
         """Integrate the Curtis-Godson columns of every resident form of the batch again, on the device, from the staged
@@ -818,6 +827,52 @@ def retrieval_step(coeffs, los, par_gas, par_w, x, grid, centers_nm, widths_nm, 
     return out, chi.value, n_used.value, dx, s_x, avk, buf
 
 
+def retrieval_loop(coeffs, los, par_gas, par_w, x0, grid, centers_nm, widths_nm, oe, positive, n_dof_par, chi_threshold=0.01,
+                   max_it=10, out_units="Wm2", n_sigma=5.0, fov=None, buf=None):
+    """The whole loop of a retrieval whose coefficient spectra stay fixed, in one library call (sr_retrieval_loop_dev):
+    retrieval_step per iteration, reduced chi square, the stopping rule and the update with the positivity rule of
+    spect_main_module.inversion_fast_limb.  positive [n_par] bool: constrain_positive of every parameter; n_dof_par: the
+    parameters in use.  Returns (out of the last iteration [n_pix, 1 + n_par, n_bands], chi history [n_it], x history
+    [n_updates + 1, n_par], stop '' | 'converged' | 'raised', S_x, AVK (None when no update was applied), buf)."""
+    a, e = _gas_stack(coeffs)
+    n_gas, n_layers, n_pts = a.shape
+    w0, step, n = grid_params(grid)
+    if n_pts != n:
+        raise ValueError("retrieval_loop needs the whole grid (a spectral shard's band integrals are partial)")
+    x_a, xp = _d(x0)
+    n_par = x_a.size
+    centers_nm, cp = _d(centers_nm)
+    widths_nm, wp = _d(widths_nm)
+    h = los.handle_par(n_layers, par_gas, par_w, grid)
+    if np.asarray(par_gas).size != n_par or oe.n_par != n_par or los.n_rays % 3:
+        raise ValueError("x, the parameters and the problem must agree; three rays per pixel")
+    n_pix = los.n_rays // 3
+    fp = None
+    if fov is not None:
+        fov, fp = _d(fov)
+        if fov.shape != (n_pix, 7):
+            raise ValueError("fov must be [n_rays / 3, 7]")
+    if buf is None or buf.shape != (los.n_rays * (1 + n_par), n_pts):
+        buf = torch.empty((los.n_rays * (1 + n_par), n_pts), dtype=torch.float64, device="cuda")
+    pos = np.ascontiguousarray(np.asarray(positive, dtype=bool).reshape(-1), dtype=np.uint8)
+    if pos.size != n_par:
+        raise ValueError("positive must be [n_par]")
+    max_it = int(max_it)
+    lp = _lib.LoopDesc(max_it, float(chi_threshold), pos.ctypes.data_as(C.POINTER(C.c_uint8)), int(n_dof_par))
+    out = np.zeros((n_pix, 1 + n_par, centers_nm.size))
+    chi_hist, x_hist = np.zeros(max(max_it, 1)), np.zeros((max_it + 1, n_par))
+    n_it, stop = C.c_int32(0), C.c_int32(0)
+    s_x, avk = np.zeros((n_par, n_par)), np.zeros((n_par, n_par))
+    check(lib.sr_retrieval_loop_dev(a.data_ptr(), e.data_ptr(), n_layers, n_pts, h, 0, xp, w0, step, cp, wp, centers_nm.size,
+                                    float(n_sigma), _UNITS[out_units], fp, buf.data_ptr(), out.ctypes.data_as(dp), C.byref(oe.desc),
+                                    C.byref(lp), chi_hist.ctypes.data_as(dp), x_hist.ctypes.data_as(dp), C.byref(n_it),
+                                    C.byref(stop), s_x.ctypes.data_as(dp), avk.ctypes.data_as(dp), _stream_ptr()),
+          "sr_retrieval_loop_dev")
+    n_upd = n_it.value if stop.value == 0 else n_it.value - 1
+    return (out, chi_hist[:n_it.value].copy(), x_hist[:n_upd + 1].copy(), ["", "converged", "raised"][stop.value],
+            s_x if n_upd > 0 else None, avk if n_upd > 0 else None, buf)
+
+
 def limb_rays_layer_jacobian(coeffs, dcoeffs, los, grid=None, g_lo=0):
     """d rad / d (one scalar per layer) [n_rays, n_layers, n_pts]; dcoeffs like coeffs: d(abs, emi of layer k) /
     d(parameter of layer k) per gas (sr_limb_rays_jac_layer_dev)."""
@@ -1047,6 +1102,12 @@ def set_overlap(on):
     """1 (default): the zones kernel runs beside the far-field kernel on an internal stream;
     0: kernels one after the other (per-kernel times in last_kernel_ms)."""
     check(lib.sr_set_overlap(int(on)), "sr_set_overlap")
+
+
+def set_band_fusion(on):
+    """1 (default): a retrieval iteration's recursion kernel integrates the instrument bands itself; 0: spectra, then the
+    instrument step's own kernels (sr_set_band_fusion; the check and the A/B partner)."""
+    check(lib.sr_set_band_fusion(int(bool(on))), "sr_set_band_fusion")
 
 
 def set_jac_layer_mode(forward):

@@ -24,6 +24,8 @@ from . import synthetic as syn
 
 STEP_IN_ONE_CALL = True   # inversion_fast_limb: forward model + chi square + the optimal-estimation algebra of an iteration
                           # in one library call (engine.retrieval_step); False: the algebra in numpy (the check)
+LOOP_IN_ONE_CALL = True   # ... and the loop around it too (engine.retrieval_loop) when the coefficient spectra stay fixed; False: the
+                          # loop below, an engine.retrieval_step per iteration (the check)
 ONE_CALL = True   # simulate(arrays=True): the iteration's forward model in one library call (engine.retrieval_forward);
                   # False: columns + Jacobians, instrument step and FOV as separate calls (the A/B partner and the check)
 
@@ -369,6 +371,35 @@ def inversion_fast_limb(scene, bayes_set, pixels, chi_threshold=0.01, max_it=10,
         oe = engine.OeProblem(obs_all, noi_all, masktot, Sa_inv, bayes_set.apriori_vector(), lambda_LM)
         assert obs_all.size == n_pb
         alts_all = [a for pix in pixels for a in pix.los_alts()]
+    if one_step and LOOP_IN_ONE_CALL and not refresh and max_it > 0:
+        # The loop in ONE library call (sr_retrieval_loop_dev): iterations, stopping rule and the updates with their
+        # positivity rule run in the library; the objects' bookkeeping is replayed here from the vectors it returns.
+        coeffs = scene.coefficient_stack(refresh=False)
+        los_b, par_gas, par_w = _one_call_batch(scene, pixels, bayes_set, alts_all, with_fov)
+        params = list(bayes_set.params())
+        for par in params:
+            par.set_used()
+        both, hist, xh, why, S_x, AVK, scene._fwd_buf = engine.retrieval_loop(
+            coeffs, los_b, par_gas, par_w, bayes_set.param_vector(), scene.grid, scene.bands_nm, scene.widths_nm, oe,
+            [bool(par.constrain_positive) for par in params], bayes_set.n_used_par(), chi_threshold=chi_threshold, max_it=max_it,
+            out_units=scene.out_units, fov=scene._fov_fac if with_fov else None, buf=getattr(scene, "_fwd_buf", None))
+        for k in range(1, len(xh)):                                            # update_params / update_par, :616-624
+            bayes_set.old_params.append(bayes_set.values())
+            for par, v in zip(params, xh[k]):
+                par.old_values.append(par.value)
+                par.value = v
+        if AVK is not None:
+            bayes_set.store_avk(AVK)
+            bayes_set.store_VCM(S_x)
+        bayes_set.history = [float(c) for c in hist]
+        if check_log is not None:
+            for num_it, c in enumerate(bayes_set.history):
+                check_log.write('Iteration {:2d}: chi is {:8.3f}\n'.format(num_it, c))
+        for name in bayes_set.sets.keys():                                     # :2984-2985
+            scene.gas(name).add_clim(bayes_set.sets[name].profile())
+        if why:
+            bayes_set.stop = why
+        return bayes_set.history[-1], obs, finish(both[:, 0, :], both[:, 1:, :]), bayes_set
     step_out = None
     for num_it in range(max_it):
         if one_step:

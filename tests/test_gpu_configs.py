@@ -974,12 +974,23 @@ def test_retrieval_step_in_one_call(eng):
         assert np.max(np.abs(AVK - S_ref @ (jac.T / noi_vec ** 2 @ jac))) <= 1e-8
     hist = {}
     try:
-        for on in (True, False):
-            retrieval.STEP_IN_ONE_CALL = on
-            r = retrieval.inversion_fast_limb(scene, copy.deepcopy(bs), pixels, max_it=20)
-            hist[on] = (np.array(r[3].history), np.array(r[3].param_vector()), r[3].stop)
+        # the loop in one call, an iteration per call, the algebra in numpy; then a loop that max_it ends
+        for key, (loop, on, max_it) in dict(loop=(True, True, 20), step=(False, True, 20), numpy=(False, False, 20),
+                                             loop3=(True, True, 3), step3=(False, True, 3)).items():
+            retrieval.LOOP_IN_ONE_CALL, retrieval.STEP_IN_ONE_CALL = loop, on
+            r = retrieval.inversion_fast_limb(scene, copy.deepcopy(bs), pixels, max_it=max_it)
+            b = r[3]
+            hist[key] = (np.array(b.history), np.array(b.param_vector()), b.stop, np.array(b.av_kernel), np.array(b.VCM),
+                         np.array(b.old_params, dtype=float), np.array([s.spectrum for s in r[2]]), np.array(b.jacobian),
+                         [len(p.old_values) for p in b.params()], float(r[0]))
     finally:
-        retrieval.STEP_IN_ONE_CALL = True
-    assert hist[True][2] == hist[False][2] and len(hist[True][0]) == len(hist[False][0]) >= 3
-    assert np.max(np.abs(hist[True][0] - hist[False][0]) / hist[False][0]) < 1e-9
-    assert np.max(np.abs(hist[True][1] - hist[False][1]) / np.abs(hist[False][1])) < 1e-8
+        retrieval.STEP_IN_ONE_CALL = retrieval.LOOP_IN_ONE_CALL = True
+    assert hist["step"][2] == hist["numpy"][2] and len(hist["step"][0]) == len(hist["numpy"][0]) >= 3
+    assert np.max(np.abs(hist["step"][0] - hist["numpy"][0]) / hist["numpy"][0]) < 1e-9
+    assert np.max(np.abs(hist["step"][1] - hist["numpy"][1]) / np.abs(hist["numpy"][1])) < 1e-8
+    # the loop in the library runs the same calls in the same order as the loop in Python: the same numbers
+    for a, c in (("loop", "step"), ("loop3", "step3")):
+        assert hist[a][2] == hist[c][2] and hist[a][8] == hist[c][8] and hist[a][9] == hist[c][9]
+        for q in (0, 1, 3, 4, 5, 6, 7):
+            assert hist[a][q].shape == hist[c][q].shape and np.array_equal(hist[a][q], hist[c][q]), (a, q)
+    assert hist["loop3"][2] == "max_it" and len(hist["loop3"][0]) == 3 and hist["loop3"][5].shape[0] == 3

@@ -412,13 +412,15 @@ def test_few_broad_parameters_many_shells_three_gases_asymmetric(eng, n_g):
         assert cmp(jac[:, 3, :], fd, 0) < 1e-6, opts
 
 
-@pytest.mark.parametrize("n_par,order", [(5, "photon"), (5, "observer"), (11, "photon")])
+@pytest.mark.parametrize("n_par,order", [(5, "photon"), (5, "observer"), (8, "photon"), (11, "photon"), (40, "photon")])
 def test_retrieval_forward_against_its_parts(eng, n_par, order):
     """engine.retrieval_forward (sr_retrieval_forward_dev: parameter vector -> VMRs on the device -> columns -> radiances
     + Jacobians -> instrument bands) against the same steps taken one by one from the host: the VMR of the retrieved
     gas as sum_p x_p w_p on the host, a fresh LimbLOS with it, limb_rays_jacobian, hires_to_lowres.  Observer order (the
     batch re-lists its sample points; the device sums its own rows) and more parameters than the one-sweep kernel
-    takes (the path-order forward sensitivities behind the same entry point).  Two gases, only the second retrieved.
+    takes (the path-order forward sensitivities behind the same entry point; 40: the parameter vector travels as kernel
+    arguments in two blocks).  Up to 8 parameters the one-sweep kernel integrates the bands itself (sr_set_band_fusion).
+    Two gases, only the second retrieved.
 
     PARITY UNPINNED: the reference's radiance recursion and Jacobians live in the absent
     spect_base_module; this test checks product kernels against OTHER product kernels and finite differences, not
@@ -459,6 +461,60 @@ def test_retrieval_forward_against_its_parts(eng, n_par, order):
     # the first gas (no parameters) kept its VMRs: the same call again gives the same doubles
     again, _ = eng.retrieval_forward(coeffs, los, par_gas, W, x, grid, bands, widths)
     assert np.array_equal(again, out)
+
+
+@pytest.mark.parametrize("n,n_par,n_g", [(3000, 7, 2), (256, 3, 1), (70001, 8, 2), (5000, 1, 3)])
+def test_band_fusion_equals_the_instrument_step(eng, n, n_par, n_g):
+    """sr_retrieval_forward_dev with the instrument bands integrated in the recursion kernel's epilogue (default) against
+    spectra + sr_hires_to_lowres_shard_dev's kernels (sr_set_band_fusion(0)): the same band integrals up to the order of
+    the sums.  Grids that do not fill their last 256-point block, one block only; a band outside the grid (exactly zero
+    both ways), a band over the whole grid, narrow bands at both ends, overlapping bands; with and without the
+    field-of-view integral; the fused call leaves `buf` untouched.  PARITY UNPINNED (product kernels against product
+    kernels: see test_retrieval_forward_against_its_parts)."""
+    import torch
+    from spectrobot_amd import synthetic as syn
+    rng = np.random.default_rng(n + n_par)
+    nl = 22
+    atm = _atm(nl)
+    z = atm["z"]
+    grid = syn.make_grid(2975.0, 5e-4, n)
+    t = lambda v: torch.tensor(np.ascontiguousarray(v), device="cuda")
+    vm = [np.full(nl, 1.2e-2), np.linspace(2e-3, 5e-4, nl), np.full(nl, 3e-4)][:n_g]
+    a = [rng.uniform(0, 4e-18, (nl, n)) * (10.0 ** (g - 1)) for g in range(n_g)]
+    e = [a[g] * rng.uniform(1e-8, 1e-7, (nl, n)) for g in range(n_g)]
+    coeffs = [(t(a[g]), t(e[g])) for g in range(n_g)]
+    L = syn.limb_los(z, atm["nd"] * 1e-6, vm, [z[0] + 5.0, z[2] + 3.0, z[5] + 1.0, z[9] + 2.0, z[12] + 1.0, z[15] + 4.0])
+    zz = np.append(z, z[-1] + (z[-1] - z[-2]))
+    nodes = np.linspace(z[0], z[-1], max(n_par, 2))[:n_par]
+    W = np.array([np.interp(L["alt"], zz, np.clip(1.0 - np.abs(zz - c) / max(nodes[-1] - nodes[0], 50.0) * max(n_par - 1, 1), 0.0, None) + 0.05)
+                  for c in nodes])
+    par_gas = (np.arange(n_par) % n_g).astype(np.int32)
+    x = rng.uniform(0.5, 1.5, n_par) * np.array([vm[g][0] for g in par_gas])
+    lam_lo, lam_hi = 1e7 / grid[-1], 1e7 / grid[0]
+    span = lam_hi - lam_lo
+    bands = np.array([lam_lo - 50 * span - 1.0, 0.5 * (lam_lo + lam_hi), lam_lo + 0.01 * span, lam_hi - 0.01 * span,
+                      lam_lo + 0.4 * span, lam_lo + 0.45 * span, lam_lo + 0.8 * span])
+    widths = np.array([0.05 * span, 3.0 * span, 0.004 * span, 0.004 * span, 0.06 * span, 0.06 * span, 0.02 * span])
+    los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827, 1.0, 1.0][:n_g])
+    fov = np.array([[0.8, 0.8 ** 3, 2 * 1.3 ** 2, 0.0, 0.0, 0.6, 0.0], [0.5, 0.5 ** 3, 2 * 1.1 ** 2, 0.3, 0.02, 0.7, 1.0]])
+    res = {}
+    try:
+        for on in (1, 0):
+            eng.set_band_fusion(on)
+            buf = torch.full((los.n_rays * (1 + n_par), n), -7.0, dtype=torch.float64, device="cuda")
+            res[on] = (eng.retrieval_forward(coeffs, los, par_gas, W, x, grid, bands, widths, buf=buf)[0],
+                       eng.retrieval_forward(coeffs, los, par_gas, W, x, grid, bands, widths, fov=fov, buf=buf)[0])
+            assert bool((buf == -7.0).all()) == bool(on), on
+    finally:
+        eng.set_band_fusion(1)
+    for k in (0, 1):
+        f, u = res[1][k], res[0][k]
+        assert f.shape == u.shape == ((2 if k else los.n_rays), 1 + n_par, 7)
+        assert np.all(f[..., 0] == 0.0) and np.all(u[..., 0] == 0.0)          # the band outside the grid
+        scale = np.max(np.abs(u), axis=(0, 2), keepdims=True)
+        assert np.all(scale[:, :, :] > 0)
+        assert np.max(np.abs(f - u) / scale) <= 1e-12, (k, np.max(np.abs(f - u) / scale))
+        assert not np.array_equal(f, u) or n <= 256                            # (two routes, not one run twice)
 
 
 def test_ray_batch_radiances_folded_vs_path_order(eng):
