@@ -373,6 +373,18 @@ __device__ inline int xcd_remap(int b, int nb) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// ... for kernels whose work ids differ in COST along the id axis (the per-line far-field kernels: widest level first,
+// a top-level box holds ten times the candidates of a level-0 box): xcd_remap hands every XCD one contiguous eighth of
+// the ids -- the first XCD all the wide boxes -- and the others wait for it (CUs idle 29 % of the sparse passes' kernel:
+// SQ_BUSY_CU_CYCLES).  Here the ids are dealt in groups of G consecutive ones, round-robin over the XCDs: neighbours
+// still share an L2, every XCD gets every level.  Bijective on [0, nb).
+__device__ inline int xcd_remap_groups(int b, int nb, int G) {
+  const int full = nb / (8 * G) * (8 * G);
+  if (b >= full) return b;
+  const int x = b & 7, i = b >> 3;
+  return ((i / G) * 8 + x) * G + i % G;
+}
+
 // Executed-work counters (counting instantiations only): sum a per-lane count over the wave, one
 // atomic per wave and counter.
 __device__ inline void count_add(unsigned long long *cnt, int which, unsigned per_lane, int lane) {
@@ -904,11 +916,11 @@ template <int N, int M>
 constexpr int lane_reduce_left() { // values per lane after lane_reduce<N, M>
   if constexpr (M >= 1) return lane_reduce_left<N / 2 + (N & 1), M / 2>(); else return N;
 }
-template <bool COUNT>
+// NW waves per workgroup, each with a box of its own (wid: the wave's work id, < n_boxes_total x layer groups)
+template <bool COUNT, int NW>
 __device__ __forceinline__ void farfield_rows_body(const FastRec *__restrict__ fast, const IcIndex ix,
                                                    const int *__restrict__ zmax, int n_sub, int g_lo, const FarParams &fp,
-                                                   unsigned long long *__restrict__ cnt, const int bx, const int gx) {
-  const int wid = xcd_remap(bx, gx);
+                                                   unsigned long long *__restrict__ cnt, const int wid) {
   const int grp = wid / fp.n_boxes_total; // group of kFarRows layers
   int idx = wid - grp * fp.n_boxes_total, level = fp.n_levels - 1;
   while (level > 0 && idx >= fp.box_count[level]) { // widest level first
@@ -916,7 +928,7 @@ __device__ __forceinline__ void farfield_rows_body(const FastRec *__restrict__ f
     --level;
   }
   const int b = idx;
-  const int lane = threadIdx.x, sub = lane % kFarLines, layer = grp * kFarRows + lane / kFarLines;
+  const int lane = threadIdx.x & 63, sub = lane % kFarLines, layer = grp * kFarRows + lane / kFarLines;
   const bool live = layer < fp.n_layers;
   const int lc = min(layer, fp.n_layers - 1);
   const int W = 64 << level, h = W >> 1;
@@ -937,24 +949,25 @@ __device__ __forceinline__ void farfield_rows_body(const FastRec *__restrict__ f
   pm_min = __builtin_amdgcn_readfirstlane(pm_min);
   pm_max = __builtin_amdgcn_readfirstlane(pm_max);
   zm_max = __builtin_amdgcn_readfirstlane(zm_max);
-  int clo[4], chi[4], nr;
+  // (the ranges live in LDS: as local arrays their dynamic indices put them in scratch memory -- 32 bytes per lane, and
+  // a wave that owns scratch is dispatched through the scratch ring)
+  __shared__ int rs_all[NW][4], re_all[NW][4];
+  int *rs = rs_all[threadIdx.x >> 6], *re = re_all[threadIdx.x >> 6];
+  int nr;
   const int mid = blo + h, near_in = kTheta * h + pm_min;
   if (top) {
-    clo[0] = blo - kHalf - 1; chi[0] = mid - near_in + 1;
-    clo[1] = mid + near_in - 2; chi[1] = bhi + kHalf + 1;
+    const int a0 = lower_bound_ic(ix, blo - kHalf - 1), b0 = lower_bound_ic(ix, mid - near_in + 1 + 1);
+    const int a1 = lower_bound_ic(ix, mid + near_in - 2), b1 = lower_bound_ic(ix, bhi + kHalf + 1 + 1);
+    rs[0] = a0; re[0] = b0; rs[1] = a1; re[1] = b1;
     nr = 2;
   } else {
     const int bn = max(2 * kTheta * h + h + pm_max, zm_max + 3 * h) + 2;
-    clo[0] = plo - kHalf; chi[0] = phi - (kHalf - 1) + 1;       // window end inside the parent
-    clo[1] = mid - bn - 1; chi[1] = mid - near_in + 1;           // left near band
-    clo[2] = mid + near_in - 2; chi[2] = mid + bn + 1;           // right near band
-    clo[3] = plo + kHalf - 1; chi[3] = phi + kHalf + 1;          // window start inside the parent
+    const int a0 = lower_bound_ic(ix, plo - kHalf), b0 = lower_bound_ic(ix, phi - (kHalf - 1) + 1 + 1); // window end inside the parent
+    const int a1 = lower_bound_ic(ix, mid - bn - 1), b1 = lower_bound_ic(ix, mid - near_in + 1 + 1);   // left near band
+    const int a2 = lower_bound_ic(ix, mid + near_in - 2), b2 = lower_bound_ic(ix, mid + bn + 1 + 1);   // right near band
+    const int a3 = lower_bound_ic(ix, plo + kHalf - 1), b3 = lower_bound_ic(ix, phi + kHalf + 1 + 1);  // window start inside the parent
+    rs[0] = a0; re[0] = b0; rs[1] = a1; re[1] = b1; rs[2] = a2; re[2] = b2; rs[3] = a3; re[3] = b3;
     nr = 4;
-  }
-  int rs[4], re[4];
-  for (int i = 0; i < nr; ++i) {
-    rs[i] = lower_bound_ic(ix, clo[i]);
-    re[i] = lower_bound_ic(ix, chi[i] + 1);
   }
   for (int i = 1; i < nr; ++i) // sort by start
     for (int k = i; k > 0 && rs[k] < rs[k - 1]; --k) {
@@ -983,17 +996,21 @@ __device__ __forceinline__ void farfield_rows_body(const FastRec *__restrict__ f
 
   // (Round 6 tried two phases -- the admissibility tests over all candidates first, every layer row queueing its
   // admissible lines in LDS, then eight queued lines of a row at a time: 333 -> 1109 us per sparse pass; the candidates
-  // of a box are mostly its own already, the queue's round trip and the second record fetch were pure cost.)
+  // of a box are mostly its own already, the queue's round trip and the second record fetch were pure cost.
+  // And two chunks at a time -- both records requested first, the two chains of 4 x kFC dependent fma interleaved, chunks
+  // without an admissible lane skipped as here; the same doubles -- : 168 VGPRs, still three waves per SIMD, a table build
+  // 13.0 -> 13.6 ms (1e5 x 1e5 x 80) and 25.2 -> 26.4 (2e5), same box: the chain's latency is not what the kernel waits for.)
   double v[2 * kFC];
 #pragma unroll
   for (int n = 0; n < 2 * kFC; ++n) v[n] = 0.;
   const FastRec *frow = fast + (size_t)lc * n_sub;
   const double hw = (double)h;
   unsigned n_exp = 0;
-  for (int i = 0; i < nm; ++i)
-  for (int l0 = rs[i] & ~(kFarLines - 1); l0 < re[i]; l0 += kFarLines) {
+  for (int i = 0; i < nm; ++i) {
+  const int rsi = __builtin_amdgcn_readfirstlane(rs[i]), rei = __builtin_amdgcn_readfirstlane(re[i]);
+  for (int l0 = rsi & ~(kFarLines - 1); l0 < rei; l0 += kFarLines) {
     const int l = l0 + sub;
-    if (l < rs[i] || l >= re[i] || !live) continue;
+    if (l < rsi || l >= rei || !live) continue;
     const FastRec r = frow[l];
     const int j1 = r.j1, il = r.il(), ir = r.ir();
     if (!ff_admissible(j1, il, ir, blo, bhi, thr2)) continue;
@@ -1028,6 +1045,7 @@ __device__ __forceinline__ void farfield_rows_body(const FastRec *__restrict__ f
       f0 = f1; f1 = f2; f2 = f3; f3 = fn;
     }
   }
+  }
   // sums over the eight lanes of a layer (lane bits 4, 2, 1); every lane is left with kLeft finished values
   lane_reduce<2 * kFC, kFarLines / 2>(v, lane);
   constexpr int kLeft = lane_reduce_left<2 * kFC, kFarLines / 2>();
@@ -1054,16 +1072,22 @@ template <bool COUNT>
 __global__ __launch_bounds__(64) SR_ROWS_ATTR void sr_farfield_rows_kernel(const FastRec *__restrict__ fast, IcIndex ix,
                                                               const int *__restrict__ zmax, int n_sub, int g_lo, FarParams fp,
                                                               unsigned long long *__restrict__ cnt) {
-  farfield_rows_body<COUNT>(fast, ix, zmax, n_sub, g_lo, fp, cnt, (int)blockIdx.x, (int)gridDim.x);
+  farfield_rows_body<COUNT, 1>(fast, ix, zmax, n_sub, g_lo, fp, cnt, xcd_remap_groups((int)blockIdx.x, (int)gridDim.x, 16));
 }
 // ... of every sparse far-only pass of a table build in one launch (grid.y = item): one at a time these launches --
 // eleven of 0.3 ms, latency-bound, each behind ~0.3 ms of host calls -- were 6 ms of a 13 ms build
-__global__ __launch_bounds__(64) SR_ROWS_ATTR void sr_farfield_rows_batch_kernel(const FarBatchItem *__restrict__ items, const int *__restrict__ zmax,
-                                                                    int g_lo, FarParams fp) {
+#ifndef SR_ROWS_BATCH_WAVES
+#define SR_ROWS_BATCH_WAVES 4
+#endif
+constexpr int kRowsBatchWaves = SR_ROWS_BATCH_WAVES; // waves (boxes) per workgroup of the batch kernel
+__global__ __launch_bounds__(64 * kRowsBatchWaves) SR_ROWS_ATTR void sr_farfield_rows_batch_kernel(const FarBatchItem *__restrict__ items, const int *__restrict__ zmax,
+                                                                    int g_lo, FarParams fp, int n_work) {
   const FarBatchItem it = items[blockIdx.y];
   fp.coef = it.coef;
-  farfield_rows_body<false>(it.fast, IcIndex{it.first, it.first_x0, it.first_n, it.line_lo, it.n_sub}, zmax, it.n_sub, g_lo, fp, nullptr,
-                            (int)blockIdx.x, (int)gridDim.x);
+  const int wid = xcd_remap_groups((int)blockIdx.x, (int)gridDim.x, 16 / kRowsBatchWaves) * kRowsBatchWaves + (int)(threadIdx.x >> 6);
+  if (wid >= n_work) return; // (wave-uniform; the kernel has no block barrier)
+  farfield_rows_body<false, kRowsBatchWaves>(it.fast, IcIndex{it.first, it.first_x0, it.first_n, it.line_lo, it.n_sub}, zmax, it.n_sub, g_lo, fp,
+                                             nullptr, wid);
 }
 
 // ------------------------------------------------------------------------
@@ -2119,7 +2143,8 @@ int launch_far_batch(const FarBatchItem *items, int n_items, int max_n_sub, cons
   hipLaunchKernelGGL(sr_prep_batch_kernel, dim3((unsigned)((max_n_sub + kPrepBlock - 1) / kPrepBlock), (unsigned)A.n_layers, (unsigned)n_items),
                      dim3(kPrepBlock), 0, st, items, A, gp);
   const unsigned gx = (unsigned)(fp.n_boxes_total * ((A.n_layers + kFarRows - 1) / kFarRows));
-  hipLaunchKernelGGL(sr_farfield_rows_batch_kernel, dim3(gx, (unsigned)n_items), dim3(64), 0, st, items, zmax, g_lo, fp);
+  hipLaunchKernelGGL(sr_farfield_rows_batch_kernel, dim3((gx + kRowsBatchWaves - 1) / kRowsBatchWaves, (unsigned)n_items), dim3(64 * kRowsBatchWaves), 0,
+                     st, items, zmax, g_lo, fp, (int)gx);
   hipLaunchKernelGGL(sr_l2l_kernel, dim3((unsigned)fp.box_count[kMaxFarLevels - 1], (unsigned)A.n_layers, (unsigned)n_items), dim3(64), 0, st,
                      (double *)nullptr, items, fp, l2l_tab);
   return (int)hipGetLastError();

@@ -9,6 +9,8 @@ import bench_configs as bc
 from spectrobot_amd import engine, synthetic as syn
 
 engine.set_device(0)
+if os.environ.get("OVERLAP") is not None:          # OVERLAP=0: the serial schedule (stand-alone kernel durations in a trace)
+    engine.set_overlap(int(os.environ["OVERLAP"]))
 n = int(os.environ.get("N", "100000"))
 rows = int(os.environ.get("ROWS", "80"))
 reps = int(os.environ.get("REPS", "5"))
