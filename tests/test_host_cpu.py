@@ -90,6 +90,11 @@ def test_argument_checks_return_before_any_launch(L):
     assert L.lib.sr_limb_step_dev(None, None, 0, 10, None, None, None, None, None) == L.SR_ERR_ARG
     assert L.lib.sr_retrieval_forward_dev(None, None, 4, 10, None, 0, None, 3000.0, 5e-4, None, None, 3, 5.0, 0, None, None,
                                           None, None) == L.SR_ERR_ARG                      # no batch, no parameters
+    # the loop and the timing read-out refuse missing handles / descriptions before anything touches a device
+    assert L.lib.sr_retrieval_loop_dev(None, None, 4, 10, None, 0, None, 3000.0, 5e-4, None, None, 3, 5.0, 0, None, None, None, None,
+                                       None, None, None, None, None, None, None, None) == L.SR_ERR_ARG
+    assert L.lib.sr_los_last_kernel_ms(None, None) == L.SR_ERR_ARG
+    assert L.lib.sr_set_band_fusion(1) == L.SR_OK
     with pytest.raises(L.SpectRobotHipError):
         L.check(L.SR_ERR_ARG, "x")
 
