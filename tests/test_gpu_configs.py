@@ -994,3 +994,47 @@ def test_retrieval_step_in_one_call(eng):
         for q in (0, 1, 3, 4, 5, 6, 7):
             assert hist[a][q].shape == hist[c][q].shape and np.array_equal(hist[a][q], hist[c][q]), (a, q)
     assert hist["loop3"][2] == "max_it" and len(hist["loop3"][0]) == 3 and hist["loop3"][5].shape[0] == 3
+    # the positivity rule (:616-624) inside the library: first guesses so small that the first steps would cross zero --
+    # sr_retrieval_loop_dev against a loop of sr_retrieval_step_dev calls with the rule applied here; and its refusals
+    b = copy.deepcopy(bs)
+    for name in b.sets.keys():
+        scene.gas(name).add_clim(b.sets[name].profile())
+    obs = np.concatenate([p.observation.spectrum for p in pixels])
+    noi = np.concatenate([p.noise.spectrum for p in pixels])
+    oe = eng.OeProblem(obs, noi, None, np.linalg.inv(np.asarray(b.VCM_apriori(), dtype=float)), b.apriori_vector(), 0.1)
+    alts = [a for pix in pixels for a in pix.los_alts()]
+    los, par_gas, par_w = retrieval._one_call_batch(scene, pixels, b, alts, len(pixels))
+    cst = scene.coefficient_stack()
+    n_par = len(par_gas)
+    x0 = np.array(b.param_vector(), dtype=float) * 3.0                      # far above the truth: large negative first steps
+    pos = np.ones(n_par, bool)
+    pos[-1] = False                                                         # one parameter free to go negative
+    x, hist_py, xs, halved, chi_old, stop_py = x0.copy(), [], [x0.copy()], 0, None, ""
+    for it in range(5):
+        both, chi_sum, n_used, dx, S_x, AVK, _ = eng.retrieval_step(cst, los, par_gas, par_w, x, scene.grid, scene.bands_nm,
+                                                                    scene.widths_nm, oe, fov=scene._fov_fac)
+        chi = chi_sum / (n_used - n_par)
+        hist_py.append(chi)
+        stop_py = smm.retrieval_converged(chi, chi_old, 0.01)
+        if stop_py:
+            break
+        chi_old = chi
+        for p in range(n_par):
+            d = dx[p]
+            if pos[p]:
+                while x[p] + d <= 0.0:
+                    d /= 2
+                    halved += 1
+            x[p] = x[p] + d
+        xs.append(x.copy())
+    out_c, hist_c, xh_c, stop_c, S_c, A_c, _ = eng.retrieval_loop(cst, los, par_gas, par_w, x0, scene.grid, scene.bands_nm, scene.widths_nm,
+                                                                  oe, pos, n_par, chi_threshold=0.01, max_it=5, fov=scene._fov_fac)
+    assert halved > 0, "the case must exercise the rule"
+    assert stop_c == stop_py and np.array_equal(hist_c, np.array(hist_py)) and np.array_equal(xh_c, np.array(xs))
+    assert np.all(xh_c[:, :-1] > 0.0)
+    with pytest.raises(Exception):                                          # a constrained parameter that is not positive
+        eng.retrieval_loop(cst, los, par_gas, par_w, -x0, scene.grid, scene.bands_nm, scene.widths_nm, oe, pos, n_par, max_it=3,
+                           fov=scene._fov_fac)
+    r0 = eng.retrieval_loop(cst, los, par_gas, par_w, x0, scene.grid, scene.bands_nm, scene.widths_nm, oe, pos, n_par, max_it=0,
+                            fov=scene._fov_fac)
+    assert len(r0[1]) == 0 and r0[2].shape == (1, n_par) and r0[3] == "" and r0[4] is None
