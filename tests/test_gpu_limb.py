@@ -463,13 +463,13 @@ def test_retrieval_forward_against_its_parts(eng, n_par, order):
     assert np.array_equal(again, out)
 
 
-@pytest.mark.parametrize("n,n_par,n_g", [(3000, 7, 2), (256, 3, 1), (70001, 8, 2), (5000, 1, 3)])
-def test_band_fusion_equals_the_instrument_step(eng, n, n_par, n_g):
+@pytest.mark.parametrize("n,n_par,n_g,n_extra", [(3000, 7, 2, 0), (256, 3, 1, 0), (70001, 8, 2, 0), (5000, 1, 3, 0), (9000, 4, 2, 30)])
+def test_band_fusion_equals_the_instrument_step(eng, n, n_par, n_g, n_extra):
     """sr_retrieval_forward_dev with the instrument bands integrated in the recursion kernel's epilogue (default) against
     spectra + sr_hires_to_lowres_shard_dev's kernels (sr_set_band_fusion(0)): the same band integrals up to the order of
     the sums.  Grids that do not fill their last 256-point block, one block only; a band outside the grid (exactly zero
-    both ways), a band over the whole grid, narrow bands at both ends, overlapping bands; with and without the
-    field-of-view integral; the fused call leaves `buf` untouched.  PARITY UNPINNED (product kernels against product
+    both ways), a band over the whole grid, narrow bands at both ends, overlapping bands, 37 bands (three tiles of 16 in
+    the kernel's MFMA product); with and without the field-of-view integral; the fused call leaves `buf` untouched.  PARITY UNPINNED (product kernels against product
     kernels: see test_retrieval_forward_against_its_parts)."""
     import torch
     from spectrobot_amd import synthetic as syn
@@ -495,6 +495,10 @@ def test_band_fusion_equals_the_instrument_step(eng, n, n_par, n_g):
     bands = np.array([lam_lo - 50 * span - 1.0, 0.5 * (lam_lo + lam_hi), lam_lo + 0.01 * span, lam_hi - 0.01 * span,
                       lam_lo + 0.4 * span, lam_lo + 0.45 * span, lam_lo + 0.8 * span])
     widths = np.array([0.05 * span, 3.0 * span, 0.004 * span, 0.004 * span, 0.06 * span, 0.06 * span, 0.02 * span])
+    if n_extra:
+        bands = np.concatenate([bands, lam_lo + span * rng.uniform(0.02, 0.98, n_extra)])
+        widths = np.concatenate([widths, span * rng.uniform(0.003, 0.2, n_extra)])
+    nb = bands.size
     los = eng.LimbLOS(L["seg_off"], L["seg_layer"], L["pt_off"], L["x"], L["nd"], L["vmr"], col_scale=[0.98827, 1.0, 1.0][:n_g])
     fov = np.array([[0.8, 0.8 ** 3, 2 * 1.3 ** 2, 0.0, 0.0, 0.6, 0.0], [0.5, 0.5 ** 3, 2 * 1.1 ** 2, 0.3, 0.02, 0.7, 1.0]])
     res = {}
@@ -509,7 +513,7 @@ def test_band_fusion_equals_the_instrument_step(eng, n, n_par, n_g):
         eng.set_band_fusion(1)
     for k in (0, 1):
         f, u = res[1][k], res[0][k]
-        assert f.shape == u.shape == ((2 if k else los.n_rays), 1 + n_par, 7)
+        assert f.shape == u.shape == ((2 if k else los.n_rays), 1 + n_par, nb)
         assert np.all(f[..., 0] == 0.0) and np.all(u[..., 0] == 0.0)          # the band outside the grid
         scale = np.max(np.abs(u), axis=(0, 2), keepdims=True)
         assert np.all(scale[:, :, :] > 0)
