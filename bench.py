@@ -39,18 +39,28 @@ FLOP_PER_EVAL = 16             # SURVEY 8-d flop model per (line, layer, grid po
 # Executed-work flop model.  Per evaluation, SURVEY 8-d: region 1 = 9, region 2 = 17,
 # core = 140, + 6 for the weighted accumulations; region 3 (no exp / cos, degree 4 / 5 instead of 6 / 7: counted from
 # core_region3: rx 8, two polynomials 9 x 2 + 11 x 2, quotient 12, weights 6) = 70, not the core's 146.  Per far-field (line, box) expansion: counted from
-# sr_farfield_kernel's source (setup 42, reciprocal 9, f0..f3 14, 23 coefficients x 2 outputs).  Per
-# (point, level) polynomial: 2 outputs x degree 22 Horner.  Per window-end expansion: series + its share
+# sr_farfield_kernel's source (setup 42, reciprocal 9, f0..f3 14, C = degree + 1 coefficients x 2 outputs).  Per
+# (point, level) polynomial: 2 outputs x Horner of the degree.  Per window-end expansion: series + its share
 # of the lane scan.
-# Box-pair far field (default): per (line, side) multipole expansion 233 -- since round 4 ONE convolution per line serves
-# both sides (per line: Laurent series 52, two anchors 28, powers 40, convolution 121 fma, two weighted accumulations 42
-# fma, first-order anchor corrections 8 fma + 4 = 466; 430 per side before); per (source box, target box, layer) translation
-# 21 x 23 x 2 outputs fma = 1932 (the MFMA tiles execute 24 x 32: padding not counted); the short series of the
-# window-band lines in the level-0 pass are not counted at all.
+# Box-pair far field (default): per (line, side) multipole expansion -- since round 4 ONE convolution per line serves
+# both sides (per line, at degree 22 = 21 moment orders: Laurent series 52, two anchors 28, powers 40, convolution 121 fma,
+# two weighted accumulations 42 fma, first-order anchor corrections 8 fma + 4 = 466; 430 per side before); per (source box,
+# target box, layer) translation Q x C x 2 outputs fma (the MFMA tiles execute padded ones: padding not counted); the short
+# series of the window-band lines in the level-0 pass are not counted at all.
+# The far field's numbers follow the expansion degree the library was built with (flop_model; degree 22 until the end of
+# round 6: 281 / 93 / 233 / 1932; degree 19 since: 253 / 81 / 188 / 1440).
 ASYNC_GATHER = os.environ.get("SR_GATHER_ASYNC", "1") != "0"   # SR_GATHER_ASYNC=0: every step waits for its all-gather
-FLOP = {"region1_evals": 15, "region2_evals": 23, "region3_evals": 70, "region4_evals": 146,
-        "farfield_expansions": 281, "poly_point_levels": 93, "window_end_expansions": 187,
-        "multipole_line_sides": 233, "box_pair_translations": 1932}
+
+
+def flop_model(degree=22):
+    C, Q = degree + 1, degree - 1
+    per_line = 52.0 * Q / 21 + 28 + 40.0 * Q / 21 + 242.0 * (Q / 21.0) ** 2 + 84.0 * Q / 21 + 20
+    return {"region1_evals": 15, "region2_evals": 23, "region3_evals": 70, "region4_evals": 146,
+            "farfield_expansions": int(round(65 + 216.0 * C / 23)), "poly_point_levels": 5 + 4 * degree, "window_end_expansions": 187,
+            "multipole_line_sides": int(round(per_line / 2)), "box_pair_translations": 4 * Q * C}
+
+
+FLOP = flop_model(22)          # (set from the loaded library in main(): engine.far_field_degree())
 KERNEL_COUNTERS = {
     "sr_farfield_kernel": ("farfield_expansions", "multipole_line_sides", "box_pair_translations"),
     "sr_abscoeff_near_wings_kernel": ("region1_evals", "window_end_expansions", "poly_point_levels"),
@@ -332,6 +342,7 @@ def main():
     rank, local, world = sd.init_from_env()
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     engine.set_device(local % max(torch.cuda.device_count(), 1))
+    FLOP.update(flop_model(engine.far_field_degree()))
     engine.set_points_per_lane(args.ppl)
     engine.set_far_field(0 if args.exact else args.far_field)
     info = engine.device_info()
@@ -517,7 +528,12 @@ def main():
                        "sharding": ("spectral window / %d, one all-gather per step (backend %s: nccl = RCCL over xGMI)"
                                     % (world, dist_rec["backend"]) if world > 1 else
                                     ("ONLY shard %s timed (tuning aid)" % args.shard if args.shard else "none")),
-                       "mode": "exact" if args.exact else ("far-field, box pairs" if args.far_field in (2, 3) else "far-field, per line"), "device": info["name"],
+                       "mode": "exact" if args.exact else ("far-field, box pairs" if args.far_field in (2, 3) else "far-field, per line"),
+                       "far_field": {"theta": 4, "degree": engine.far_field_degree(),
+                                     "truncation_bound_rel_to_a_lines_own_contribution": engine.far_field_truncation_bound(),
+                                     "note": "the degree follows the accuracy budget (required 1e-6; parity tests 1e-10); "
+                                             "degree 22 = bound 2.6e-13 until the end of round 6 (-DSR_KFD=22)"},
+                       "device": info["name"],
                        "cu_count": info["cu_count"]},
             "roofline": roofline,
             "roofline_hbm": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -331,6 +331,8 @@ def main(args):
     rank, local, world = sd.init_from_env()
     assert world == args.gpus
     engine.set_device(local % max(torch.cuda.device_count(), 1))
+    import bench as _B
+    _B.FLOP.update(_B.flop_model(engine.far_field_degree()))
     engine.set_level_route(getattr(args, "level_route", 1))
     info = engine.device_info()
     base = {"unit": "spectra/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -488,7 +488,8 @@ int sr_hires_to_lowres_shard_dev(const double *rad, int n_rays, int64_t n_pts, i
                                  int out_units, double *out_host, void *stream);
 
 /* Evaluation mode of the coefficient op.  Far region-1 wings by local Taylor expansions per box of grid
- * points (truncation <= 2.6e-13 of a line's own contribution), near field exact, with the expansions built
+ * points (truncation <= sr_far_field_truncation_bound() of a line's own contribution: 1.6e-11 as built by default, degree
+ * 19; 2.6e-13 with -DSR_KFD=22), near field exact, with the expansions built
  * 2: from box pairs -- multipole moments of the lines of a source box (sr_s2m_kernel, sr_m2m_kernel)
  *    translated to every well-separated target box of the level (sr_m2l_kernel), per-line expansions only for
  *    the (line, box) pairs no box pair covers;
@@ -528,6 +529,10 @@ int sr_set_table_budget(int64_t bytes);
  * of 16) -- kept as the check of the others.  2: one pass per ray in path order, one ray per thread, always.
  * 3: path order, two rays per thread sharing a shell's coefficient loads (sr_limb_adjoint_sync_kernel; the bits of 2). */
 int sr_set_jac_layer_mode(int forward);
+/* The far field's truncation bound, relative to a line's own contribution at the point: 18 theta^-(degree + 1) of the
+ * library as built (theta = 4, degree 19: 1.6e-11; -DSR_KFD=22: 2.6e-13).  The exact mode (sr_set_far_field(0)) has none.
+ * What the far-field mode may differ by from the exact mode and from the CPU oracle beyond rounding. */
+double sr_far_field_truncation_bound(void);
 /* sr_retrieval_forward_dev / _step_dev / _loop_dev with up to 8 parameters on a folded batch: 1 (default) the recursion
  * kernel integrates the instrument bands in its epilogue (partial sums per 64 points; the 1 + n_par spectra per ray
  * are never written: `buf` stays untouched); 0: spectra into `buf`, then sr_hires_to_lowres_shard_dev's kernels -- the

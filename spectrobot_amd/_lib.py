@@ -140,6 +140,7 @@ SYMBOLS = {
                                                C.c_int, C.c_double, C.c_int, dp, C.c_void_p]),
     "sr_set_points_per_lane": (C.c_int, [C.c_int]),
     "sr_set_band_fusion": (C.c_int, [C.c_int]),
+    "sr_far_field_truncation_bound": (C.c_double, []),
     "sr_los_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sr_set_jac_layer_mode": (C.c_int, [C.c_int]),
     "sr_last_limb_route": (C.c_int, []),

@@ -466,6 +466,8 @@ int sr_set_jac_layer_mode(int forward) {
   return SR_OK;
 }
 
+double sr_far_field_truncation_bound(void) { return 18.0 * std::pow((double)kTheta, -(double)(kFD + 1)); }
+
 int sr_set_band_fusion(int on) {
   g_band_fusion.store(on ? 1 : 0);
   return SR_OK;

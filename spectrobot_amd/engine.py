@@ -1104,6 +1104,18 @@ def set_overlap(on):
     check(lib.sr_set_overlap(int(on)), "sr_set_overlap")
 
 
+def far_field_truncation_bound():
+    """18 theta^-(degree + 1): what the far-field mode may differ by from the exact mode, relative to a line's own
+    contribution (sr_far_field_truncation_bound; 1.6e-11 as built by default)."""
+    return float(lib.sr_far_field_truncation_bound())
+
+
+def far_field_degree(theta=4):
+    """The expansion degree the library was built with (from its truncation bound 18 theta^-(degree + 1))."""
+    import math
+    return int(round(math.log(18.0 / far_field_truncation_bound()) / math.log(theta))) - 1
+
+
 def set_band_fusion(on):
     """1 (default): a retrieval iteration's recursion kernel integrates the instrument bands itself; 0: spectra, then the
     instrument step's own kernels (sr_set_band_fusion; the check and the A/B partner)."""

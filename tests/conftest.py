@@ -37,6 +37,17 @@ def oracle():
     return O
 
 
+def far_tol(base, amp=1.0):
+    """Tolerance of a comparison in which the far field's truncation takes part (far-field mode against the exact mode,
+    a spectral shard -- whose boxes start at its own first point -- against the whole grid): `base` (the bound the test
+    held at expansion degree 22: rounding) or amp x the library's truncation bound 18 theta^-(degree + 1), whichever is
+    larger (sr_far_field_truncation_bound: 1.6e-11 at the default degree 19; 2.6e-13 with -DSR_KFD=22, where `base`
+    decides).  amp > 1: measures relative to a NET quantity whose parts cancel (the bound is relative to a line's own
+    contribution)."""
+    from spectrobot_amd import engine
+    return max(float(base), float(amp) * engine.far_field_truncation_bound())
+
+
 def relerr(a, b):
     a = np.asarray(a, float)
     b = np.asarray(b, float)

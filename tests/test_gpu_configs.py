@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import relerr
+from conftest import relerr, far_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -97,8 +97,8 @@ def test_config2_64_rays_and_eight_shards(eng, oracle, cfg1):
         parts_a.append(a_s)
         parts_r.append(eng.limb_rays((a_s, e_s), los))
     a_cat, r_cat = torch.cat(parts_a, dim=1), torch.cat(parts_r, dim=1)
-    assert float(((a_cat - cfg1["ab"]).abs() / cfg1["ab"].abs()).max()) < 1e-12
-    assert float(((r_cat - rad).abs() / rad.abs().clamp_min(1e-300)).max()) < 1e-12
+    assert float(((a_cat - cfg1["ab"]).abs() / cfg1["ab"].abs()).max()) < far_tol(1e-12)   # (a shard's boxes start at its first point)
+    assert float(((r_cat - rad).abs() / rad.abs().clamp_min(1e-300)).max()) < far_tol(1e-12)
 
 
 def test_config3_2e5_grid_T_and_vmr_jacobians(eng, oracle):
@@ -241,7 +241,7 @@ for bounds in ([sd.shard_bounds(n, world, r) for r in range(world)], sd.shard_bo
         assert torch.equal(full, seq), "gathered != shards computed one after the other"
         whole = shard(0, n)
         rel = float(((full - whole).abs() / whole.abs().clamp_min(1e-300)).max())
-        assert rel < 1e-12, rel
+        assert rel < max(1e-12, engine.far_field_truncation_bound()), rel   # (shards anchor their far-field boxes themselves)
         assert bounds[0][1] != n // 2 or bounds is not None
 torch.distributed.barrier()
 print("rank", rank, "ok")
@@ -462,7 +462,7 @@ def test_retrieval_forward_in_one_call(eng):
     both_ways(flat)
     n = len(scene.grid)
     parts = [both_ways(pixels, shard=(lo, hi))[0] for lo, hi in ((0, n // 3), (n // 3, n))]
-    assert np.max(np.abs(parts[0] + parts[1] - whole)) <= 1e-12 * np.max(np.abs(whole))
+    assert np.max(np.abs(parts[0] + parts[1] - whole)) <= far_tol(1e-12) * np.max(np.abs(whole))
     hist = []
     for one in (False, True):
         retrieval.ONE_CALL = one
@@ -622,7 +622,11 @@ def test_frozen_boundaries_at_other_temperatures_lose_nothing(eng):
                         rp = env_rel(res[mode][2], res[0][2])
                         print("%d lines, boundaries at T%+.0f K%s: far-field mode %d vs exact mode, same boundaries: abs %.1e emi "
                               "%.1e pair tables %.1e" % (n_lines, dTb, ", linear weights" if linear else "", mode, ra, re, rp))
-                        assert ra < 1e-11 and re < 1e-11 and rp < 1e-11, (n_lines, dTb, linear, mode)
+                        # (relative to the envelope of the NET spectrum: under non-LTE populations -- and more so under
+                        # linearised weights -- the lines' weights nearly cancel, and the truncation bound, which is relative
+                        # to a line's own contribution, is seen amplified: 19 x measured at degree 20; a dropped zone is 1e-5..1)
+                        tol = far_tol(1e-11, amp=32.0)
+                        assert ra < tol and re < tol and rp < tol, (n_lines, dTb, linear, mode)
                     if not linear:
                         for mode in (0, 3):
                             eng.set_far_field(mode)
