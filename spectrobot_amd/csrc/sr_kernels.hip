@@ -891,13 +891,14 @@ __global__ __launch_bounds__(64) SR_FAR_ATTR void sr_farfield_kernel(const FastR
 // The per-line scheme for SPARSE line sets (the per-level passes of the pair tables: 0.09-0.16 lines per grid point):
 // sr_farfield_kernel gives a (box, level, layer) a wave whatever the box holds -- five or six lines in one chunk body
 // of ~230 instructions at a tenth of its lanes, behind ~450 of range searches, reduction and indexing: 0.34 of the pass's
-// 0.53 ms were that.  Here a wave takes a box for kFarRows LAYERS: lane = (line of the chunk, layer), eight lines x
-// eight layers per chunk body; the candidate ranges are the union over the wave's layers (the exact admissibility tests
-// run per lane with its layer's margins), the 2 kFC sums are reduced over the eight lanes of a layer (three exchange
+// 0.53 ms were that.  Here a wave takes a box for kFarRows LAYERS: lane = (line of the chunk, layer), kFarLines lines x
+// kFarRows layers per chunk body (8 x 8 when this was written, 4 x 16 as built now); the candidate ranges are the union over the wave's layers (the exact admissibility tests
+// run per lane with its layer's margins), the 2 kFC sums are reduced over the kFarLines lanes of a layer (log2 of them exchange
 // steps instead of six).  Same expansions, same owner of every (line, box): the coefficients differ from
 // sr_farfield_kernel<., false>'s by the summation order.
 #ifndef SR_FAR_ROWS
-#define SR_FAR_ROWS 8 // layers per wave (8 x 8 lines; 16 x 4 and 4 x 16: tools/r04_ab.sh with variant builds)
+#define SR_FAR_ROWS 16 // layers per wave x 64 / that many lines.  8 x 8 through round 6 (degree 22: 16 x 4 and 4 x 16 lost, tools/r04_ab.sh);
+                       // at degree 19 a table build of 12 levels: 16 x 4 11.94 / 23.92 ms (1e5 / 2e5 lines), 8 x 8 12.27 / 24.42, 4 x 16 13.45 / 26.74
 #endif
 constexpr int kFarRows = SR_FAR_ROWS, kFarLines = 64 / kFarRows; // lanes: kFarRows layers x kFarLines lines of a chunk
 static_assert(kFarRows == 4 || kFarRows == 8 || kFarRows == 16, "SR_FAR_ROWS");
